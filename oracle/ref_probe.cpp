@@ -1,0 +1,300 @@
+// ref_probe.cpp - drives the COMPILED REFERENCE (Stormphrax 8.0.2) as the parity oracle's anchor.
+//
+// TEST INFRASTRUCTURE ONLY. This translation unit is the repo's own code; it is compiled together with the
+// reference's sources *where they lie* under /root/reference (see oracle/Makefile, target _ref/sp_ref_probe) and
+// calls the reference's public C++ API:
+//   eval::init / eval::getNetwork              src/eval/nnue.h:38-44
+//   eval::NnueState::{reset,push,pop,evaluate,evaluateOnce}   src/eval/nnue_state.h:85-116
+//   nnue::features::psq::featureIndex          src/eval/nnue/features/psq.h:338-365
+//   nnue::features::threats::{threatFeatureIndex,ppFeatureIndex,kPpMasks}  src/eval/nnue/features/threats.h:106-136
+//   Position::{fromFen,startpos,fromDfrcIndex,applyMove,isLegal,toFen}     src/position.h
+//   generateAll                                src/movegen.h:36
+// Nothing from the reference is copied into this repository; the binary lives in oracle/_ref/ (git-ignored).
+//
+// Protocol: one command per stdin line, one or more result lines on stdout, each batch terminated by "OK".
+//   eval <fen>                 -> "E <raw evaluateOnce>"
+//   feat <fen>                 -> "F <raw> <bucket> <stm>" + 4 lines "R <colour> <psq|thr> <n> ids..."
+//   playout <seed> <count> <minPly> <maxPly> <dfrc>  -> count lines "P <raw> <fen>"
+//   trace <seed> <maxEvals> <depth> <fen>            -> opcode stream of a DFS make/unmake walk with evaluate() values
+//   add <fen> / bench <threads> <seconds>            -> timing of evaluateOnce over the added positions
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "attacks/attacks.h"
+#include "cuckoo.h"
+#include "eval/nnue.h"
+#include "eval/nnue_state.h"
+#include "movegen.h"
+#include "opts.h"
+#include "position.h"
+#include "tunable.h"
+#include "util/numa/numa.h"
+
+using namespace stormphrax;
+
+namespace {
+    struct SplitMix64 {
+        u64 s;
+        u64 next() {
+            u64 z = (s += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        }
+        u32 below(u32 n) {
+            return static_cast<u32>((next() >> 32) % n);
+        }
+    };
+
+    std::vector<Move> legalMoves(const Position& pos) {
+        ScoredMoveList moves{};
+        generateAll(moves, pos);
+        std::vector<Move> out;
+        for (const auto& [move, score] : moves) {
+            if (pos.isLegal(move)) {
+                out.push_back(move);
+            }
+        }
+        return out;
+    }
+
+    // Row lists of one perspective, enumerated in the same order as the reference does internally
+    // (nnue_state.cpp:440-449 for psq, :309-354 for threats + pawn pairs), through the reference's own indexers.
+    void featureRows(const Position& pos, Color c, std::vector<u32>& psq, std::vector<u32>& thr) {
+        using namespace eval;
+        namespace threats = eval::nnue::features::threats;
+        const auto kingSq = pos.king(c);
+        for (const auto [piece, sq] : pos) {
+            psq.push_back(nnue::features::psq::featureIndex<InputFeatureSet>(c, piece, sq, kingSq));
+        }
+        const auto occ = pos.occ();
+        const auto kings = pos.bb(PieceTypes::kKing);
+        for (const auto from : occ & ~kings) {
+            const auto piece = pos.pieceOn(from);
+            for (const auto to : occ & attacks::getAttacks(piece, from, occ) & ~kings) {
+                const auto f = threats::threatFeatureIndex(c, kingSq, piece, from, pos.pieceOn(to), to);
+                if (f >= 0) {
+                    thr.push_back(static_cast<u32>(f));
+                }
+            }
+        }
+        const auto ours = pos.bb(PieceTypes::kPawn, c);
+        const auto theirs = pos.bb(PieceTypes::kPawn, c.flip());
+        for (const auto [a, remaining] : ours.iterWithRemaining()) {
+            const auto mask = threats::kPpMasks[a.idx()];
+            for (const auto b : remaining & mask) {
+                thr.push_back(threats::ppFeatureIndex(c, kingSq, c, a, c, b));
+            }
+            for (const auto b : theirs & mask) {
+                thr.push_back(threats::ppFeatureIndex(c, kingSq, c, a, c.flip(), b));
+            }
+        }
+        for (const auto [a, remaining] : theirs.iterWithRemaining()) {
+            for (const auto b : remaining & threats::kPpMasks[a.idx()]) {
+                thr.push_back(threats::ppFeatureIndex(c, kingSq, c.flip(), a, c.flip(), b));
+            }
+        }
+    }
+
+    void printRows(int colour, const char* kind, const std::vector<u32>& rows) {
+        std::printf("R %d %s %zu", colour, kind, rows.size());
+        for (const auto r : rows) {
+            std::printf(" %u", r);
+        }
+        std::printf("\n");
+    }
+
+    // DFS make/unmake walk that mimics how search drives NnueState (thread.cpp:46-67, thread.h:116-122):
+    // PUSH <uci> applies a move through the observer, EVAL prints the lazily-updated evaluate(), POP unwinds.
+    struct Tracer {
+        eval::NnueState state;
+        SplitMix64 rng;
+        u64 evals{};
+        u64 maxEvals{};
+
+        void walk(const Position& pos, i32 depth) {
+            if (evals >= maxEvals) {
+                return;
+            }
+            // evaluate lazily only at some nodes so multi-ply walk-backs (nnue_state.cpp:636-697) are exercised
+            if (depth == 0 || rng.below(3) != 0) {
+                const auto v = state.evaluate(pos, pos.stm());
+                const auto once = eval::NnueState::evaluateOnce(pos, pos.stm());
+                std::printf("EVAL %d %d\n", v, once);
+                ++evals;
+            }
+            if (depth == 0) {
+                return;
+            }
+            auto moves = legalMoves(pos);
+            // visit a random subset so deep traces stay bounded
+            const u32 branch = 2 + rng.below(3);
+            for (u32 i = 0; i < branch && !moves.empty() && evals < maxEvals; ++i) {
+                const auto idx = rng.below(static_cast<u32>(moves.size()));
+                const auto move = moves[idx];
+                moves.erase(moves.begin() + idx);
+                std::printf("PUSH %s\n", fmt::format("{}", move).c_str());
+                const auto next = pos.applyMove(move, state.push());
+                walk(next, depth - 1);
+                state.pop();
+                std::printf("POP\n");
+            }
+        }
+    };
+} // namespace
+
+int main() {
+    if (!numa::init()) {
+        return 1;
+    }
+    tunable::init();
+    cuckoo::init();
+    eval::init();
+    if (!eval::isNetworkLoaded()) {
+        std::fprintf(stderr, "reference failed to load the embedded network\n");
+        return 2;
+    }
+    opts::mutableOpts().chess960 = true; // harmless for standard FENs; required for DFRC castling rights
+
+    std::vector<Position> added;
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::istringstream in{line};
+        std::string cmd;
+        in >> cmd;
+        if (cmd == "eval" || cmd == "feat" || cmd == "add") {
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            if (cmd == "add") {
+                added.push_back(*pos);
+            } else {
+                const auto raw = eval::NnueState::evaluateOnce(*pos, pos->stm());
+                if (cmd == "eval") {
+                    std::printf("E %d\n", raw);
+                } else {
+                    std::printf(
+                        "F %d %u %d\n",
+                        raw,
+                        eval::OutputBucketing::getBucket(*pos),
+                        pos->stm() == Colors::kWhite ? 1 : 0
+                    );
+                    for (const auto c : {Colors::kBlack, Colors::kWhite}) {
+                        std::vector<u32> psq, thr;
+                        featureRows(*pos, c, psq, thr);
+                        printRows(c == Colors::kWhite ? 1 : 0, "psq", psq);
+                        printRows(c == Colors::kWhite ? 1 : 0, "thr", thr);
+                    }
+                }
+            }
+        } else if (cmd == "playout") {
+            u64 seed;
+            u32 count, minPly, maxPly, dfrc;
+            in >> seed >> count >> minPly >> maxPly >> dfrc;
+            SplitMix64 rng{seed};
+            u32 produced = 0;
+            while (produced < count) {
+                auto pos = dfrc ? *Position::fromDfrcIndex(rng.below(960 * 960)) : Position::startpos();
+                const u32 plies = minPly + rng.below(maxPly - minPly + 1);
+                bool dead = false;
+                for (u32 i = 0; i < plies; ++i) {
+                    const auto moves = legalMoves(pos);
+                    if (moves.empty()) {
+                        dead = true;
+                        break;
+                    }
+                    pos = pos.applyMove(moves[rng.below(static_cast<u32>(moves.size()))]);
+                }
+                if (dead) {
+                    continue;
+                }
+                const auto raw = eval::NnueState::evaluateOnce(pos, pos.stm());
+                std::printf("P %d %s\n", raw, pos.toFen().c_str());
+                ++produced;
+            }
+        } else if (cmd == "trace") {
+            u64 seed, maxEvals;
+            i32 depth;
+            in >> seed >> maxEvals >> depth;
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            Tracer tracer{};
+            tracer.state.setNetwork(eval::getNetwork(0));
+            tracer.rng = SplitMix64{seed};
+            tracer.maxEvals = maxEvals;
+            tracer.state.reset(*pos);
+            std::printf("ROOT %s\n", pos->toFen().c_str());
+            tracer.walk(*pos, depth);
+        } else if (cmd == "bench") {
+            u32 threads;
+            double seconds;
+            in >> threads >> seconds;
+            if (added.empty() || threads == 0) {
+                std::printf("ERR nothing to bench\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            std::atomic<u64> total{0};
+            std::atomic<i64> checksum{0};
+            std::atomic<bool> stop{false};
+            std::vector<std::thread> pool;
+            const auto start = std::chrono::steady_clock::now();
+            for (u32 t = 0; t < threads; ++t) {
+                pool.emplace_back([&, t] {
+                    u64 n = 0;
+                    i64 sum = 0;
+                    usize i = t % added.size();
+                    while (!stop.load(std::memory_order_relaxed)) {
+                        for (u32 k = 0; k < 256; ++k) {
+                            const auto& pos = added[i];
+                            sum += eval::NnueState::evaluateOnce(pos, pos.stm());
+                            i = i + 1 == added.size() ? 0 : i + 1;
+                        }
+                        n += 256;
+                    }
+                    total += n;
+                    checksum += sum;
+                });
+            }
+            std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+            stop = true;
+            for (auto& th : pool) {
+                th.join();
+            }
+            const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - start;
+            std::printf(
+                "B %.1f evals_per_sec %llu evals %.3f s %u threads checksum %lld\n",
+                static_cast<double>(total.load()) / dt.count(),
+                static_cast<unsigned long long>(total.load()),
+                dt.count(),
+                threads,
+                static_cast<long long>(checksum.load())
+            );
+        } else if (cmd == "quit") {
+            break;
+        } else if (!cmd.empty()) {
+            std::printf("ERR unknown command\n");
+        }
+        std::printf("OK\n");
+        std::fflush(stdout);
+    }
+    eval::shutdown();
+    return 0;
+}

@@ -1,0 +1,20 @@
+// Internal (non-ABI) declarations shared between the host translation units of libspx_nnue.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "spx_arch.h"
+
+namespace spx {
+
+// spx_synth.cpp
+size_t synthNetBytes();
+bool synthNet(uint64_t seed, int preset, void* buf, size_t n);
+uint64_t fnv1a64(const void* data, size_t n);
+
+// error plumbing (spx_api): thread-local last error string, returned by spx_last_error()
+void setError(const std::string& msg);
+
+}  // namespace spx

@@ -1,0 +1,112 @@
+// Synthetic CBNF network generator.
+//
+// The reference's default net (net093_255_128_q6, /root/reference/network.txt:1) is downloaded at build time and is
+// not obtainable offline, so parity and benchmarks run on a random-weight net with a valid header
+// (/root/reference/src/eval/header.h:38-52) and the exact array order/sizes of preprocess/permute.cpp:33-56.
+// The stream comes from the repo's own splitmix64 so the same 89 381 984-byte file is regenerated bit-identically
+// on any box (tests pin its FNV-1a digest).
+//
+// The file produced here is in LOGICAL column order (what a trainer writes); the reference's build permutes FT
+// columns per ISA before embedding (permute.cpp:121-126) - the GPU path consumes the logical order.
+#include <cstring>
+
+#include "spx_arch.h"
+#include "spx_internal.h"
+
+namespace spx {
+
+namespace {
+struct SplitMix64 {
+    uint64_t s;
+    inline uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    // uniform integer in [lo, hi]; modulo bias is irrelevant for synthetic weights
+    inline int32_t range(int32_t lo, int32_t hi) {
+        const uint32_t span = uint32_t(hi - lo) + 1u;
+        return lo + int32_t(uint32_t(next() >> 32) % span);
+    }
+};
+
+struct Ranges {
+    int psq, thr, biasLo, biasHi, l1w, l1b, l2w, l2b, l3w, l3b;
+};
+
+// preset 0 "tame": no i32 wrap in L2/L3, raw evals inside +-24999 (oracle `raweval` clamp safe)
+// preset 1 "wild": L3 products and t*t wrap in i32
+// preset 2 "extreme": additionally the i16 accumulators wrap
+// l3B is 0 in the wrapping presets: the reference's final `l3Biases[b] + hsum(s)` (multilayer.h:446) is a SCALAR
+// signed add - overflow there is UB (the AVX2 build was observed to widen it to i64), unlike every SIMD op on the
+// path, which wraps by definition. Keeping that one add overflow-free keeps the reference's result well-defined.
+constexpr Ranges kPresets[3] = {
+    {48, 12, -64, 191, 127, 4096, 8, 4096, 8, 65536},
+    {48, 12, -64, 191, 127, 4096, 64, 1 << 20, 64, 0},
+    {6000, 127, -32768, 32767, 127, 1 << 22, 1 << 20, 1 << 30, 1 << 24, 0},
+};
+
+template <typename T>
+void fill(SplitMix64& rng, unsigned char* dst, size_t count, int32_t lo, int32_t hi) {
+    T* p = reinterpret_cast<T*>(dst);
+    for (size_t i = 0; i < count; ++i) {
+        p[i] = static_cast<T>(rng.range(lo, hi));
+    }
+}
+}  // namespace
+
+size_t synthNetBytes() {
+    return kNetFileBytes;
+}
+
+bool synthNet(uint64_t seed, int preset, void* buf, size_t n) {
+    if (!buf || n < kNetFileBytes || preset < 0 || preset > 2) {
+        return false;
+    }
+    auto* out = static_cast<unsigned char*>(buf);
+    const Ranges& r = kPresets[preset];
+
+    // ---- header ----
+    std::memset(out, 0, kHeaderBytes);
+    std::memcpy(out, "CBNF", 4);
+    const uint16_t version = 1;
+    const uint16_t flags = kFlagMirrored | kFlagMergedKings | kFlagPairwise;
+    std::memcpy(out + 4, &version, 2);
+    std::memcpy(out + 6, &flags, 2);
+    out[8] = 0;  // padding
+    out[9] = kArchId;
+    out[10] = kActivationId;
+    const uint16_t hidden = kL1;
+    std::memcpy(out + 11, &hidden, 2);
+    out[13] = uint8_t(kInputBuckets | 0x80);  // bit 7 = threat inputs (nnue.cpp:153)
+    out[14] = uint8_t(kOutputBuckets);
+    char name[48] = {};
+    static const char* kNames[3] = {"spx_synth_tame", "spx_synth_wild", "spx_synth_extreme"};
+    std::strncpy(name, kNames[preset], sizeof(name) - 1);
+    out[15] = uint8_t(std::strlen(name));
+    std::memcpy(out + 16, name, 48);
+
+    SplitMix64 rng{seed ^ (0xC0FFEEull * uint64_t(preset + 1))};
+    fill<int16_t>(rng, out + kOffPsqW, size_t(kPsqRows) * kL1, -r.psq, r.psq);
+    fill<int8_t>(rng, out + kOffThreatW, size_t(kThreatRows) * kL1, -r.thr, r.thr);
+    fill<int16_t>(rng, out + kOffFtBias, kL1, r.biasLo, r.biasHi);
+    fill<int8_t>(rng, out + kOffL1W, kL1WBytes, -r.l1w, r.l1w);
+    fill<int32_t>(rng, out + kOffL1B, kOutputBuckets * kL2, -r.l1b, r.l1b);
+    fill<int32_t>(rng, out + kOffL2W, size_t(kOutputBuckets) * kL2Full * kL3, -r.l2w, r.l2w);
+    fill<int32_t>(rng, out + kOffL2B, kOutputBuckets * kL3, -r.l2b, r.l2b);
+    fill<int32_t>(rng, out + kOffL3W, kOutputBuckets * kL3, -r.l3w, r.l3w);
+    fill<int32_t>(rng, out + kOffL3B, kOutputBuckets, -r.l3b, r.l3b);
+    return true;
+}
+
+uint64_t fnv1a64(const void* data, size_t n) {
+    const auto* p = static_cast<const unsigned char*>(data);
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) {
+        h = (h ^ p[i]) * 0x100000001b3ull;
+    }
+    return h;
+}
+
+}  // namespace spx
