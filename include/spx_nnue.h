@@ -1,0 +1,127 @@
+/*
+ * spx_nnue.h - C ABI of libspx_nnue: a batched, MI355X-native (gfx950) evaluator for Stormphrax's NNUE.
+ *
+ * Drop-in boundary. Stormphrax has no plugin/FFI layer; the seam is the C++ API of src/eval. Each entry point below
+ * names the reference interface it replaces (paths relative to /root/reference). Signatures use only plain pointers
+ * and sizes. Status: 0 = SPX_OK, otherwise an spx_status code; spx_last_error() returns the message of the calling
+ * thread's last failure (the reference reports errors as `bool` + a line on stderr, src/eval/nnue.cpp:85-185,201-291).
+ *
+ * Encodings (identical to the reference's, src/core.h:336-350,389-415): squares a1 = 0 ... h8 = 63; colours
+ * black = 0, white = 1; pieces type<<1|colour with pawn=0, knight=1, bishop=2, rook=3, queen=4, king=5.
+ *
+ * Threading: an spx_net is immutable and shareable; an spx_ctx belongs to one caller thread / one HIP stream at a
+ * time (Lazy-SMP analogue: one NnueState per search thread, src/thread.h:147). Contexts on different GPUs are
+ * independent. The library never frees or retains caller memory beyond a call (async variants: until the stream
+ * reaches the enqueued work).
+ */
+#ifndef SPX_NNUE_H
+#define SPX_NNUE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum spx_status {
+    SPX_OK = 0,
+    SPX_ERR_INVALID_ARG = 1,
+    SPX_ERR_BAD_NET = 2,      /* header / size validation failed (nnue.cpp:85-185, loader.cpp:29-46) */
+    SPX_ERR_HIP = 3,          /* a HIP runtime call failed */
+    SPX_ERR_NO_DEVICE = 4,    /* no gfx950 device visible: the library never falls back to a CPU path */
+    SPX_ERR_CAPACITY = 5,     /* batch larger than the context was created for */
+    SPX_ERR_BAD_POSITION = 6  /* unparsable FEN / record without both kings */
+} spx_status;
+
+const char* spx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Position record: marlinformat PackedBoard, 32 bytes (src/datagen/marlinformat.h:32-84).
+ *   occupancy   bit i set = square i occupied
+ *   pieces      one nibble per occupied square in ascending square order (low nibble first): type | colour<<3,
+ *               colour bit set = BLACK, type 6 = rook that still has castling rights
+ *   stm_ep      bit 7 = black to move; low 7 bits = en-passant square or 64
+ * The evaluator reads occupancy, pieces and bit 7 of stm_ep only.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct spx_packed_pos {
+    uint64_t occupancy;
+    uint8_t pieces[16];
+    uint8_t stm_ep;
+    uint8_t halfmove;
+    uint16_t fullmove;
+    int16_t eval;
+    uint8_t wdl;
+    uint8_t extra;
+} spx_packed_pos;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Network (replaces eval::init / eval::getNetwork / eval::shutdown, src/eval/nnue.h:38-44, nnue.cpp:200-321).
+ * `blob` is a CBNF file image: 64-byte header (src/eval/header.h:38-52) + arrays in the order of
+ * preprocess/permute.cpp:33-56, in LOGICAL (unpermuted) column order, uncompressed. Validation mirrors
+ * nnue.cpp:85-185. The blob is copied; the caller may free it after the call.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct spx_net spx_net;
+int spx_net_load(const void* blob, size_t nbytes, spx_net** out);
+void spx_net_free(spx_net* net);
+const char* spx_net_name(const spx_net* net); /* eval::defaultNetworkName, nnue.h:44 */
+
+/* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
+ * 2 extreme (i16 accumulator wraps too). Writes spx_synth_net_bytes() bytes. */
+size_t spx_synth_net_bytes(void);
+int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
+uint64_t spx_fnv1a64(const void* data, size_t nbytes);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Device context: weights resident in HBM (re-laid out for the kernels), LUTs, scratch for `max_batch` positions.
+ * Replaces the per-thread NnueState construction + setNetwork (src/eval/nnue_state.h:87-94, search.cpp:206,381).
+ * Fails with SPX_ERR_NO_DEVICE when no HIP device is present.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct spx_ctx spx_ctx;
+int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out);
+void spx_ctx_destroy(spx_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Full-refresh evaluation == n x NnueState::evaluateOnce(pos, pos.stm()) (src/eval/nnue_state.cpp:612-634): raw
+ * network output in centipawn-like units from the side to move's point of view, BEFORE eval::adjustStatic's
+ * contempt/clamp (src/eval/eval.cpp:25-28).
+ *   spx_eval_full        host buffers in/out, synchronous (H2D, kernels, D2H on the context's stream)
+ *   spx_eval_full_device device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = the context's own
+ *                        stream) without synchronising; n <= max_batch
+ * ---------------------------------------------------------------------------------------------------------------- */
+int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32_t* out);
+int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream);
+
+/* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
+ * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
+ * feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */
+int spx_profile_begin(spx_ctx* ctx, size_t max_calls);
+int spx_profile_end(spx_ctx* ctx, double* ft_ms, double* mlp_ms, size_t* calls);
+
+/* Active feature rows of a batch, both perspectives summed (what a full refresh gathers): algorithmic bytes =
+ * 2048 * psq_rows + 1024 * threat_rows (+ 36 B per position of record and score). Host-side count. */
+int spx_count_rows(const spx_packed_pos* positions, size_t n, uint64_t* psq_rows, uint64_t* threat_rows);
+
+/* Device-side intermediates of the last spx_eval_full* call on this context, for tests and profiling:
+ * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
+int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host helpers (position plumbing for harnesses; counterparts: src/position.cpp FEN parsing, marlinformat pack,
+ * src/datagen/datagen.cpp:146-171 random openings).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int spx_pos_from_fen(const char* fen, spx_packed_pos* out);
+int spx_pos_to_fen(const spx_packed_pos* pos, char* buf, size_t nbytes);
+int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm);
+int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
+uint64_t spx_perft(const char* fen, int depth);
+
+/* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):
+ * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */
+int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows, int* n_psq, uint32_t* threat_rows,
+                       int* n_threat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_NNUE_H */

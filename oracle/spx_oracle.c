@@ -574,6 +574,28 @@ int spxo_eval_mailbox(const uint8_t* mailbox, int stm, int32_t* out) {
     return 0;
 }
 
+/* activateFt output (u8[1024], stm half first) of a mailbox position - lets tests localise a GPU mismatch to the
+ * feature-transformer kernel or to the MLP kernel. */
+int spxo_ft_mailbox(const uint8_t* mailbox, int stm, uint8_t* ftOut) {
+    Board b;
+    memcpy(b.mailbox, mailbox, 64);
+    b.stm = stm;
+    uint64_t occ, kings, pawns[2];
+    int kingSq[2];
+    boardSets(&b, &occ, &kings, pawns, kingSq);
+    if (kingSq[0] < 0 || kingSq[1] < 0) return -1;
+    uint16_t psq[2 * L1], thr[2 * L1];
+    uint32_t rows[256];
+    for (int c = 0; c < 2; ++c) {
+        int n = psqRows(&b, c, kingSq[c], rows);
+        accumulatePsq(rows, n, psq + c * L1);
+        n = threatRows(&b, c, kingSq[c], occ, kings, pawns, rows);
+        accumulateThreat(rows, n, thr + c * L1);
+    }
+    (void)spxo_forward(psq, thr, stm, (popcnt(occ) - 2) / 4, ftOut);
+    return 0;
+}
+
 int spxo_eval_fen(const char* fen, int32_t* out) {
     Board b;
     if (parseFen(fen, &b) != 0) return -1;

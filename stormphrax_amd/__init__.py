@@ -1,0 +1,18 @@
+"""stormphrax_amd: MI355X-native batched NNUE evaluator for Stormphrax (hot path only).
+
+The product is the C-ABI shared library `libspx_nnue.so` (include/spx_nnue.h; sources in stormphrax_amd/csrc,
+hand-written HIP for gfx950). This package is the Python plumbing the tests and bench.py use.
+"""
+from .nnue import (  # noqa: F401
+    PACKED_DTYPE,
+    Network,
+    NnueState,
+    count_rows,
+    debug_features,
+    perft,
+    position_to_fen,
+    positions_from_fens,
+    positions_to_mailboxes,
+    random_positions,
+    synthetic_net_bytes,
+)

@@ -1,0 +1,87 @@
+"""ctypes binding of libspx_nnue.so (C ABI declared in include/spx_nnue.h).
+
+The shared library is the product; this module is plumbing for the Python harnesses (tests, bench.py). It fails
+loudly when the in-tree library is missing - there is no Python or CPU fallback for the evaluation path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspx_nnue.so")
+
+
+class PackedPos(ctypes.Structure):
+    """spx_packed_pos: marlinformat PackedBoard (reference src/datagen/marlinformat.h:32-84), 32 bytes."""
+
+    _pack_ = 1
+    _fields_ = [
+        ("occupancy", ctypes.c_uint64),
+        ("pieces", ctypes.c_uint8 * 16),
+        ("stm_ep", ctypes.c_uint8),
+        ("halfmove", ctypes.c_uint8),
+        ("fullmove", ctypes.c_uint16),
+        ("eval", ctypes.c_int16),
+        ("wdl", ctypes.c_uint8),
+        ("extra", ctypes.c_uint8),
+    ]
+
+
+assert ctypes.sizeof(PackedPos) == 32
+
+# every symbol include/spx_nnue.h declares: (restype, argtypes)
+_P = ctypes.c_void_p
+SYMBOLS = {
+    "spx_last_error": (ctypes.c_char_p, []),
+    "spx_net_load": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(_P)]),
+    "spx_net_free": (None, [_P]),
+    "spx_net_name": (ctypes.c_char_p, [_P]),
+    "spx_synth_net_bytes": (ctypes.c_size_t, []),
+    "spx_synth_net": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_size_t]),
+    "spx_fnv1a64": (ctypes.c_uint64, [_P, ctypes.c_size_t]),
+    "spx_ctx_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_P)]),
+    "spx_ctx_destroy": (None, [_P]),
+    "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
+    "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
+    "spx_profile_begin": (ctypes.c_int, [_P, ctypes.c_size_t]),
+    "spx_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
+    "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),
+    "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
+    "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
+    "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
+    "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libspx_nnue.so and declare prototypes. Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback implementation."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class SpxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"spx error {code}: {message}")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise SpxError(rc, load().spx_last_error().decode(errors="replace"))

@@ -1,0 +1,210 @@
+// Per-lane integer math of the feature extractor, written once for host and device (SPX_HD).
+//
+// The gfx950 kernels map one wavefront to one (position, perspective) and one LANE to one SQUARE (64 lanes = 64
+// squares). Everything a lane needs - its piece's attack set, the threat / pawn-pair / piece-square row ids - is
+// pure register arithmetic on the 64-bit occupancy; the only tables are the two small threat LUTs (4.2 KB, staged in
+// LDS). Because the functions are SPX_HD the same code is exercised lane-by-lane on the CPU by spx_debug_features()
+// (host logic tests, no GPU needed).
+//
+// Reference semantics restated here (paths relative to /root/reference/src):
+//   attacks::getAttacks / getPseudoAttacks        attacks/attacks.h:130-170
+//   psq::featureIndex + KingBucketsMergedMirrored eval/nnue/features/psq.h:204-284,317-365 ; eval/arch.h:53-65
+//   threats::threatFeatureIndex                   eval/nnue/features/threats.cpp:170-198
+//   threats::ppPawnId / ppFeatureIndex, kPpMasks  eval/nnue/features/threats.cpp:200-221 ; threats.h:106-123
+//   marlinformat::PackedBoard                     datagen/marlinformat.h:32-84
+#pragma once
+
+#include <cstdint>
+
+#include "spx_arch.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPX_HD __host__ __device__ inline
+#else
+#define SPX_HD inline
+#endif
+
+namespace spx {
+
+constexpr uint64_t kFileA = 0x0101010101010101ull;
+constexpr uint64_t kFileH = 0x8080808080808080ull;
+
+SPX_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+SPX_HD int ctz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll(static_cast<unsigned long long>(x)) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+SPX_HD uint64_t brev64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+
+// ---- line masks through a square (including the square itself) ----
+SPX_HD uint64_t fileMask(int sq) {
+    return kFileA << (sq & 7);
+}
+SPX_HD uint64_t rankMask(int sq) {
+    return 0xFFull << (sq & 56);
+}
+SPX_HD uint64_t diagMask(int sq) {  // a1-h8 direction
+    const int d = 8 * ((sq & 7) - (sq >> 3));
+    const uint64_t m = 0x8040201008040201ull;
+    return d >= 0 ? (m >> d) : (m << (-d));
+}
+SPX_HD uint64_t antiMask(int sq) {  // a8-h1 direction
+    const int d = 8 * (7 - (sq & 7) - (sq >> 3));
+    const uint64_t m = 0x0102040810204080ull;
+    return d >= 0 ? (m >> d) : (m << (-d));
+}
+
+// Hyperbola quintessence with a full 64-bit bit reversal: sliding attacks along one line, blockers included.
+SPX_HD uint64_t lineAttacks(uint64_t occ, uint64_t bit, uint64_t lineIncl) {
+    const uint64_t maskEx = lineIncl & ~bit;
+    uint64_t fwd = occ & maskEx;
+    uint64_t rev = brev64(fwd);
+    fwd -= bit;
+    rev -= brev64(bit);
+    return (fwd ^ brev64(rev)) & maskEx;
+}
+
+SPX_HD uint64_t knightAttacks(uint64_t b) {
+    const uint64_t notA = ~kFileA, notAB = ~(kFileA | (kFileA << 1));
+    const uint64_t notH = ~kFileH, notGH = ~(kFileH | (kFileH >> 1));
+    return ((b << 17) & notA) | ((b << 10) & notAB) | ((b >> 6) & notAB) | ((b >> 15) & notA) | ((b << 15) & notH) |
+           ((b << 6) & notGH) | ((b >> 10) & notGH) | ((b >> 17) & notH);
+}
+// colour: 1 = white (attacks up the board), 0 = black
+SPX_HD uint64_t pawnAttacks(uint64_t b, int colour) {
+    return colour ? (((b << 7) & ~kFileH) | ((b << 9) & ~kFileA)) : (((b >> 9) & ~kFileH) | ((b >> 7) & ~kFileA));
+}
+
+// attacks::getAttacks for the non-king piece types (kings never attack or get attacked in the threat features,
+// nnue_state.cpp:319-323). `piece` = type<<1|colour.
+SPX_HD uint64_t pieceAttacks(int piece, int sq, uint64_t occ) {
+    const uint64_t bit = 1ull << sq;
+    const int type = piece >> 1;
+    uint64_t att = 0;
+    if (type == 0) {
+        att = pawnAttacks(bit, piece & 1);
+    } else if (type == 1) {
+        att = knightAttacks(bit);
+    } else if (type <= 4) {
+        if (type != 3) {  // bishop, queen
+            att |= lineAttacks(occ, bit, diagMask(sq)) | lineAttacks(occ, bit, antiMask(sq));
+        }
+        if (type != 2) {  // rook, queen
+            att |= lineAttacks(occ, bit, fileMask(sq)) | lineAttacks(occ, bit, rankMask(sq));
+        }
+    }
+    return att;
+}
+
+// attacks::getPseudoAttacks (empty board) for the non-king types.
+SPX_HD uint64_t piecePseudoAttacks(int piece, int sq) {
+    const uint64_t bit = 1ull << sq;
+    const int type = piece >> 1;
+    uint64_t att = 0;
+    if (type == 0) {
+        att = pawnAttacks(bit, piece & 1);
+    } else if (type == 1) {
+        att = knightAttacks(bit);
+    } else if (type <= 4) {
+        if (type != 3) {
+            att |= diagMask(sq) | antiMask(sq);
+        }
+        if (type != 2) {
+            att |= fileMask(sq) | rankMask(sq);
+        }
+        att &= ~bit;
+    }
+    return att;
+}
+
+// kPpMasks[sq]: own file and both neighbours, whole files (threats.h:106-123)
+SPX_HD uint64_t ppMask(int sq) {
+    const uint64_t f = fileMask(sq);
+    return f | ((f << 1) & ~kFileA) | ((f >> 1) & ~kFileH);
+}
+
+// ---- perspective transform ----
+// xorMask = (c == black ? 56 : 0) ^ (king on files e-h ? 7 : 0); colour flip = (c == black)
+SPX_HD int perspXor(int c, int kingSq) {
+    return (c == 0 ? 56 : 0) ^ ((kingSq & 7) >= 4 ? 7 : 0);
+}
+
+// arch.h:53-65 half-board buckets (a1 = 0), expanded by KingBucketsMirrored::kBuckets (psq.h:209-226).
+// Packed as 32 nibbles: index = rank*4 + min(file, 7-file).
+SPX_HD int kingBucket(int kingSqRel) {  // kingSqRel: king square already rank-flipped for black
+    const int rank = kingSqRel >> 3, file = kingSqRel & 7;
+    const int f = file < 4 ? file : 7 - file;
+    const int i = rank * 4 + f;
+    // rows: 0 1 2 3 | 4 5 6 7 | 8 9 10 11 | 8 9 10 11 | 12 12 13 13 | 12 12 13 13 | 14 14 15 15 | 14 14 15 15
+    const uint64_t lo = 0xBA98BA9876543210ull;  // entries 0..15
+    const uint64_t hi = 0xFFEEFFEEDDCCDDCCull;  // entries 16..31
+    return int(((i < 16 ? lo : hi) >> ((i & 15) * 4)) & 0xF);
+}
+
+// psq::featureIndex (psq.h:338-365): row of (piece, sq) for perspective c whose own king stands on kingSq.
+SPX_HD uint32_t psqRow(int c, int piece, int sq, int kingSq) {
+    const uint32_t type = uint32_t(piece >> 1);
+    const uint32_t colour = (type == 5) ? 0u : (((piece & 1) == c) ? 0u : 1u);  // merged kings
+    const int x = perspXor(c, kingSq);
+    const int bucket = kingBucket(c == 0 ? (kingSq ^ 56) : kingSq);
+    return uint32_t(bucket) * kPsqInputSize + colour * 384u + type * 64u + uint32_t(sq ^ x);
+}
+
+// Threat LUT layout shared by host builder and kernels (u32 words):
+//   [0, 768)      offsets[piece][sq]            kOffsets.offsets   (threats.cpp:108-136)
+//   [768, 1056)   attackIdx[attacker][attacked][forwards]  kAttackIndices (threats.cpp:138-167), INT_MIN = excluded
+constexpr int kLutOffsetsWords = 12 * 64;
+constexpr int kLutAttackWords = 12 * 12 * 2;
+constexpr int kLutWords = kLutOffsetsWords + kLutAttackWords;
+
+// threats::threatFeatureIndex. pseudoRel = piecePseudoAttacks(attacker', asq') precomputed by the caller in the
+// transformed frame (it replaces the 48 KB kPieceIndices table: popcount of pseudo-attacked squares below vsq').
+SPX_HD int32_t threatRow(const uint32_t* lut, int attackerRel, int asqRel, uint64_t pseudoRel, int attackedRel,
+                         int vsqRel) {
+    const int forwards = asqRel < vsqRel;
+    const int32_t attackIdx = int32_t(lut[kLutOffsetsWords + (attackerRel * 12 + attackedRel) * 2 + forwards]);
+    const int32_t offset = int32_t(lut[attackerRel * 64 + asqRel]);
+    const int32_t pieceIdx = popc64(pseudoRel & ((1ull << vsqRel) - 1));
+    // excluded pairs carry INT_MIN: the sum stays negative exactly as in the reference's i32 arithmetic
+    return int32_t(kPpRows) + attackIdx + offset + pieceIdx;
+}
+
+// threats::ppPawnId / ppFeatureIndex
+SPX_HD uint32_t ppId(int sqRel, bool enemy) {
+    return uint32_t((enemy ? 48 : 0) + sqRel - 8);
+}
+SPX_HD uint32_t ppRow(uint32_t a, uint32_t b) {
+    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    return hi * (hi - 1) / 2 + lo;
+}
+
+// marlinformat nibble -> piece id (type<<1|colour, white = 1). Nibble: type | colour<<3 with black = 8 and
+// type 6 = "unmoved rook" (marlinformat.h:39,52-58).
+SPX_HD int nibbleToPiece(int nib) {
+    int type = nib & 7;
+    if (type == 6) {
+        type = 3;
+    }
+    return (type << 1) | ((nib & 8) ? 0 : 1);
+}
+
+}  // namespace spx

@@ -1,0 +1,41 @@
+// Kernel parameter blocks and launch wrappers (spx_kernels.hip). Device pointers only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace spx {
+
+struct FtParams {
+    const void* positions;   // spx_packed_pos[nPositions] (32 B records)
+    uint32_t nPositions;
+    const uint32_t* order;   // optional permutation of perspective ids (2*pos + colour), or nullptr
+    const int16_t* psqW;     // [11264][1024] i16, logical column order
+    const uint8_t* thrW;     // [64368][1024] u8: value+128, columns interleaved per lane (see relayout in spx_api)
+    const int16_t* ftBias;   // [1024]
+    const uint32_t* lut;     // kLutWords threat LUT
+    uint8_t* ftOut;          // [nPositions][1024] u8: stm half, then nstm half
+};
+
+struct MlpParams {
+    const uint64_t* positions;  // same records, viewed as u64[4] each (occupancy = word 0)
+    uint32_t nPositions;
+    const uint8_t* ftOut;       // [nPositions][1024]
+    const int8_t* l1W;          // device layout [8 buckets][16 ksteps][2 ntiles][64 lanes][16 B]
+    const int32_t* l1B;         // [8][32]
+    const int32_t* l2W;         // [8][64][64]
+    const int32_t* l2B;         // [8][64]
+    const int32_t* l3W;         // [8][64]
+    const int32_t* l3B;         // [8]
+    int32_t* out;               // [nPositions]
+};
+
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchMlp(const MlpParams& p, hipStream_t stream);
+size_t mlpSharedBytes();
+hipError_t prepareKernels();
+uint32_t ftWavesPerBlock();
+
+}  // namespace spx

@@ -1,0 +1,425 @@
+// gfx950 (MI355X, CDNA4) kernels of the batched NNUE evaluator. Hand-written HIP; wave64 throughout.
+//
+//   spx_ft_kernel    feature extraction + feature-transformer accumulation + pairwise activation.
+//                    One wavefront per (position, perspective); lane l IS square l during extraction and owns
+//                    accumulator columns {8l..8l+7} U {512+8l..512+8l+7} during accumulation, so the pairwise
+//                    product (column j with j+512) is lane-local. A 1 KiB threat row is ONE coalesced 16 B/lane
+//                    wave load, a 2 KiB piece-square row is two. HBM/L2-bound gather: this is the roofline kernel.
+//   spx_mlp_kernel   int8 L1 (1024 -> 32, x8 output buckets) on v_mfma_i32_16x16x64_i8, then the i32 tail
+//                    (dual activation, L2 64x64, L3 + skip, scale). < 1 % of int8 MFMA peak by construction.
+//
+// Reference semantics (paths relative to /root/reference/src/eval):
+//   nnue_state.cpp:612-634 evaluateOnce; :440-449 resetPsqAccumulator; :309-354 addThreatFeatures;
+//   nnue/input.h:72-75,283-293 Accumulator::initBoth/add; nnue_state.cpp:89-145 applyThreatRows (i8 -> i16 widening);
+//   nnue/arch/multilayer.h:92-152 activateFt; :154-257 propagateL1; :261-343 propagateL2; :345-447 propagateL3;
+//   :484-489 final scale; nnue/output.h:51-54 output bucket.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "spx_device_math.h"
+#include "spx_kernels.h"
+
+namespace spx {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
+constexpr int kPsqCap = 32;
+
+__device__ __forceinline__ uint32_t laneId() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t prefixCount(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+__device__ __forceinline__ uint32_t pkAdd16(uint32_t a, uint32_t b) {
+    // two independent wrapping 16-bit adds (v_pk_add_u16): exactly the reference's add_epi16 semantics
+    const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pkSub16(uint32_t a, uint32_t b) {
+    const u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// zero-extend bytes (0,1) / (2,3) of x into two packed u16 lanes
+__device__ __forceinline__ uint32_t unpackLo(uint32_t x) {
+    return (x & 0xFFu) | ((x & 0xFF00u) << 8);
+}
+__device__ __forceinline__ uint32_t unpackHi(uint32_t x) {
+    return ((x >> 16) & 0xFFu) | ((x >> 8) & 0xFF0000u);
+}
+
+// pairwise clipped ReLU of one column pair (multilayer.h:108-145): a = column j, b = column j+512 (i16, wrapped)
+__device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
+    const int32_t i1 = min(max(a, 0), 255);
+    const int32_t i2 = min(b, 255);              // NOT clamped at zero
+    const int32_t p = ((i1 << 7) * i2) >> 16;    // mulhi_epi16(i1 << 7, i2): arithmetic shift (floor)
+    return uint32_t(max(p, 0));                  // packus: negatives saturate to 0; p <= 127 always
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Feature transformer kernel.
+// grid-stride over perspectives q = 2*position + colour; `order` (optional) is a permutation of perspective ids
+// (king-bucket sorted for L2 locality) - results are written by q, so any order gives identical output.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // byte offsets into the threat table
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
+
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.lut[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t nPersp = p.nPositions * 2;
+    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
+
+    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < nPersp; it += wavesTotal) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
+        const uint32_t posIdx = q >> 1;
+        const int c = int(q & 1);
+
+        // ---- decode the packed record: lane = square ----
+        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
+        const uint64_t occ = *reinterpret_cast<const uint64_t*>(rec);
+        const int stm = (rec[24] & 0x80) ? 0 : 1;
+        const bool occupied = (occ >> lane) & 1;
+        const uint32_t nibIdx = popc64(occ & ((1ull << lane) - 1));
+        int piece = kNoPiece;
+        if (occupied) {
+            const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
+            piece = nibbleToPiece(nib);
+        }
+        const int type = piece >> 1;  // 6 for empty
+        const int colour = piece & 1;
+
+        const uint64_t kingsBb = __ballot(type == 5);
+        const uint64_t ownKingBb = __ballot(piece == (10 | c));
+        const int kingSq = ctz64(ownKingBb);
+        const uint64_t whiteBb = __ballot(occupied && colour == 1);
+        const uint64_t pawnsBb = __ballot(type == 0);
+        const uint64_t ownPawns = pawnsBb & (c ? whiteBb : ~whiteBb);
+        const uint64_t theirPawns = pawnsBb & ~ownPawns;
+
+        const int x = perspXor(c, kingSq);
+        const int flipColour = (c == 0) ? 1 : 0;
+
+        // ---- piece-square rows: one per occupied square (resetPsqAccumulator) ----
+        {
+            const uint32_t slot = prefixCount(occ);
+            if (occupied && slot < kPsqCap) {
+                sPsq[wave][slot] = psqRow(c, piece, int(lane), kingSq) * (kL1 * 2);
+            }
+        }
+        const uint32_t nPsq = min(uint32_t(popc64(occ)), uint32_t(kPsqCap));
+
+        // ---- threat rows (addThreatFeatures): attacker = this lane's piece, victims popped one per iteration ----
+        uint32_t nThr = 0;
+        {
+            const bool attacker = occupied && type != 5;
+            uint64_t targets = 0, pseudoRel = 0;
+            const int pieceRel = piece ^ flipColour;
+            const int sqRel = int(lane) ^ x;
+            if (attacker) {
+                targets = pieceAttacks(piece, int(lane), occ) & occ & ~kingsBb;
+                pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
+            }
+            while (__ballot(targets != 0)) {
+                const bool active = targets != 0;
+                const int to = active ? ctz64(targets) : 0;
+                targets &= targets - 1;
+                const int victim = __shfl(piece, to, 64);
+                int32_t row = -1;
+                if (active) {
+                    row = threatRow(sLut, pieceRel, sqRel, pseudoRel, victim ^ flipColour, to ^ x);
+                }
+                const uint64_t valid = __ballot(row >= 0);
+                const uint32_t slot = nThr + prefixCount(valid);
+                if (row >= 0 && slot < kThreatCap) {
+                    sThr[wave][slot] = uint32_t(row) * kL1;
+                }
+                nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+            }
+        }
+
+        // ---- pawn-pair rows (nnue_state.cpp:330-351) ----
+        {
+            const bool isPawn = type == 0;
+            const bool own = isPawn && colour == c;
+            uint64_t partners = 0;
+            if (isPawn) {
+                const uint64_t above = ~((2ull << lane) - 1);
+                partners = own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane)))
+                               : (theirPawns & above & ppMask(int(lane)));
+            }
+            const uint32_t idA = ppId(int(lane) ^ x, !own);
+            while (__ballot(partners != 0)) {
+                const bool active = partners != 0;
+                const int b = active ? ctz64(partners) : 0;
+                partners &= partners - 1;
+                const bool bEnemy = !((ownPawns >> b) & 1);
+                const uint64_t valid = __ballot(active);
+                const uint32_t slot = nThr + prefixCount(valid);
+                if (active && slot < kThreatCap) {
+                    sThr[wave][slot] = ppRow(idA, ppId(b ^ x, bEnemy)) * kL1;
+                }
+                nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+            }
+        }
+
+        __builtin_amdgcn_wave_barrier();  // row lists are produced and consumed by the same wave: LDS order suffices
+
+        // ---- accumulate: bias + piece-square rows (i16) + threat rows (u8 biased by +128, widened) ----
+        // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1
+        uint32_t acc[8];
+        {
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(p.ftBias + 8 * lane);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(p.ftBias + 512 + 8 * lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = b0[r];
+                acc[4 + r] = b1[r];
+            }
+        }
+        const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(p.psqW) + 16 * lane;
+        for (uint32_t i = 0; i < nPsq; i += 4) {
+            u32x4 lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                lo[u] = u32x4{0, 0, 0, 0};
+                hi[u] = u32x4{0, 0, 0, 0};
+                if (i + u < nPsq) {  // wave-uniform
+                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsq[wave][i + u]);
+                    lo[u] = *reinterpret_cast<const u32x4*>(row);
+                    hi[u] = *reinterpret_cast<const u32x4*>(row + 1024);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r] = pkAdd16(acc[r], lo[u][r]);
+                    acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
+                }
+            }
+        }
+        const uint8_t* thrBase = p.thrW + 16 * lane;
+        for (uint32_t i = 0; i < nThr; i += 8) {
+            u32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[u] = u32x4{0, 0, 0, 0};
+                if (i + u < nThr) {  // wave-uniform
+                    w[u] = *reinterpret_cast<const u32x4*>(thrBase +
+                                                           __builtin_amdgcn_readfirstlane(sThr[wave][i + u]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[2 * d] = pkAdd16(acc[2 * d], unpackLo(w[u][d]));
+                    acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], unpackHi(w[u][d]));
+                }
+            }
+        }
+        {
+            // remove the +128 storage bias: every threat row contributed 128 to every column (mod 2^16 exact)
+            const uint32_t corr = (nThr * 128u) & 0xFFFFu;
+            const uint32_t corr2 = corr | (corr << 16);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc[r] = pkSub16(acc[r], corr2);
+            }
+        }
+
+        // ---- pairwise activation -> 8 bytes per lane ----
+        uint32_t outLo = 0, outHi = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int32_t a0 = int16_t(acc[r] & 0xFFFF), a1 = int16_t(acc[r] >> 16);
+            const int32_t b0 = int16_t(acc[4 + r] & 0xFFFF), b1 = int16_t(acc[4 + r] >> 16);
+            const uint32_t v = pairAct(a0, b0) | (pairAct(a1, b1) << 8);
+            if (r < 2) {
+                outLo |= v << (16 * r);
+            } else {
+                outHi |= v << (16 * (r - 2));
+            }
+        }
+        const uint32_t half = (c == stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
+        u32x2 o;
+        o[0] = outLo;
+        o[1] = outHi;
+        *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLP kernel: 64 positions per workgroup, 4 waves. Wave w contracts all 64 positions against output buckets 2w and
+// 2w+1 (A = activations from LDS, B = pre-swizzled L1 weights, 16 k-steps x 16 MFMAs), keeps only the rows whose
+// position selects that bucket, then each wave runs the i32 tail for 16 positions.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMlpTile = 64;
+constexpr int kActStride = kL1 + 16;  // +16 B pad: consecutive rows land 4 banks apart for ds_read_b128
+
+__global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* sAct = smem;                                                   // [64][kActStride]
+    int32_t* sSum = reinterpret_cast<int32_t*>(smem + kMlpTile * kActStride);  // [64][32] L1 pre-activations
+    uint8_t* sBucket = reinterpret_cast<uint8_t*>(sSum + kMlpTile * kL2);  // [64]
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kMlpTile;
+    const uint32_t nHere = min(uint32_t(kMlpTile), p.nPositions - base);
+
+    // ---- stage activations (coalesced 16 B/lane) and output buckets ----
+    for (uint32_t i = threadIdx.x; i < kMlpTile * (kL1 / 16); i += blockDim.x) {
+        const uint32_t row = i / (kL1 / 16), chunk = i % (kL1 / 16);
+        u32x4 v = {0, 0, 0, 0};
+        if (row < nHere) {
+            v = *reinterpret_cast<const u32x4*>(p.ftOut + size_t(base + row) * kL1 + chunk * 16);
+        }
+        *reinterpret_cast<u32x4*>(sAct + row * kActStride + chunk * 16) = v;
+    }
+    if (threadIdx.x < kMlpTile) {
+        uint32_t bucket = 0;
+        if (threadIdx.x < nHere) {
+            const uint64_t occ = p.positions[(base + threadIdx.x) * 4];  // first u64 of the 32-byte record
+            bucket = (uint32_t(popc64(occ)) - 2) / 4;                     // MaterialCount<8> (output.h:51-54)
+        }
+        sBucket[threadIdx.x] = uint8_t(bucket);
+    }
+    __syncthreads();
+
+    // ---- L1 on MFMA: D[pos][o] += A[pos][k] * B[k][o], i8 x i8 -> i32 (activations <= 127, so u8 == i8) ----
+    i32x4 accum[2][4][2];  // [bucket of this wave][m-tile][n-tile]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) accum[b][m][n] = i32x4{0, 0, 0, 0};
+
+    const uint32_t rowInTile = lane & 15, kGroup = lane >> 4;
+    for (int ks = 0; ks < 16; ++ks) {
+        i32x4 a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a[m] = *reinterpret_cast<const i32x4*>(sAct + (m * 16 + rowInTile) * kActStride + ks * 64 + kGroup * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t bucket = wave * 2 + b;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                // device layout [bucket][kstep][ntile][lane][16 B]: one coalesced 1 KiB wave load per fragment
+                const i32x4 w = *reinterpret_cast<const i32x4*>(
+                    p.l1W + ((size_t(bucket) * 16 + ks) * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    accum[b][m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], w, accum[b][m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of 16x16 MFMA: lane holds column (lane & 15), rows (lane >> 4) * 4 + r
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint32_t bucket = wave * 2 + b;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t pos = m * 16 + kGroup * 4 + r;
+                if (sBucket[pos] == bucket) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        sSum[pos * kL2 + n * 16 + rowInTile] = accum[b][m][n][r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- i32 tail, one position at a time per wave; lane = output neuron (L1 neuron = lane & 31) ----
+    for (uint32_t j = 0; j < kMlpTile / 4; ++j) {
+        const uint32_t pos = wave * (kMlpTile / 4) + j;
+        if (pos >= nHere) {
+            break;
+        }
+        const uint32_t bucket = sBucket[pos];
+        const uint32_t o1 = lane & 31;
+        const int32_t s = sSum[pos * kL2 + o1];
+        const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(p.l1B[bucket * kL2 + o1]);  // wraps
+        const int32_t ts = int32_t(t);
+        const int32_t c0 = min(max(ts, 0), 4096) << kQBits;  // CReLU side, pre-shifted for the skip connection
+        const int32_t sq = int32_t(t * t);                    // mullo wraps BEFORE the signed min
+        const int32_t c1 = min(sq, 1 << 24) >> kQBits;        // SCReLU side
+        const int32_t mine = lane < kL2 ? c0 : c1;            // l1o[lane]: [CReLU(32) | SCReLU(32)]
+        // L2: l2[o] = bias + sum_i (l1o[i] >> 6) * W2[b][i][o]   (wrapping i32); l1o[i] broadcast by v_readlane
+        const int32_t* w2 = p.l2W + size_t(bucket) * kL2Full * kL3 + lane;
+        uint32_t acc2 = uint32_t(p.l2B[bucket * kL3 + lane]);
+#pragma unroll
+        for (int i = 0; i < int(kL2); ++i) {
+            acc2 += uint32_t(__builtin_amdgcn_readlane(c0, i) >> kQBits) * uint32_t(w2[i * kL3]);
+        }
+#pragma unroll
+        for (int i = 0; i < int(kL2); ++i) {
+            acc2 += uint32_t(__builtin_amdgcn_readlane(c1, i) >> kQBits) * uint32_t(w2[(kL2 + i) * kL3]);
+        }
+        // L3 with skip connection: (clamp(l2, 0, Q^3) + l1o) * W3, wrapping; wave-wide wrapping sum
+        const int32_t l2v = min(max(int32_t(acc2), 0), 262144);
+        uint32_t term = (uint32_t(l2v) + uint32_t(mine)) * uint32_t(p.l3W[bucket * kL3 + lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            term += uint32_t(__shfl_xor(int32_t(term), off, 64));
+        }
+        if (lane == 0) {
+            const int32_t l3 = int32_t(term + uint32_t(p.l3B[bucket]));
+            const int64_t scaled = int64_t(l3) * kScale / (int64_t(1) << (4 * kQBits));  // truncating division
+            p.out[base + pos] = int32_t(scaled);
+        }
+    }
+}
+
+size_t mlpSharedBytes() {
+    return size_t(kMlpTile) * kActStride + size_t(kMlpTile) * kL2 * 4 + kMlpTile;
+}
+
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_ft_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchMlp(const MlpParams& p, hipStream_t stream) {
+    const uint32_t blocks = (p.nPositions + kMlpTile - 1) / kMlpTile;
+    hipLaunchKernelGGL(spx_mlp_kernel, dim3(blocks), dim3(256), mlpSharedBytes(), stream, p);
+    return hipGetLastError();
+}
+
+hipError_t prepareKernels() {
+    // the MLP tile (64 x 1 KiB activations + sums) needs more than the default 64 KiB of dynamic LDS
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_mlp_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(mlpSharedBytes()));
+}
+
+uint32_t ftWavesPerBlock() {
+    return kWavesPerBlock;
+}
+
+}  // namespace spx

@@ -1,0 +1,165 @@
+"""Host-side mirror of the reference's eval interface (src/eval/nnue.h:38-63, src/eval/nnue_state.h:85-116),
+batched. Thin wrappers over the C ABI; numpy arrays in, numpy arrays out.
+
+    net = Network.synthetic(preset="tame")            # eval::init() analogue (the default net is not available offline)
+    state = NnueState(net, device=0, max_batch=65536)  # one per caller thread, like the reference's NnueState
+    evals = state.evaluate_once(positions)             # == [NnueState::evaluateOnce(pos, pos.stm()) for pos in ...]
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import PackedPos, check
+
+PACKED_DTYPE = np.dtype(
+    [
+        ("occupancy", "<u8"),
+        ("pieces", "u1", (16,)),
+        ("stm_ep", "u1"),
+        ("halfmove", "u1"),
+        ("fullmove", "<u2"),
+        ("eval", "<i2"),
+        ("wdl", "u1"),
+        ("extra", "u1"),
+    ]
+)
+assert PACKED_DTYPE.itemsize == 32
+
+PRESETS = {"tame": 0, "wild": 1, "extreme": 2}
+DEFAULT_SEED = 20260927
+
+
+def synthetic_net_bytes(preset="tame", seed=DEFAULT_SEED):
+    lib = _lib.load()
+    n = lib.spx_synth_net_bytes()
+    buf = np.empty(n, dtype=np.uint8)
+    check(lib.spx_synth_net(seed, PRESETS[preset], buf.ctypes.data, n))
+    return buf
+
+
+class Network:
+    """Immutable, shareable network (spx_net). Mirrors eval::init / getNetwork / defaultNetworkName."""
+
+    def __init__(self, blob):
+        lib = _lib.load()
+        blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        handle = ctypes.c_void_p()
+        check(lib.spx_net_load(blob.ctypes.data, blob.size, ctypes.byref(handle)))
+        self._h = handle
+        self.blob = blob
+
+    @classmethod
+    def synthetic(cls, preset="tame", seed=DEFAULT_SEED):
+        return cls(synthetic_net_bytes(preset, seed))
+
+    @property
+    def name(self):
+        return _lib.load().spx_net_name(self._h).decode()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.load().spx_net_free(h)
+
+
+class NnueState:
+    """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
+
+    def __init__(self, network, device=0, max_batch=65536):
+        lib = _lib.load()
+        handle = ctypes.c_void_p()
+        check(lib.spx_ctx_create(network._h, device, max_batch, ctypes.byref(handle)))
+        self._h = handle
+        self._net = network
+        self.max_batch = max_batch
+
+    def evaluate_once(self, positions):
+        """Batched NnueState::evaluateOnce: packed positions (PACKED_DTYPE array) -> int32 raw evals (stm view)."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        out = np.empty(pos.shape[0], dtype=np.int32)
+        check(_lib.load().spx_eval_full(self._h, pos.ctypes.data, pos.shape[0], out.ctypes.data))
+        return out
+
+    def evaluate_once_device(self, d_positions_ptr, n, d_out_ptr, stream_ptr=None):
+        """Device-resident variant: raw device pointers (e.g. torch tensors' data_ptr()), enqueued on `stream_ptr`."""
+        check(_lib.load().spx_eval_full_device(self._h, d_positions_ptr, n, d_out_ptr, stream_ptr))
+
+    def profile_begin(self, max_calls):
+        check(_lib.load().spx_profile_begin(self._h, max_calls))
+
+    def profile_end(self):
+        """-> (ft_kernel_ms_total, mlp_kernel_ms_total, calls) since profile_begin."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
+        check(_lib.load().spx_profile_end(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def debug_ft(self, n):
+        out = np.empty((n, 1024), dtype=np.uint8)
+        check(_lib.load().spx_debug_copy_ft(self._h, n, out.ctypes.data))
+        return out
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.load().spx_ctx_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+
+# ---- position plumbing ----
+def positions_from_fens(fens):
+    lib = _lib.load()
+    out = np.zeros(len(fens), dtype=PACKED_DTYPE)
+    for i, fen in enumerate(fens):
+        check(lib.spx_pos_from_fen(fen.encode(), out[i : i + 1].ctypes.data))
+    return out
+
+
+def position_to_fen(rec):
+    buf = ctypes.create_string_buffer(128)
+    rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)
+    check(_lib.load().spx_pos_to_fen(rec.ctypes.data, buf, 128))
+    return buf.value.decode()
+
+
+def positions_to_mailboxes(positions):
+    lib = _lib.load()
+    pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+    mail = np.empty((pos.shape[0], 64), dtype=np.uint8)
+    stm = np.empty(pos.shape[0], dtype=np.uint8)
+    s = ctypes.c_int()
+    for i in range(pos.shape[0]):
+        check(lib.spx_pos_to_mailbox(pos[i : i + 1].ctypes.data, mail[i].ctypes.data, ctypes.byref(s)))
+        stm[i] = s.value
+    return mail, stm
+
+
+def random_positions(count, seed=1, min_ply=8, max_ply=120, dfrc_every=4):
+    """Seeded random legal positions (random playouts), the synthetic batches of BASELINE config 2."""
+    out = np.zeros(count, dtype=PACKED_DTYPE)
+    check(_lib.load().spx_random_positions(seed, count, min_ply, max_ply, dfrc_every, out.ctypes.data))
+    return out
+
+
+def debug_features(rec, colour):
+    lib = _lib.load()
+    rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)
+    psq = np.empty(32, dtype=np.uint32)
+    thr = np.empty(256, dtype=np.uint32)
+    n1, n2 = ctypes.c_int(), ctypes.c_int()
+    check(lib.spx_debug_features(rec.ctypes.data, colour, psq.ctypes.data, ctypes.byref(n1), thr.ctypes.data, ctypes.byref(n2)))
+    return psq[: n1.value].copy(), thr[: n2.value].copy()
+
+
+def count_rows(positions):
+    """(psq_rows, threat_rows) gathered by a full refresh of the batch, both perspectives summed."""
+    pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    check(_lib.load().spx_count_rows(pos.ctypes.data, pos.shape[0], ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+def perft(fen, depth):
+    return int(_lib.load().spx_perft(fen.encode(), depth))

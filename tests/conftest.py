@@ -1,0 +1,97 @@
+"""Shared fixtures. `-m "not gpu"` tests run on CPU (oracle, host logic, ABI surface); `-m gpu` tests are the parity
+tests proper and call the HIP path through the C ABI.
+
+The oracle (oracle/spx_oracle.c, plain C) is TEST INFRASTRUCTURE: it is loaded here and nowhere in the product.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
+
+
+class Oracle:
+    """ctypes view of oracle/libspx_oracle.so (built on demand with gcc)."""
+
+    def __init__(self):
+        so = os.path.join(ROOT, "oracle", "libspx_oracle.so")
+        src = os.path.join(ROOT, "oracle", "spx_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"], stdout=subprocess.DEVNULL)
+        self.lib = ctypes.CDLL(so)
+        self.lib.spxo_init.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        self.lib.spxo_eval_mailboxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        self.lib.spxo_eval_fen.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32)]
+        self.lib.spxo_features_mailbox.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+            ctypes.POINTER(ctypes.c_int)]
+        self.lib.spxo_eval_accumulators.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self.lib.spxo_eval_accumulators.restype = ctypes.c_int32
+        self._preset = None
+
+    def use(self, blob, tag):
+        if self._preset != tag:
+            blob = np.ascontiguousarray(blob)
+            assert self.lib.spxo_init(blob.ctypes.data, blob.size) == 0
+            self._preset = tag
+
+    def eval_fen(self, fen):
+        out = ctypes.c_int32()
+        assert self.lib.spxo_eval_fen(fen.encode(), ctypes.byref(out)) == 0, fen
+        return out.value
+
+    def eval_mailboxes(self, mail, stm):
+        mail = np.ascontiguousarray(mail, dtype=np.uint8)
+        stm = np.ascontiguousarray(stm, dtype=np.uint8)
+        out = np.empty(mail.shape[0], dtype=np.int32)
+        assert self.lib.spxo_eval_mailboxes(mail.ctypes.data, stm.ctypes.data, mail.shape[0], out.ctypes.data) == 0
+        return out
+
+    def ft(self, mailbox, stm):
+        mailbox = np.ascontiguousarray(mailbox, dtype=np.uint8)
+        out = np.empty(1024, dtype=np.uint8)
+        assert self.lib.spxo_ft_mailbox(mailbox.ctypes.data_as(ctypes.c_void_p), int(stm), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+    def features(self, mailbox, colour):
+        mailbox = np.ascontiguousarray(mailbox, dtype=np.uint8)
+        psq = np.empty(32, dtype=np.uint32)
+        thr = np.empty(256, dtype=np.uint32)
+        n1, n2 = ctypes.c_int(), ctypes.c_int()
+        assert self.lib.spxo_features_mailbox(mailbox.ctypes.data, colour, psq.ctypes.data, ctypes.byref(n1),
+                                              thr.ctypes.data, ctypes.byref(n2)) == 0
+        return psq[: n1.value].copy(), thr[: n2.value].copy()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def sp():
+    import stormphrax_amd
+
+    return stormphrax_amd
+
+
+_NETS = {}
+
+
+@pytest.fixture(scope="session")
+def net_blob(sp):
+    def get(preset):
+        if preset not in _NETS:
+            _NETS[preset] = sp.synthetic_net_bytes(preset)
+        return _NETS[preset]
+
+    return get

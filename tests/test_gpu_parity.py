@@ -1,0 +1,72 @@
+"""GPU parity: the HIP path (through the C ABI) must equal the CPU oracle bit for bit.
+
+Reference behaviour under test: NnueState::evaluateOnce (src/eval/nnue_state.cpp:612-634)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STARTPOS = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+
+
+@pytest.fixture(scope="module")
+def states(sp, net_blob):
+    cache = {}
+
+    def get(preset):
+        if preset not in cache:
+            cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=1 << 16)
+        return cache[preset]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+@pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
+def test_random_positions_bit_exact(sp, oracle, net_blob, states, preset):
+    pos = sp.random_positions(4096, seed=101, min_ply=0, max_ply=160, dfrc_every=3)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    oracle.use(net_blob(preset), preset)
+    want = oracle.eval_mailboxes(mail, stm)
+    got = states(preset).evaluate_once(pos)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first: {sp.position_to_fen(pos[bad[0]])} got {got[bad[0]]} want {want[bad[0]]}"
+    assert len(set(want.tolist())) > 1000  # the batch is not degenerate
+
+
+def test_ft_activations_bit_exact(sp, oracle, net_blob, states):
+    """Localises failures: the feature-transformer kernel's u8 activations vs activateFt (multilayer.h:92-152)."""
+    oracle.use(net_blob("extreme"), "extreme")
+    pos = sp.random_positions(200, seed=55)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    st = states("extreme")
+    st.evaluate_once(pos)
+    got = st.debug_ft(len(pos))
+    for i in range(len(pos)):
+        want = oracle.ft(mail[i], stm[i])
+        assert np.array_equal(got[i], want), f"position {i}: {sp.position_to_fen(pos[i])}"
+
+
+def test_ragged_and_tiny_batches(sp, oracle, net_blob, states):
+    oracle.use(net_blob("tame"), "tame")
+    st = states("tame")
+    pos = sp.random_positions(300, seed=7)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    want = oracle.eval_mailboxes(mail, stm)
+    for n in (1, 2, 3, 63, 64, 65, 127, 129, 300):
+        got = st.evaluate_once(pos[:n])
+        assert np.array_equal(got, want[:n]), n
+    assert st.evaluate_once(pos[:0]).shape == (0,)
+
+
+def test_startpos_and_bare_kings(sp, oracle, net_blob, states):
+    oracle.use(net_blob("tame"), "tame")
+    fens = [STARTPOS, "8/8/4k3/8/8/3K4/8/8 w - - 0 1", "8/8/4k3/8/8/3K4/8/8 b - - 0 1",
+            "k7/8/8/8/8/8/8/7K w - - 0 1", "7k/8/8/8/8/8/8/K7 b - - 0 1",
+            # 32 pieces with many mutual threats and the maximum number of pawns
+            "r1bqkb1r/pppppppp/2n2n2/8/8/2N2N2/PPPPPPPP/R1BQKB1R w KQkq - 4 3"]
+    pos = sp.positions_from_fens(fens)
+    got = states("tame").evaluate_once(pos)
+    want = np.array([oracle.eval_fen(f) for f in fens], dtype=np.int32)
+    assert np.array_equal(got, want)
