@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspx_nnue.so")
+# SPX_LIB lets kernel experiments point the harness at an alternative build of the same ABI (A/B runs on the GPU box)
+LIB_PATH = os.environ.get("SPX_LIB") or os.path.join(_HERE, "libspx_nnue.so")
 
 
 class PackedPos(ctypes.Structure):

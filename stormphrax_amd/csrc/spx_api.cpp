@@ -3,6 +3,7 @@
 // SPX_ERR_NO_DEVICE (the CPU oracle lives in oracle/ and is test infrastructure only).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -54,6 +55,10 @@ struct spx_ctx {
     void* dPositions = nullptr;  // staging for the host-buffer entry point
     int32_t* dOut = nullptr;
     uint8_t* dFtOut = nullptr;
+    uint8_t* dKeys = nullptr;     // king-bucket sort scratch
+    uint32_t* dHist = nullptr;    // hist[16] + cursor[16]
+    uint32_t* dOrder = nullptr;   // sorted perspective ids
+    bool sortEnabled = true;
     uint32_t ftGridCap = 0;
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
     std::vector<hipEvent_t> profEvents;  // 3 per recorded call: before ft, between, after mlp
@@ -274,6 +279,10 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipMalloc(&ctx->dPositions, max_batch * sizeof(spx_packed_pos)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOut), max_batch * sizeof(int32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dFtOut), max_batch * size_t(kL1)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKeys), max_batch * 2));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 32 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOrder), max_batch * 2 * sizeof(uint32_t)));
+    if (const char* env = std::getenv("SPX_NO_SORT")) ctx->sortEnabled = env[0] == '0';
 
     hipDeviceProp_t prop;
     SPX_HIP(hipGetDeviceProperties(&prop, device));
@@ -288,7 +297,8 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
-                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut};
+                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut,
+                    ctx->dKeys, ctx->dHist, ctx->dOrder};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
@@ -310,10 +320,28 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         return SPX_OK;
     }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    // small batches fit the L2s anyway; sorting only pays once the gather is bandwidth-bound
+    const bool sorted = ctx->sortEnabled && n >= 4096;
+    hipEvent_t* ev = nullptr;
+    if (ctx->profUsed + 3 <= ctx->profEvents.size()) {
+        ev = &ctx->profEvents[ctx->profUsed];
+        ctx->profUsed += 3;
+        SPX_HIP(hipEventRecord(ev[0], s));
+    }
+    if (sorted) {
+        SortParams sp{};
+        sp.positions = static_cast<const uint64_t*>(d_positions);
+        sp.nPositions = uint32_t(n);
+        sp.keys = ctx->dKeys;
+        sp.hist = ctx->dHist;
+        sp.cursor = ctx->dHist + 16;
+        sp.order = ctx->dOrder;
+        SPX_HIP(launchSort(sp, s));
+    }
     FtParams fp{};
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
-    fp.order = nullptr;
+    fp.order = sorted ? ctx->dOrder : nullptr;
     fp.psqW = ctx->dPsqW;
     fp.thrW = ctx->dThrW;
     fp.ftBias = ctx->dFtBias;
@@ -322,12 +350,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     const uint32_t wavesPerBlock = ftWavesPerBlock();
     uint32_t blocks = uint32_t((2 * n + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
-    hipEvent_t* ev = nullptr;
-    if (ctx->profUsed + 3 <= ctx->profEvents.size()) {
-        ev = &ctx->profEvents[ctx->profUsed];
-        ctx->profUsed += 3;
-        SPX_HIP(hipEventRecord(ev[0], s));
-    }
+    blocks = (blocks + 7u) & ~7u;  // whole multiples of the 8 XCDs
     SPX_HIP(launchFt(fp, blocks, s));
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
 

@@ -19,6 +19,15 @@ struct FtParams {
     uint8_t* ftOut;          // [nPositions][1024] u8: stm half, then nstm half
 };
 
+struct SortParams {
+    const uint64_t* positions;  // records as u64[4]
+    uint32_t nPositions;
+    uint8_t* keys;              // [2 * nPositions] scratch
+    uint32_t* hist;             // [16] followed by cursor[16] (contiguous, zeroed by launchSort)
+    uint32_t* cursor;           // = hist + 16
+    uint32_t* order;            // out: [2 * nPositions] perspective ids grouped by king bucket
+};
+
 struct MlpParams {
     const uint64_t* positions;  // same records, viewed as u64[4] each (occupancy = word 0)
     uint32_t nPositions;
@@ -34,6 +43,7 @@ struct MlpParams {
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, hipStream_t stream);
+hipError_t launchSort(const SortParams& p, hipStream_t stream);
 size_t mlpSharedBytes();
 hipError_t prepareKernels();
 uint32_t ftWavesPerBlock();

@@ -30,6 +30,9 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+#ifndef SPX_FT_WAVES_PER_SIMD
+#define SPX_FT_WAVES_PER_SIMD 4  // launch_bounds 2nd arg = min waves per SIMD (A/B: 4 beats 5/6/8 - the kernel is VALU-bound)
+#endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
 
@@ -49,12 +52,12 @@ __device__ __forceinline__ uint32_t pkSub16(uint32_t a, uint32_t b) {
     const u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
     return __builtin_bit_cast(uint32_t, r);
 }
-// zero-extend bytes (0,1) / (2,3) of x into two packed u16 lanes
+// zero-extend bytes (0,1) / (2,3) of x into two 16-bit fields: one v_perm_b32 each (selector 0x0c = constant 0)
 __device__ __forceinline__ uint32_t unpackLo(uint32_t x) {
-    return (x & 0xFFu) | ((x & 0xFF00u) << 8);
+    return __builtin_amdgcn_perm(0u, x, 0x0C010C00u);
 }
 __device__ __forceinline__ uint32_t unpackHi(uint32_t x) {
-    return ((x >> 16) & 0xFFu) | ((x >> 8) & 0xFF0000u);
+    return __builtin_amdgcn_perm(0u, x, 0x0C030C02u);
 }
 
 // pairwise clipped ReLU of one column pair (multilayer.h:108-145): a = column j, b = column j+512 (i16, wrapped)
@@ -72,7 +75,7 @@ __device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
 // grid-stride over perspectives q = 2*position + colour; `order` (optional) is a permutation of perspective ids
 // (king-bucket sorted for L2 locality) - results are written by q, so any order gives identical output.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
@@ -85,9 +88,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t nPersp = p.nPositions * 2;
-    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
+    // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch order; affects speed only). Each XCD walks
+    // one contiguous eighth of the (king-bucket sorted) perspective order, so its private 4 MiB L2 only ever holds
+    // the 1.4 MiB piece-square slab of the bucket(s) in its slice plus the hot threat rows.
+    const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
+    const uint32_t sliceBegin = uint32_t(uint64_t(nPersp) * xcd / 8);
+    const uint32_t sliceEnd = uint32_t(uint64_t(nPersp) * (xcd + 1) / 8);
+    const uint32_t stride = blocksPerXcd * kWavesPerBlock;
 
-    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < nPersp; it += wavesTotal) {
+    for (uint32_t it = sliceBegin + blockInXcd * kWavesPerBlock + wave; it < sliceEnd; it += stride) {
         const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
         const uint32_t posIdx = q >> 1;
         const int c = int(q & 1);
@@ -129,7 +138,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
         // ---- threat rows (addThreatFeatures): attacker = this lane's piece, victims popped one per iteration ----
         uint32_t nThr = 0;
         {
+#if defined(SPX_ABLATE_FIXED_LISTS)
+            const bool attacker = false;
+#else
             const bool attacker = occupied && type != 5;
+#endif
             uint64_t targets = 0, pseudoRel = 0;
             const int pieceRel = piece ^ flipColour;
             const int sqRel = int(lane) ^ x;
@@ -157,7 +170,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
 
         // ---- pawn-pair rows (nnue_state.cpp:330-351) ----
         {
+#if defined(SPX_ABLATE_FIXED_LISTS)
+            const bool isPawn = false;
+#else
             const bool isPawn = type == 0;
+#endif
             const bool own = isPawn && colour == c;
             uint64_t partners = 0;
             if (isPawn) {
@@ -181,6 +198,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
         }
 
         __builtin_amdgcn_wave_barrier();  // row lists are produced and consumed by the same wave: LDS order suffices
+#if defined(SPX_ABLATE_FIXED_LISTS)
+        // ablation: ignore the extracted lists, gather pseudo-random rows of typical counts (accumulate-only cost)
+        {
+            uint32_t h = q * 2654435761u;
+            if (lane < 24) sPsq[wave][lane] = ((h + lane * 40503u) % kPsqRows) * (kL1 * 2);
+            if (lane < 41) sThr[wave][lane] = ((h * 31u + lane * 9973u) % kThreatRows) * kL1;
+        }
+        const uint32_t nPsqUse = 24, nThrUse = 41;
+#elif defined(SPX_ABLATE_NO_ACC)
+        const uint32_t nPsqUse = nPsq ? 1 : 0, nThrUse = nThr ? 1 : 0;  // extraction-only cost
+#else
+        const uint32_t nPsqUse = nPsq, nThrUse = nThr;
+#endif
 
         // ---- accumulate: bias + piece-square rows (i16) + threat rows (u8 biased by +128, widened) ----
         // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1
@@ -195,54 +225,86 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
             }
         }
         const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(p.psqW) + 16 * lane;
-        for (uint32_t i = 0; i < nPsq; i += 4) {
-            u32x4 lo[4], hi[4];
+        {
+            uint32_t i = 0;
+            for (; i + 4 <= nPsqUse; i += 4) {  // 8 x 1 KiB wave loads in flight
+                u32x4 lo[4], hi[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                lo[u] = u32x4{0, 0, 0, 0};
-                hi[u] = u32x4{0, 0, 0, 0};
-                if (i + u < nPsq) {  // wave-uniform
+                for (int u = 0; u < 4; ++u) {
                     const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsq[wave][i + u]);
                     lo[u] = *reinterpret_cast<const u32x4*>(row);
                     hi[u] = *reinterpret_cast<const u32x4*>(row + 1024);
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] = pkAdd16(acc[r], lo[u][r]);
+                        acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
+                    }
+                }
+            }
+            for (; i < nPsqUse; ++i) {
+                const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsq[wave][i]);
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[r] = pkAdd16(acc[r], lo[u][r]);
-                    acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
+                    acc[r] = pkAdd16(acc[r], lo[r]);
+                    acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
                 }
             }
         }
+        // Threat rows go to their own accumulator: <= 256 rows x 255 never overflows a 16-bit field, so plain 32-bit
+        // adds (v_add3_u32: two rows per add) are exact and no carry crosses fields. Folded into acc (mod 2^16) below.
+        uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint8_t* thrBase = p.thrW + 16 * lane;
-        for (uint32_t i = 0; i < nThr; i += 8) {
-            u32x4 w[8];
+        {
+            uint32_t i = 0;
+            for (; i + 8 <= nThrUse; i += 8) {  // 8 x 1 KiB wave loads in flight
+                u32x4 w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[u] = u32x4{0, 0, 0, 0};
-                if (i + u < nThr) {  // wave-uniform
+                for (int u = 0; u < 8; ++u) {
                     w[u] = *reinterpret_cast<const u32x4*>(thrBase +
                                                            __builtin_amdgcn_readfirstlane(sThr[wave][i + u]));
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
+                        tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
+                    }
+                }
+            }
+            for (; i + 2 <= nThrUse; i += 2) {
+                const u32x4 w0 =
+                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
+                const u32x4 w1 =
+                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i + 1]));
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    acc[2 * d] = pkAdd16(acc[2 * d], unpackLo(w[u][d]));
-                    acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], unpackHi(w[u][d]));
+                    tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
+                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
+                }
+            }
+            if (i < nThrUse) {
+                const u32x4 w0 =
+                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    tacc[2 * d] += unpackLo(w0[d]);
+                    tacc[2 * d + 1] += unpackHi(w0[d]);
                 }
             }
         }
         {
-            // remove the +128 storage bias: every threat row contributed 128 to every column (mod 2^16 exact)
-            const uint32_t corr = (nThr * 128u) & 0xFFFFu;
+            // fold in, removing the +128 storage bias: every threat row contributed 128 to every column
+            const uint32_t corr = (nThrUse * 128u) & 0xFFFFu;
             const uint32_t corr2 = corr | (corr << 16);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                acc[r] = pkSub16(acc[r], corr2);
+                acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
             }
         }
 
@@ -265,6 +327,74 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ft_kernel(FtParams p)
         o[1] = outHi;
         *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = o;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// King-bucket counting sort of perspective ids (2 tiny kernels). Purely a locality optimisation: the FT kernel writes
+// results by perspective id, so any permutation gives identical output. Key = piece-square king bucket (16 values,
+// arch.h:53-65) - all perspectives of one bucket gather from the same 1.4 MiB slab of the piece-square table.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSortKeys = 16;
+
+__global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
+    __shared__ uint32_t sHist[kSortKeys];
+    if (threadIdx.x < kSortKeys) sHist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < p.nPositions) {
+        const uint64_t* rec = p.positions + size_t(pos) * 4;
+        uint64_t occ = rec[0];
+        const uint64_t nibLo = rec[1], nibHi = rec[2];
+        int kingSq[2] = {0, 0};
+        uint32_t idx = 0;
+        while (occ) {
+            const int sq = ctz64(occ);
+            occ &= occ - 1;
+            const uint32_t nib = uint32_t(((idx < 16 ? nibLo : nibHi) >> ((idx & 15) * 4)) & 0xF);
+            ++idx;
+            if ((nib & 7) == 5) kingSq[(nib & 8) ? 0 : 1] = sq;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t key = uint32_t(kingBucket(c == 0 ? (kingSq[c] ^ 56) : kingSq[c]));
+            p.keys[2 * pos + c] = uint8_t(key);
+            atomicAdd(&sHist[key], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kSortKeys && sHist[threadIdx.x]) atomicAdd(&p.hist[threadIdx.x], sHist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p) {
+    __shared__ uint32_t sCount[kSortKeys];
+    __shared__ uint32_t sBase[kSortKeys];
+    if (threadIdx.x < kSortKeys) sCount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nPersp = p.nPositions * 2;
+    uint32_t key = 0, rank = 0;
+    if (q < nPersp) {
+        key = p.keys[q];
+        rank = atomicAdd(&sCount[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSortKeys) {
+        uint32_t prefix = 0;
+        for (uint32_t k = 0; k < threadIdx.x; ++k) prefix += p.hist[k];
+        const uint32_t mine = sCount[threadIdx.x];
+        sBase[threadIdx.x] = prefix + (mine ? atomicAdd(&p.cursor[threadIdx.x], mine) : 0u);
+    }
+    __syncthreads();
+    if (q < nPersp) p.order[sBase[key] + rank] = q;
+}
+
+hipError_t launchSort(const SortParams& p, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(p.hist, 0, 2 * kSortKeys * sizeof(uint32_t), stream);  // hist + cursor
+    if (e != hipSuccess) return e;
+    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = (2 * p.nPositions + 255) / 256;
+    hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
