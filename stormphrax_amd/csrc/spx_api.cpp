@@ -55,10 +55,13 @@ struct spx_ctx {
     void* dPositions = nullptr;  // staging for the host-buffer entry point
     int32_t* dOut = nullptr;
     uint8_t* dFtOut = nullptr;
-    uint8_t* dKeys = nullptr;     // king-bucket sort scratch
-    uint32_t* dHist = nullptr;    // hist[16] + cursor[16]
-    uint32_t* dOrder = nullptr;   // sorted perspective ids
-    bool sortEnabled = true;
+    uint8_t* dKingKeys = nullptr;  // counting-sort scratch
+    uint8_t* dOutKeys = nullptr;
+    uint32_t* dHist = nullptr;     // 64 words: counts + cursors
+    uint32_t* dPerspOrder = nullptr;  // perspective ids grouped by king bucket
+    uint32_t* dPosOrder = nullptr;    // position ids grouped by output bucket
+    bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
+    bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
     std::vector<hipEvent_t> profEvents;  // 3 per recorded call: before ft, between, after mlp
@@ -279,16 +282,23 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipMalloc(&ctx->dPositions, max_batch * sizeof(spx_packed_pos)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOut), max_batch * sizeof(int32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dFtOut), max_batch * size_t(kL1)));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKeys), max_batch * 2));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 32 * sizeof(uint32_t)));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOrder), max_batch * 2 * sizeof(uint32_t)));
-    if (const char* env = std::getenv("SPX_NO_SORT")) ctx->sortEnabled = env[0] == '0';
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKingKeys), max_batch * 2));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOutKeys), max_batch));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
+    if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
+    {
+        const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
+        bool small = true;
+        for (size_t i = 0; i < kL2WBytes / 4 && small; ++i) small = w[i] > -(1 << 23) && w[i] < (1 << 23);
+        ctx->smallL2Weights = small;
+    }
 
     hipDeviceProp_t prop;
     SPX_HIP(hipGetDeviceProperties(&prop, device));
     // persistent-ish grid: 8 workgroups (of 4 waves) per CU, grid-stride over perspectives
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * 8u;
-    SPX_HIP(prepareKernels());
     *out = ctx.release();
     return SPX_OK;
 }
@@ -298,7 +308,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut,
-                    ctx->dKeys, ctx->dHist, ctx->dOrder};
+                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
@@ -320,28 +330,27 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         return SPX_OK;
     }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    // small batches fit the L2s anyway; sorting only pays once the gather is bandwidth-bound
-    const bool sorted = ctx->sortEnabled && n >= 4096;
     hipEvent_t* ev = nullptr;
     if (ctx->profUsed + 3 <= ctx->profEvents.size()) {
         ev = &ctx->profEvents[ctx->profUsed];
         ctx->profUsed += 3;
         SPX_HIP(hipEventRecord(ev[0], s));
     }
-    if (sorted) {
+    {
         SortParams sp{};
         sp.positions = static_cast<const uint64_t*>(d_positions);
         sp.nPositions = uint32_t(n);
-        sp.keys = ctx->dKeys;
+        sp.kingKeys = ctx->dKingKeys;
+        sp.outKeys = ctx->dOutKeys;
         sp.hist = ctx->dHist;
-        sp.cursor = ctx->dHist + 16;
-        sp.order = ctx->dOrder;
+        sp.perspOrder = ctx->dPerspOrder;
+        sp.posOrder = ctx->dPosOrder;
         SPX_HIP(launchSort(sp, s));
     }
     FtParams fp{};
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
-    fp.order = sorted ? ctx->dOrder : nullptr;
+    fp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
     fp.psqW = ctx->dPsqW;
     fp.thrW = ctx->dThrW;
     fp.ftBias = ctx->dFtBias;
@@ -355,8 +364,9 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
 
     MlpParams mp{};
-    mp.positions = static_cast<const uint64_t*>(d_positions);
     mp.nPositions = uint32_t(n);
+    mp.posOrder = ctx->dPosOrder;
+    mp.hist = ctx->dHist;
     mp.ftOut = ctx->dFtOut;
     mp.l1W = ctx->dL1W;
     mp.l1B = ctx->dL1B;
@@ -365,7 +375,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     mp.l3W = ctx->dL3W;
     mp.l3B = ctx->dL3B;
     mp.out = static_cast<int32_t*>(d_out);
-    SPX_HIP(launchMlp(mp, s));
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     return SPX_OK;
 }

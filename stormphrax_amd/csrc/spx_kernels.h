@@ -22,15 +22,17 @@ struct FtParams {
 struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
-    uint8_t* keys;              // [2 * nPositions] scratch
-    uint32_t* hist;             // [16] followed by cursor[16] (contiguous, zeroed by launchSort)
-    uint32_t* cursor;           // = hist + 16
-    uint32_t* order;            // out: [2 * nPositions] perspective ids grouped by king bucket
+    uint8_t* kingKeys;          // [2 * nPositions] scratch
+    uint8_t* outKeys;           // [nPositions] scratch
+    uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip), zeroed by launchSort
+    uint32_t* perspOrder;       // out: [2 * nPositions] perspective ids grouped by king bucket
+    uint32_t* posOrder;         // out: [nPositions] position ids grouped by output bucket
 };
 
 struct MlpParams {
-    const uint64_t* positions;  // same records, viewed as u64[4] each (occupancy = word 0)
     uint32_t nPositions;
+    const uint32_t* posOrder;   // positions grouped by output bucket
+    const uint32_t* hist;       // counts per output bucket at hist[16..23]
     const uint8_t* ftOut;       // [nPositions][1024]
     const int8_t* l1W;          // device layout [8 buckets][16 ksteps][2 ntiles][64 lanes][16 B]
     const int32_t* l1B;         // [8][32]
@@ -42,10 +44,8 @@ struct MlpParams {
 };
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
-hipError_t launchMlp(const MlpParams& p, hipStream_t stream);
+hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
-size_t mlpSharedBytes();
-hipError_t prepareKernels();
 uint32_t ftWavesPerBlock();
 
 }  // namespace spx

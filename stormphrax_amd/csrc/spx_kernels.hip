@@ -330,21 +330,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// King-bucket counting sort of perspective ids (2 tiny kernels). Purely a locality optimisation: the FT kernel writes
-// results by perspective id, so any permutation gives identical output. Key = piece-square king bucket (16 values,
-// arch.h:53-65) - all perspectives of one bucket gather from the same 1.4 MiB slab of the piece-square table.
+// Counting sorts (2 tiny kernels, both keys in one pass). Purely locality / tiling optimisations - results are written
+// by perspective id / position id, so any permutation gives identical output.
+//   perspectives by piece-square KING BUCKET (16 keys, arch.h:53-65): all perspectives of one bucket gather from the
+//     same 1.4 MiB slab of the piece-square table (L2-resident per XCD);
+//   positions by OUTPUT BUCKET (8 keys, output.h:51-54): every 16-position MFMA tile of the MLP kernel shares one
+//     set of L1/L2/L3 weights.
+// hist layout (u32 words): [0,16) king counts  [16,24) output counts  [32,48) king cursors  [48,56) output cursors
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSortKeys = 16;
+constexpr int kKingKeys = 16;
+constexpr int kOutKeys = 8;
+constexpr int kHistOut = 16, kCursorKing = 32, kCursorOut = 48;
 
 __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
-    __shared__ uint32_t sHist[kSortKeys];
-    if (threadIdx.x < kSortKeys) sHist[threadIdx.x] = 0;
+    __shared__ uint32_t sHist[kKingKeys + kOutKeys];
+    if (threadIdx.x < kKingKeys + kOutKeys) sHist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos < p.nPositions) {
         const uint64_t* rec = p.positions + size_t(pos) * 4;
         uint64_t occ = rec[0];
         const uint64_t nibLo = rec[1], nibHi = rec[2];
+        const uint32_t outKey = min((uint32_t(popc64(occ)) - 2u) / 4u, uint32_t(kOutKeys - 1));  // MaterialCount<8>
         int kingSq[2] = {0, 0};
         uint32_t idx = 0;
         while (occ) {
@@ -357,178 +364,175 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const uint32_t key = uint32_t(kingBucket(c == 0 ? (kingSq[c] ^ 56) : kingSq[c]));
-            p.keys[2 * pos + c] = uint8_t(key);
+            p.kingKeys[2 * pos + c] = uint8_t(key);
             atomicAdd(&sHist[key], 1u);
         }
+        p.outKeys[pos] = uint8_t(outKey);
+        atomicAdd(&sHist[kHistOut + outKey], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kSortKeys && sHist[threadIdx.x]) atomicAdd(&p.hist[threadIdx.x], sHist[threadIdx.x]);
+    if (threadIdx.x < kKingKeys + kOutKeys && sHist[threadIdx.x]) atomicAdd(&p.hist[threadIdx.x], sHist[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p) {
-    __shared__ uint32_t sCount[kSortKeys];
-    __shared__ uint32_t sBase[kSortKeys];
-    if (threadIdx.x < kSortKeys) sCount[threadIdx.x] = 0;
+// blocks [0, nb) scatter perspectives by king key; blocks [nb, nb + nb2) scatter positions by output key
+__global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uint32_t perspBlocks) {
+    __shared__ uint32_t sCount[kKingKeys];
+    __shared__ uint32_t sBase[kKingKeys];
+    if (threadIdx.x < kKingKeys) sCount[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nPersp = p.nPositions * 2;
+    const bool persp = blockIdx.x < perspBlocks;
+    const uint32_t id = (persp ? blockIdx.x : blockIdx.x - perspBlocks) * blockDim.x + threadIdx.x;
+    const uint32_t count = persp ? p.nPositions * 2 : p.nPositions;
+    const uint32_t nKeys = persp ? kKingKeys : kOutKeys;
+    const uint32_t histOff = persp ? 0 : kHistOut, cursorOff = persp ? kCursorKing : kCursorOut;
     uint32_t key = 0, rank = 0;
-    if (q < nPersp) {
-        key = p.keys[q];
+    if (id < count) {
+        key = persp ? p.kingKeys[id] : p.outKeys[id];
         rank = atomicAdd(&sCount[key], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kSortKeys) {
+    if (threadIdx.x < nKeys) {
         uint32_t prefix = 0;
-        for (uint32_t k = 0; k < threadIdx.x; ++k) prefix += p.hist[k];
+        for (uint32_t k = 0; k < threadIdx.x; ++k) prefix += p.hist[histOff + k];
         const uint32_t mine = sCount[threadIdx.x];
-        sBase[threadIdx.x] = prefix + (mine ? atomicAdd(&p.cursor[threadIdx.x], mine) : 0u);
+        sBase[threadIdx.x] = prefix + (mine ? atomicAdd(&p.hist[cursorOff + threadIdx.x], mine) : 0u);
     }
     __syncthreads();
-    if (q < nPersp) p.order[sBase[key] + rank] = q;
+    if (id < count) (persp ? p.perspOrder : p.posOrder)[sBase[key] + rank] = id;
 }
 
 hipError_t launchSort(const SortParams& p, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(p.hist, 0, 2 * kSortKeys * sizeof(uint32_t), stream);  // hist + cursor
+    hipError_t e = hipMemsetAsync(p.hist, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const uint32_t b1 = (p.nPositions + 255) / 256, b2 = (2 * p.nPositions + 255) / 256;
     hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2 + b1), dim3(256), 0, stream, p, b2);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// MLP kernel: 64 positions per workgroup, 4 waves. Wave w contracts all 64 positions against output buckets 2w and
-// 2w+1 (A = activations from LDS, B = pre-swizzled L1 weights, 16 k-steps x 16 MFMAs), keeps only the rows whose
-// position selects that bucket, then each wave runs the i32 tail for 16 positions.
+// MLP kernel. One wavefront per TILE of 16 positions that share an output bucket (positions arrive sorted by bucket,
+// tiles never straddle buckets):
+//   L1   D[16 pos][32] = A[16][1024] (u8 activations, <= 127 so u8 == i8) x B[1024][32] (i8) on
+//        v_mfma_i32_16x16x64_i8: 16 k-steps x 2 n-tiles = 32 MFMAs, exact i32 sums (multilayer.h:154-217)
+//   tail per position, lane = output neuron: shift/bias/dual activation (multilayer.h:219-257), L2 64x64 in wrapping
+//        i32 (multilayer.h:261-343) with this lane's 64 weights held in registers for the whole tile, L3 + skip
+//        connection (multilayer.h:345-447) reduced across the wave, i64 scale with truncating division (:484-489).
+// kSmallL2W: every |l2W| < 2^23 (checked on the host at context creation), so with the L2 inputs always inside
+//   (-2^20, 2^12] the product is one full-rate v_mad_i32_i24; otherwise the exact-but-slow v_mul_lo_u32 path runs.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kMlpTile = 64;
-constexpr int kActStride = kL1 + 16;  // +16 B pad: consecutive rows land 4 banks apart for ds_read_b128
-
+template <bool kSmallL2W>
 __global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* sAct = smem;                                                   // [64][kActStride]
-    int32_t* sSum = reinterpret_cast<int32_t*>(smem + kMlpTile * kActStride);  // [64][32] L1 pre-activations
-    uint8_t* sBucket = reinterpret_cast<uint8_t*>(sSum + kMlpTile * kL2);  // [64]
+    __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
+    __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
 
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * kMlpTile;
-    const uint32_t nHere = min(uint32_t(kMlpTile), p.nPositions - base);
+    const uint32_t tile = blockIdx.x * 4 + wave;
 
-    // ---- stage activations (coalesced 16 B/lane) and output buckets ----
-    for (uint32_t i = threadIdx.x; i < kMlpTile * (kL1 / 16); i += blockDim.x) {
-        const uint32_t row = i / (kL1 / 16), chunk = i % (kL1 / 16);
-        u32x4 v = {0, 0, 0, 0};
-        if (row < nHere) {
-            v = *reinterpret_cast<const u32x4*>(p.ftOut + size_t(base + row) * kL1 + chunk * 16);
+    // ---- locate this tile: bucket, first sorted index, number of real positions ----
+    uint32_t bucket = 0, sortedBase = 0, count = 0;
+    {
+        uint32_t tileStart = 0, posStart = 0;
+        bool found = false;
+#pragma unroll
+        for (uint32_t b = 0; b < kOutputBuckets; ++b) {
+            const uint32_t cnt = p.hist[kHistOut + b];
+            const uint32_t tiles = (cnt + 15u) >> 4;
+            if (!found && tile < tileStart + tiles) {
+                found = true;
+                bucket = b;
+                const uint32_t j = tile - tileStart;
+                sortedBase = posStart + j * 16;
+                count = min(16u, cnt - j * 16);
+            }
+            tileStart += tiles;
+            posStart += cnt;
         }
-        *reinterpret_cast<u32x4*>(sAct + row * kActStride + chunk * 16) = v;
-    }
-    if (threadIdx.x < kMlpTile) {
-        uint32_t bucket = 0;
-        if (threadIdx.x < nHere) {
-            const uint64_t occ = p.positions[(base + threadIdx.x) * 4];  // first u64 of the 32-byte record
-            bucket = (uint32_t(popc64(occ)) - 2) / 4;                     // MaterialCount<8> (output.h:51-54)
+        if (!found) {
+            return;  // grid is sized for the worst-case number of tiles
         }
-        sBucket[threadIdx.x] = uint8_t(bucket);
     }
-    __syncthreads();
+    bucket = __builtin_amdgcn_readfirstlane(bucket);
+    sortedBase = __builtin_amdgcn_readfirstlane(sortedBase);
+    count = __builtin_amdgcn_readfirstlane(count);
 
-    // ---- L1 on MFMA: D[pos][o] += A[pos][k] * B[k][o], i8 x i8 -> i32 (activations <= 127, so u8 == i8) ----
-    i32x4 accum[2][4][2];  // [bucket of this wave][m-tile][n-tile]
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) accum[b][m][n] = i32x4{0, 0, 0, 0};
-
+    // ---- L1 on MFMA ----
     const uint32_t rowInTile = lane & 15, kGroup = lane >> 4;
+    const uint32_t myPos = p.posOrder[sortedBase + min(rowInTile, count - 1)];  // rows past `count` replicate the last
+    const uint8_t* aRow = p.ftOut + size_t(myPos) * kL1 + kGroup * 16;
+    const int8_t* bBase = p.l1W + size_t(bucket) * (kL1 * kL2) + lane * 16;
+    i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        i32x4 a[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            a[m] = *reinterpret_cast<const i32x4*>(sAct + (m * 16 + rowInTile) * kActStride + ks * 64 + kGroup * 16);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint32_t bucket = wave * 2 + b;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                // device layout [bucket][kstep][ntile][lane][16 B]: one coalesced 1 KiB wave load per fragment
-                const i32x4 w = *reinterpret_cast<const i32x4*>(
-                    p.l1W + ((size_t(bucket) * 16 + ks) * 2 + n) * 1024 + lane * 16);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    accum[b][m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], w, accum[b][m][n], 0, 0, 0);
-                }
-            }
-        }
+        const i32x4 a = *reinterpret_cast<const i32x4*>(aRow + ks * 64);
+        // device layout [bucket][kstep][ntile][lane][16 B]: one coalesced 1 KiB wave load per B fragment
+        const i32x4 w0 = *reinterpret_cast<const i32x4*>(bBase + (ks * 2 + 0) * 1024);
+        const i32x4 w1 = *reinterpret_cast<const i32x4*>(bBase + (ks * 2 + 1) * 1024);
+        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, w1, acc1, 0, 0, 0);
     }
-    // C/D layout of 16x16 MFMA: lane holds column (lane & 15), rows (lane >> 4) * 4 + r
+    // C/D layout of the 16x16 MFMA: lane holds column (lane & 15), rows (lane >> 4) * 4 + r
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const uint32_t bucket = wave * 2 + b;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t pos = m * 16 + kGroup * 4 + r;
-                if (sBucket[pos] == bucket) {
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        sSum[pos * kL2 + n * 16 + rowInTile] = accum[b][m][n][r];
-                    }
-                }
-            }
-        }
+    for (int r = 0; r < 4; ++r) {
+        sSum[wave][kGroup * 4 + r][rowInTile] = acc0[r];
+        sSum[wave][kGroup * 4 + r][16 + rowInTile] = acc1[r];
     }
-    __syncthreads();
 
-    // ---- i32 tail, one position at a time per wave; lane = output neuron (L1 neuron = lane & 31) ----
-    for (uint32_t j = 0; j < kMlpTile / 4; ++j) {
-        const uint32_t pos = wave * (kMlpTile / 4) + j;
-        if (pos >= nHere) {
-            break;
+    // ---- per-lane constants of this bucket: lane = L2/L3 output neuron o, L1 neuron = lane & 31 ----
+    const uint32_t o1 = lane & 31;
+    const int32_t l1Bias = p.l1B[bucket * kL2 + o1];
+    const int32_t l2Bias = p.l2B[bucket * kL3 + lane];
+    const int32_t l3Weight = p.l3W[bucket * kL3 + lane];
+    const int32_t l3Bias = p.l3B[bucket];
+    int32_t w2[kL2Full];
+    {
+        const int32_t* w2p = p.l2W + size_t(bucket) * kL2Full * kL3 + lane;
+#pragma unroll
+        for (int i = 0; i < int(kL2Full); ++i) {
+            w2[i] = w2p[i * kL3];
         }
-        const uint32_t bucket = sBucket[pos];
-        const uint32_t o1 = lane & 31;
-        const int32_t s = sSum[pos * kL2 + o1];
-        const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(p.l1B[bucket * kL2 + o1]);  // wraps
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for (uint32_t r = 0; r < count; ++r) {
+        const int32_t s = sSum[wave][r][o1];
+        const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
         const int32_t ts = int32_t(t);
         const int32_t c0 = min(max(ts, 0), 4096) << kQBits;  // CReLU side, pre-shifted for the skip connection
         const int32_t sq = int32_t(t * t);                    // mullo wraps BEFORE the signed min
         const int32_t c1 = min(sq, 1 << 24) >> kQBits;        // SCReLU side
-        const int32_t mine = lane < kL2 ? c0 : c1;            // l1o[lane]: [CReLU(32) | SCReLU(32)]
-        // L2: l2[o] = bias + sum_i (l1o[i] >> 6) * W2[b][i][o]   (wrapping i32); l1o[i] broadcast by v_readlane
-        const int32_t* w2 = p.l2W + size_t(bucket) * kL2Full * kL3 + lane;
-        uint32_t acc2 = uint32_t(p.l2B[bucket * kL3 + lane]);
+        const int32_t mine = lane < kL2 ? c0 : c1;            // l1o[lane] = [CReLU(32) | SCReLU(32)]
+        sIn[wave][lane] = mine >> kQBits;                     // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
+        __builtin_amdgcn_wave_barrier();
+        // L2: l2[o] = bias + sum_i in[i] * W2[b][i][o], wrapping i32; in[] broadcast from LDS (same address per lane)
+        uint32_t acc2 = uint32_t(l2Bias);
 #pragma unroll
-        for (int i = 0; i < int(kL2); ++i) {
-            acc2 += uint32_t(__builtin_amdgcn_readlane(c0, i) >> kQBits) * uint32_t(w2[i * kL3]);
-        }
+        for (int i = 0; i < int(kL2Full); i += 4) {
+            const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sIn[wave][i]);
 #pragma unroll
-        for (int i = 0; i < int(kL2); ++i) {
-            acc2 += uint32_t(__builtin_amdgcn_readlane(c1, i) >> kQBits) * uint32_t(w2[(kL2 + i) * kL3]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (kSmallL2W) {
+                    acc2 += uint32_t(__mul24(in4[j], w2[i + j]));
+                } else {
+                    acc2 += uint32_t(in4[j]) * uint32_t(w2[i + j]);
+                }
+            }
         }
         // L3 with skip connection: (clamp(l2, 0, Q^3) + l1o) * W3, wrapping; wave-wide wrapping sum
         const int32_t l2v = min(max(int32_t(acc2), 0), 262144);
-        uint32_t term = (uint32_t(l2v) + uint32_t(mine)) * uint32_t(p.l3W[bucket * kL3 + lane]);
+        uint32_t term = (uint32_t(l2v) + uint32_t(mine)) * uint32_t(l3Weight);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             term += uint32_t(__shfl_xor(int32_t(term), off, 64));
         }
         if (lane == 0) {
-            const int32_t l3 = int32_t(term + uint32_t(p.l3B[bucket]));
+            const int32_t l3 = int32_t(term + uint32_t(l3Bias));
             const int64_t scaled = int64_t(l3) * kScale / (int64_t(1) << (4 * kQBits));  // truncating division
-            p.out[base + pos] = int32_t(scaled);
+            p.out[p.posOrder[sortedBase + r]] = int32_t(scaled);
         }
+        __builtin_amdgcn_wave_barrier();
     }
-}
-
-size_t mlpSharedBytes() {
-    return size_t(kMlpTile) * kActStride + size_t(kMlpTile) * kL2 * 4 + kMlpTile;
 }
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
@@ -536,16 +540,15 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) 
     return hipGetLastError();
 }
 
-hipError_t launchMlp(const MlpParams& p, hipStream_t stream) {
-    const uint32_t blocks = (p.nPositions + kMlpTile - 1) / kMlpTile;
-    hipLaunchKernelGGL(spx_mlp_kernel, dim3(blocks), dim3(256), mlpSharedBytes(), stream, p);
+hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream) {
+    const uint32_t tiles = (p.nPositions + 15) / 16 + kOutputBuckets;  // worst case: every bucket ends in a partial tile
+    const uint32_t blocks = (tiles + 3) / 4;
+    if (smallL2Weights) {
+        hipLaunchKernelGGL(spx_mlp_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(spx_mlp_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
-}
-
-hipError_t prepareKernels() {
-    // the MLP tile (64 x 1 KiB activations + sums) needs more than the default 64 KiB of dynamic LDS
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_mlp_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(mlpSharedBytes()));
 }
 
 uint32_t ftWavesPerBlock() {

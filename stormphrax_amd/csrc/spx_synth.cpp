@@ -37,14 +37,14 @@ struct Ranges {
 
 // preset 0 "tame": no i32 wrap in L2/L3, raw evals inside +-24999 (oracle `raweval` clamp safe)
 // preset 1 "wild": L3 products and t*t wrap in i32
-// preset 2 "extreme": additionally the i16 accumulators wrap
+// preset 2 "extreme": additionally the i16 accumulators wrap and |l2W| reaches 2^30 (general 32-bit multiply path)
 // l3B is 0 in the wrapping presets: the reference's final `l3Biases[b] + hsum(s)` (multilayer.h:446) is a SCALAR
 // signed add - overflow there is UB (the AVX2 build was observed to widen it to i64), unlike every SIMD op on the
 // path, which wraps by definition. Keeping that one add overflow-free keeps the reference's result well-defined.
 constexpr Ranges kPresets[3] = {
     {48, 12, -64, 191, 127, 4096, 8, 4096, 8, 65536},
     {48, 12, -64, 191, 127, 4096, 64, 1 << 20, 64, 0},
-    {6000, 127, -32768, 32767, 127, 1 << 22, 1 << 20, 1 << 30, 1 << 24, 0},
+    {6000, 127, -32768, 32767, 127, 1 << 22, 1 << 30, 1 << 30, 1 << 24, 0},
 };
 
 template <typename T>
