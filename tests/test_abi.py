@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/spx_nnue.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "spx_nnue.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree(sp):
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in include/spx_nnue.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "ctypes prototypes drifted from the header"
+    assert ctypes.sizeof(_lib.PackedPos) == 32 and sp.PACKED_DTYPE.itemsize == 32
+
+
+def test_no_cpu_fallback_without_device(sp, net_blob):
+    """On a box without a GPU the context must refuse to exist (SPX_ERR_NO_DEVICE): there is no CPU evaluation path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from stormphrax_amd import _lib
+
+    net = sp.Network(net_blob("tame"))
+    with pytest.raises(_lib.SpxError) as err:
+        sp.NnueState(net, device=0, max_batch=16)
+    assert err.value.code == 4 and "no CPU fallback" in str(err.value)
+
+
+def test_product_never_references_the_oracle():
+    """The shipped sources must not include, link or load anything under oracle/."""
+    for sub in ("stormphrax_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for name in files:
+                if name.endswith((".cpp", ".h", ".hip", ".py", "Makefile")):
+                    text = open(os.path.join(dirpath, name), errors="replace").read()
+                    assert "libspx_oracle" not in text and "spxo_" not in text and "oracle/" not in text.replace(
+                        "the CPU oracle lives in oracle/", ""), os.path.join(dirpath, name)

@@ -70,3 +70,42 @@ def test_startpos_and_bare_kings(sp, oracle, net_blob, states):
     got = states("tame").evaluate_once(pos)
     want = np.array([oracle.eval_fen(f) for f in fens], dtype=np.int32)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
+def test_reference_golden_vectors(sp, net_blob, states, preset):
+    """GPU vs the COMPILED REFERENCE directly (tests/golden/evals.jsonl), without going through the oracle."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "evals.jsonl")
+    recs = [json.loads(line) for line in open(path)]
+    pos = sp.positions_from_fens([r["fen"] for r in recs])
+    got = states(preset).evaluate_once(pos)
+    want = np.array([r[preset] for r in recs], dtype=np.int32)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (recs[bad[0]]["fen"], int(got[bad[0]]), int(want[bad[0]]))
+
+
+def test_full_size_batch_properties(sp, oracle, net_blob, states):
+    """BASELINE config 2 at full size (65 536 positions): size-independent properties instead of a full oracle pass.
+    (1) order independence: a shuffled batch gives the shuffled result; (2) batch-split independence: two halves equal
+    the whole; (3) a 2 048-position random sample equals the oracle; (4) colour-flip symmetry is NOT assumed (the net is
+    random) but stm dependence is: flipping only the stm bit changes the perspective order, checked against the oracle."""
+    st = states("wild")
+    oracle.use(net_blob("wild"), "wild")
+    pos = sp.random_positions(65536, seed=20260927, min_ply=8, max_ply=120, dfrc_every=4)
+    full = st.evaluate_once(pos)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(pos))
+    assert np.array_equal(st.evaluate_once(pos[perm]), full[perm])
+    halves = np.concatenate([st.evaluate_once(pos[:30001]), st.evaluate_once(pos[30001:])])
+    assert np.array_equal(halves, full)
+    idx = rng.choice(len(pos), 2048, replace=False)
+    mail, stm = sp.positions_to_mailboxes(pos[idx])
+    assert np.array_equal(full[idx], oracle.eval_mailboxes(mail, stm))
+    flipped = pos[idx].copy()
+    flipped["stm_ep"] ^= 0x80
+    assert np.array_equal(st.evaluate_once(flipped), oracle.eval_mailboxes(mail, 1 - stm))
+    # checksum of checksums: a stable digest of the whole batch for cross-run comparison
+    assert int(full.astype(np.int64).sum()) == int(halves.astype(np.int64).sum())

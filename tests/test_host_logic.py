@@ -1,0 +1,125 @@
+"""CPU tests of the host side of libspx_nnue: chess core, packed records, net validation, and the lane-by-lane
+emulation of the kernels' feature extraction (same SPX_HD code as the HIP kernels) against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+STARTPOS = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+
+# well-known perft results (chessprogramming.org perft results; FRC row from the Chess960 perft suite)
+PERFT = [
+    (STARTPOS, 4, 197281),
+    ("r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", 3, 97862),
+    ("8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1", 4, 43238),
+    ("r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1", 3, 9467),
+    ("rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8", 3, 62379),
+    ("r4rk1/1pp1qppp/p1np1n2/2b1p1B1/2B1P1b1/P1NP1N2/1PP1QPPP/R4RK1 w - - 0 10", 3, 89890),
+    ("bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9", 3, 12189),
+]
+
+
+@pytest.mark.parametrize("fen,depth,nodes", PERFT)
+def test_perft(sp, fen, depth, nodes):
+    assert sp.perft(fen, depth) == nodes
+
+
+def test_packed_record_layout(sp):
+    """marlinformat PackedBoard (datagen/marlinformat.h:32-84): nibble order, colour bit, unmoved-rook code, stm bit."""
+    (rec,) = sp.positions_from_fens([STARTPOS])
+    assert rec["occupancy"] == 0xFFFF00000000FFFF
+    nib = [(rec["pieces"][i // 2] >> (4 * (i % 2))) & 0xF for i in range(32)]
+    assert nib[:8] == [6, 1, 2, 4, 5, 2, 1, 6]        # white back rank a1..h1: rooks carry castling rights -> 6
+    assert nib[8:16] == [0] * 8                       # white pawns
+    assert nib[16:24] == [8] * 8                      # black pawns: colour bit 3
+    assert nib[24:] == [14, 9, 10, 12, 13, 10, 9, 14]
+    assert rec["stm_ep"] == 64                        # white to move, no ep square
+    (rec,) = sp.positions_from_fens(["rnbqkbnr/pppppppp/8/8/4P3/8/PPPP1PPP/RNBQKBNR b KQkq e3 0 1"])
+    assert rec["stm_ep"] & 0x80
+    (rec,) = sp.positions_from_fens(["4k3/8/8/8/8/8/8/R3K2R w K - 0 1"])
+    nib = [(rec["pieces"][i // 2] >> (4 * (i % 2))) & 0xF for i in range(4)]
+    assert nib == [3, 5, 6, 13]  # a1 rook lost its rights, h1 rook keeps them
+
+
+def test_fen_round_trip_and_mailbox(sp):
+    fens = [STARTPOS, "8/8/4k3/8/8/3K4/8/8 b - - 12 80", "r3k2r/8/8/8/8/8/8/R3K2R w HAha - 3 9"]
+    pos = sp.positions_from_fens(fens)
+    for fen, rec in zip(fens, pos):
+        out = sp.position_to_fen(rec)
+        assert out.split()[0] == fen.split()[0] and out.split()[1] == fen.split()[1]
+    mail, stm = sp.positions_to_mailboxes(pos)
+    assert mail[0][4] == 11 and mail[0][60] == 10 and mail[0][0] == 7 and mail[0][8] == 1 and mail[0][20] == 12
+    assert stm.tolist() == [1, 0, 1]
+
+
+def test_random_positions_are_seeded_and_legal_looking(sp):
+    a = sp.random_positions(512, seed=99)
+    b = sp.random_positions(512, seed=99)
+    c = sp.random_positions(512, seed=100)
+    assert a.tobytes() == b.tobytes() and a.tobytes() != c.tobytes()
+    mail, stm = sp.positions_to_mailboxes(a)
+    assert np.all((mail == 10).sum(axis=1) == 1) and np.all((mail == 11).sum(axis=1) == 1)
+    assert set(np.unique(stm)) == {0, 1}
+    # pawns never stand on the back ranks
+    assert not np.any(np.isin(mail[:, :8], [0, 1])) and not np.any(np.isin(mail[:, 56:], [0, 1]))
+
+
+def test_kernel_feature_extraction_matches_oracle(sp, oracle, net_blob):
+    """spx_debug_features runs the kernels' SPX_HD per-lane code on the CPU; rows must equal the oracle's as multisets
+    (the wave emits them in a different order; i16 sums are order-independent)."""
+    oracle.use(net_blob("tame"), "tame")
+    pos = sp.random_positions(1500, seed=31337, min_ply=0, max_ply=200, dfrc_every=2)
+    mail, _ = sp.positions_to_mailboxes(pos)
+    for i in range(len(pos)):
+        for c in (0, 1):
+            want_psq, want_thr = oracle.features(mail[i], c)
+            got_psq, got_thr = sp.debug_features(pos[i], c)
+            assert sorted(got_psq.tolist()) == sorted(want_psq.tolist())
+            assert sorted(got_thr.tolist()) == sorted(want_thr.tolist())
+    psq_rows, thr_rows = sp.count_rows(pos[:64])
+    assert psq_rows == sum(int(np.count_nonzero(m != 12)) for m in mail[:64]) * 2 and thr_rows > 0
+
+
+def test_synthetic_net_is_reproducible(sp):
+    """Digest pins of the three presets (seed 20260927): the GPU box regenerates bit-identical files."""
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    want = {"tame": 0x4177798691D12739, "wild": 0xAE32025FCF2471C1}
+    for preset, digest in want.items():
+        blob = sp.synthetic_net_bytes(preset)
+        assert blob.size == 89381984
+        assert lib.spx_fnv1a64(blob.ctypes.data, blob.size) == digest
+
+
+def test_net_validation_mirrors_reference(sp, net_blob):
+    """Header checks in the order and wording of validate() (src/eval/nnue.cpp:85-185)."""
+    from stormphrax_amd import _lib
+
+    good = net_blob("tame")
+    assert sp.Network(good).name == "spx_synth_tame"
+
+    def expect(mutate, fragment):
+        blob = good[:4096].copy() if False else good.copy()
+        mutate(blob)
+        with pytest.raises(_lib.SpxError) as err:
+            sp.Network(blob)
+        assert err.value.code == 2 and fragment in str(err.value), str(err.value)
+
+    expect(lambda b: b.__setitem__(0, ord("X")), "invalid magic bytes")
+    expect(lambda b: b.__setitem__(4, 2), "unsupported network format version 2")
+    expect(lambda b: b.__setitem__(9, 4), "wrong network architecture")
+    expect(lambda b: b.__setitem__(6, 0x0C), "unmirrored network")
+    expect(lambda b: b.__setitem__(6, 0x0A), "merged king planes")
+    expect(lambda b: b.__setitem__(6, 0x06), "pairwise")
+    expect(lambda b: b.__setitem__(10, 1), "wrong l1 activation function")
+    expect(lambda b: b.__setitem__(12, 2), "wrong number of l1 neurons")
+    expect(lambda b: b.__setitem__(13, 16), "threat inputs")
+    expect(lambda b: b.__setitem__(13, 0x80 | 8), "wrong number of input buckets")
+    expect(lambda b: b.__setitem__(14, 4), "wrong number of output buckets")
+    expect(lambda b: b.__setitem__(6, 0x0F), "zstd")
+    with pytest.raises(_lib.SpxError) as err:
+        sp.Network(good[: good.size - 64])
+    assert "too small" in str(err.value)
+    with pytest.raises(_lib.SpxError):
+        sp.Network(good[:32])
