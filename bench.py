@@ -123,7 +123,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ft_ms, mlp_ms, calls = state.profile_end()
+    sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
 
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -158,7 +158,7 @@ def main():
                 "batch_per_gpu": args.batch,
                 "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path",
-                "kernel_ms": {"ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
+                "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
             },
             "roofline": {
                 "kernel": "spx_ft_kernel",

@@ -92,11 +92,36 @@ void spx_ctx_destroy(spx_ctx* ctx);
 int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32_t* out);
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Incremental path: an arena of accumulator "slots" resident in HBM (4 KiB of i16 accumulators + the 32-byte record
+ * per slot) replaces NnueState's accumulator stack (src/eval/nnue_state.h:47-83,87-116). A caller that used to do
+ *     state.reset(pos)                          -> spx_acc_refresh(slot of the root, pos)
+ *     pos2 = pos.applyMove(m, state.push())     -> record (parent slot, child slot, packed pos2); no observer needed
+ *     state.evaluate(pos2, stm)                 -> spx_acc_update(records of this ply...) then spx_acc_eval(slots)
+ *     state.pop()                               -> nothing: the parent's slot is still materialised
+ * Batching rule: the records of ONE spx_acc_update call are independent parent->child pairs - every parent slot is
+ * already materialised and no child slot of the call is a parent in the same call (process a tree level by level).
+ *   spx_acc_refresh  == NnueState::reset (nnue_state.cpp:539-560) for n (position, slot) pairs
+ *   spx_acc_update   == updatePsq + applyThreatUpdates / refreshes (nnue_state.cpp:34-87,356-394,458-536): the delta is
+ *                       derived on the device from the parent slot's record and the child record
+ *   spx_acc_eval     == evaluateNetwork on materialised slots (nnue_state.cpp:396-438); stm comes from the slot's record
+ * Host-buffer variants synchronise; *_device variants take device pointers and enqueue on `stream` (NULL = context's).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int spx_acc_reserve(spx_ctx* ctx, size_t n_slots);
+int spx_acc_refresh(spx_ctx* ctx, const spx_packed_pos* positions, const uint32_t* slots, size_t n);
+int spx_acc_update(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                   const spx_packed_pos* child_positions, size_t n);
+int spx_acc_eval(spx_ctx* ctx, const uint32_t* slots, size_t n, int32_t* out);
+int spx_acc_refresh_device(spx_ctx* ctx, const void* d_positions, const void* d_slots, size_t n, void* stream);
+int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                          const void* d_child_positions, size_t n, void* stream);
+int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream);
+
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
- * feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */
+ * sort kernels, the feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */
 int spx_profile_begin(spx_ctx* ctx, size_t max_calls);
-int spx_profile_end(spx_ctx* ctx, double* ft_ms, double* mlp_ms, size_t* calls);
+int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms, size_t* calls);
 
 /* Active feature rows of a batch, both perspectives summed (what a full refresh gathers): algorithmic bytes =
  * 2048 * psq_rows + 1024 * threat_rows (+ 36 B per position of record and score). Host-side count. */
@@ -113,6 +138,9 @@ int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
 int spx_pos_from_fen(const char* fen, spx_packed_pos* out);
 int spx_pos_to_fen(const spx_packed_pos* pos, char* buf, size_t nbytes);
 int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm);
+/* Position::applyMove for a move in UCI notation (castling as king-takes-rook, e.g. e1h1, or standard e1g1);
+ * legality is checked against the generated legal moves (src/position.cpp:109-197, Position::moveFromUci). */
+int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out);
 int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
 uint64_t spx_perft(const char* fen, int depth);
 

@@ -7,6 +7,7 @@ from .nnue import (  # noqa: F401
     PACKED_DTYPE,
     Network,
     NnueState,
+    apply_uci,
     count_rows,
     debug_features,
     perft,

@@ -44,12 +44,20 @@ SYMBOLS = {
     "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_profile_begin": (ctypes.c_int, [_P, ctypes.c_size_t]),
-    "spx_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_acc_reserve": (ctypes.c_int, [_P, ctypes.c_size_t]),
+    "spx_acc_refresh": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t]),
+    "spx_acc_update": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t]),
+    "spx_acc_eval": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
+    "spx_acc_refresh_device": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "spx_acc_update_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
+    "spx_pos_apply_uci": (ctypes.c_int, [_P, ctypes.c_char_p, _P]),
     "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
     "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),

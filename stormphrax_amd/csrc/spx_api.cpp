@@ -60,6 +60,12 @@ struct spx_ctx {
     uint32_t* dHist = nullptr;     // 64 words: counts + cursors
     uint32_t* dPerspOrder = nullptr;  // perspective ids grouped by king bucket
     uint32_t* dPosOrder = nullptr;    // position ids grouped by output bucket
+    // accumulator arena (incremental path): nSlots x (4 KiB accumulators + 32 B record)
+    uint8_t* dArena = nullptr;
+    uint8_t* dSlotRecords = nullptr;
+    size_t nSlots = 0;
+    uint32_t *dSlotsA = nullptr, *dSlotsB = nullptr;  // staging for the host-buffer entry points [max_batch]
+    uint8_t* dStaged = nullptr;                        // [max_batch][32] records of the slots being evaluated
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
@@ -165,6 +171,15 @@ void relayoutL1(const int8_t* src, int8_t* dst) {
                         dst[(((size_t(b) * 16 + ks) * 2 + n) * 64 + lane) * 16 + i] =
                             src[size_t(b) * kL1 * kL2 + size_t(k / 4) * (kL2 * 4) + o * 4 + (k % 4)];
                     }
+}
+
+FtTables tablesOf(const spx_ctx* ctx) {
+    FtTables t{};
+    t.psqW = ctx->dPsqW;
+    t.thrW = ctx->dThrW;
+    t.ftBias = ctx->dFtBias;
+    t.lut = ctx->dLut;
+    return t;
 }
 
 template <typename T>
@@ -287,6 +302,9 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 64 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
@@ -308,13 +326,51 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut,
-                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder};
+                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder,
+                    ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// sort (both keys) on `d_records`, then the MLP over ctx->dFtOut[0..n) -> d_out
+static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp) {
+    if (!mlp) {
+        SortParams sp{};
+        sp.positions = static_cast<const uint64_t*>(d_records);
+        sp.nPositions = uint32_t(n);
+        sp.kingKeys = ctx->dKingKeys;
+        sp.outKeys = ctx->dOutKeys;
+        sp.hist = ctx->dHist;
+        sp.perspOrder = ctx->dPerspOrder;
+        sp.posOrder = ctx->dPosOrder;
+        SPX_HIP(launchSort(sp, s));
+        return SPX_OK;
+    }
+    MlpParams mp{};
+    mp.nPositions = uint32_t(n);
+    mp.posOrder = ctx->dPosOrder;
+    mp.hist = ctx->dHist;
+    mp.ftOut = ctx->dFtOut;
+    mp.l1W = ctx->dL1W;
+    mp.l1B = ctx->dL1B;
+    mp.l2W = ctx->dL2W;
+    mp.l2B = ctx->dL2B;
+    mp.l3W = ctx->dL3W;
+    mp.l3B = ctx->dL3B;
+    mp.out = static_cast<int32_t*>(d_out);
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, s));
+    return SPX_OK;
+}
+
+static uint32_t ftGrid(const spx_ctx* ctx, size_t waves) {
+    const uint32_t wavesPerBlock = ftWavesPerBlock();
+    uint32_t blocks = uint32_t((waves + wavesPerBlock - 1) / wavesPerBlock);
+    if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
+    return (blocks + 7u) & ~7u;  // whole multiples of the 8 XCDs
 }
 
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream) {
@@ -331,52 +387,183 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipEvent_t* ev = nullptr;
-    if (ctx->profUsed + 3 <= ctx->profEvents.size()) {
+    if (ctx->profUsed + 4 <= ctx->profEvents.size()) {
         ev = &ctx->profEvents[ctx->profUsed];
-        ctx->profUsed += 3;
+        ctx->profUsed += 4;
         SPX_HIP(hipEventRecord(ev[0], s));
     }
-    {
-        SortParams sp{};
-        sp.positions = static_cast<const uint64_t*>(d_positions);
-        sp.nPositions = uint32_t(n);
-        sp.kingKeys = ctx->dKingKeys;
-        sp.outKeys = ctx->dOutKeys;
-        sp.hist = ctx->dHist;
-        sp.perspOrder = ctx->dPerspOrder;
-        sp.posOrder = ctx->dPosOrder;
-        SPX_HIP(launchSort(sp, s));
-    }
+    int rc = runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
+    if (rc != SPX_OK) return rc;
+    if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     FtParams fp{};
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
     fp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
-    fp.psqW = ctx->dPsqW;
-    fp.thrW = ctx->dThrW;
-    fp.ftBias = ctx->dFtBias;
-    fp.lut = ctx->dLut;
+    fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
-    const uint32_t wavesPerBlock = ftWavesPerBlock();
-    uint32_t blocks = uint32_t((2 * n + wavesPerBlock - 1) / wavesPerBlock);
-    if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
-    blocks = (blocks + 7u) & ~7u;  // whole multiples of the 8 XCDs
-    SPX_HIP(launchFt(fp, blocks, s));
-    if (ev) SPX_HIP(hipEventRecord(ev[1], s));
-
-    MlpParams mp{};
-    mp.nPositions = uint32_t(n);
-    mp.posOrder = ctx->dPosOrder;
-    mp.hist = ctx->dHist;
-    mp.ftOut = ctx->dFtOut;
-    mp.l1W = ctx->dL1W;
-    mp.l1B = ctx->dL1B;
-    mp.l2W = ctx->dL2W;
-    mp.l2B = ctx->dL2B;
-    mp.l3W = ctx->dL3W;
-    mp.l3B = ctx->dL3B;
-    mp.out = static_cast<int32_t*>(d_out);
-    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, s));
+    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
+    rc = runSortAndMlp(ctx, d_positions, n, d_out, s, true);
+    if (rc != SPX_OK) return rc;
+    if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    return SPX_OK;
+}
+
+// ---- incremental path: accumulator arena ----
+int spx_acc_reserve(spx_ctx* ctx, size_t n_slots) {
+    if (!ctx || n_slots == 0 || n_slots > (1ull << 31)) {
+        setError("spx_acc_reserve: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    if (n_slots <= ctx->nSlots) return SPX_OK;
+    SPX_HIP(hipDeviceSynchronize());
+    if (ctx->dArena) (void)hipFree(ctx->dArena);
+    if (ctx->dSlotRecords) (void)hipFree(ctx->dSlotRecords);
+    ctx->dArena = nullptr;
+    ctx->dSlotRecords = nullptr;
+    ctx->nSlots = 0;
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dArena), n_slots * kAccSlotBytes));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotRecords), n_slots * 32));
+    SPX_HIP(hipMemset(ctx->dSlotRecords, 0, n_slots * 32));
+    ctx->nSlots = n_slots;
+    return SPX_OK;
+}
+
+static int checkAcc(spx_ctx* ctx, size_t n, const char* who) {
+    if (!ctx) {
+        setError(std::string(who) + ": null context");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (!ctx->dArena) {
+        setError(std::string(who) + ": call spx_acc_reserve first");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (n > ctx->maxBatch) {
+        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->maxBatch));
+        return SPX_ERR_CAPACITY;
+    }
+    return SPX_OK;
+}
+
+int spx_acc_refresh_device(spx_ctx* ctx, const void* d_positions, const void* d_slots, size_t n, void* stream) {
+    int rc = checkAcc(ctx, n, "spx_acc_refresh_device");
+    if (rc != SPX_OK || n == 0) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    rc = runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
+    if (rc != SPX_OK) return rc;
+    FtParams fp{};
+    fp.positions = d_positions;
+    fp.nPositions = uint32_t(n);
+    fp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
+    fp.t = tablesOf(ctx);
+    fp.ftOut = nullptr;
+    fp.accOut = ctx->dArena;
+    fp.slots = static_cast<const uint32_t*>(d_slots);
+    fp.slotRecords = ctx->dSlotRecords;
+    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
+    return SPX_OK;
+}
+
+int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                          const void* d_child_positions, size_t n, void* stream) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_device");
+    if (rc != SPX_OK || n == 0) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    UpdateParams up{};
+    up.nRecords = uint32_t(n);
+    up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
+    up.childSlots = static_cast<const uint32_t*>(d_child_slots);
+    up.childPositions = d_child_positions;
+    up.t = tablesOf(ctx);
+    up.arena = ctx->dArena;
+    up.slotRecords = ctx->dSlotRecords;
+    SPX_HIP(launchUpdate(up, ftGrid(ctx, n), s));
+    return SPX_OK;
+}
+
+int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream) {
+    int rc = checkAcc(ctx, n, "spx_acc_eval_device");
+    if (rc != SPX_OK || n == 0) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    SlotActParams ap{};
+    ap.nSlots = uint32_t(n);
+    ap.slots = static_cast<const uint32_t*>(d_slots);
+    ap.arena = ctx->dArena;
+    ap.slotRecords = ctx->dSlotRecords;
+    ap.ftOut = ctx->dFtOut;
+    ap.stagedRecords = ctx->dStaged;
+    uint32_t blocks = uint32_t((n + 3) / 4);
+    if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
+    SPX_HIP(launchSlotAct(ap, blocks, s));
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    if (rc != SPX_OK) return rc;
+    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
+}
+
+static int checkSlots(const spx_ctx* ctx, const uint32_t* slots, size_t n, const char* who) {
+    for (size_t i = 0; i < n; ++i) {
+        if (slots[i] >= ctx->nSlots) {
+            setError(std::string(who) + ": slot " + std::to_string(slots[i]) + " out of range (reserved " +
+                     std::to_string(ctx->nSlots) + ")");
+            return SPX_ERR_INVALID_ARG;
+        }
+    }
+    return SPX_OK;
+}
+
+int spx_acc_refresh(spx_ctx* ctx, const spx_packed_pos* positions, const uint32_t* slots, size_t n) {
+    int rc = checkAcc(ctx, n, "spx_acc_refresh");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!positions || !slots) {
+        setError("spx_acc_refresh: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, slots, n, "spx_acc_refresh")) != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipMemcpyAsync(ctx->dPositions, positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice, ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_refresh_device(ctx, ctx->dPositions, ctx->dSlotsA, n, ctx->stream);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    return SPX_OK;
+}
+
+int spx_acc_update(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                   const spx_packed_pos* child_positions, size_t n) {
+    int rc = checkAcc(ctx, n, "spx_acc_update");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!parent_slots || !child_slots || !child_positions) {
+        setError("spx_acc_update: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, parent_slots, n, "spx_acc_update")) != SPX_OK) return rc;
+    if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update")) != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipMemcpyAsync(ctx->dPositions, child_positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
+                           ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, parent_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_update_device(ctx, ctx->dSlotsA, ctx->dSlotsB, ctx->dPositions, n, ctx->stream);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    return SPX_OK;
+}
+
+int spx_acc_eval(spx_ctx* ctx, const uint32_t* slots, size_t n, int32_t* out) {
+    int rc = checkAcc(ctx, n, "spx_acc_eval");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!slots || !out) {
+        setError("spx_acc_eval: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, slots, n, "spx_acc_eval")) != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_eval_device(ctx, ctx->dSlotsA, n, ctx->dOut, ctx->stream);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
     return SPX_OK;
 }
 
@@ -386,7 +573,7 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
         return SPX_ERR_INVALID_ARG;
     }
     SPX_HIP(hipSetDevice(ctx->device));
-    while (ctx->profEvents.size() < max_calls * 3) {
+    while (ctx->profEvents.size() < max_calls * 4) {
         hipEvent_t e;
         SPX_HIP(hipEventCreate(&e));
         ctx->profEvents.push_back(e);
@@ -395,21 +582,23 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
     return SPX_OK;
 }
 
-int spx_profile_end(spx_ctx* ctx, double* ft_ms, double* mlp_ms, size_t* calls) {
-    if (!ctx || !ft_ms || !mlp_ms || !calls) {
+int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms, size_t* calls) {
+    if (!ctx || !sort_ms || !ft_ms || !mlp_ms || !calls) {
         setError("spx_profile_end: null argument");
         return SPX_ERR_INVALID_ARG;
     }
     SPX_HIP(hipSetDevice(ctx->device));
-    *ft_ms = *mlp_ms = 0.0;
-    *calls = ctx->profUsed / 3;
-    for (size_t i = 0; i + 2 < ctx->profUsed + 0 && i < ctx->profUsed; i += 3) {
-        float a = 0.f, b = 0.f;
-        SPX_HIP(hipEventSynchronize(ctx->profEvents[i + 2]));
+    *sort_ms = *ft_ms = *mlp_ms = 0.0;
+    *calls = ctx->profUsed / 4;
+    for (size_t i = 0; i + 3 < ctx->profUsed; i += 4) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        SPX_HIP(hipEventSynchronize(ctx->profEvents[i + 3]));
         SPX_HIP(hipEventElapsedTime(&a, ctx->profEvents[i], ctx->profEvents[i + 1]));
         SPX_HIP(hipEventElapsedTime(&b, ctx->profEvents[i + 1], ctx->profEvents[i + 2]));
-        *ft_ms += a;
-        *mlp_ms += b;
+        SPX_HIP(hipEventElapsedTime(&c, ctx->profEvents[i + 2], ctx->profEvents[i + 3]));
+        *sort_ms += a;
+        *ft_ms += b;
+        *mlp_ms += c;
     }
     ctx->profUsed = ctx->profEvents.size();  // stop recording until the next spx_profile_begin
     return SPX_OK;
@@ -500,6 +689,22 @@ int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm)
     }
     std::memcpy(mailbox, b.mailbox, 64);
     if (stm) *stm = b.stm;
+    return SPX_OK;
+}
+
+int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out) {
+    Board b;
+    if (!pos || !uci || !out || !unpackBoard(*pos, b)) {
+        setError("spx_pos_apply_uci: bad record");
+        return SPX_ERR_BAD_POSITION;
+    }
+    Move m;
+    if (!moveFromUci(b, uci, m)) {
+        setError(std::string("spx_pos_apply_uci: illegal or unparsable move ") + uci);
+        return SPX_ERR_INVALID_ARG;
+    }
+    makeMove(b, m);
+    packBoard(b, *out);
     return SPX_OK;
 }
 

@@ -8,15 +8,44 @@
 
 namespace spx {
 
-struct FtParams {
-    const void* positions;   // spx_packed_pos[nPositions] (32 B records)
-    uint32_t nPositions;
-    const uint32_t* order;   // optional permutation of perspective ids (2*pos + colour), or nullptr
+constexpr size_t kAccSlotBytes = 2 * 1024 * 2;  // one arena slot: 2 perspectives x i16[1024] (psq + threat combined)
+
+// device-resident network tables shared by the feature-transformer and update kernels
+struct FtTables {
     const int16_t* psqW;     // [11264][1024] i16, logical column order
     const uint8_t* thrW;     // [64368][1024] u8: value+128, columns interleaved per lane (see relayout in spx_api)
     const int16_t* ftBias;   // [1024]
     const uint32_t* lut;     // kLutWords threat LUT
-    uint8_t* ftOut;          // [nPositions][1024] u8: stm half, then nstm half
+};
+
+struct FtParams {
+    const void* positions;   // spx_packed_pos[nPositions] (32 B records)
+    uint32_t nPositions;
+    const uint32_t* order;   // optional permutation of perspective ids (2*pos + colour), or nullptr
+    FtTables t;
+    uint8_t* ftOut;          // mode A: [nPositions][1024] u8 activations (stm half, then nstm half)
+    uint8_t* accOut;         // mode B (ftOut == nullptr): accumulator arena ...
+    const uint32_t* slots;   //         ... slot of each position
+    uint8_t* slotRecords;    //         ... and the per-slot record store [nSlots][32]
+};
+
+struct UpdateParams {
+    uint32_t nRecords;
+    const uint32_t* parentSlots;   // [nRecords] materialised slots
+    const uint32_t* childSlots;    // [nRecords] slots to write (distinct from every parent of this batch)
+    const void* childPositions;    // spx_packed_pos[nRecords]: the boards after the move
+    FtTables t;
+    uint8_t* arena;                // [nSlots][kAccSlotBytes]
+    uint8_t* slotRecords;          // [nSlots][32]
+};
+
+struct SlotActParams {
+    uint32_t nSlots;
+    const uint32_t* slots;
+    const uint8_t* arena;
+    const uint8_t* slotRecords;
+    uint8_t* ftOut;           // [nSlots][1024]
+    uint8_t* stagedRecords;   // [nSlots][32] contiguous copy of the slots' records (input of the bucket sort)
 };
 
 struct SortParams {
@@ -46,6 +75,8 @@ struct MlpParams {
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
+hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();
 
 }  // namespace spx

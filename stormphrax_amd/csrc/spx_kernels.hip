@@ -68,12 +68,277 @@ __device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
     return uint32_t(max(p, 0));                  // packus: negatives saturate to 0; p <= 127 always
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared wave-level building blocks (one wavefront = one board, lane = square).
+// ---------------------------------------------------------------------------------------------------------------------
+struct LaneBoard {
+    uint64_t occ, kingsBb, whiteBb, pawnsBb;  // wave-uniform bitboards
+    int piece;                                // this lane's piece (type<<1|colour) or kNoPiece
+    int stm;                                  // side to move, 1 = white
+};
+
+__device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
+    LaneBoard b;
+    b.occ = *reinterpret_cast<const uint64_t*>(rec);
+    b.stm = (rec[24] & 0x80) ? 0 : 1;
+    const bool occupied = (b.occ >> lane) & 1;
+    const uint32_t nibIdx = popc64(b.occ & ((1ull << lane) - 1));
+    b.piece = kNoPiece;
+    if (occupied) {
+        const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
+        b.piece = nibbleToPiece(nib);
+    }
+    const int type = b.piece >> 1;  // 6 for empty
+    b.kingsBb = __ballot(type == 5);
+    b.whiteBb = __ballot(occupied && (b.piece & 1) == 1);
+    b.pawnsBb = __ballot(type == 0);
+    return b;
+}
+
+// Appends one threat row per set bit of this lane's `targets` (victims popped one per wave iteration):
+// attacker = this lane's `piece` on square `lane`, victim piece fetched from the lane that owns the target square.
+// Rows the reference excludes (threatFeatureIndex < 0) are dropped. Returns the new list length (capacity kThreatCap).
+__device__ __forceinline__ uint32_t emitThreatRows(uint32_t* list, uint32_t n, uint64_t targets, int piece,
+                                                   uint32_t lane, int x, int flipColour, const uint32_t* lut) {
+    const int pieceRel = piece ^ flipColour;
+    const int sqRel = int(lane) ^ x;
+    uint64_t pseudoRel = 0;
+    if (targets) {
+        pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
+    }
+    while (__ballot(targets != 0)) {
+        const bool active = targets != 0;
+        const int to = active ? ctz64(targets) : 0;
+        targets &= targets - 1;
+        const int victim = __shfl(piece, to, 64);
+        int32_t row = -1;
+        if (active) {
+            row = threatRow(lut, pieceRel, sqRel, pseudoRel, victim ^ flipColour, to ^ x);
+        }
+        const uint64_t valid = __ballot(row >= 0);
+        const uint32_t slot = n + prefixCount(valid);
+        if (row >= 0 && slot < kThreatCap) {
+            list[slot] = uint32_t(row) * kL1;
+        }
+        n = min(n + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+    }
+    return n;
+}
+
+// Appends one pawn-pair row per set bit of this lane's `partners`; `ownPawns` classifies the partner's side.
+__device__ __forceinline__ uint32_t emitPawnPairRows(uint32_t* list, uint32_t n, uint64_t partners, uint32_t idA,
+                                                     uint64_t ownPawns, int x) {
+    while (__ballot(partners != 0)) {
+        const bool active = partners != 0;
+        const int b = active ? ctz64(partners) : 0;
+        partners &= partners - 1;
+        const bool bEnemy = !((ownPawns >> b) & 1);
+        const uint64_t valid = __ballot(active);
+        const uint32_t slot = n + prefixCount(valid);
+        if (active && slot < kThreatCap) {
+            list[slot] = ppRow(idA, ppId(b ^ x, bEnemy)) * kL1;
+        }
+        n = min(n + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+    }
+    return n;
+}
+
+// this lane's pawn-pair partner set for perspective c (nnue_state.cpp:330-351): own pawns pair with own pawns on
+// higher squares and with every enemy pawn inside kPpMasks; enemy pawns pair with enemy pawns on higher squares
+__device__ __forceinline__ uint64_t pawnPartners(bool isPawn, bool own, uint32_t lane, uint64_t ownPawns,
+                                                 uint64_t theirPawns) {
+    if (!isPawn) {
+        return 0;
+    }
+    const uint64_t above = ~((2ull << lane) - 1);
+    return own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane))) : (theirPawns & above & ppMask(int(lane)));
+}
+
+// Row lists of one perspective of one board (the full-refresh feature set). psqList capacity kPsqCap, thrList kThreatCap.
+__device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
+                                               uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr) {
+    const int piece = b.piece;
+    const bool occupied = piece != kNoPiece;
+    const int type = piece >> 1;
+    const int kingSq = ctz64(__ballot(piece == (10 | c)));
+    const uint64_t ownPawns = b.pawnsBb & (c ? b.whiteBb : ~b.whiteBb);
+    const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
+    const int x = perspXor(c, kingSq);
+    const int flipColour = (c == 0) ? 1 : 0;
+
+    // piece-square rows: one per occupied square (resetPsqAccumulator, nnue_state.cpp:440-449)
+    {
+        const uint32_t slot = prefixCount(b.occ);
+        if (occupied && slot < kPsqCap) {
+            psqList[slot] = psqRow(c, piece, int(lane), kingSq) * (kL1 * 2);
+        }
+    }
+    nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
+
+    // threat rows (addThreatFeatures, nnue_state.cpp:309-328)
+    uint64_t targets = 0;
+    if (occupied && type != 5) {
+        targets = pieceAttacks(piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
+    }
+    nThr = emitThreatRows(thrList, 0, targets, piece, lane, x, flipColour, lut);
+
+    // pawn-pair rows (nnue_state.cpp:330-351)
+    const bool isPawn = type == 0;
+    const bool own = isPawn && (piece & 1) == c;
+    nThr = emitPawnPairRows(thrList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
+                            ppId(int(lane) ^ x, !own), ownPawns, x);
+    __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
+}
+
+// acc = ftBias + sum(piece-square rows) + sum(threat rows), all mod 2^16 per column.
+// acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
+__device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
+                                           const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8]) {
+    {
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(t.ftBias + 8 * lane);
+        const u32x4 b1 = *reinterpret_cast<const u32x4*>(t.ftBias + 512 + 8 * lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = b0[r];
+            acc[4 + r] = b1[r];
+        }
+    }
+    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
+    {
+        uint32_t i = 0;
+        for (; i + 4 <= nPsq; i += 4) {  // 8 x 1 KiB wave loads in flight
+            u32x4 lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqList[i + u]);
+                lo[u] = *reinterpret_cast<const u32x4*>(row);
+                hi[u] = *reinterpret_cast<const u32x4*>(row + 1024);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r] = pkAdd16(acc[r], lo[u][r]);
+                    acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
+                }
+            }
+        }
+        for (; i < nPsq; ++i) {
+            const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqList[i]);
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = pkAdd16(acc[r], lo[r]);
+                acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
+            }
+        }
+    }
+    // Threat rows go to their own accumulator: <= 256 rows x 255 never overflows a 16-bit field, so plain 32-bit
+    // adds (v_add3_u32: two rows per add) are exact and no carry crosses fields. Folded into acc (mod 2^16) below.
+    uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t* thrBase = t.thrW + 16 * lane;
+    {
+        uint32_t i = 0;
+        for (; i + 8 <= nThr; i += 8) {  // 8 x 1 KiB wave loads in flight
+            u32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[u] = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i + u]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
+                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
+                }
+            }
+        }
+        for (; i + 2 <= nThr; i += 2) {
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
+            const u32x4 w1 =
+                *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i + 1]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
+                tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
+            }
+        }
+        if (i < nThr) {
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                tacc[2 * d] += unpackLo(w0[d]);
+                tacc[2 * d + 1] += unpackHi(w0[d]);
+            }
+        }
+    }
+    {
+        // fold in, removing the +128 storage bias: every threat row contributed 128 to every column
+        const uint32_t corr = (nThr * 128u) & 0xFFFFu;
+        const uint32_t corr2 = corr | (corr << 16);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
+        }
+    }
+}
+
+// pairwise activation of one perspective's accumulator -> 8 bytes per lane (columns 8l..8l+7 of the 512 outputs)
+__device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
+    uint32_t outLo = 0, outHi = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int32_t a0 = int16_t(acc[r] & 0xFFFF), a1 = int16_t(acc[r] >> 16);
+        const int32_t b0 = int16_t(acc[4 + r] & 0xFFFF), b1 = int16_t(acc[4 + r] >> 16);
+        const uint32_t v = pairAct(a0, b0) | (pairAct(a1, b1) << 8);
+        if (r < 2) {
+            outLo |= v << (16 * r);
+        } else {
+            outHi |= v << (16 * (r - 2));
+        }
+    }
+    u32x2 o;
+    o[0] = outLo;
+    o[1] = outHi;
+    return o;
+}
+
+// Accumulator arena slot: [colour 0: i16[1024]][colour 1: i16[1024]] = 4 KiB, natural column order. Lane l owns
+// columns {8l..8l+7} (16 B at 16l) and {512+8l..} (16 B at 1024+16l) - the same split as a piece-square row.
+__device__ __forceinline__ void storeAcc(uint8_t* arena, uint32_t slot, int c, uint32_t lane, const uint32_t (&acc)[8]) {
+    uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
+    u32x4 lo, hi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        lo[r] = acc[r];
+        hi[r] = acc[4 + r];
+    }
+    *reinterpret_cast<u32x4*>(base) = lo;
+    *reinterpret_cast<u32x4*>(base + 1024) = hi;
+}
+__device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int c, uint32_t lane, uint32_t (&acc)[8]) {
+    const uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(base);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(base + 1024);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc[r] = lo[r];
+        acc[4 + r] = hi[r];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Feature transformer kernel.
-// grid-stride over perspectives q = 2*position + colour; `order` (optional) is a permutation of perspective ids
-// (king-bucket sorted for L2 locality) - results are written by q, so any order gives identical output.
+// Feature transformer kernel (full refresh).
+// One wavefront per (position, perspective): grid-stride over perspectives q = 2*position + colour; `order` (optional)
+// is a permutation of perspective ids (king-bucket sorted for L2 locality) - results are written by q, so any order
+// gives identical output. Two output modes:
+//   ftOut   != nullptr: pairwise-activated u8[512] halves (stm first) for the MLP kernel     == evaluateOnce
+//   accOut  != nullptr: raw i16 accumulators into arena slot slots[position] + the record     == NnueState::reset
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
@@ -81,7 +346,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
 
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
-        sLut[i] = p.lut[i];
+        sLut[i] = p.t.lut[i];
     }
     __syncthreads();
 
@@ -101,231 +366,208 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         const uint32_t posIdx = q >> 1;
         const int c = int(q & 1);
 
-        // ---- decode the packed record: lane = square ----
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
-        const uint64_t occ = *reinterpret_cast<const uint64_t*>(rec);
-        const int stm = (rec[24] & 0x80) ? 0 : 1;
-        const bool occupied = (occ >> lane) & 1;
-        const uint32_t nibIdx = popc64(occ & ((1ull << lane) - 1));
-        int piece = kNoPiece;
-        if (occupied) {
-            const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
-            piece = nibbleToPiece(nib);
-        }
-        const int type = piece >> 1;  // 6 for empty
-        const int colour = piece & 1;
-
-        const uint64_t kingsBb = __ballot(type == 5);
-        const uint64_t ownKingBb = __ballot(piece == (10 | c));
-        const int kingSq = ctz64(ownKingBb);
-        const uint64_t whiteBb = __ballot(occupied && colour == 1);
-        const uint64_t pawnsBb = __ballot(type == 0);
-        const uint64_t ownPawns = pawnsBb & (c ? whiteBb : ~whiteBb);
-        const uint64_t theirPawns = pawnsBb & ~ownPawns;
-
-        const int x = perspXor(c, kingSq);
-        const int flipColour = (c == 0) ? 1 : 0;
-
-        // ---- piece-square rows: one per occupied square (resetPsqAccumulator) ----
-        {
-            const uint32_t slot = prefixCount(occ);
-            if (occupied && slot < kPsqCap) {
-                sPsq[wave][slot] = psqRow(c, piece, int(lane), kingSq) * (kL1 * 2);
-            }
-        }
-        const uint32_t nPsq = min(uint32_t(popc64(occ)), uint32_t(kPsqCap));
-
-        // ---- threat rows (addThreatFeatures): attacker = this lane's piece, victims popped one per iteration ----
-        uint32_t nThr = 0;
-        {
-#if defined(SPX_ABLATE_FIXED_LISTS)
-            const bool attacker = false;
-#else
-            const bool attacker = occupied && type != 5;
-#endif
-            uint64_t targets = 0, pseudoRel = 0;
-            const int pieceRel = piece ^ flipColour;
-            const int sqRel = int(lane) ^ x;
-            if (attacker) {
-                targets = pieceAttacks(piece, int(lane), occ) & occ & ~kingsBb;
-                pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
-            }
-            while (__ballot(targets != 0)) {
-                const bool active = targets != 0;
-                const int to = active ? ctz64(targets) : 0;
-                targets &= targets - 1;
-                const int victim = __shfl(piece, to, 64);
-                int32_t row = -1;
-                if (active) {
-                    row = threatRow(sLut, pieceRel, sqRel, pseudoRel, victim ^ flipColour, to ^ x);
-                }
-                const uint64_t valid = __ballot(row >= 0);
-                const uint32_t slot = nThr + prefixCount(valid);
-                if (row >= 0 && slot < kThreatCap) {
-                    sThr[wave][slot] = uint32_t(row) * kL1;
-                }
-                nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
-            }
-        }
-
-        // ---- pawn-pair rows (nnue_state.cpp:330-351) ----
-        {
-#if defined(SPX_ABLATE_FIXED_LISTS)
-            const bool isPawn = false;
-#else
-            const bool isPawn = type == 0;
-#endif
-            const bool own = isPawn && colour == c;
-            uint64_t partners = 0;
-            if (isPawn) {
-                const uint64_t above = ~((2ull << lane) - 1);
-                partners = own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane)))
-                               : (theirPawns & above & ppMask(int(lane)));
-            }
-            const uint32_t idA = ppId(int(lane) ^ x, !own);
-            while (__ballot(partners != 0)) {
-                const bool active = partners != 0;
-                const int b = active ? ctz64(partners) : 0;
-                partners &= partners - 1;
-                const bool bEnemy = !((ownPawns >> b) & 1);
-                const uint64_t valid = __ballot(active);
-                const uint32_t slot = nThr + prefixCount(valid);
-                if (active && slot < kThreatCap) {
-                    sThr[wave][slot] = ppRow(idA, ppId(b ^ x, bEnemy)) * kL1;
-                }
-                nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
-            }
-        }
-
-        __builtin_amdgcn_wave_barrier();  // row lists are produced and consumed by the same wave: LDS order suffices
-#if defined(SPX_ABLATE_FIXED_LISTS)
-        // ablation: ignore the extracted lists, gather pseudo-random rows of typical counts (accumulate-only cost)
-        {
-            uint32_t h = q * 2654435761u;
-            if (lane < 24) sPsq[wave][lane] = ((h + lane * 40503u) % kPsqRows) * (kL1 * 2);
-            if (lane < 41) sThr[wave][lane] = ((h * 31u + lane * 9973u) % kThreatRows) * kL1;
-        }
-        const uint32_t nPsqUse = 24, nThrUse = 41;
-#elif defined(SPX_ABLATE_NO_ACC)
-        const uint32_t nPsqUse = nPsq ? 1 : 0, nThrUse = nThr ? 1 : 0;  // extraction-only cost
-#else
-        const uint32_t nPsqUse = nPsq, nThrUse = nThr;
-#endif
-
-        // ---- accumulate: bias + piece-square rows (i16) + threat rows (u8 biased by +128, widened) ----
-        // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1
+        const LaneBoard board = decodeBoard(rec, lane);
+        uint32_t nPsq, nThr;
+        buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
         uint32_t acc[8];
-        {
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(p.ftBias + 8 * lane);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(p.ftBias + 512 + 8 * lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r] = b0[r];
-                acc[4 + r] = b1[r];
+        gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+
+        if (p.accOut) {
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
+            storeAcc(p.accOut, slot, c, lane, acc);
+            if (c == 0 && lane < 8) {  // the record travels with the slot (parent of later incremental updates)
+                reinterpret_cast<uint32_t*>(p.slotRecords + size_t(slot) * 32)[lane] =
+                    reinterpret_cast<const uint32_t*>(rec)[lane];
             }
+        } else {
+            const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
+            *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
         }
-        const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(p.psqW) + 16 * lane;
-        {
-            uint32_t i = 0;
-            for (; i + 4 <= nPsqUse; i += 4) {  // 8 x 1 KiB wave loads in flight
-                u32x4 lo[4], hi[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsq[wave][i + u]);
-                    lo[u] = *reinterpret_cast<const u32x4*>(row);
-                    hi[u] = *reinterpret_cast<const u32x4*>(row + 1024);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Incremental update kernel: child accumulator = parent accumulator + added rows - removed rows.
+// One wavefront per (parent slot -> child slot) record, both perspectives. Replaces, for a batch of independent
+// records, what the reference does per ply in ensureUpToDate (nnue_state.cpp:636-697): updatePsq (:34-87),
+// applyThreatUpdates (:356-394) with generatePpRows (:163-307), and the refreshes (:458-536).
+//
+// The reference captures deltas on the HOST while the move is made (BoardObserver, nnue_state.h:118-186). Here the
+// wave derives the same delta on the DEVICE from the parent and child boards (lane = square): changed squares give the
+// piece-square rows; for threats each lane compares its parent and child target sets and only emits the symmetric
+// difference (kept pairs: same attacker, same victim, still attacking); pawn pairs likewise. Accumulators are sums of
+// rows mod 2^16, so any exact delta yields bit-identical results to the reference's event-driven one
+// (the invariant Stormphrax asserts itself, datagen.cpp:262). A perspective whose king changed piece-square bucket or
+// crossed the d/e mirror line (psq.h:264-283, nnue_state.h:118-128) is rebuilt from scratch, as the reference does.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_update_kernel(UpdateParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // full rebuild: threat rows; incremental: rows to ADD
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
+    __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];  // incremental: threat rows to SUBTRACT
+    __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];   // incremental: psq rows to subtract / add (<= 4 each)
+
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
+
+    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < p.nRecords; it += wavesTotal) {
+        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
+        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
+        const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
+        const LaneBoard pb = decodeBoard(parentRec, lane);
+        const LaneBoard cb = decodeBoard(childRec, lane);
+
+        const bool changedSq = pb.piece != cb.piece;
+        const uint64_t changed = __ballot(changedSq);
+        // attack sets are perspective independent: compute once per board
+        uint64_t tP = 0, tC = 0;
+        if (pb.piece != kNoPiece && (pb.piece >> 1) != 5) {
+            tP = pieceAttacks(pb.piece, int(lane), pb.occ) & pb.occ & ~pb.kingsBb;
+        }
+        if (cb.piece != kNoPiece && (cb.piece >> 1) != 5) {
+            tC = pieceAttacks(cb.piece, int(lane), cb.occ) & cb.occ & ~cb.kingsBb;
+        }
+        // pairs kept: attacker unchanged, victim unchanged, attacked before and after
+        const uint64_t keep = changedSq ? 0 : (tP & tC & ~changed);
+        const uint64_t subTargets = tP & ~keep, addTargets = tC & ~keep;
+
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const int kingP = ctz64(__ballot(pb.piece == (10 | c)));
+            const int kingC = ctz64(__ballot(cb.piece == (10 | c)));
+            const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
+            const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4);
+            uint32_t acc[8];
+            if (refresh) {
+                uint32_t nPsq, nThr;
+                buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
+                gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+            } else {
+                const int x = perspXor(c, kingC);  // bucket and mirror half are those of the parent too
+                const int flipColour = (c == 0) ? 1 : 0;
+                // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
+                const uint64_t subMask = __ballot(changedSq && pb.piece != kNoPiece);
+                const uint64_t addMask = __ballot(changedSq && cb.piece != kNoPiece);
+                const uint32_t nPsqSub = min(uint32_t(popc64(subMask)), 8u), nPsqAdd = min(uint32_t(popc64(addMask)), 8u);
+                if (changedSq && pb.piece != kNoPiece) {
+                    const uint32_t slot = prefixCount(subMask);
+                    if (slot < 8) sPsqDelta[wave][0][slot] = psqRow(c, pb.piece, int(lane), kingC) * (kL1 * 2);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                if (changedSq && cb.piece != kNoPiece) {
+                    const uint32_t slot = prefixCount(addMask);
+                    if (slot < 8) sPsqDelta[wave][1][slot] = psqRow(c, cb.piece, int(lane), kingC) * (kL1 * 2);
+                }
+                // ---- threat delta ----
+                uint32_t nSub = emitThreatRows(sSub[wave], 0, subTargets, pb.piece, lane, x, flipColour, sLut);
+                uint32_t nAdd = emitThreatRows(sThr[wave], 0, addTargets, cb.piece, lane, x, flipColour, sLut);
+                // ---- pawn-pair delta (generatePpRows): pairs that exist on one board only ----
+                {
+                    const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
+                    const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
+                    const bool pawnP = (pb.piece >> 1) == 0, pawnC = (cb.piece >> 1) == 0;
+                    const bool ownSideP = pawnP && (pb.piece & 1) == c, ownSideC = pawnC && (cb.piece & 1) == c;
+                    const uint64_t partP = pawnPartners(pawnP, ownSideP, lane, ownP, theirP);
+                    const uint64_t partC = pawnPartners(pawnC, ownSideC, lane, ownC, theirC);
+                    // a pair survives iff both pawns are unchanged (same square, same colour) and it is in both sets
+                    const uint64_t unchangedPawns = pb.pawnsBb & cb.pawnsBb & ~changed;
+                    const uint64_t kept = (pawnP && pawnC && !changedSq) ? (partP & partC & unchangedPawns) : 0;
+                    nSub = emitPawnPairRows(sSub[wave], nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
+                    nAdd = emitPawnPairRows(sThr[wave], nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
+                }
+                __builtin_amdgcn_wave_barrier();
+
+                // ---- apply: acc = parent - subs + adds (wrapping i16; threat sums kept in 32-bit fields) ----
+                loadAcc(p.arena, parentSlot, c, lane, acc);
+                const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(p.t.psqW) + 16 * lane;
+                for (uint32_t i = 0; i < nPsqSub; ++i) {
+                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsqDelta[wave][0][i]);
+                    const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+                    const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        acc[r] = pkAdd16(acc[r], lo[u][r]);
-                        acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
+                        acc[r] = pkSub16(acc[r], lo[r]);
+                        acc[4 + r] = pkSub16(acc[4 + r], hi[r]);
                     }
                 }
-            }
-            for (; i < nPsqUse; ++i) {
-                const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsq[wave][i]);
-                const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-                const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+                for (uint32_t i = 0; i < nPsqAdd; ++i) {
+                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsqDelta[wave][1][i]);
+                    const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+                    const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r] = pkAdd16(acc[r], lo[r]);
-                    acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] = pkAdd16(acc[r], lo[r]);
+                        acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
+                    }
                 }
-            }
-        }
-        // Threat rows go to their own accumulator: <= 256 rows x 255 never overflows a 16-bit field, so plain 32-bit
-        // adds (v_add3_u32: two rows per add) are exact and no carry crosses fields. Folded into acc (mod 2^16) below.
-        uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const uint8_t* thrBase = p.thrW + 16 * lane;
-        {
-            uint32_t i = 0;
-            for (; i + 8 <= nThrUse; i += 8) {  // 8 x 1 KiB wave loads in flight
-                u32x4 w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    w[u] = *reinterpret_cast<const u32x4*>(thrBase +
-                                                           __builtin_amdgcn_readfirstlane(sThr[wave][i + u]));
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
+                const uint8_t* thrBase = p.t.thrW + 16 * lane;
+                uint32_t tadd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t i = 0; i < nAdd; ++i) {
+                    const u32x4 w =
+                        *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
-                        tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
+                        tadd[2 * d] += unpackLo(w[d]);
+                        tadd[2 * d + 1] += unpackHi(w[d]);
+                    }
+                }
+                for (uint32_t i = 0; i < nSub; ++i) {
+                    const u32x4 w =
+                        *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sSub[wave][i]));
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        tsub[2 * d] += unpackLo(w[d]);
+                        tsub[2 * d + 1] += unpackHi(w[d]);
+                    }
+                }
+                {
+                    // +128 storage bias: (nAdd - nSub) * 128 per column, mod 2^16
+                    const uint32_t corr = ((nAdd - nSub) * 128u) & 0xFFFFu;
+                    const uint32_t corr2 = corr | (corr << 16);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        acc[r] = pkSub16(pkSub16(pkAdd16(acc[r], tadd[r]), tsub[r]), corr2);
                     }
                 }
             }
-            for (; i + 2 <= nThrUse; i += 2) {
-                const u32x4 w0 =
-                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
-                const u32x4 w1 =
-                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i + 1]));
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
-                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
-                }
-            }
-            if (i < nThrUse) {
-                const u32x4 w0 =
-                    *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    tacc[2 * d] += unpackLo(w0[d]);
-                    tacc[2 * d + 1] += unpackHi(w0[d]);
-                }
-            }
+            storeAcc(p.arena, childSlot, c, lane, acc);
         }
-        {
-            // fold in, removing the +128 storage bias: every threat row contributed 128 to every column
-            const uint32_t corr = (nThrUse * 128u) & 0xFFFFu;
-            const uint32_t corr2 = corr | (corr << 16);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
-            }
+        if (lane < 8) {
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] =
+                reinterpret_cast<const uint32_t*>(childRec)[lane];
         }
+    }
+}
 
-        // ---- pairwise activation -> 8 bytes per lane ----
-        uint32_t outLo = 0, outHi = 0;
+// ---------------------------------------------------------------------------------------------------------------------
+// Activation from arena slots: evaluateNetwork's front half (nnue_state.cpp:396-438 + multilayer.h:92-152) for
+// already-materialised accumulators. One wavefront per slot; also stages the slot's record for the MLP's bucket sort.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spx_slot_act_kernel(SlotActParams p) {
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i = blockIdx.x * 4 + wave; i < p.nSlots; i += gridDim.x * 4) {
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[i]);
+        const uint8_t* rec = p.slotRecords + size_t(slot) * 32;
+        const int stm = (rec[24] & 0x80) ? 0 : 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int32_t a0 = int16_t(acc[r] & 0xFFFF), a1 = int16_t(acc[r] >> 16);
-            const int32_t b0 = int16_t(acc[4 + r] & 0xFFFF), b1 = int16_t(acc[4 + r] >> 16);
-            const uint32_t v = pairAct(a0, b0) | (pairAct(a1, b1) << 8);
-            if (r < 2) {
-                outLo |= v << (16 * r);
-            } else {
-                outHi |= v << (16 * (r - 2));
-            }
+        for (int c = 0; c < 2; ++c) {
+            uint32_t acc[8];
+            loadAcc(p.arena, slot, c, lane, acc);
+            const uint32_t half = (c == stm) ? 0u : 1u;
+            *reinterpret_cast<u32x2*>(p.ftOut + size_t(i) * kL1 + half * kPairs + 8 * lane) = activate(acc);
         }
-        const uint32_t half = (c == stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
-        u32x2 o;
-        o[0] = outLo;
-        o[1] = outHi;
-        *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = o;
+        if (lane < 8) {
+            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(i) * 32)[lane] =
+                reinterpret_cast<const uint32_t*>(rec)[lane];
+        }
     }
 }
 
@@ -537,6 +779,16 @@ __global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
     hipLaunchKernelGGL(spx_ft_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_update_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_slot_act_kernel, dim3(gridBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -89,10 +89,36 @@ class NnueState:
         check(_lib.load().spx_profile_begin(self._h, max_calls))
 
     def profile_end(self):
-        """-> (ft_kernel_ms_total, mlp_kernel_ms_total, calls) since profile_begin."""
-        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
-        check(_lib.load().spx_profile_end(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return a.value, b.value, c.value
+        """-> (sort_ms_total, ft_kernel_ms_total, mlp_kernel_ms_total, calls) since profile_begin."""
+        s, a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
+        check(_lib.load().spx_profile_end(self._h, ctypes.byref(s), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return s.value, a.value, b.value, c.value
+
+    # ---- incremental path: accumulator arena (mirrors NnueState::reset / push+applyMove / evaluate) ----
+    def reserve_slots(self, n_slots):
+        check(_lib.load().spx_acc_reserve(self._h, n_slots))
+
+    def reset(self, positions, slots):
+        """NnueState::reset for each (position, slot): full refresh into the arena."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        assert pos.shape[0] == slots.shape[0]
+        check(_lib.load().spx_acc_refresh(self._h, pos.ctypes.data, slots.ctypes.data, pos.shape[0]))
+
+    def update(self, parent_slots, child_slots, child_positions):
+        """One ply of incremental updates for independent (parent slot -> child slot) pairs."""
+        pos = np.ascontiguousarray(child_positions, dtype=PACKED_DTYPE)
+        ps = np.ascontiguousarray(parent_slots, dtype=np.uint32)
+        cs = np.ascontiguousarray(child_slots, dtype=np.uint32)
+        assert pos.shape[0] == ps.shape[0] == cs.shape[0]
+        check(_lib.load().spx_acc_update(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data, pos.shape[0]))
+
+    def evaluate(self, slots):
+        """NnueState::evaluate on materialised slots -> int32 raw evals (side to move of each slot's position)."""
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.empty(slots.shape[0], dtype=np.int32)
+        check(_lib.load().spx_acc_eval(self._h, slots.ctypes.data, slots.shape[0], out.ctypes.data))
+        return out
 
     def debug_ft(self, n):
         out = np.empty((n, 1024), dtype=np.uint8)
@@ -134,6 +160,14 @@ def positions_to_mailboxes(positions):
         check(lib.spx_pos_to_mailbox(pos[i : i + 1].ctypes.data, mail[i].ctypes.data, ctypes.byref(s)))
         stm[i] = s.value
     return mail, stm
+
+
+def apply_uci(rec, uci):
+    """Position::applyMove on a packed record (legal moves only)."""
+    rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)
+    out = np.zeros(1, dtype=PACKED_DTYPE)
+    check(_lib.load().spx_pos_apply_uci(rec.ctypes.data, uci.encode(), out.ctypes.data))
+    return out[0]
 
 
 def random_positions(count, seed=1, min_ply=8, max_ply=120, dfrc_every=4):

@@ -1,0 +1,75 @@
+"""Recorded make/unmake traces -> level-synchronous batches for the accumulator arena (BASELINE config 3).
+
+Trace format (tests/golden/trace_*.txt, written by the compiled reference through oracle/ref_probe.cpp):
+    ROOT <fen>          the position NnueState::reset was called on
+    PUSH <uci>          thread.applyMove: NnueState::push + Position::applyMove (src/thread.cpp:46-67)
+    POP                 the guard's NnueState::pop (src/thread.h:116-122)
+    EVAL <inc> <once>   NnueState::evaluate at the current node (lazy multi-ply update, nnue_state.cpp:636-697) and
+                        evaluateOnce of the same position, as computed by the reference
+
+The reference walks the tree depth-first with ONE accumulator stack. On the GPU every visited node gets an arena slot
+and the tree is processed level by level: all (parent -> child) updates of depth d form one spx_acc_update batch.
+"""
+import numpy as np
+
+from . import nnue
+
+
+class Trace:
+    def __init__(self, path):
+        self.root_fen = None
+        self.parent = [-1]          # node -> parent node (node 0 = root)
+        self.depth = [0]
+        self.moves = [None]
+        self.evals = []             # (node, incremental value, evaluateOnce value) as recorded by the reference
+        stack = [0]
+        with open(path) as f:
+            for line in f:
+                t = line.split()
+                if not t or t[0].startswith("#"):
+                    continue
+                if t[0] == "ROOT":
+                    self.root_fen = " ".join(t[1:])
+                elif t[0] == "PUSH":
+                    self.parent.append(stack[-1])
+                    self.depth.append(len(stack))
+                    self.moves.append(t[1])
+                    stack.append(len(self.parent) - 1)
+                elif t[0] == "POP":
+                    stack.pop()
+                elif t[0] == "EVAL":
+                    self.evals.append((stack[-1], int(t[1]), int(t[2])))
+        self.n_nodes = len(self.parent)
+
+    def positions(self):
+        """Packed record of every node, by replaying the moves with the host chess core."""
+        pos = np.zeros(self.n_nodes, dtype=nnue.PACKED_DTYPE)
+        pos[0] = nnue.positions_from_fens([self.root_fen])[0]
+        for node in range(1, self.n_nodes):  # nodes are numbered in visiting order: parents come first
+            pos[node] = nnue.apply_uci(pos[self.parent[node]], self.moves[node])
+        return pos
+
+    def levels(self):
+        """[(parent_nodes, child_nodes)] per depth 1, 2, ... - each a batch of independent updates."""
+        depth = np.asarray(self.depth)
+        parent = np.asarray(self.parent)
+        out = []
+        for d in range(1, int(depth.max()) + 1):
+            nodes = np.nonzero(depth == d)[0].astype(np.uint32)
+            out.append((parent[nodes].astype(np.uint32), nodes))
+        return out
+
+
+def replay(state, trace, positions=None):
+    """Materialise every node of `trace` in the arena (slot = node id) and evaluate the recorded EVAL nodes.
+    Returns (gpu values, reference incremental values, reference evaluateOnce values)."""
+    pos = trace.positions() if positions is None else positions
+    state.reserve_slots(trace.n_nodes)
+    state.reset(pos[:1], np.zeros(1, dtype=np.uint32))
+    for parents, children in trace.levels():
+        for lo in range(0, len(children), state.max_batch):
+            hi = lo + state.max_batch
+            state.update(parents[lo:hi], children[lo:hi], pos[children[lo:hi]])
+    nodes = np.array([e[0] for e in trace.evals], dtype=np.uint32)
+    got = np.concatenate([state.evaluate(nodes[lo:lo + state.max_batch]) for lo in range(0, len(nodes), state.max_batch)])
+    return got, np.array([e[1] for e in trace.evals], dtype=np.int32), np.array([e[2] for e in trace.evals], dtype=np.int32)
