@@ -444,7 +444,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
             const int kingP = ctz64(__ballot(pb.piece == (10 | c)));
             const int kingC = ctz64(__ballot(cb.piece == (10 | c)));
             const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
-            const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4);
+            // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the caller
+            // paired unrelated boards) and is rebuilt from scratch rather than overflowing the small delta lists
+            const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) ||
+                                 popc64(changed) > 4;
             uint32_t acc[8];
             if (refresh) {
                 uint32_t nPsq, nThr;

@@ -60,7 +60,10 @@ class Network:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _lib.load().spx_net_free(h)
+            try:
+                _lib.load().spx_net_free(h)
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
 
 
 class NnueState:
@@ -128,7 +131,10 @@ class NnueState:
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _lib.load().spx_ctx_destroy(h)
+            try:
+                _lib.load().spx_ctx_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
 
     def __del__(self):
         self.close()

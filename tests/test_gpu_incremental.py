@@ -90,3 +90,20 @@ def test_incremental_equals_full_refresh_over_long_games(sp, states):
         cur[idx] = child
         pos[idx] = nxt_pos[idx]
     assert ply > 100
+
+
+def test_update_between_unrelated_boards_falls_back_to_rebuild(sp, states):
+    """spx_acc_update is exact for ANY (parent, child) pair: boards more than one move apart are rebuilt from scratch
+    instead of overflowing the delta lists (the reference would assert: 'Materialising a piece from nowhere?')."""
+    st = states("wild")
+    a = sp.random_positions(512, seed=1)
+    b = sp.random_positions(512, seed=2)
+    st.reserve_slots(1024)
+    st.reset(a, np.arange(512, dtype=np.uint32))
+    st.update(np.arange(512, dtype=np.uint32), np.arange(512, 1024, dtype=np.uint32), b)
+    assert np.array_equal(st.evaluate(np.arange(512, 1024, dtype=np.uint32)), st.evaluate_once(b))
+    # null move (no square changes, side to move flips): accumulators are copied, perspective order swaps
+    flipped = a.copy()
+    flipped["stm_ep"] ^= 0x80
+    st.update(np.arange(512, dtype=np.uint32), np.arange(512, 1024, dtype=np.uint32), flipped)
+    assert np.array_equal(st.evaluate(np.arange(512, 1024, dtype=np.uint32)), st.evaluate_once(flipped))

@@ -24,8 +24,8 @@ import glob, sqlite3
 out = "$OUT"
 for f in glob.glob(out + "/stats/*.db"):
     c = sqlite3.connect(f).cursor()
-    print("== kernel stats (rocprofv3 --kernel-trace --stats): name, calls, total_us, avg_us, pct")
-    for r in c.execute("select name, total_calls, total_duration/1000.0, average/1000.0, percentage from top_kernels"):
+    print("== kernel stats (rocprofv3 --kernel-trace --stats): name, calls, total, average, pct of GPU time")
+    for r in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         print("   %-48s calls %5d total %10.1f us avg %9.2f us  %5.1f%%" % (r[0][:48], r[1], r[2], r[3], r[4]))
     print("== per-kernel launch config")
     for r in c.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, count(*) from kernels group by name, grid_x"):
