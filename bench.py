@@ -66,6 +66,20 @@ def cpu_baseline(sp, positions, blob, seconds):
             "sample": f"scalar C restatement (oracle/spx_oracle.c) over the first {len(sample)} positions, {dt:.1f} s, 1 thread"}
 
 
+def pmc_traffic(args):
+    """HBM/fabric bytes per launch of the FT kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/ft_traffic_pmc.json; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE).
+    bench.py cannot collect counters on itself; null when the run's configuration differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "ft_traffic_pmc.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    if rec.get("batch") != args.batch or rec.get("preset") != args.preset:
+        return None
+    return rec["traffic_bytes_per_launch"] / 1e9 / rec["ft_kernel_ms"] * 1e3  # GB/s, comparable with `achieved`
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,20 +95,15 @@ def main():
 
     import stormphrax_amd as sp
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from stormphrax_amd.distributed import Group, env_rank
+
+    rank, local_rank, world = env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    group = Group(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL over xGMI; no-op for 1 GPU
 
     # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     blob = sp.synthetic_net_bytes(args.preset)
@@ -111,27 +120,20 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize()
     state.profile_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
 
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # checksum of checksums: every rank's shard went through the same code path
-        chk = d_out.to(torch.int64).sum().reshape(1)
-        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    elapsed = group.max_float(elapsed)  # slowest rank defines the step time
+    checksum = group.sum_int(int(d_out.to(torch.int64).sum().item()))  # checksum of checksums over all shards
 
     if rank == 0:
         psq_rows, thr_rows = sp.count_rows(positions)
@@ -158,6 +160,7 @@ def main():
                 "batch_per_gpu": args.batch,
                 "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path",
+                "checksum": checksum,
                 "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
             },
             "roofline": {
@@ -167,7 +170,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_position": algo_bytes / args.batch,
             },
@@ -175,9 +178,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sp, positions, blob, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
