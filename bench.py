@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="positions per GPU per step")
     ap.add_argument("--preset", default="tame", choices=["tame", "wild", "extreme"])
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="diagnostic: tile this many distinct positions to fill the batch (cache-locality ablation)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -110,6 +112,8 @@ def main():
     net = sp.Network(blob)
     state = sp.NnueState(net, device=local_rank, max_batch=args.batch)
     positions = sp.random_positions(args.batch, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
+    if args.distinct:
+        positions = np.resize(positions[: args.distinct], args.batch)
     d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
     d_out = torch.empty(args.batch, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream()
