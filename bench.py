@@ -80,6 +80,94 @@ def pmc_traffic(args):
     return rec["traffic_bytes_per_launch"] / 1e9 / rec["ft_kernel_ms"] * 1e3  # GB/s, comparable with `achieved`
 
 
+def delta_rows_sample(sp, parents, children, sample=256):
+    """Mean (psq, threat) rows added+removed per position update (both perspectives), from exact set differences of the
+    host-emulated feature lists on a sample - the algorithmic bytes of the incremental kernel."""
+    psq = thr = 0
+    n = min(sample, len(parents))
+    for i in range(n):
+        for c in (0, 1):
+            p0, t0 = sp.debug_features(parents[i], c)
+            p1, t1 = sp.debug_features(children[i], c)
+            psq += len(set(p0.tolist()) ^ set(p1.tolist()))
+            thr += len(set(t0.tolist()) ^ set(t1.tolist()))
+    return psq / n, thr / n
+
+
+def incremental_bench(args, sp, torch, group, rank, local_rank, world):
+    """--mode incremental: G = --batch concurrent games per GPU; a step = one ply for every game (one spx_acc_update
+    batch of G independent parent->child records + one spx_acc_eval batch). Boards come from seeded random playouts
+    (32-ply chains walked forward then backward: an unmake is a one-move delta too)."""
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    G, L = args.batch, 32
+    blob = sp.synthetic_net_bytes(args.preset)
+    net = sp.Network(blob)
+    state = sp.NnueState(net, device=local_rank, max_batch=G)
+    chain = [sp.random_positions(G, seed=777 + rank, min_ply=6, max_ply=60, dfrc_every=4)]
+    for ply in range(L - 1):
+        nxt, _ = sp.random_successors(chain[-1], seed=1000 + ply + 97 * rank)
+        chain.append(nxt)
+    d_boards = [torch.from_numpy(c.view(np.uint8).reshape(-1, 32)).cuda() for c in chain]
+    state.reserve_slots(2 * G)
+    slots = [torch.arange(G, dtype=torch.int32, device="cuda"), torch.arange(G, 2 * G, dtype=torch.int32, device="cuda")]
+    d_out = torch.empty(G, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    h = state._h
+    _lib.check(lib.spx_acc_refresh_device(h, d_boards[0].data_ptr(), slots[0].data_ptr(), G, stream))
+
+    def board_index(step):  # 0,1,..,L-1,L-2,..,0,1,..
+        k = step % (2 * L - 2)
+        return k if k < L else 2 * L - 2 - k
+
+    step_no = [0]
+
+    def step():
+        s = step_no[0]
+        cur, nxt = slots[s & 1], slots[(s + 1) & 1]
+        _lib.check(lib.spx_acc_update_device(h, cur.data_ptr(), nxt.data_ptr(), d_boards[board_index(s + 1)].data_ptr(), G, stream))
+        _lib.check(lib.spx_acc_eval_device(h, nxt.data_ptr(), G, d_out.data_ptr(), stream))
+        step_no[0] = s + 1
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    group.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    group.barrier()
+    torch.cuda.synchronize()
+    elapsed = group.max_float(time.perf_counter() - t0)
+    # parity inside the bench: the incrementally maintained evals equal a full refresh of the final boards
+    full = torch.empty(G, dtype=torch.int32, device="cuda")
+    state.evaluate_once_device(d_boards[board_index(step_no[0])].data_ptr(), G, full.data_ptr(), stream)
+    torch.cuda.synchronize()
+    exact = group.sum_int(int(torch.equal(full, d_out))) == world
+    if rank == 0:
+        psq_d, thr_d = delta_rows_sample(sp, chain[3], chain[4])
+        algo = 2048 * psq_d + 1024 * thr_d + 2 * 4096 + 72
+        value = world * G * args.steps / elapsed
+        print(json.dumps({
+            "metric": "nnue_incremental_updates_per_sec", "value": value, "unit": "updates+evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i16 accumulate / i8 MFMA L1 / i32 tail", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3] shape: per step one ply of incremental accumulator updates "
+                                   "(device-derived add/sub deltas) + evaluation for every one of the concurrent games",
+                       "games_per_gpu": G, "bit_exact_vs_full_refresh": bool(exact),
+                       "mean_delta_rows_per_update": {"psq": psq_d, "threat": thr_d}},
+            "roofline": {"kernel": "spx_update_kernel + spx_slot_act_kernel + spx_mlp_kernel", "bound": "hbm",
+                         "achieved": algo * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo * value / world / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_update": algo},
+        }), flush=True)
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +175,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="positions per GPU per step")
     ap.add_argument("--preset", default="tame", choices=["tame", "wild", "extreme"])
+    ap.add_argument("--mode", default="full", choices=["full", "incremental"],
+                    help="full = BASELINE configs[1] (headline); incremental = configs[2]/[3] shape: one ply of "
+                         "parent->child accumulator updates + evaluation for --batch concurrent games per step")
     ap.add_argument("--distinct", type=int, default=0,
                     help="diagnostic: tile this many distinct positions to fill the batch (cache-locality ablation)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -106,6 +197,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
     torch.cuda.set_device(local_rank)
     group = Group(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL over xGMI; no-op for 1 GPU
+
+    if args.mode == "incremental":
+        return incremental_bench(args, sp, torch, group, rank, local_rank, world)
 
     # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     blob = sp.synthetic_net_bytes(args.preset)

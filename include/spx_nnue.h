@@ -85,7 +85,8 @@ void spx_ctx_destroy(spx_ctx* ctx);
  * Full-refresh evaluation == n x NnueState::evaluateOnce(pos, pos.stm()) (src/eval/nnue_state.cpp:612-634): raw
  * network output in centipawn-like units from the side to move's point of view, BEFORE eval::adjustStatic's
  * contempt/clamp (src/eval/eval.cpp:25-28).
- *   spx_eval_full        host buffers in/out, synchronous (H2D, kernels, D2H on the context's stream)
+ *   spx_eval_full        host buffers in/out, synchronous (H2D, kernels, D2H on the context's stream); any n
+ *                        (processed in chunks of max_batch)
  *   spx_eval_full_device device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = the context's own
  *                        stream) without synchronising; n <= max_batch
  * ---------------------------------------------------------------------------------------------------------------- */
@@ -142,6 +143,9 @@ int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm)
  * legality is checked against the generated legal moves (src/position.cpp:109-197, Position::moveFromUci). */
 int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out);
 int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
+/* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
+ * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */
+int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);
 uint64_t spx_perft(const char* fen, int depth);
 
 /* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):

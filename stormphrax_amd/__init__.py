@@ -15,5 +15,6 @@ from .nnue import (  # noqa: F401
     positions_from_fens,
     positions_to_mailboxes,
     random_positions,
+    random_successors,
     synthetic_net_bytes,
 )

@@ -634,17 +634,18 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
         setError("spx_eval_full: null argument");
         return SPX_ERR_INVALID_ARG;
     }
-    if (n > ctx->maxBatch) {
-        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->maxBatch));
-        return SPX_ERR_CAPACITY;
-    }
     if (n == 0) return SPX_OK;
     SPX_HIP(hipSetDevice(ctx->device));
-    SPX_HIP(hipMemcpyAsync(ctx->dPositions, positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice, ctx->stream));
-    const int rc = spx_eval_full_device(ctx, ctx->dPositions, n, ctx->dOut, ctx->stream);
-    if (rc != SPX_OK) return rc;
-    SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    // host buffers of any length: processed in chunks of the context's capacity (device variants are strict)
+    for (size_t lo = 0; lo < n; lo += ctx->maxBatch) {
+        const size_t m = std::min(ctx->maxBatch, n - lo);
+        SPX_HIP(hipMemcpyAsync(ctx->dPositions, positions + lo, m * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
+                               ctx->stream));
+        const int rc = spx_eval_full_device(ctx, ctx->dPositions, m, ctx->dOut, ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipMemcpyAsync(out + lo, ctx->dOut, m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SPX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return SPX_OK;
 }
 
@@ -718,6 +719,38 @@ int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, 
         return SPX_ERR_INVALID_ARG;
     }
     randomPositions(seed, count, min_ply, max_ply, dfrc_every, out);
+    return SPX_OK;
+}
+
+int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved) {
+    if ((n && (!positions || !out))) {
+        setError("spx_random_successors: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    uint64_t s = seed;
+    auto next = [&s]() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    std::vector<Move> moves;
+    for (size_t i = 0; i < n; ++i) {
+        Board b;
+        if (!unpackBoard(positions[i], b)) {
+            setError("spx_random_successors: bad record at index " + std::to_string(i));
+            return SPX_ERR_BAD_POSITION;
+        }
+        generateLegal(b, moves);
+        const bool any = !moves.empty();
+        if (any) {
+            makeMove(b, moves[size_t((next() >> 32) % moves.size())]);
+            packBoard(b, out[i]);
+        } else {
+            out[i] = positions[i];  // checkmate / stalemate: the game stays where it is
+        }
+        if (moved) moved[i] = any ? 1 : 0;
+    }
     return SPX_OK;
 }
 

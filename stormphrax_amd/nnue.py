@@ -183,6 +183,15 @@ def random_positions(count, seed=1, min_ply=8, max_ply=120, dfrc_every=4):
     return out
 
 
+def random_successors(positions, seed=1):
+    """One uniformly random legal move per record -> (successor records, moved mask)."""
+    pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+    out = np.zeros(pos.shape[0], dtype=PACKED_DTYPE)
+    moved = np.zeros(pos.shape[0], dtype=np.uint8)
+    check(_lib.load().spx_random_successors(seed, pos.ctypes.data, pos.shape[0], out.ctypes.data, moved.ctypes.data))
+    return out, moved.astype(bool)
+
+
 def debug_features(rec, colour):
     lib = _lib.load()
     rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)
