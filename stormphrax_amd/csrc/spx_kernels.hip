@@ -31,7 +31,7 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 #ifndef SPX_FT_WAVES_PER_SIMD
-#define SPX_FT_WAVES_PER_SIMD 4  // launch_bounds 2nd arg = min waves per SIMD (A/B: 4 beats 5/6/8 - the kernel is VALU-bound)
+#define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
