@@ -146,6 +146,13 @@ int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, 
 /* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
  * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */
 int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);
+/* viriformat game streams (src/datagen/viriformat.cpp:28-63: PackedBoard + {u16 move, i16 score}* + 4 zero bytes per
+ * game) -> one record per played move (the position BEFORE the move, `eval` = the recorded score, `wdl` = the game's
+ * outcome), i.e. what Marlinformat::push would have stored (marlinformat.cpp:31-36). Pass out = NULL to count only.
+ * spx_viri_random_game writes one random game (test / demo input; scores are random). */
+int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, size_t capacity,
+                    size_t* n_positions, size_t* n_games);
+int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 uint64_t spx_perft(const char* fen, int depth);
 
 /* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):

@@ -17,4 +17,6 @@ from .nnue import (  # noqa: F401
     random_positions,
     random_successors,
     synthetic_net_bytes,
+    viri_expand,
+    viri_random_game,
 )

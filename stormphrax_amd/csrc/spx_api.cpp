@@ -754,6 +754,133 @@ int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t
     return SPX_OK;
 }
 
+// ---- viriformat game streams (src/datagen/viriformat.cpp:28-63) ----
+// game = PackedBoard (32 B) + { u16 move, i16 score }* + 4 zero bytes.
+// move: bits 0-5 from, 6-11 to (castling: own rook square), 12-13 promotion (0 = knight .. 3 = queen),
+//       bits 14-15 type (0 normal, 1 = 0x4000 en passant, 2 = 0x8000 castling, 3 = 0xC000 promotion).
+static bool viriDecodeMove(const Board& b, uint16_t v, Move& out) {
+    Move want{};
+    want.from = uint8_t(v & 63);
+    want.to = uint8_t((v >> 6) & 63);
+    const int type = v >> 14;
+    want.kind = type == 0 ? kNormal : type == 1 ? kEnPassant : type == 2 ? kCastling : kPromotion;
+    want.promo = want.kind == kPromotion ? uint8_t(((v >> 12) & 3) + 1) : 0;
+    std::vector<Move> moves;
+    generateLegal(b, moves);
+    for (const Move& m : moves) {
+        if (m.from == want.from && m.to == want.to && m.kind == want.kind && m.promo == want.promo) {
+            out = m;
+            return true;
+        }
+    }
+    return false;
+}
+
+static uint16_t viriEncodeMove(const Move& m) {
+    static const uint16_t kTypes[4] = {0x0000, 0xC000, 0x8000, 0x4000};  // by MoveKind (normal, promo, castling, ep)
+    return uint16_t(m.from | (m.to << 6) | ((m.kind == kPromotion ? m.promo - 1 : 0) << 12) | kTypes[m.kind]);
+}
+
+int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, size_t capacity,
+                    size_t* n_positions, size_t* n_games) {
+    if (!data || !n_positions) {
+        setError("spx_viri_expand: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const auto* p = static_cast<const unsigned char*>(data);
+    size_t off = 0, count = 0, games = 0;
+    while (off + sizeof(spx_packed_pos) + 4 <= nbytes) {
+        spx_packed_pos initial;
+        std::memcpy(&initial, p + off, sizeof(initial));
+        off += sizeof(initial);
+        Board b;
+        if (!unpackBoard(initial, b)) {
+            setError("spx_viri_expand: bad initial board in game " + std::to_string(games));
+            return SPX_ERR_BAD_POSITION;
+        }
+        for (;;) {
+            if (off + 4 > nbytes) {
+                setError("spx_viri_expand: truncated game " + std::to_string(games));
+                return SPX_ERR_INVALID_ARG;
+            }
+            uint16_t mv;
+            int16_t score;
+            std::memcpy(&mv, p + off, 2);
+            std::memcpy(&score, p + off + 2, 2);
+            off += 4;
+            if (mv == 0 && score == 0) break;  // null terminator
+            Move m;
+            if (!viriDecodeMove(b, mv, m)) {
+                setError("spx_viri_expand: illegal move in game " + std::to_string(games));
+                return SPX_ERR_BAD_POSITION;
+            }
+            if (out) {
+                if (count >= capacity) {
+                    setError("spx_viri_expand: output capacity exceeded");
+                    return SPX_ERR_CAPACITY;
+                }
+                packBoard(b, out[count]);
+                out[count].eval = score;
+                out[count].wdl = initial.wdl;
+                if (scores) scores[count] = score;
+            }
+            ++count;
+            makeMove(b, m);
+        }
+        ++games;
+    }
+    *n_positions = count;
+    if (n_games) *n_games = games;
+    return SPX_OK;
+}
+
+int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes) {
+    if (!buf || !nbytes || plies < 0) {
+        setError("spx_viri_random_game: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    uint64_t s = seed;
+    auto next = [&s]() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    Board b = dfrc ? dfrcStart(uint32_t(next() % 960), uint32_t(next() % 960)) : startpos();
+    auto* p = static_cast<unsigned char*>(buf);
+    size_t off = 0;
+    if (capacity < sizeof(spx_packed_pos) + 4) {
+        setError("spx_viri_random_game: buffer too small");
+        return SPX_ERR_CAPACITY;
+    }
+    spx_packed_pos initial;
+    packBoard(b, initial);
+    initial.wdl = 1;
+    std::memcpy(p, &initial, sizeof(initial));
+    off += sizeof(initial);
+    std::vector<Move> moves;
+    for (int i = 0; i < plies; ++i) {
+        generateLegal(b, moves);
+        if (moves.empty()) break;
+        const Move m = moves[size_t((next() >> 32) % moves.size())];
+        if (off + 8 > capacity) {
+            setError("spx_viri_random_game: buffer too small");
+            return SPX_ERR_CAPACITY;
+        }
+        uint16_t mv = viriEncodeMove(m);
+        const int16_t score = int16_t(int(next() % 2001) - 1000);
+        if (mv == 0 && score == 0) mv = 0;  // a1a1 cannot be legal; kept for clarity
+        std::memcpy(p + off, &mv, 2);
+        std::memcpy(p + off + 2, &score, 2);
+        off += 4;
+        makeMove(b, m);
+    }
+    std::memset(p + off, 0, 4);
+    off += 4;
+    *nbytes = off;
+    return SPX_OK;
+}
+
 uint64_t spx_perft(const char* fen, int depth) {
     Board b;
     if (!boardFromFen(fen, b) || depth < 0) return 0;

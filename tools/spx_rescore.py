@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Re-evaluate recorded training data on the GPU (needs an MI355X).
+
+    python tools/spx_rescore.py <in.bin|in.vf> <out.bin> [--net file.nnue | --preset tame] [--batch 1048576]
+
+Input: marlinformat `.bin` (32-byte PackedBoard records, src/datagen/marlinformat.h:32-84) or viriformat `.vf` game
+streams (src/datagen/viriformat.cpp:28-63, expanded to one record per played move). Output: marlinformat records whose
+`eval` field holds the raw network output of the position (clamped to i16), everything else unchanged - the same 32-byte
+records bullet/marlinflow-style trainers consume."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stormphrax_amd as sp  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("--net")
+    ap.add_argument("--preset", default="tame")
+    ap.add_argument("--batch", type=int, default=1 << 20)
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args()
+    raw = open(args.src, "rb").read()
+    if args.src.endswith(".vf"):
+        positions, games = sp.viri_expand(raw)
+        print(f"{games} games -> {len(positions)} positions")
+    else:
+        positions = np.frombuffer(raw, dtype=sp.PACKED_DTYPE).copy()
+    net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
+    state = sp.NnueState(net, device=args.device, max_batch=min(args.batch, max(len(positions), 1)))
+    evals = state.evaluate_once(positions)  # chunked internally
+    positions["eval"] = np.clip(evals, -32768, 32767).astype(np.int16)
+    positions.tofile(args.dst)
+    print(f"wrote {len(positions)} records to {args.dst} (net '{net.name}')")
+
+
+if __name__ == "__main__":
+    main()
