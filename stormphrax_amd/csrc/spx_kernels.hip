@@ -646,7 +646,68 @@ __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uin
     if (id < count) (persp ? p.perspOrder : p.posOrder)[sBase[key] + rank] = id;
 }
 
+// Small batches (<= kSmallSortMax positions, e.g. the one-position drop-in call): the whole two-key counting sort in
+// ONE workgroup and one launch - at these sizes the three-launch version is pure launch latency.
+constexpr uint32_t kSmallSortMax = 1024;  // measured: one workgroup beats three launches only up to ~1K positions
+
+__global__ __launch_bounds__(1024) void spx_sort_small_kernel(SortParams p) {
+    __shared__ uint32_t sHist[kKingKeys + kOutKeys];
+    __shared__ uint32_t sBase[kKingKeys + kOutKeys];
+    __shared__ uint32_t sCursor[kKingKeys + kOutKeys];
+    __shared__ uint8_t sKing[2 * kSmallSortMax];
+    __shared__ uint8_t sOut[kSmallSortMax];
+    if (threadIdx.x < kKingKeys + kOutKeys) {
+        sHist[threadIdx.x] = 0;
+        sCursor[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t pos = threadIdx.x; pos < p.nPositions; pos += blockDim.x) {
+        const uint64_t* rec = p.positions + size_t(pos) * 4;
+        uint64_t occ = rec[0];
+        const uint64_t nibLo = rec[1], nibHi = rec[2];
+        const uint32_t outKey = min((uint32_t(popc64(occ)) - 2u) / 4u, uint32_t(kOutKeys - 1));
+        int kingSq[2] = {0, 0};
+        uint32_t idx = 0;
+        while (occ) {
+            const int sq = ctz64(occ);
+            occ &= occ - 1;
+            const uint32_t nib = uint32_t(((idx < 16 ? nibLo : nibHi) >> ((idx & 15) * 4)) & 0xF);
+            ++idx;
+            if ((nib & 7) == 5) kingSq[(nib & 8) ? 0 : 1] = sq;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t key = uint32_t(kingBucket(c == 0 ? (kingSq[c] ^ 56) : kingSq[c]));
+            sKing[2 * pos + c] = uint8_t(key);
+            atomicAdd(&sHist[key], 1u);
+        }
+        sOut[pos] = uint8_t(outKey);
+        atomicAdd(&sHist[kHistOut + outKey], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kKingKeys + kOutKeys) {
+        const uint32_t first = threadIdx.x < kKingKeys ? 0 : kHistOut;
+        uint32_t prefix = 0;
+        for (uint32_t k = first; k < threadIdx.x; ++k) prefix += sHist[k];
+        sBase[threadIdx.x] = prefix;
+        p.hist[threadIdx.x] = sHist[threadIdx.x];  // the MLP kernel maps tiles from the output-bucket counts
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < 2 * p.nPositions; q += blockDim.x) {
+        const uint32_t key = sKing[q];
+        p.perspOrder[sBase[key] + atomicAdd(&sCursor[key], 1u)] = q;
+    }
+    for (uint32_t pos = threadIdx.x; pos < p.nPositions; pos += blockDim.x) {
+        const uint32_t key = kHistOut + sOut[pos];
+        p.posOrder[sBase[key] + atomicAdd(&sCursor[key], 1u)] = pos;
+    }
+}
+
 hipError_t launchSort(const SortParams& p, hipStream_t stream) {
+    if (p.nPositions <= kSmallSortMax) {
+        hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(p.hist, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const uint32_t b1 = (p.nPositions + 255) / 256, b2 = (2 * p.nPositions + 255) / 256;

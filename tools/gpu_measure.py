@@ -31,7 +31,7 @@ dt = time.perf_counter() - t0
 out["host_buffer_evals_per_s"] = N * reps / dt
 
 # 2) small batches (latency of one synchronous call)
-for n in (1, 64, 1024):
+for n in (1, 64, 1024, 4096, 8192):
     for _ in range(5):
         state.evaluate_once(pos[:n])
     t0 = time.perf_counter()
