@@ -126,8 +126,8 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
     def step():
         s = step_no[0]
         cur, nxt = slots[s & 1], slots[(s + 1) & 1]
-        _lib.check(lib.spx_acc_update_device(h, cur.data_ptr(), nxt.data_ptr(), d_boards[board_index(s + 1)].data_ptr(), G, stream))
-        _lib.check(lib.spx_acc_eval_device(h, nxt.data_ptr(), G, d_out.data_ptr(), stream))
+        _lib.check(lib.spx_acc_update_eval_device(h, cur.data_ptr(), nxt.data_ptr(), d_boards[board_index(s + 1)].data_ptr(),
+                                                  G, d_out.data_ptr(), stream))
         step_no[0] = s + 1
 
     for _ in range(args.warmup):

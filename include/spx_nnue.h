@@ -117,6 +117,12 @@ int spx_acc_refresh_device(spx_ctx* ctx, const void* d_positions, const void* d_
 int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                           const void* d_child_positions, size_t n, void* stream);
 int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream);
+/* update immediately followed by evaluation of the children (== push + applyMove + evaluate, the common search step):
+ * one launch fewer and no re-read of the fresh accumulators */
+int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                        const spx_packed_pos* child_positions, size_t n, int32_t* out);
+int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                               const void* d_child_positions, size_t n, void* d_out, void* stream);
 
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the

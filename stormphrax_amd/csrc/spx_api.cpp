@@ -67,6 +67,9 @@ struct spx_ctx {
     size_t nSlots = 0;
     uint32_t *dSlotsA = nullptr, *dSlotsB = nullptr;  // staging for the host-buffer entry points [max_batch]
     uint8_t* dStaged = nullptr;                        // [max_batch][32] records of the slots being evaluated
+    int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
+                                   // the other one for its successor), [2] belongs to the single-launch small sort
+    uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
@@ -300,7 +303,8 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dFtOut), max_batch * size_t(kL1)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKingKeys), max_batch * 2));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOutKeys), max_batch));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 3 * 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMemset(ctx->dHist, 0, 3 * 64 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
@@ -348,7 +352,15 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
         sp.nPositions = uint32_t(n);
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
-        sp.hist = ctx->dHist;
+        if (n <= 1024) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
+            sp.hist = ctx->dHist + 128;
+            sp.histNext = sp.hist;
+        } else {
+            sp.hist = ctx->dHist + 64 * ctx->histCur;
+            sp.histNext = ctx->dHist + 64 * (ctx->histCur ^ 1);
+            ctx->histCur ^= 1;
+        }
+        ctx->histUsed = sp.hist;
         sp.perspOrder = ctx->dPerspOrder;
         sp.posOrder = ctx->dPosOrder;
         SPX_HIP(launchSort(sp, s));
@@ -357,7 +369,7 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
     MlpParams mp{};
     mp.nPositions = uint32_t(n);
     mp.posOrder = ctx->dPosOrder;
-    mp.hist = ctx->dHist;
+    mp.hist = ctx->histUsed;
     mp.ftOut = ctx->dFtOut;
     mp.l1W = ctx->dL1W;
     mp.l1B = ctx->dL1B;
@@ -486,6 +498,27 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
     return SPX_OK;
 }
 
+int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                               const void* d_child_positions, size_t n, void* d_out, void* stream) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_eval_device");
+    if (rc != SPX_OK || n == 0) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    UpdateParams up{};
+    up.nRecords = uint32_t(n);
+    up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
+    up.childSlots = static_cast<const uint32_t*>(d_child_slots);
+    up.childPositions = d_child_positions;
+    up.t = tablesOf(ctx);
+    up.arena = ctx->dArena;
+    up.slotRecords = ctx->dSlotRecords;
+    up.ftOut = ctx->dFtOut;          // activations of the children straight from the update kernel's registers
+    up.stagedRecords = ctx->dStaged;
+    SPX_HIP(launchUpdate(up, ftGrid(ctx, n), s));
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    if (rc != SPX_OK) return rc;
+    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
+}
+
 int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream) {
     int rc = checkAcc(ctx, n, "spx_acc_eval_device");
     if (rc != SPX_OK || n == 0) return rc;
@@ -550,6 +583,28 @@ int spx_acc_update(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* c
     SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     rc = spx_acc_update_device(ctx, ctx->dSlotsA, ctx->dSlotsB, ctx->dPositions, n, ctx->stream);
     if (rc != SPX_OK) return rc;
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    return SPX_OK;
+}
+
+int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                        const spx_packed_pos* child_positions, size_t n, int32_t* out) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_eval");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!parent_slots || !child_slots || !child_positions || !out) {
+        setError("spx_acc_update_eval: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, parent_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
+    if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipMemcpyAsync(ctx->dPositions, child_positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
+                           ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, parent_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_update_eval_device(ctx, ctx->dSlotsA, ctx->dSlotsB, ctx->dPositions, n, ctx->dOut, ctx->stream);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     return SPX_OK;
 }

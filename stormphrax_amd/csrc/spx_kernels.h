@@ -37,6 +37,8 @@ struct UpdateParams {
     FtTables t;
     uint8_t* arena;                // [nSlots][kAccSlotBytes]
     uint8_t* slotRecords;          // [nSlots][32]
+    uint8_t* ftOut;                // optional fused evaluation: [nRecords][1024] activations of the children ...
+    uint8_t* stagedRecords;        // ... and [nRecords][32] their records (input of the MLP's bucket sort)
 };
 
 struct SlotActParams {
@@ -53,7 +55,8 @@ struct SortParams {
     uint32_t nPositions;
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
-    uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip), zeroed by launchSort
+    uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)
+    uint32_t* histNext;         // [64] cleared by this sort for the next large sort
     uint32_t* perspOrder;       // out: [2 * nPositions] perspective ids grouped by king bucket
     uint32_t* posOrder;         // out: [nPositions] position ids grouped by output bucket
 };

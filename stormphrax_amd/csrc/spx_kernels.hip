@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // (the invariant Stormphrax asserts itself, datagen.cpp:262). A perspective whose king changed piece-square bucket or
 // crossed the d/e mirror line (psq.h:264-283, nnue_state.h:118-128) is rebuilt from scratch, as the reference does.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_update_kernel(UpdateParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
@@ -541,10 +541,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
                 }
             }
             storeAcc(p.arena, childSlot, c, lane, acc);
+            if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
+                const uint32_t half = (c == cb.stm) ? 0u : 1u;
+                *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            }
         }
         if (lane < 8) {
-            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] =
-                reinterpret_cast<const uint32_t*>(childRec)[lane];
+            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
         }
     }
 }
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uin
     }
     __syncthreads();
     if (id < count) (persp ? p.perspOrder : p.posOrder)[sBase[key] + rank] = id;
+    if (blockIdx.x == 0 && threadIdx.x < 64) p.histNext[threadIdx.x] = 0;
 }
 
 // Small batches (<= kSmallSortMax positions, e.g. the one-position drop-in call): the whole two-key counting sort in
@@ -703,13 +709,13 @@ __global__ __launch_bounds__(1024) void spx_sort_small_kernel(SortParams p) {
     }
 }
 
+// p.hist must be all-zero on entry of the multi-launch path; its scatter kernel clears p.histNext (the buffer the NEXT
+// large sort will use), so no memset launch is ever needed (spx_api alternates two buffers; small sorts use a third).
 hipError_t launchSort(const SortParams& p, hipStream_t stream) {
     if (p.nPositions <= kSmallSortMax) {
         hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
         return hipGetLastError();
     }
-    hipError_t e = hipMemsetAsync(p.hist, 0, 64 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
     const uint32_t b1 = (p.nPositions + 255) / 256, b2 = (2 * p.nPositions + 255) / 256;
     hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2 + b1), dim3(256), 0, stream, p, b2);
@@ -756,8 +762,11 @@ __global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
             posStart += cnt;
         }
         if (!found) {
-            return;  // grid is sized for the worst-case number of tiles
+            count = 0;  // grid is sized for the worst-case number of tiles: nothing to do for this wave
         }
+    }
+    if (count == 0) {
+        return;
     }
     bucket = __builtin_amdgcn_readfirstlane(bucket);
     sortedBase = __builtin_amdgcn_readfirstlane(sortedBase);

@@ -116,6 +116,16 @@ class NnueState:
         assert pos.shape[0] == ps.shape[0] == cs.shape[0]
         check(_lib.load().spx_acc_update(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data, pos.shape[0]))
 
+    def update_evaluate(self, parent_slots, child_slots, child_positions):
+        """update() followed by evaluate(child_slots) in one fused call (push + applyMove + evaluate)."""
+        pos = np.ascontiguousarray(child_positions, dtype=PACKED_DTYPE)
+        ps = np.ascontiguousarray(parent_slots, dtype=np.uint32)
+        cs = np.ascontiguousarray(child_slots, dtype=np.uint32)
+        out = np.empty(pos.shape[0], dtype=np.int32)
+        check(_lib.load().spx_acc_update_eval(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data, pos.shape[0],
+                                              out.ctypes.data))
+        return out
+
     def evaluate(self, slots):
         """NnueState::evaluate on materialised slots -> int32 raw evals (side to move of each slot's position)."""
         slots = np.ascontiguousarray(slots, dtype=np.uint32)

@@ -83,8 +83,12 @@ def test_incremental_equals_full_refresh_over_long_games(sp, states):
         if idx.size == 0:
             break
         child = (cur[idx] + games) % (2 * games)
-        st.update(cur[idx], child, nxt_pos[idx])
-        got = st.evaluate(child)
+        if ply % 2:
+            st.update(cur[idx], child, nxt_pos[idx])
+            got = st.evaluate(child)
+        else:  # fused variant
+            got = st.update_evaluate(cur[idx], child, nxt_pos[idx])
+            assert np.array_equal(got, st.evaluate(child))
         want = st.evaluate_once(nxt_pos[idx])
         assert np.array_equal(got, want), f"ply {ply}: {np.count_nonzero(got != want)} mismatches"
         cur[idx] = child
