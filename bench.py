@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--mode", default="full", choices=["full", "incremental"],
                     help="full = BASELINE configs[1] (headline); incremental = configs[2]/[3] shape: one ply of "
                          "parent->child accumulator updates + evaluation for --batch concurrent games per step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts/HIP streams the steps are issued round-robin on (2 lets the small sort/MLP kernels of "
+                         "one step overlap the texture-bound gather of the next)")
     ap.add_argument("--distinct", type=int, default=0,
                     help="diagnostic: tile this many distinct positions to fill the batch (cache-locality ablation)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -195,8 +198,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
+    # Debug knobs for exercising the N > 1 control flow on a single-GPU box (never used by the driver):
+    #   SPX_BENCH_SHARE_GPU=1 maps every rank to GPU 0, SPX_BENCH_BACKEND=gloo swaps RCCL for gloo (CPU tensors).
+    if os.environ.get("SPX_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    group = Group(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL over xGMI; no-op for 1 GPU
+    backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
+    group = Group(backend=backend, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     if args.mode == "incremental":
         return incremental_bench(args, sp, torch, group, rank, local_rank, world)
@@ -204,23 +212,30 @@ def main():
     # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     blob = sp.synthetic_net_bytes(args.preset)
     net = sp.Network(blob)
-    state = sp.NnueState(net, device=local_rank, max_batch=args.batch)
+    n_ctx = max(1, args.streams)
+    states = [sp.NnueState(net, device=local_rank, max_batch=args.batch) for _ in range(n_ctx)]
+    state = states[0]
     positions = sp.random_positions(args.batch, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
     if args.distinct:
         positions = np.resize(positions[: args.distinct], args.batch)
     d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
-    d_out = torch.empty(args.batch, dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream()
+    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
+    d_out = d_outs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_ctx - 1)]
+    counter = [0]
 
     def step():
-        state.evaluate_once_device(d_pos.data_ptr(), args.batch, d_out.data_ptr(), stream.cuda_stream)
+        k = counter[0] % n_ctx
+        counter[0] += 1
+        states[k].evaluate_once_device(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr(), streams[k].cuda_stream)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     group.barrier()
     torch.cuda.synchronize()
-    state.profile_begin(args.steps)
+    for st in states:
+        st.profile_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -228,7 +243,8 @@ def main():
     group.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
+    prof = [st.profile_end() for st in states]
+    sort_ms, ft_ms, mlp_ms, calls = (sum(p[i] for p in prof) for i in range(4))
 
     elapsed = group.max_float(elapsed)  # slowest rank defines the step time
     checksum = group.sum_int(int(d_out.to(torch.int64).sum().item()))  # checksum of checksums over all shards
@@ -257,7 +273,8 @@ def main():
                             "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU",
                 "batch_per_gpu": args.batch,
                 "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
-                "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path",
+                "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path; "
+                               f"steps issued round-robin on {n_ctx} HIP stream(s) per GPU",
                 "checksum": checksum,
                 "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
             },
@@ -269,6 +286,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args),
+                "traffic_note": "fabric+HBM GB/s of the FT kernel from the committed rocprofv3 PMC passes "
+                                "(profiles/ft_traffic_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); null if "
+                                "this run's configuration was not profiled",
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_position": algo_bytes / args.batch,
             },

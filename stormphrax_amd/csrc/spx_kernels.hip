@@ -821,19 +821,21 @@ __global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
         sIn[wave][lane] = mine >> kQBits;                     // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
         __builtin_amdgcn_wave_barrier();
         // L2: l2[o] = bias + sum_i in[i] * W2[b][i][o], wrapping i32; in[] broadcast from LDS (same address per lane)
-        uint32_t acc2 = uint32_t(l2Bias);
+        // four independent partial sums: a single accumulator is a 64-long dependent multiply-add chain
+        uint32_t part[4] = {uint32_t(l2Bias), 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < int(kL2Full); i += 4) {
             const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sIn[wave][i]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (kSmallL2W) {
-                    acc2 += uint32_t(__mul24(in4[j], w2[i + j]));
+                    part[j] += uint32_t(__mul24(in4[j], w2[i + j]));
                 } else {
-                    acc2 += uint32_t(in4[j]) * uint32_t(w2[i + j]);
+                    part[j] += uint32_t(in4[j]) * uint32_t(w2[i + j]);
                 }
             }
         }
+        const uint32_t acc2 = (part[0] + part[1]) + (part[2] + part[3]);
         // L3 with skip connection: (clamp(l2, 0, Q^3) + l1o) * W3, wrapping; wave-wide wrapping sum
         const int32_t l2v = min(max(int32_t(acc2), 0), 262144);
         uint32_t term = (uint32_t(l2v) + uint32_t(mine)) * uint32_t(l3Weight);
