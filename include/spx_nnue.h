@@ -148,6 +148,35 @@ int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm)
 /* Position::applyMove for a move in UCI notation (castling as king-takes-rook, e.g. e1h1, or standard e1g1);
  * legality is checked against the generated legal moves (src/position.cpp:109-197, Position::moveFromUci). */
 int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out);
+/* Position::applyMove WITH the reference's observer: besides the successor record, the UpdateContext the BoardObserver
+ * would have captured (src/eval/nnue_state.h:28-31,118-186; src/eval/nnue.cpp:490-599): piece-square subs/adds in event
+ * order, threat descriptors added/removed (x-ray extensions/retractions included, cancelling pairs kept exactly as the
+ * reference emits them), per-colour refresh flags, pawn bitboards before/after, kings after. The GPU update path does not
+ * need it (it derives deltas from the two boards); it exists for hosts that keep the reference's bookkeeping and as a
+ * parity check of that bookkeeping (tests/golden/deltas.txt). */
+typedef struct spx_threat_desc {
+    uint8_t attacker, attacker_sq, attacked, attacked_sq; /* ThreatDescriptor, psq.h:30-35 */
+} spx_threat_desc;
+typedef struct spx_move_delta {
+    uint8_t n_sub, n_add, n_threats_added, n_threats_removed;
+    uint8_t sub_piece[2], sub_sq[2], add_piece[2], add_sq[2];
+    uint8_t psq_refresh[2], threat_refresh[2]; /* [black, white] */
+    uint8_t kings[2];
+    uint8_t reserved[2];
+    uint64_t pawns_before[2], pawns_after[2];
+    spx_threat_desc threats_added[128], threats_removed[128];
+} spx_move_delta;
+int spx_pos_apply_uci_observed(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out, spx_move_delta* delta);
+/* Incremental update from observer-captured deltas - the reference's own bookkeeping applied on the device
+ * (updatePsq nnue_state.cpp:34-87, applyThreatUpdates :356-394 with generatePpRows :163-307, refreshes :458-536).
+ * Same batching rule and same results as spx_acc_update; `out` (host) / `d_out` (device) may be NULL, otherwise the
+ * children are evaluated as in spx_acc_update_eval. */
+int spx_acc_update_observed(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                            const spx_packed_pos* child_positions, const spx_move_delta* deltas, size_t n,
+                            int32_t* out);
+int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                   const void* d_child_positions, const void* d_deltas, size_t n, void* d_out,
+                                   void* stream);
 int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
 /* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
  * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */

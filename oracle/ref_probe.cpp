@@ -16,6 +16,7 @@
 //   feat <fen>                 -> "F <raw> <bucket> <stm>" + 4 lines "R <colour> <psq|thr> <n> ids..."
 //   playout <seed> <count> <minPly> <maxPly> <dfrc>  -> count lines "P <raw> <fen>"
 //   trace <seed> <maxEvals> <depth> <fen>            -> opcode stream of a DFS make/unmake walk with evaluate() values
+//   deltas <seed> <count> <dfrc>                     -> per played move the BoardObserver's UpdateContext
 //   add <fen> / bench <threads> <seconds>            -> timing of evaluateOnce over the added positions
 #include <atomic>
 #include <chrono>
@@ -222,6 +223,58 @@ int main() {
                 const auto raw = eval::NnueState::evaluateOnce(pos, pos.stm());
                 std::printf("P %d %s\n", raw, pos.toFen().c_str());
                 ++produced;
+            }
+        } else if (cmd == "deltas") {
+            // `deltas <seed> <count> <dfrc>`: random playouts; for every played move print the UpdateContext the
+            // reference's BoardObserver captured (nnue_state.h:118-186): piece-square subs/adds, threat descriptors
+            // added/removed, refresh flags.
+            u64 seed;
+            u32 count, dfrc;
+            in >> seed >> count >> dfrc;
+            SplitMix64 rng{seed};
+            u32 produced = 0;
+            const auto pc = [](Piece p) { return static_cast<int>(p.idx()); };
+            while (produced < count) {
+                auto pos = dfrc ? *Position::fromDfrcIndex(rng.below(960 * 960)) : Position::startpos();
+                for (u32 ply = 0; ply < 200 && produced < count; ++ply) {
+                    const auto moves = legalMoves(pos);
+                    if (moves.empty()) {
+                        break;
+                    }
+                    // castling, en passant and promotions are rare in uniform playouts: prefer them half of the time
+                    std::vector<Move> special;
+                    for (const auto mv : moves) {
+                        if (mv.type() != MoveType::kStandard) {
+                            special.push_back(mv);
+                        }
+                    }
+                    const auto& pool = (!special.empty() && rng.below(2) == 0) ? special : moves;
+                    const auto move = pool[rng.below(static_cast<u32>(pool.size()))];
+                    eval::UpdateContext ctx{};
+                    const auto next = pos.applyMove(move, eval::BoardObserver{ctx});
+                    std::printf("D %s | %s |", pos.toFen().c_str(), fmt::format("{}", move).c_str());
+                    for (const auto [p, sq] : ctx.updates.sub) {
+                        std::printf(" s%d,%d", pc(p), static_cast<int>(sq.idx()));
+                    }
+                    for (const auto [p, sq] : ctx.updates.add) {
+                        std::printf(" a%d,%d", pc(p), static_cast<int>(sq.idx()));
+                    }
+                    for (const auto& t : ctx.updates.threatsAdded) {
+                        std::printf(" +%d,%d,%d,%d", pc(t.attacker), static_cast<int>(t.attackerSq.idx()), pc(t.attacked), static_cast<int>(t.attackedSq.idx()));
+                    }
+                    for (const auto& t : ctx.updates.threatsRemoved) {
+                        std::printf(" -%d,%d,%d,%d", pc(t.attacker), static_cast<int>(t.attackerSq.idx()), pc(t.attacked), static_cast<int>(t.attackedSq.idx()));
+                    }
+                    std::printf(
+                        " f%d%d%d%d\n",
+                        ctx.updates.requiresPsqRefresh(Colors::kBlack),
+                        ctx.updates.requiresPsqRefresh(Colors::kWhite),
+                        ctx.updates.requiresThreatRefresh(Colors::kBlack),
+                        ctx.updates.requiresThreatRefresh(Colors::kWhite)
+                    );
+                    pos = next;
+                    ++produced;
+                }
             }
         } else if (cmd == "trace") {
             u64 seed, maxEvals;

@@ -29,6 +29,29 @@ class PackedPos(ctypes.Structure):
 
 assert ctypes.sizeof(PackedPos) == 32
 
+
+class ThreatDesc(ctypes.Structure):
+    _fields_ = [("attacker", ctypes.c_uint8), ("attacker_sq", ctypes.c_uint8), ("attacked", ctypes.c_uint8),
+                ("attacked_sq", ctypes.c_uint8)]
+
+
+class MoveDelta(ctypes.Structure):
+    """spx_move_delta: the reference's UpdateContext (src/eval/nnue_state.h:28-31)."""
+
+    _fields_ = [
+        ("n_sub", ctypes.c_uint8), ("n_add", ctypes.c_uint8),
+        ("n_threats_added", ctypes.c_uint8), ("n_threats_removed", ctypes.c_uint8),
+        ("sub_piece", ctypes.c_uint8 * 2), ("sub_sq", ctypes.c_uint8 * 2),
+        ("add_piece", ctypes.c_uint8 * 2), ("add_sq", ctypes.c_uint8 * 2),
+        ("psq_refresh", ctypes.c_uint8 * 2), ("threat_refresh", ctypes.c_uint8 * 2),
+        ("kings", ctypes.c_uint8 * 2), ("reserved", ctypes.c_uint8 * 2),
+        ("pawns_before", ctypes.c_uint64 * 2), ("pawns_after", ctypes.c_uint64 * 2),
+        ("threats_added", ThreatDesc * 128), ("threats_removed", ThreatDesc * 128),
+    ]
+
+
+assert ctypes.sizeof(MoveDelta) == 1080
+
 # every symbol include/spx_nnue.h declares: (restype, argtypes)
 _P = ctypes.c_void_p
 SYMBOLS = {
@@ -60,6 +83,9 @@ SYMBOLS = {
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
     "spx_pos_apply_uci": (ctypes.c_int, [_P, ctypes.c_char_p, _P]),
+    "spx_pos_apply_uci_observed": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _P]),
+    "spx_acc_update_observed": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "spx_acc_update_observed_device": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_random_successors": (ctypes.c_int, [ctypes.c_uint64, _P, ctypes.c_size_t, _P, _P]),
     "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),

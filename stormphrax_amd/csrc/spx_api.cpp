@@ -67,6 +67,7 @@ struct spx_ctx {
     size_t nSlots = 0;
     uint32_t *dSlotsA = nullptr, *dSlotsB = nullptr;  // staging for the host-buffer entry points [max_batch]
     uint8_t* dStaged = nullptr;                        // [max_batch][32] records of the slots being evaluated
+    uint8_t* dDeltas = nullptr;                        // [max_batch] spx_move_delta staging (allocated on first use)
     int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
                                    // the other one for its successor), [2] belongs to the single-launch small sort
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
@@ -335,7 +336,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut,
                     ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder,
-                    ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged};
+                    ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
@@ -446,6 +447,8 @@ int spx_acc_reserve(spx_ctx* ctx, size_t n_slots) {
     return SPX_OK;
 }
 
+static int checkSlots(const spx_ctx* ctx, const uint32_t* slots, size_t n, const char* who);
+
 static int checkAcc(spx_ctx* ctx, size_t n, const char* who) {
     if (!ctx) {
         setError(std::string(who) + ": null context");
@@ -517,6 +520,62 @@ int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const v
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
+}
+
+static_assert(sizeof(spx_move_delta) == 1080, "spx_update_observed_kernel hard-codes the spx_move_delta layout");
+
+int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                   const void* d_child_positions, const void* d_deltas, size_t n, void* d_out,
+                                   void* stream) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_observed_device");
+    if (rc != SPX_OK || n == 0) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    UpdateParams up{};
+    up.nRecords = uint32_t(n);
+    up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
+    up.childSlots = static_cast<const uint32_t*>(d_child_slots);
+    up.childPositions = d_child_positions;
+    up.t = tablesOf(ctx);
+    up.arena = ctx->dArena;
+    up.slotRecords = ctx->dSlotRecords;
+    up.deltas = static_cast<const uint8_t*>(d_deltas);
+    if (d_out) {
+        up.ftOut = ctx->dFtOut;
+        up.stagedRecords = ctx->dStaged;
+    }
+    SPX_HIP(launchUpdateObserved(up, ftGrid(ctx, n), s));
+    if (!d_out) return SPX_OK;
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    if (rc != SPX_OK) return rc;
+    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
+}
+
+int spx_acc_update_observed(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
+                            const spx_packed_pos* child_positions, const spx_move_delta* deltas, size_t n,
+                            int32_t* out) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_observed");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!parent_slots || !child_slots || !child_positions || !deltas) {
+        setError("spx_acc_update_observed: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, parent_slots, n, "spx_acc_update_observed")) != SPX_OK) return rc;
+    if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update_observed")) != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    if (!ctx->dDeltas) {
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dDeltas), ctx->maxBatch * sizeof(spx_move_delta)));
+    }
+    SPX_HIP(hipMemcpyAsync(ctx->dPositions, child_positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
+                           ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, parent_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SPX_HIP(hipMemcpyAsync(ctx->dDeltas, deltas, n * sizeof(spx_move_delta), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_update_observed_device(ctx, ctx->dSlotsA, ctx->dSlotsB, ctx->dPositions, ctx->dDeltas, n,
+                                        out ? ctx->dOut : nullptr, ctx->stream);
+    if (rc != SPX_OK) return rc;
+    if (out) SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    return SPX_OK;
 }
 
 int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream) {
@@ -765,6 +824,55 @@ int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos
     }
     makeMove(b, m);
     packBoard(b, *out);
+    return SPX_OK;
+}
+
+int spx_pos_apply_uci_observed(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out, spx_move_delta* delta) {
+    Board b;
+    if (!pos || !uci || !out || !delta || !unpackBoard(*pos, b)) {
+        setError("spx_pos_apply_uci_observed: bad argument");
+        return SPX_ERR_BAD_POSITION;
+    }
+    Move m;
+    if (!moveFromUci(b, uci, m)) {
+        setError(std::string("spx_pos_apply_uci_observed: illegal or unparsable move ") + uci);
+        return SPX_ERR_INVALID_ARG;
+    }
+    MoveDelta d;
+    makeMoveObserved(b, m, d);
+    packBoard(b, *out);
+    if (d.threatsAdded.size() > 128 || d.threatsRemoved.size() > 128) {  // kMaxThreatsAdded/Removed, threats.h:35-36
+        setError("spx_pos_apply_uci_observed: more than 128 threat descriptors");
+        return SPX_ERR_CAPACITY;
+    }
+    std::memset(delta, 0, sizeof(*delta));
+    delta->n_sub = d.nSub;
+    delta->n_add = d.nAdd;
+    for (int i = 0; i < d.nSub; ++i) {
+        delta->sub_piece[i] = d.subPiece[i];
+        delta->sub_sq[i] = d.subSq[i];
+    }
+    for (int i = 0; i < d.nAdd; ++i) {
+        delta->add_piece[i] = d.addPiece[i];
+        delta->add_sq[i] = d.addSq[i];
+    }
+    for (int c = 0; c < 2; ++c) {
+        delta->psq_refresh[c] = d.psqRefresh[c];
+        delta->threat_refresh[c] = d.threatRefresh[c];
+        delta->kings[c] = d.kings[c];
+        delta->pawns_before[c] = d.pawnsBefore[c];
+        delta->pawns_after[c] = d.pawnsAfter[c];
+    }
+    delta->n_threats_added = uint8_t(d.threatsAdded.size());
+    delta->n_threats_removed = uint8_t(d.threatsRemoved.size());
+    for (size_t i = 0; i < d.threatsAdded.size(); ++i) {
+        const ThreatDescriptor& t = d.threatsAdded[i];
+        delta->threats_added[i] = {t.attacker, t.attackerSq, t.attacked, t.attackedSq};
+    }
+    for (size_t i = 0; i < d.threatsRemoved.size(); ++i) {
+        const ThreatDescriptor& t = d.threatsRemoved[i];
+        delta->threats_removed[i] = {t.attacker, t.attackerSq, t.attacked, t.attackedSq};
+    }
     return SPX_OK;
 }
 

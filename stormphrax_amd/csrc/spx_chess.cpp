@@ -366,6 +366,239 @@ void makeMove(Board& b, const Move& m) {
     b.stm = uint8_t(them);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Delta capture (scalar restatement of the reference's SIMD "ray geometry").
+// Focus square f: 8 rays (N, NE, E, SE, S, SW, W, NW); `closest` = first occupied square along each ray plus every
+// occupied knight-jump square (geometry_avx2.h:134-142). All functions look at `mb` exactly as it is at the moment of
+// the observer hook; `ignore` is a square treated as empty (permuteMailbox(..., ignore), geometry_avx2.h:114-132).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kRayDf[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+constexpr int kRayDr[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+constexpr int kJumpDf[8] = {-1, 1, 2, 2, 1, -1, -2, -2};
+constexpr int kJumpDr[8] = {2, 2, 1, -1, -2, -2, -1, 1};
+
+struct FocusGeometry {
+    int raySq[8], rayDist[8];  // closest occupied square per ray (-1: none) and its distance
+    int jumpSq[8];             // occupied knight-jump squares (-1: empty / off board)
+};
+
+void focusGeometry(const uint8_t* mb, int f, int ignore, FocusGeometry& g) {
+    const int ff = f & 7, fr = f >> 3;
+    for (int r = 0; r < 8; ++r) {
+        g.raySq[r] = -1;
+        g.rayDist[r] = 0;
+        int file = ff, rank = fr;
+        for (int d = 1; d < 8; ++d) {
+            file += kRayDf[r];
+            rank += kRayDr[r];
+            if (file < 0 || file > 7 || rank < 0 || rank > 7) break;
+            const int sq = rank * 8 + file;
+            if (sq != ignore && mb[sq] != kNoPiece) {
+                g.raySq[r] = sq;
+                g.rayDist[r] = d;
+                break;
+            }
+        }
+        const int jf = ff + kJumpDf[r], jr = fr + kJumpDr[r];
+        g.jumpSq[r] = -1;
+        if (jf >= 0 && jf < 8 && jr >= 0 && jr < 8) {
+            const int sq = jr * 8 + jf;
+            if (sq != ignore && mb[sq] != kNoPiece) g.jumpSq[r] = sq;
+        }
+    }
+}
+
+// outgoingThreats (geometry.h:89-104): squares among `closest` the focus piece attacks
+int outgoingSquares(int piece, const FocusGeometry& g, int out[8]) {
+    int n = 0;
+    const int type = piece >> 1;
+    if (type == 0) {
+        const int a = (piece & 1) ? 1 : 3, b = (piece & 1) ? 7 : 5;  // white: NE, NW; black: SE, SW
+        if (g.raySq[a] >= 0 && g.rayDist[a] == 1) out[n++] = g.raySq[a];
+        if (g.raySq[b] >= 0 && g.rayDist[b] == 1) out[n++] = g.raySq[b];
+    } else if (type == 1) {
+        for (int i = 0; i < 8; ++i)
+            if (g.jumpSq[i] >= 0) out[n++] = g.jumpSq[i];
+    } else if (type <= 4) {
+        for (int r = 0; r < 8; ++r) {
+            const bool diag = r & 1;
+            if ((diag && type == 3) || (!diag && type == 2)) continue;
+            if (g.raySq[r] >= 0) out[n++] = g.raySq[r];
+        }
+    }
+    return n;  // kings: none ("Ignore king threats")
+}
+
+// can the piece standing on ray r at distance d attack the focus square? (kIncomingThreatsMask, geometry.h:106-125)
+bool rayAttacker(int piece, int r, int d, bool slidersOnly) {
+    const int type = piece >> 1;
+    const bool diag = r & 1;
+    if (type == 4 || (diag && type == 2) || (!diag && type == 3)) return true;
+    if (slidersOnly || type != 0 || d != 1 || !diag) return false;
+    const bool above = (r == 1 || r == 7);       // NE / NW of the focus square
+    return above ? (piece & 1) == 0 : (piece & 1) == 1;  // black pawns attack downwards, white pawns upwards
+}
+
+struct Emitter {
+    MoveDelta& d;
+    void add(int a, int asq, int v, int vsq) {
+        d.threatsAdded.push_back({uint8_t(a), uint8_t(asq), uint8_t(v), uint8_t(vsq)});
+    }
+    void remove(int a, int asq, int v, int vsq) {
+        d.threatsRemoved.push_back({uint8_t(a), uint8_t(asq), uint8_t(v), uint8_t(vsq)});
+    }
+    void emit(bool isAdd, int a, int asq, int v, int vsq) {
+        isAdd ? add(a, asq, v, vsq) : remove(a, asq, v, vsq);
+    }
+};
+
+void focusThreats(Emitter& e, const uint8_t* mb, const FocusGeometry& g, int piece, int f, bool isAdd, bool outgoing,
+                  bool incoming) {
+    if (outgoing) {
+        int out[8];
+        const int n = outgoingSquares(piece, g, out);
+        for (int i = 0; i < n; ++i) e.emit(isAdd, piece, f, mb[out[i]], out[i]);
+    }
+    if (incoming) {
+        for (int i = 0; i < 8; ++i) {
+            if (g.jumpSq[i] >= 0 && (mb[g.jumpSq[i]] >> 1) == 1) e.emit(isAdd, mb[g.jumpSq[i]], g.jumpSq[i], piece, f);
+            if (g.raySq[i] >= 0 && rayAttacker(mb[g.raySq[i]], i, g.rayDist[i], false)) {
+                e.emit(isAdd, mb[g.raySq[i]], g.raySq[i], piece, f);
+            }
+        }
+    }
+}
+
+// x-ray threats through the focus square: slider on ray r, closest piece on the opposite ray (nnue.cpp:380-415,450-483)
+// pieceAddedAtFocus = true retracts them (removed), false extends them (added)
+void discoveredThreats(Emitter& e, const uint8_t* mb, const FocusGeometry& g, bool pieceAddedAtFocus) {
+    for (int r = 0; r < 8; ++r) {
+        const int s = g.raySq[r], v = g.raySq[(r + 4) & 7];
+        if (s < 0 || v < 0 || !rayAttacker(mb[s], r, g.rayDist[r], true)) continue;
+        e.emit(!pieceAddedAtFocus, mb[s], s, mb[v], v);
+    }
+}
+
+// updatePieceThreatsOnChange<kAdd> (nnue.cpp:490-523)
+void threatsOnChange(Emitter& e, const uint8_t* mb, bool isAdd, int piece, int f) {
+    FocusGeometry g;
+    focusGeometry(mb, f, -1, g);
+    focusThreats(e, mb, g, piece, f, isAdd, true, true);
+    discoveredThreats(e, mb, g, isAdd);
+}
+// updatePieceThreatsOnMutate (nnue.cpp:525-549): no x-ray change, the square stays occupied
+void threatsOnMutate(Emitter& e, const uint8_t* mb, int oldPiece, int newPiece, int f) {
+    FocusGeometry g;
+    focusGeometry(mb, f, -1, g);
+    focusThreats(e, mb, g, oldPiece, f, false, true, false);
+    focusThreats(e, mb, g, newPiece, f, true, true, false);
+    focusThreats(e, mb, g, oldPiece, f, false, false, true);
+    focusThreats(e, mb, g, newPiece, f, true, false, true);
+}
+// updatePieceThreatsOnMove (nnue.cpp:551-599): src side sees dst as empty, dst side sees the real board
+void threatsOnMove(Emitter& e, const uint8_t* mb, int oldPiece, int src, int newPiece, int dst) {
+    FocusGeometry gs, gd;
+    focusGeometry(mb, src, dst, gs);
+    focusGeometry(mb, dst, -1, gd);
+    focusThreats(e, mb, gs, oldPiece, src, false, true, false);
+    focusThreats(e, mb, gd, newPiece, dst, true, true, false);
+    focusThreats(e, mb, gs, oldPiece, src, false, false, true);
+    focusThreats(e, mb, gd, newPiece, dst, true, false, true);
+    discoveredThreats(e, mb, gs, false);
+    discoveredThreats(e, mb, gd, true);
+}
+
+// KingBucketsMirrored::refreshRequired (psq.h:264-283) with the arch.h:53-65 bucket layout
+bool psqRefreshRequired(int c, int prevKing, int king) {
+    if (((prevKing & 7) > 3) != ((king & 7) > 3)) return true;
+    if (c == 0) {
+        prevKing ^= 56;
+        king ^= 56;
+    }
+    return kingBucket(prevKing) != kingBucket(king);
+}
+}  // namespace
+
+void makeMoveObserved(Board& b, const Move& m, MoveDelta& d) {
+    d = MoveDelta{};
+    Emitter e{d};
+    const int us = b.stm;
+    const int moving = b.mailbox[m.from];
+    d.pawnsBefore[0] = b.pieces[0];
+    d.pawnsBefore[1] = b.pieces[1];
+    uint8_t mb[64];
+    std::memcpy(mb, b.mailbox, 64);
+    auto pushSub = [&](int piece, int sq) {
+        d.subPiece[d.nSub] = uint8_t(piece);
+        d.subSq[d.nSub++] = uint8_t(sq);
+    };
+    auto pushAdd = [&](int piece, int sq) {
+        d.addPiece[d.nAdd] = uint8_t(piece);
+        d.addSq[d.nAdd++] = uint8_t(sq);
+    };
+    auto prepareKingMove = [&](int c, int src, int dst) {  // nnue_state.h:118-128
+        if (psqRefreshRequired(c, src, dst)) d.psqRefresh[c] = true;
+        if (((src & 7) >= 4) != ((dst & 7) >= 4)) d.threatRefresh[c] = true;
+    };
+
+    if (m.kind == kCastling) {  // position.cpp:1396-1437
+        const int base = us ? 0 : 56;
+        const bool shortSide = (m.from & 7) < (m.to & 7);
+        const int kDst = base + (shortSide ? 6 : 2), rDst = base + (shortSide ? 5 : 3);
+        const int king = 10 | us, rook = 6 | us;
+        prepareKingMove(us, m.from, kDst);
+        mb[m.from] = kNoPiece;
+        pushSub(king, m.from);
+        threatsOnChange(e, mb, false, king, m.from);
+        mb[m.to] = kNoPiece;
+        pushSub(rook, m.to);
+        threatsOnChange(e, mb, false, rook, m.to);
+        mb[kDst] = uint8_t(king);
+        pushAdd(king, kDst);
+        threatsOnChange(e, mb, true, king, kDst);
+        mb[rDst] = uint8_t(rook);
+        pushAdd(rook, rDst);
+        threatsOnChange(e, mb, true, rook, rDst);
+    } else if (m.kind == kEnPassant) {  // position.cpp:1439-1466
+        const int capSq = m.to ^ 8;  // flipRankParity
+        const int enemyPawn = moving ^ 1;
+        mb[capSq] = kNoPiece;
+        pushSub(enemyPawn, capSq);
+        threatsOnChange(e, mb, false, enemyPawn, capSq);
+        mb[m.from] = kNoPiece;
+        mb[m.to] = uint8_t(moving);
+        pushSub(moving, m.from);
+        pushAdd(moving, m.to);
+        threatsOnMove(e, mb, moving, m.from, moving, m.to);
+    } else {  // movePiece / promotePawn (position.cpp:1306-1394)
+        if ((moving >> 1) == 5) prepareKingMove(us, b.kingSq[us], m.to);
+        const int landed = m.kind == kPromotion ? ((m.promo << 1) | us) : moving;
+        const int captured = b.mailbox[m.to];
+        if (captured != kNoPiece) {
+            mb[m.from] = kNoPiece;
+            pushSub(moving, m.from);
+            threatsOnChange(e, mb, false, moving, m.from);
+            mb[m.to] = uint8_t(landed);
+            pushSub(captured, m.to);
+            pushAdd(landed, m.to);
+            threatsOnMutate(e, mb, captured, landed, m.to);
+        } else {
+            mb[m.from] = kNoPiece;
+            mb[m.to] = uint8_t(landed);
+            pushSub(moving, m.from);
+            pushAdd(landed, m.to);
+            threatsOnMove(e, mb, moving, m.from, landed, m.to);
+        }
+    }
+    makeMove(b, m);
+    // finalize (nnue_state.h:174-186)
+    d.kings[0] = uint8_t(b.kingSq[0]);
+    d.kings[1] = uint8_t(b.kingSq[1]);
+    d.pawnsAfter[0] = b.pieces[0];
+    d.pawnsAfter[1] = b.pieces[1];
+}
+
 void generateLegal(const Board& b, std::vector<Move>& out) {
     std::vector<Move> pseudo;
     pseudo.reserve(64);

@@ -55,6 +55,22 @@ uint64_t perft(const Board& b, int depth);
 std::string moveToUci(const Board& b, const Move& m);  // Chess960-style castling (king takes rook)
 bool moveFromUci(const Board& b, const char* uci, Move& out);
 
+// ---- make-move delta capture: what the reference's BoardObserver records while Position::applyMove runs
+// (src/eval/nnue_state.h:118-186, src/eval/nnue.cpp:490-599, geometry in nnue/features/threats/geometry.h:44-141) ----
+struct ThreatDescriptor {  // psq.h:30-35
+    uint8_t attacker, attackerSq, attacked, attackedSq;
+};
+struct MoveDelta {         // UpdateContext: NnueUpdates + kings (nnue_state.h:28-31, threats.h:41-104)
+    uint8_t nSub = 0, nAdd = 0;
+    uint8_t subPiece[2], subSq[2], addPiece[2], addSq[2];
+    bool psqRefresh[2] = {false, false}, threatRefresh[2] = {false, false};
+    uint8_t kings[2] = {0, 0};
+    uint64_t pawnsBefore[2] = {0, 0}, pawnsAfter[2] = {0, 0};
+    std::vector<ThreatDescriptor> threatsAdded, threatsRemoved;
+};
+// makeMove + the observer's event stream, in the reference's event order (position.cpp:1306-1471)
+void makeMoveObserved(Board& b, const Move& m, MoveDelta& delta);
+
 void packBoard(const Board& b, spx_packed_pos& out);
 bool unpackBoard(const spx_packed_pos& in, Board& out);  // placement + stm (+ep); castling rights from code-6 rooks
 

@@ -37,6 +37,7 @@ struct UpdateParams {
     FtTables t;
     uint8_t* arena;                // [nSlots][kAccSlotBytes]
     uint8_t* slotRecords;          // [nSlots][32]
+    const uint8_t* deltas;         // spx_update_observed_kernel only: spx_move_delta[nRecords] (1080 B each)
     uint8_t* ftOut;                // optional fused evaluation: [nRecords][1024] activations of the children ...
     uint8_t* stagedRecords;        // ... and [nRecords][32] their records (input of the MLP's bucket sort)
 };
@@ -79,6 +80,7 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();
 

@@ -330,6 +330,61 @@ __device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int
     }
 }
 
+// child accumulator = parent accumulator - removed rows + added rows (updatePsq, nnue_state.cpp:34-87;
+// applyThreatRows, :89-145). Lists hold byte offsets; wrapping i16; threat sums kept in non-overflowing 32-bit fields.
+__device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* arena, uint32_t parentSlot, int c,
+                                           uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
+                                           const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
+                                           uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]) {
+    loadAcc(arena, parentSlot, c, lane, acc);
+    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
+    for (uint32_t i = 0; i < nPsqSub; ++i) {
+        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqSub[i]);
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = pkSub16(acc[r], lo[r]);
+            acc[4 + r] = pkSub16(acc[4 + r], hi[r]);
+        }
+    }
+    for (uint32_t i = 0; i < nPsqAdd; ++i) {
+        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqAdd[i]);
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = pkAdd16(acc[r], lo[r]);
+            acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
+        }
+    }
+    const uint8_t* thrBase = t.thrW + 16 * lane;
+    uint32_t tadd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < nAdd; ++i) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrAdd[i]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            tadd[2 * d] += unpackLo(w[d]);
+            tadd[2 * d + 1] += unpackHi(w[d]);
+        }
+    }
+    for (uint32_t i = 0; i < nSub; ++i) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrSub[i]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            tsub[2 * d] += unpackLo(w[d]);
+            tsub[2 * d + 1] += unpackHi(w[d]);
+        }
+    }
+    // +128 storage bias: (nAdd - nSub) * 128 per column, mod 2^16
+    const uint32_t corr = ((nAdd - nSub) * 128u) & 0xFFFFu;
+    const uint32_t corr2 = corr | (corr << 16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = pkSub16(pkSub16(pkAdd16(acc[r], tadd[r]), tsub[r]), corr2);
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -487,64 +542,126 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
                 }
                 __builtin_amdgcn_wave_barrier();
 
-                // ---- apply: acc = parent - subs + adds (wrapping i16; threat sums kept in 32-bit fields) ----
-                loadAcc(p.arena, parentSlot, c, lane, acc);
-                const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(p.t.psqW) + 16 * lane;
-                for (uint32_t i = 0; i < nPsqSub; ++i) {
-                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsqDelta[wave][0][i]);
-                    const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-                    const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[r] = pkSub16(acc[r], lo[r]);
-                        acc[4 + r] = pkSub16(acc[4 + r], hi[r]);
-                    }
-                }
-                for (uint32_t i = 0; i < nPsqAdd; ++i) {
-                    const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(sPsqDelta[wave][1][i]);
-                    const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-                    const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[r] = pkAdd16(acc[r], lo[r]);
-                        acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
-                    }
-                }
-                const uint8_t* thrBase = p.t.thrW + 16 * lane;
-                uint32_t tadd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t i = 0; i < nAdd; ++i) {
-                    const u32x4 w =
-                        *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sThr[wave][i]));
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        tadd[2 * d] += unpackLo(w[d]);
-                        tadd[2 * d + 1] += unpackHi(w[d]);
-                    }
-                }
-                for (uint32_t i = 0; i < nSub; ++i) {
-                    const u32x4 w =
-                        *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(sSub[wave][i]));
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        tsub[2 * d] += unpackLo(w[d]);
-                        tsub[2 * d + 1] += unpackHi(w[d]);
-                    }
-                }
-                {
-                    // +128 storage bias: (nAdd - nSub) * 128 per column, mod 2^16
-                    const uint32_t corr = ((nAdd - nSub) * 128u) & 0xFFFFu;
-                    const uint32_t corr2 = corr | (corr << 16);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        acc[r] = pkSub16(pkSub16(pkAdd16(acc[r], tadd[r]), tsub[r]), corr2);
-                    }
-                }
+                applyDelta(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd,
+                           sThr[wave], nAdd, sSub[wave], nSub, acc);
             }
             storeAcc(p.arena, childSlot, c, lane, acc);
             if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
                 const uint32_t half = (c == cb.stm) ? 0u : 1u;
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
             }
+        }
+        if (lane < 8) {
+            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Incremental update from HOST-CAPTURED deltas: the reference's own bookkeeping, applied on the device. Each record
+// carries the UpdateContext a BoardObserver captured while the move was made (spx_move_delta: piece-square subs/adds,
+// threat descriptors added/removed, pawn bitboards before/after, refresh flags, kings). Per perspective, exactly as
+// ensureUpToDate does (nnue_state.cpp:636-697): refresh -> rebuild from the child board; otherwise updatePsq (:34-87)
+// and applyThreatUpdates (:356-394: descriptors -> threatFeatureIndex, negatives dropped; generatePpRows :163-307 when
+// the pawn structure changed). One lane maps one descriptor. Cheaper than spx_update_kernel (no attack generation)
+// but it needs ~1 KB of host-built delta per move; both produce identical accumulators.
+// spx_move_delta layout (bytes): 0 n_sub, 1 n_add, 2 n_added, 3 n_removed, 4 sub_piece[2], 6 sub_sq[2], 8 add_piece[2],
+// 10 add_sq[2], 12 psq_refresh[2], 14 threat_refresh[2], 16 kings[2], 24 pawns_before[2] (u64), 40 pawns_after[2],
+// 56 threats_added[128] (4 B each), 568 threats_removed[128]; sizeof = 1080.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kDeltaBytes = 1080;
+
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_kernel(UpdateParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];
+    __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];
+
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < p.nRecords; it += gridDim.x * kWavesPerBlock) {
+        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
+        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
+        const uint8_t* delta = p.deltas + size_t(it) * kDeltaBytes;
+        const uint32_t nPsqSub = min(uint32_t(delta[0]), 2u), nPsqAdd = min(uint32_t(delta[1]), 2u);
+        const uint32_t nAdded = min(uint32_t(delta[2]), 128u), nRemoved = min(uint32_t(delta[3]), 128u);
+        const uint64_t* pawnBbs = reinterpret_cast<const uint64_t*>(delta + 24);
+        const uint64_t blackBefore = pawnBbs[0], whiteBefore = pawnBbs[1], blackAfter = pawnBbs[2], whiteAfter = pawnBbs[3];
+        const bool pawnsChanged = blackBefore != blackAfter || whiteBefore != whiteAfter;
+        const int childStm = (childRec[24] & 0x80) ? 0 : 1;
+
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            uint32_t acc[8];
+            if (delta[12 + c] || delta[14 + c]) {  // requiresPsqRefresh / requiresThreatRefresh
+                const LaneBoard cb = decodeBoard(childRec, lane);
+                uint32_t nPsq, nThr;
+                buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
+                gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+            } else {
+                const int kingSq = delta[16 + c];
+                const int x = perspXor(c, kingSq);
+                const int flipColour = (c == 0) ? 1 : 0;
+                // updatePsq: <= 2 subs, <= 2 adds
+                if (lane < nPsqSub) sPsqDelta[wave][0][lane] = psqRow(c, delta[4 + lane], delta[6 + lane], kingSq) * (kL1 * 2);
+                if (lane < nPsqAdd) sPsqDelta[wave][1][lane] = psqRow(c, delta[8 + lane], delta[10 + lane], kingSq) * (kL1 * 2);
+                // applyThreatUpdates: one lane per descriptor, two passes of 64 per list
+                uint32_t nAdd = 0, nSub = 0;
+#pragma unroll 1
+                for (int list = 0; list < 2; ++list) {
+                    const uint8_t* descs = delta + (list == 0 ? 56 : 568);
+                    const uint32_t count = list == 0 ? nAdded : nRemoved;
+                    uint32_t* out = list == 0 ? sThr[wave] : sSub[wave];
+                    uint32_t n = 0;
+                    for (uint32_t base = 0; base < count; base += 64) {
+                        int32_t row = -1;
+                        if (base + lane < count) {
+                            const uint32_t d = reinterpret_cast<const uint32_t*>(descs)[base + lane];
+                            const int attacker = int(d & 0xFF) ^ flipColour, asq = int((d >> 8) & 0xFF) ^ x;
+                            const int attacked = int((d >> 16) & 0xFF) ^ flipColour, vsq = int(d >> 24) ^ x;
+                            if (attacker < 12 && attacked < 12 && (attacker >> 1) != 5) {
+                                row = threatRow(sLut, attacker, asq, piecePseudoAttacks(attacker, asq), attacked, vsq);
+                            }
+                        }
+                        const uint64_t valid = __ballot(row >= 0);
+                        if (row >= 0) out[n + prefixCount(valid)] = uint32_t(row) * kL1;
+                        n += popc64(valid);
+                    }
+                    (list == 0 ? nAdd : nSub) = n;
+                }
+                // generatePpRows: pairs that exist on one side only (lane = square)
+                if (pawnsChanged) {
+                    const uint64_t ownP = c ? whiteBefore : blackBefore, theirP = c ? blackBefore : whiteBefore;
+                    const uint64_t ownC = c ? whiteAfter : blackAfter, theirC = c ? blackAfter : whiteAfter;
+                    const bool ownSideP = (ownP >> lane) & 1, ownSideC = (ownC >> lane) & 1;
+                    const bool pawnP = ownSideP || ((theirP >> lane) & 1), pawnC = ownSideC || ((theirC >> lane) & 1);
+                    const uint64_t partP = pawnPartners(pawnP, ownSideP, lane, ownP, theirP);
+                    const uint64_t partC = pawnPartners(pawnC, ownSideC, lane, ownC, theirC);
+                    const uint64_t unchanged = (ownP & ownC) | (theirP & theirC);
+                    const bool same = pawnP && pawnC && ownSideP == ownSideC;
+                    const uint64_t kept = same ? (partP & partC & unchanged) : 0;
+                    nSub = emitPawnPairRows(sSub[wave], nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
+                    nAdd = emitPawnPairRows(sThr[wave], nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
+                }
+                __builtin_amdgcn_wave_barrier();
+                applyDelta(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd,
+                           sThr[wave], nAdd, sSub[wave], nSub, acc);
+            }
+            storeAcc(p.arena, childSlot, c, lane, acc);
+            if (p.ftOut) {
+                const uint32_t half = (c == childStm) ? 0u : 1u;
+                *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane < 8) {
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
@@ -859,6 +976,11 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) 
 
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream) {
     hipLaunchKernelGGL(spx_update_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_update_observed_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -126,6 +126,17 @@ class NnueState:
                                               out.ctypes.data))
         return out
 
+    def update_observed(self, parent_slots, child_slots, child_positions, deltas, evaluate=True):
+        """Incremental update from host-captured observer deltas (a ctypes array of MoveDelta); optional evaluation."""
+        pos = np.ascontiguousarray(child_positions, dtype=PACKED_DTYPE)
+        ps = np.ascontiguousarray(parent_slots, dtype=np.uint32)
+        cs = np.ascontiguousarray(child_slots, dtype=np.uint32)
+        out = np.empty(pos.shape[0], dtype=np.int32) if evaluate else None
+        check(_lib.load().spx_acc_update_observed(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data,
+                                                  ctypes.addressof(deltas), pos.shape[0],
+                                                  out.ctypes.data if evaluate else None))
+        return out
+
     def evaluate(self, slots):
         """NnueState::evaluate on materialised slots -> int32 raw evals (side to move of each slot's position)."""
         slots = np.ascontiguousarray(slots, dtype=np.uint32)

@@ -12,6 +12,7 @@ reference itself computes:
                   from the repo's own seeded generator, (c) positions the reference's own move generator produced
   features.jsonl  {"fen", "bucket", "stm", "psq": [black, white], "thr": [black, white]}: per-perspective row ids in the
                   reference's enumeration order, through its own featureIndex / threatFeatureIndex / ppFeatureIndex
+  deltas.txt      per played move of random playouts: the UpdateContext captured by the reference's BoardObserver
   trace_*.txt     PUSH/POP/EVAL opcode streams of a make/unmake walk driven through NnueState::push/evaluate
                   (the lazily-updated incremental path), with the reference's evaluate() at every EVAL
 
@@ -108,6 +109,12 @@ def main():
         with open(os.path.join(HERE, name), "w") as f:
             f.write(f"# preset {preset}; produced by oracle/ref_probe.cpp `trace {seed} {evals} {depth}`\n")
             f.write("\n".join(out) + "\n")
+    # make-move deltas exactly as the reference's BoardObserver captured them (nnue_state.h:118-186)
+    with open(os.path.join(HERE, "deltas.txt"), "w") as f:
+        f.write("# D <fen> | <uci> | s<piece>,<sq> subs  a<piece>,<sq> adds  +a,asq,v,vsq threats added  -... removed  "
+                "f<psqRefresh b,w><threatRefresh b,w>\n")
+        for line in probes["tame"].cmd("deltas 31337 900 0") + probes["tame"].cmd("deltas 4242 300 1"):
+            f.write(line + "\n")
     for p in probes.values():
         p.close()
     print("golden vectors written:", len(fens), "positions")

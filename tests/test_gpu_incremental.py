@@ -111,3 +111,37 @@ def test_update_between_unrelated_boards_falls_back_to_rebuild(sp, states):
     flipped["stm_ep"] ^= 0x80
     st.update(np.arange(512, dtype=np.uint32), np.arange(512, 1024, dtype=np.uint32), flipped)
     assert np.array_equal(st.evaluate(np.arange(512, 1024, dtype=np.uint32)), st.evaluate_once(flipped))
+
+
+def test_observer_delta_path_matches_reference_traces(sp, states):
+    """The reference's own bookkeeping end to end: host observer deltas (spx_pos_apply_uci_observed, pinned against the
+    reference's BoardObserver in tests/test_host_logic.py) applied by spx_update_observed_kernel must reproduce every
+    EVAL the reference recorded, and agree with the board-diff kernel."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+    from stormphrax_amd.trace import Trace
+
+    lib = _lib.load()
+    for name in ("trace_startpos_tame.txt", "trace_promo_extreme.txt", "trace_frc_tame.txt"):
+        path = os.path.join(GOLDEN, name)
+        trace = Trace(path)
+        st = states(preset_of(path))
+        pos = np.zeros(trace.n_nodes, dtype=sp.PACKED_DTYPE)
+        pos[0] = sp.positions_from_fens([trace.root_fen])[0]
+        deltas = (_lib.MoveDelta * trace.n_nodes)()
+        for node in range(1, trace.n_nodes):
+            parent = np.ascontiguousarray(pos[trace.parent[node]]).reshape(1)
+            rc = lib.spx_pos_apply_uci_observed(parent.ctypes.data, trace.moves[node].encode(), pos[node:node + 1].ctypes.data,
+                                                ctypes.byref(deltas[node]))
+            assert rc == 0
+        st.reserve_slots(trace.n_nodes)
+        st.reset(pos[:1], np.zeros(1, dtype=np.uint32))
+        values = np.zeros(trace.n_nodes, dtype=np.int32)
+        for parents, children in trace.levels():
+            batch = (_lib.MoveDelta * len(children))(*[deltas[int(c)] for c in children])
+            values[children] = st.update_observed(parents, children, pos[children], batch)
+        nodes = np.array([e[0] for e in trace.evals])
+        want = np.array([e[1] for e in trace.evals], dtype=np.int32)
+        assert np.array_equal(values[nodes[nodes > 0]], want[nodes > 0]), name
+        assert np.array_equal(st.evaluate(nodes.astype(np.uint32)), want), name

@@ -145,3 +145,46 @@ def test_viriformat_round_trip(sp):
     assert total > 3000 and kinds == {0, 1, 2, 3}  # normal, en passant, castling and promotion all occurred
     two, games = sp.viri_expand(sp.viri_random_game(1, 30) + sp.viri_random_game(2, 40))
     assert games == 2 and len(two) == 70
+
+
+def test_host_observer_matches_reference_board_observer(sp):
+    """spx_pos_apply_uci_observed vs the UpdateContext the COMPILED REFERENCE's BoardObserver captured for the same move
+    (tests/golden/deltas.txt): identical piece-square subs/adds (event order), identical MULTISETS of threat descriptors
+    added/removed (x-ray pairs that cancel included), identical refresh flags."""
+    import collections
+    import ctypes
+    import os
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    path = os.path.join(os.path.dirname(__file__), "golden", "deltas.txt")
+    n = castles = eps = promos = refreshes = 0
+    for line in open(path):
+        if not line.startswith("D "):
+            continue
+        fen, uci, rest = [x.strip() for x in line[2:].split("|")]
+        toks = rest.split()
+        want_sub = [tuple(map(int, t[1:].split(","))) for t in toks if t[0] == "s"]
+        want_add = [tuple(map(int, t[1:].split(","))) for t in toks if t[0] == "a"]
+        want_ta = collections.Counter(tuple(map(int, t[1:].split(","))) for t in toks if t[0] == "+")
+        want_tr = collections.Counter(tuple(map(int, t[1:].split(","))) for t in toks if t[0] == "-")
+        flags = [int(ch) for ch in [t for t in toks if t[0] == "f"][0][1:]]
+        (rec,) = sp.positions_from_fens([fen])
+        out = np.zeros(1, dtype=sp.PACKED_DTYPE)
+        d = _lib.MoveDelta()
+        rc = lib.spx_pos_apply_uci_observed(np.ascontiguousarray(rec).reshape(1).ctypes.data, uci.encode(), out.ctypes.data,
+                                            ctypes.byref(d))
+        assert rc == 0, (fen, uci, lib.spx_last_error())
+        got_sub = [(d.sub_piece[i], d.sub_sq[i]) for i in range(d.n_sub)]
+        got_add = [(d.add_piece[i], d.add_sq[i]) for i in range(d.n_add)]
+        got_ta = collections.Counter((t.attacker, t.attacker_sq, t.attacked, t.attacked_sq) for t in d.threats_added[: d.n_threats_added])
+        got_tr = collections.Counter((t.attacker, t.attacker_sq, t.attacked, t.attacked_sq) for t in d.threats_removed[: d.n_threats_removed])
+        assert got_sub == want_sub and got_add == want_add, (fen, uci)
+        assert got_ta == want_ta and got_tr == want_tr, (fen, uci, got_ta - want_ta, want_ta - got_ta, got_tr - want_tr, want_tr - got_tr)
+        assert [d.psq_refresh[0], d.psq_refresh[1], d.threat_refresh[0], d.threat_refresh[1]] == flags, (fen, uci)
+        n += 1
+        castles += len(want_sub) == 2 and len(want_add) == 2
+        promos += any(a[0] != s[0] for a in want_add for s in want_sub[:1]) and len(want_add) == 1 and want_sub[0][0] in (0, 1) and want_add[0][0] not in (0, 1)
+        refreshes += sum(flags) > 0
+    assert n >= 1200 and castles >= 3 and promos >= 1 and refreshes >= 20
