@@ -190,6 +190,32 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 uint64_t spx_perft(const char* fen, int depth);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched self-play driver (BASELINE config 4 shape; control flow of src/datagen/datagen.cpp:96-318): n_games concurrent
+ * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),
+ * i.e. a depth-1 "search" - Stormphrax's alpha-beta search is out of scope), random 8-9 ply openings, the reference's
+ * adjudication counters, viriformat game records appended to out_path (NULL = discard). Needs spx_ctx with
+ * max_batch >= 1; reserves n_games * 129 arena slots. Scores are raw network outputs from the mover's point of view.
+ * Multi-GPU: games are independent - run one process per GPU with its own seed / slice of games.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct spx_selfplay_params {
+    uint32_t n_games;        /* concurrent games (e.g. 4096) */
+    uint32_t target_games;   /* games to finish in total */
+    uint32_t max_plies;      /* draw by length */
+    uint32_t opening_plies;  /* random opening plies before play starts (0 = 8, plus a coin flip as datagen.cpp:153) */
+    uint32_t dfrc;           /* 1 = double-Chess960 starts */
+    int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
+    uint32_t host_threads;   /* move-generation threads (0 = hardware concurrency) */
+    uint32_t reserved;
+    uint64_t seed;
+} spx_selfplay_params;
+typedef struct spx_selfplay_stats {
+    uint64_t games, positions, evals, steps;
+    uint64_t outcomes[3];    /* white loss / draw / white win (datagen/common.h:24-28) */
+    double seconds, gpu_seconds;
+} spx_selfplay_stats;
+int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* params, const char* out_path, spx_selfplay_stats* stats);
+
 /* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):
  * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */
 int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows, int* n_psq, uint32_t* threat_rows,

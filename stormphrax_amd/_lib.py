@@ -52,6 +52,18 @@ class MoveDelta(ctypes.Structure):
 
 assert ctypes.sizeof(MoveDelta) == 1080
 
+class SelfplayParams(ctypes.Structure):
+    _fields_ = [("n_games", ctypes.c_uint32), ("target_games", ctypes.c_uint32), ("max_plies", ctypes.c_uint32),
+                ("opening_plies", ctypes.c_uint32), ("dfrc", ctypes.c_uint32), ("temperature_cp", ctypes.c_int32),
+                ("host_threads", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
+
+
+class SelfplayStats(ctypes.Structure):
+    _fields_ = [("games", ctypes.c_uint64), ("positions", ctypes.c_uint64), ("evals", ctypes.c_uint64),
+                ("steps", ctypes.c_uint64), ("outcomes", ctypes.c_uint64 * 3), ("seconds", ctypes.c_double),
+                ("gpu_seconds", ctypes.c_double)]
+
+
 # every symbol include/spx_nnue.h declares: (restype, argtypes)
 _P = ctypes.c_void_p
 SYMBOLS = {
@@ -90,6 +102,7 @@ SYMBOLS = {
     "spx_random_successors": (ctypes.c_int, [ctypes.c_uint64, _P, ctypes.c_size_t, _P, _P]),
     "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
     "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),
 }

@@ -79,6 +79,12 @@ struct spx_ctx {
     size_t profUsed = 0;
 };
 
+namespace spx {
+size_t ctxMaxBatch(const spx_ctx* ctx) {
+    return ctx->maxBatch;
+}
+}  // namespace spx
+
 namespace {
 
 #define SPX_HIP(call)                                                                              \

@@ -14,6 +14,13 @@ size_t synthNetBytes();
 bool synthNet(uint64_t seed, int preset, void* buf, size_t n);
 uint64_t fnv1a64(const void* data, size_t n);
 
+// spx_api.cpp: capacity of a context (spx_ctx is opaque outside spx_api.cpp)
+struct spx_ctx_fwd;
+}  // namespace spx
+struct spx_ctx;
+namespace spx {
+size_t ctxMaxBatch(const spx_ctx* ctx);
+
 // error plumbing (spx_api): thread-local last error string, returned by spx_last_error()
 void setError(const std::string& msg);
 

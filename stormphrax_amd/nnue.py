@@ -144,6 +144,16 @@ class NnueState:
         check(_lib.load().spx_acc_eval(self._h, slots.ctypes.data, slots.shape[0], out.ctypes.data))
         return out
 
+    def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1,
+                 host_threads=0):
+        """Batched depth-1 self-play (config 4 shape); returns the stats dict. See spx_selfplay_run."""
+        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, host_threads, 0, seed)
+        stats = _lib.SelfplayStats()
+        check(_lib.load().spx_selfplay_run(self._h, ctypes.byref(params), out_path.encode() if out_path else None,
+                                           ctypes.byref(stats)))
+        return {"games": stats.games, "positions": stats.positions, "evals": stats.evals, "steps": stats.steps,
+                "outcomes": list(stats.outcomes), "seconds": stats.seconds, "gpu_seconds": stats.gpu_seconds}
+
     def debug_ft(self, n):
         out = np.empty((n, 1024), dtype=np.uint8)
         check(_lib.load().spx_debug_copy_ft(self._h, n, out.ctypes.data))

@@ -145,3 +145,51 @@ def test_observer_delta_path_matches_reference_traces(sp, states):
         want = np.array([e[1] for e in trace.evals], dtype=np.int32)
         assert np.array_equal(values[nodes[nodes > 0]], want[nodes > 0]), name
         assert np.array_equal(st.evaluate(nodes.astype(np.uint32)), want), name
+
+
+def test_selfplay_driver_records_are_consistent(sp, states, tmp_path):
+    """Config-4 driver in miniature: 96 concurrent games through the fused incremental update+eval path. Every recorded
+    score must equal -evaluate_once(position after the move) (the driver's accumulators, maintained incrementally over the
+    whole game, agree with a from-scratch evaluation - the reference's own datagen assert, datagen.cpp:262), every move
+    must be legal (spx_viri_expand re-validates them) and be the best move within the exploration margin."""
+    st = states("tame")
+    path = str(tmp_path / "games.vf")
+    margin = 25
+    stats = st.selfplay(n_games=96, target_games=160, out_path=path, max_plies=120, dfrc=True, temperature_cp=margin, seed=9)
+    assert stats["games"] == 160 and stats["positions"] > 3000 and sum(stats["outcomes"]) == 160
+    blob = open(path, "rb").read()
+    positions, games = sp.viri_expand(blob)
+    assert games == 160 and len(positions) == stats["positions"]
+    # game boundaries from the stream itself
+    lengths, off = [], 0
+    while off < len(blob):
+        off += 32
+        n = 0
+        while blob[off:off + 4] != b"\x00\x00\x00\x00":
+            off += 4
+            n += 1
+        off += 4
+        lengths.append(n)
+    assert sum(lengths) == len(positions)
+    full = st.evaluate_once(positions)
+    start = 0
+    checked = 0
+    for n in lengths:
+        for k in range(start, start + n - 1):
+            want = -int(full[k + 1])
+            want = 0 if abs(want) <= 2 else max(-32000, min(32000, want))
+            assert int(positions["eval"][k]) == want, (k, sp.position_to_fen(positions[k]))
+            checked += 1
+        start += n
+    assert checked > 2500
+    # optimality within the margin on a sample: no legal reply scores more than `margin` above the recorded one
+    rng = np.random.default_rng(0)
+    for k in rng.choice(len(positions), 40, replace=False):
+        succ = []
+        cur = positions[k:k + 1]
+        for seed in range(200):
+            nxt, moved = sp.random_successors(cur, seed=seed)
+            if moved[0]:
+                succ.append(nxt[0])
+        best = max(-int(v) for v in st.evaluate_once(np.array(succ, dtype=sp.PACKED_DTYPE)))
+        assert int(positions["eval"][k]) >= min(best, 32000) - margin - 2 or abs(int(positions["eval"][k])) == 0

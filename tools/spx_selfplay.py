@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Batched self-play on the GPU (BASELINE config 4 shape): N concurrent games per GPU, every candidate move of every game
+evaluated in one incremental update+eval batch per ply (depth-1 policy), viriformat output.
+
+    python tools/spx_selfplay.py --games 4096 --target 8192 --out /tmp/games            # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/spx_selfplay.py --games 4096 ...
+
+Games are independent: each rank plays its own games on its own GPU (seed + rank) and writes <out>.<rank>.vf; the only
+communication is the final SUM of the counters (gloo). Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stormphrax_amd as sp  # noqa: E402
+from stormphrax_amd.distributed import Group  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--target", type=int, default=8192, help="games to finish per GPU")
+    ap.add_argument("--max-plies", type=int, default=300)
+    ap.add_argument("--temperature", type=int, default=30)
+    ap.add_argument("--dfrc", action="store_true")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--preset", default="tame")
+    ap.add_argument("--net")
+    ap.add_argument("--out")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    group = Group(backend="gloo")
+    net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
+    state = sp.NnueState(net, device=group.local_rank, max_batch=args.games * 64)
+    out = f"{args.out}.{group.rank}.vf" if args.out else None
+    stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
+                           temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads)
+    slowest = group.max_float(stats["seconds"])
+    total = {k: group.sum_int(stats[k]) for k in ("games", "positions", "evals", "steps")}
+    gpu_seconds = group.max_float(stats["gpu_seconds"])
+    if group.rank == 0:
+        print(json.dumps({
+            "metric": "selfplay_leaf_evals_per_sec", "value": total["evals"] / slowest, "unit": "evals/s",
+            "n_gpus": group.world, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
+            "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
+            "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
+            "outcomes_white_loss_draw_win": stats["outcomes"], "host_threads": args.threads or os.cpu_count(),
+            "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
+        }))
+    group.close()
+
+
+if __name__ == "__main__":
+    main()
