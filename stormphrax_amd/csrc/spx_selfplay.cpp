@@ -103,7 +103,9 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
         return SPX_ERR_INVALID_ARG;
     }
     const uint32_t G = p->n_games;
-    const uint32_t threads = std::max(1u, p->host_threads ? p->host_threads : std::thread::hardware_concurrency());
+    // threads are spawned per ply (no pool): beyond ~32 the spawn cost outweighs the move generation they share
+    const uint32_t threads =
+        std::max(1u, p->host_threads ? p->host_threads : std::min(32u, std::thread::hardware_concurrency()));
     const size_t maxChildren = size_t(G) * 64;  // scratch slots per step parity (more children are processed in chunks)
     int rc = spx_acc_reserve(ctx, size_t(G) + 2 * maxChildren);
     if (rc != SPX_OK) return rc;
