@@ -1078,7 +1078,7 @@ int spx_debug_features(const spx_packed_pos* pos, int c, uint32_t* psqRows, int*
             if ((piece[lane] >> 1) == 5) kingsBb |= 1ull << lane;
             if (piece[lane] == (10 | c)) kingSq = lane;
             if (piece[lane] & 1) whiteBb |= 1ull << lane;
-            if ((piece[lane] >> 1) == 0) pawnsBb |= 1ull << lane;
+            if ((piece[lane] >> 1) == 0 && lane >= 8 && lane < 56) pawnsBb |= 1ull << lane;
         }
     }
     if (kingSq < 0) {

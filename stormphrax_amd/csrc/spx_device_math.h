@@ -204,6 +204,9 @@ SPX_HD int nibbleToPiece(int nib) {
     if (type == 6) {
         type = 3;
     }
+    if (type == 7) {
+        type = 0;  // not a marlinformat code: malformed record. Any valid piece keeps every table index in range.
+    }
     return (type << 1) | ((nib & 8) ? 0 : 1);
 }
 

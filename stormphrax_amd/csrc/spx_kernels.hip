@@ -83,7 +83,8 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
     b.occ = *reinterpret_cast<const uint64_t*>(rec);
     b.stm = (rec[24] & 0x80) ? 0 : 1;
     const bool occupied = (b.occ >> lane) & 1;
-    const uint32_t nibIdx = popc64(b.occ & ((1ull << lane) - 1));
+    // malformed records (> 32 pieces) must not read past the 32-byte record: results are unspecified, accesses are not
+    const uint32_t nibIdx = min(uint32_t(popc64(b.occ & ((1ull << lane) - 1))), 31u);
     b.piece = kNoPiece;
     if (occupied) {
         const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
@@ -92,7 +93,9 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
     const int type = b.piece >> 1;  // 6 for empty
     b.kingsBb = __ballot(type == 5);
     b.whiteBb = __ballot(occupied && (b.piece & 1) == 1);
-    b.pawnsBb = __ballot(type == 0);
+    // pawn-pair ids are (square - 8): pawns on the back ranks exist only in malformed records and are left out of the
+    // pawn-pair features (kPpMasks is empty for those squares anyway, threats.h:109)
+    b.pawnsBb = __ballot(type == 0) & 0x00FFFFFFFFFFFF00ull;
     return b;
 }
 
@@ -161,7 +164,8 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     const int piece = b.piece;
     const bool occupied = piece != kNoPiece;
     const int type = piece >> 1;
-    const int kingSq = ctz64(__ballot(piece == (10 | c)));
+    const uint64_t ownKing = __ballot(piece == (10 | c));
+    const int kingSq = ownKing ? ctz64(ownKing) : 0;  // a record without that king is malformed: stay in bounds
     const uint64_t ownPawns = b.pawnsBb & (c ? b.whiteBb : ~b.whiteBb);
     const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
     const int x = perspXor(c, kingSq);
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
 
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
-            const int kingP = ctz64(__ballot(pb.piece == (10 | c)));
-            const int kingC = ctz64(__ballot(cb.piece == (10 | c)));
+            const uint64_t kingMaskP = __ballot(pb.piece == (10 | c)), kingMaskC = __ballot(cb.piece == (10 | c));
+            const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
             const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
             // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the caller
             // paired unrelated boards) and is rebuilt from scratch rather than overflowing the small delta lists

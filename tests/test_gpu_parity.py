@@ -109,3 +109,23 @@ def test_full_size_batch_properties(sp, oracle, net_blob, states):
     assert np.array_equal(st.evaluate_once(flipped), oracle.eval_mailboxes(mail, 1 - stm))
     # checksum of checksums: a stable digest of the whole batch for cross-run comparison
     assert int(full.astype(np.int64).sum()) == int(halves.astype(np.int64).sum())
+
+
+def test_malformed_records_do_not_fault(sp, states):
+    """Garbage in the batch (no kings, 64 occupied squares, invalid nibbles) must neither crash the device nor disturb
+    the valid records around it: hot calls do not validate per position (like the reference, which only asserts)."""
+    st = states("tame")
+    good = sp.random_positions(256, seed=3)
+    want = st.evaluate_once(good)
+    bad = good.copy()
+    rng = np.random.default_rng(5)
+    raw = bad.view(np.uint8).reshape(-1, 32)
+    for i in range(0, 256, 4):
+        raw[i] = rng.integers(0, 256, 32, dtype=np.uint8)
+    raw[8] = 0xFF           # all squares occupied, every nibble 0xF
+    raw[12] = 0             # empty board
+    got = st.evaluate_once(bad)
+    keep = np.ones(256, dtype=bool)
+    keep[::4] = False
+    assert np.array_equal(got[keep], want[keep])
+    assert np.array_equal(st.evaluate_once(good), want)  # the context is still healthy
