@@ -252,6 +252,9 @@ def main():
     if rank == 0:
         psq_rows, thr_rows = sp.count_rows(positions)
         algo_bytes = 2048 * psq_rows + 1024 * thr_rows + 36 * args.batch  # per launch
+        compact_rows = states[0].compact_psq_rows
+        psq_bytes = {11264: 1024, 0: 2048}.get(compact_rows)  # mixed nets: not derivable from the row totals
+        requested = None if psq_bytes is None else psq_bytes * psq_rows + 1024 * thr_rows + 36 * args.batch
         ft_avg_s = ft_ms / max(calls, 1) / 1e3
         achieved = algo_bytes / ft_avg_s / 1e9
         value = world * args.batch * args.steps / elapsed
@@ -291,6 +294,11 @@ def main():
                                 "this run's configuration was not profiled",
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_position": algo_bytes / args.batch,
+                "compact_psq_rows": compact_rows,
+                "requested_bytes_per_launch": requested,
+                "requested_note": "bytes the kernel's loads ask for: piece-square rows whose weights all fit i8 "
+                                  f"({compact_rows} of 11264 in this net) are fetched as 1 KiB u8 copies instead of "
+                                  "2 KiB i16 rows (bit-identical sums); `achieved` stays in algorithmic bytes",
             },
         }
         if not args.no_cpu_baseline:

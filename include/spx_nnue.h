@@ -134,6 +134,11 @@ int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms
  * 2048 * psq_rows + 1024 * threat_rows (+ 36 B per position of record and score). Host-side count. */
 int spx_count_rows(const spx_packed_pos* positions, size_t n, uint64_t* psq_rows, uint64_t* threat_rows);
 
+/* Number of piece-square rows (of 11264) whose weights all fit i8: the context keeps a 1 KiB u8 copy of those and the
+ * full-refresh kernel fetches it instead of the 2 KiB i16 row (identical sums, fewer bytes). Net dependent; 0 when
+ * the environment sets SPX_NO_COMPACT=1. Reported by bench.py next to the algorithmic byte count. */
+uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx);
+
 /* Device-side intermediates of the last spx_eval_full* call on this context, for tests and profiling:
  * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
 int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);

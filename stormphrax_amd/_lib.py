@@ -89,6 +89,7 @@ SYMBOLS = {
     "spx_acc_update_eval": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_eval_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
+    "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),

@@ -71,6 +71,7 @@ struct spx_ctx {
     int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
                                    // the other one for its successor), [2] belongs to the single-launch small sort
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
+    uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
@@ -278,11 +279,28 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
 
     int rc;
     const unsigned char* b = net->blob.data();
+    uint32_t compactBits[kLutCompactWords] = {};
     if ((rc = uploadArray(ctx->dPsqW, b + kOffPsqW, kPsqWBytes, ctx->stream)) != SPX_OK) return rc;
     {
-        std::vector<uint8_t> thr(kThreatWBytes);
+        // u8 row table: the threat rows, then one slot per piece-square row holding its i8 copy when every weight of
+        // that row fits i8 ("compact" rows: the kernels read 1 KiB instead of the 2 KiB i16 row; bit-identical sums)
+        std::vector<uint8_t> thr(kThreatWBytes + size_t(kPsqRows) * kL1, 0x80);
         for (uint32_t r = 0; r < kThreatRows; ++r) {
             relayoutThreatRow(net->threatW() + size_t(r) * kL1, thr.data() + size_t(r) * kL1);
+        }
+        bool useCompact = true;
+        if (const char* env = std::getenv("SPX_NO_COMPACT")) useCompact = env[0] == '0';
+        const int16_t* psq = reinterpret_cast<const int16_t*>(b + kOffPsqW);
+        for (uint32_t r = 0; r < kPsqRows && useCompact; ++r) {
+            const int16_t* row = psq + size_t(r) * kL1;
+            bool fits = true;
+            for (uint32_t j = 0; j < kL1 && fits; ++j) fits = row[j] >= -128 && row[j] <= 127;
+            if (!fits) continue;
+            int8_t narrow[kL1];
+            for (uint32_t j = 0; j < kL1; ++j) narrow[j] = int8_t(row[j]);
+            relayoutThreatRow(narrow, thr.data() + (size_t(kThreatRows) + r) * kL1);
+            compactBits[r >> 5] |= 1u << (r & 31);
+            ++ctx->compactPsqRows;
         }
         if ((rc = uploadArray(ctx->dThrW, thr.data(), thr.size(), ctx->stream)) != SPX_OK) return rc;
     }
@@ -303,6 +321,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
             setError("internal: threat LUT does not cover 59808 features");
             return SPX_ERR_BAD_NET;
         }
+        std::memcpy(lut + kLutCompactBase, compactBits, sizeof(compactBits));
         if ((rc = uploadArray(ctx->dLut, lut, sizeof(lut), ctx->stream)) != SPX_OK) return rc;
     }
     SPX_HIP(hipMalloc(&ctx->dPositions, max_batch * sizeof(spx_packed_pos)));
@@ -704,6 +723,10 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
     }
     ctx->profUsed = 0;
     return SPX_OK;
+}
+
+uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx) {
+    return ctx ? ctx->compactPsqRows : 0;
 }
 
 int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms, size_t* calls) {

@@ -172,9 +172,14 @@ SPX_HD uint32_t psqRow(int c, int piece, int sq, int kingSq) {
 // Threat LUT layout shared by host builder and kernels (u32 words):
 //   [0, 768)      offsets[piece][sq]            kOffsets.offsets   (threats.cpp:108-136)
 //   [768, 1056)   attackIdx[attacker][attacked][forwards]  kAttackIndices (threats.cpp:138-167), INT_MIN = excluded
+//   [1056, 1408)  one bit per piece-square row: 1 = every weight of the row fits i8, so the row is ALSO stored in
+//                 the u8 row table (at row kThreatRows + r) and the kernels fetch that 1 KiB copy instead of the
+//                 2 KiB i16 row. Derived from the loaded net (spx_ctx_create); lossless by construction.
 constexpr int kLutOffsetsWords = 12 * 64;
 constexpr int kLutAttackWords = 12 * 12 * 2;
-constexpr int kLutWords = kLutOffsetsWords + kLutAttackWords;
+constexpr int kLutCompactBase = kLutOffsetsWords + kLutAttackWords;
+constexpr int kLutCompactWords = int(kPsqRows) / 32;
+constexpr int kLutWords = kLutCompactBase + kLutCompactWords;
 
 // threats::threatFeatureIndex. pseudoRel = piecePseudoAttacks(attacker', asq') precomputed by the caller in the
 // transformed frame (it replaces the 48 KB kPieceIndices table: popcount of pseudo-attacked squares below vsq').

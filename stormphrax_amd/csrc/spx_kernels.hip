@@ -35,6 +35,7 @@ constexpr int kWavesPerBlock = 4;
 #endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
+constexpr int kU8Cap = kThreatCap + kPsqCap;  // u8-row list: compact piece-square rows first, then <= 256 threat rows
 
 __device__ __forceinline__ uint32_t laneId() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -158,7 +159,9 @@ __device__ __forceinline__ uint64_t pawnPartners(bool isPawn, bool own, uint32_t
     return own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane))) : (theirPawns & above & ppMask(int(lane)));
 }
 
-// Row lists of one perspective of one board (the full-refresh feature set). psqList capacity kPsqCap, thrList kThreatCap.
+// Row lists of one perspective of one board (the full-refresh feature set): psqList (capacity kPsqCap) = byte offsets
+// into the i16 piece-square table, thrList (capacity kU8Cap) = byte offsets into the u8 row table; nThr counts both the
+// compact piece-square rows and the threat / pawn-pair rows in it.
 __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
                                                uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr) {
     const int piece = b.piece;
@@ -171,27 +174,42 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     const int x = perspXor(c, kingSq);
     const int flipColour = (c == 0) ? 1 : 0;
 
-    // piece-square rows: one per occupied square (resetPsqAccumulator, nnue_state.cpp:440-449)
+    // piece-square rows: one per occupied square (resetPsqAccumulator, nnue_state.cpp:440-449). Rows whose weights all
+    // fit i8 have a 1 KiB copy in the u8 table: those go to the head of the u8 list, the rest to the i16 list.
+    uint32_t nCompact;
     {
-        const uint32_t slot = prefixCount(b.occ);
-        if (occupied && slot < kPsqCap) {
-            psqList[slot] = psqRow(c, piece, int(lane), kingSq) * (kL1 * 2);
+        uint32_t row = 0;
+        bool compact = false;
+        if (occupied) {
+            row = psqRow(c, piece, int(lane), kingSq);
+            compact = (lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u;
         }
+        const uint64_t compactMask = __ballot(occupied && compact), wideMask = b.occ & ~compactMask;
+        const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
+        if (occupied && slot < kPsqCap) {
+            if (compact) {
+                thrList[slot] = (kThreatRows + row) * kL1;
+            } else {
+                psqList[slot] = row * (kL1 * 2);
+            }
+        }
+        nCompact = min(uint32_t(popc64(compactMask)), uint32_t(kPsqCap));
+        nPsq = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
     }
-    nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
+    uint32_t* threatList = thrList + nCompact;  // the reference's <= 256-entry threat list proper
 
     // threat rows (addThreatFeatures, nnue_state.cpp:309-328)
     uint64_t targets = 0;
     if (occupied && type != 5) {
         targets = pieceAttacks(piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
     }
-    nThr = emitThreatRows(thrList, 0, targets, piece, lane, x, flipColour, lut);
+    nThr = emitThreatRows(threatList, 0, targets, piece, lane, x, flipColour, lut);
 
     // pawn-pair rows (nnue_state.cpp:330-351)
     const bool isPawn = type == 0;
     const bool own = isPawn && (piece & 1) == c;
-    nThr = emitPawnPairRows(thrList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
-                            ppId(int(lane) ^ x, !own), ownPawns, x);
+    nThr = nCompact + emitPawnPairRows(threatList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
+                                       ppId(int(lane) ^ x, !own), ownPawns, x);
     __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
 }
 
@@ -239,13 +257,16 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
     }
-    // Threat rows go to their own accumulator: <= 256 rows x 255 never overflows a 16-bit field, so plain 32-bit
-    // adds (v_add3_u32: two rows per add) are exact and no carry crosses fields. Folded into acc (mod 2^16) below.
-    uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // u8 rows (threat, pawn-pair and compact piece-square rows, stored +128) go to their own accumulator: <= 256 rows
+    // x 255 never overflows a 16-bit field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry
+    // crosses fields. Folded into acc (mod 2^16) per segment of 256 rows; a second segment exists only when compact
+    // piece-square rows push the list beyond 256 entries.
     const uint8_t* thrBase = t.thrW + 16 * lane;
-    {
-        uint32_t i = 0;
-        for (; i + 8 <= nThr; i += 8) {  // 8 x 1 KiB wave loads in flight
+    for (uint32_t segBegin = 0; segBegin < nThr; segBegin += uint32_t(kThreatCap)) {
+        const uint32_t segEnd = min(nThr, segBegin + uint32_t(kThreatCap));
+        uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t i = segBegin;
+        for (; i + 8 <= segEnd; i += 8) {  // 8 x 1 KiB wave loads in flight
             u32x4 w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -260,7 +281,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
                 }
             }
         }
-        for (; i + 2 <= nThr; i += 2) {
+        for (; i + 2 <= segEnd; i += 2) {
             const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
             const u32x4 w1 =
                 *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i + 1]));
@@ -270,7 +291,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
                 tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
             }
         }
-        if (i < nThr) {
+        if (i < segEnd) {
             const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -278,10 +299,8 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
                 tacc[2 * d + 1] += unpackHi(w0[d]);
             }
         }
-    }
-    {
-        // fold in, removing the +128 storage bias: every threat row contributed 128 to every column
-        const uint32_t corr = (nThr * 128u) & 0xFFFFu;
+        // fold in, removing the +128 storage bias: every u8 row contributed 128 to every column
+        const uint32_t corr = ((segEnd - segBegin) * 128u) & 0xFFFFu;
         const uint32_t corr2 = corr | (corr << 16);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -401,7 +420,7 @@ __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* are
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // byte offsets into the threat table
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
 
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];  // full rebuild: threat rows; incremental: rows to ADD
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
     __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];  // incremental: threat rows to SUBTRACT
     __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];   // incremental: psq rows to subtract / add (<= 4 each)
@@ -579,7 +598,7 @@ constexpr uint32_t kDeltaBytes = 1080;
 
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_kernel(UpdateParams p) {
     __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
     __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];
     __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];

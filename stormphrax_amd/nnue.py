@@ -88,6 +88,11 @@ class NnueState:
         """Device-resident variant: raw device pointers (e.g. torch tensors' data_ptr()), enqueued on `stream_ptr`."""
         check(_lib.load().spx_eval_full_device(self._h, d_positions_ptr, n, d_out_ptr, stream_ptr))
 
+    @property
+    def compact_psq_rows(self):
+        """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
+        return int(_lib.load().spx_ctx_compact_psq_rows(self._h))
+
     def profile_begin(self, max_calls):
         check(_lib.load().spx_profile_begin(self._h, max_calls))
 

@@ -129,3 +129,34 @@ def test_malformed_records_do_not_fault(sp, states):
     keep[::4] = False
     assert np.array_equal(got[keep], want[keep])
     assert np.array_equal(st.evaluate_once(good), want)  # the context is still healthy
+
+
+def test_mixed_compact_and_wide_piece_square_rows(sp, oracle, net_blob, states):
+    """Piece-square rows whose weights all fit i8 are served from a 1 KiB u8 copy, the others from the i16 table.
+    A net with both kinds (every third row gets out-of-i8-range weights, boundary values -128/127/128/-129 included)
+    must still equal the oracle bit for bit; per-row classification is checked through the context's count."""
+    blob = np.array(net_blob("wild"), copy=True)
+    psq = blob[64 : 64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
+    rng = np.random.default_rng(9)
+    wide = np.arange(11264) % 3 == 0
+    cols = rng.integers(0, 1024, size=11264)
+    vals = rng.choice(np.array([128, -129, 3000, -3000, 32767, -32768], dtype=np.int16), size=11264)
+    psq[np.nonzero(wide)[0], cols[wide]] = vals[wide]
+    edge = np.nonzero(~wide)[0]
+    psq[edge, cols[edge]] = rng.choice(np.array([127, -128], dtype=np.int16), size=edge.size)  # still compact
+    st = sp.NnueState(sp.Network(blob), device=0, max_batch=4096)
+    try:
+        assert st.compact_psq_rows == int((~wide).sum())
+        assert states("tame").compact_psq_rows == 11264 and states("extreme").compact_psq_rows < 11264
+        pos = sp.random_positions(4096, seed=77, min_ply=0, max_ply=140, dfrc_every=4)
+        mail, stm = sp.positions_to_mailboxes(pos)
+        oracle.use(blob, "mixed-compact")
+        want = oracle.eval_mailboxes(mail, stm)
+        got = st.evaluate_once(pos)
+        assert np.array_equal(got, want)
+        # accumulators written by the refresh path (same lists) feed the incremental path unchanged
+        st.reserve_slots(4096)
+        st.reset(pos, np.arange(4096, dtype=np.uint32))
+        assert np.array_equal(st.evaluate(np.arange(4096, dtype=np.uint32)), want)
+    finally:
+        st.close()
