@@ -124,6 +124,30 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream);
 
+/* ---- post-processing of raw evals on the device -------------------------------------------
+ * eval::adjustStatic (src/eval/eval.cpp:24-27: + contempt[stm], clamp to +-24999) and eval::adjustEval
+ * (src/eval/eval.cpp:30-67: material scaling + optimism, halfmove damping, optional correction / 2048, clamp) applied
+ * in place to n raw evals that belong to the n records (piece counts, side to move and the halfmove clock are read from
+ * the 32-byte records). spx_eval_full + SPX_ADJUST_STATIC == eval::staticEvalOnce; + SPX_ADJUST_EVAL ==
+ * eval::adjustedStaticEval. The correction-history table itself stays with the search on the host: pass its
+ * per-position `correction(pos, keyHistory)` values, or NULL for adjustEval<false>. i32 arithmetic wraps where the
+ * reference's would overflow (undefined there). */
+enum { SPX_ADJUST_STATIC = 1, SPX_ADJUST_EVAL = 2 };
+typedef struct spx_adjust_params {
+    int32_t contempt[2];             /* eval::Contempt, by colour: [0] black, [1] white (eval.h:31) */
+    int32_t optimism[2];             /* eval::Optimism (eval.h:32) */
+    int32_t scaling_value[5];        /* pawn, knight, bishop, rook, queen (tunable.h:161-165) */
+    int32_t material_scaling_base;   /* tunable.h:167 */
+    int32_t optimism_base;           /* tunable.h:168 */
+    int32_t optimism_material_scale; /* tunable.h:169 */
+    uint32_t stages;                 /* SPX_ADJUST_STATIC | SPX_ADJUST_EVAL */
+} spx_adjust_params;
+void spx_adjust_defaults(spx_adjust_params* params); /* the reference's default tunables, no contempt / optimism, both stages */
+int spx_adjust(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const spx_adjust_params* params,
+               const int32_t* corrections, int32_t* evals);
+int spx_adjust_device(spx_ctx* ctx, const void* d_positions, size_t n, const spx_adjust_params* params,
+                      const void* d_corrections, void* d_evals, void* stream);
+
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
  * sort kernels, the feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */

@@ -17,6 +17,7 @@
 //   playout <seed> <count> <minPly> <maxPly> <dfrc>  -> count lines "P <raw> <fen>"
 //   trace <seed> <maxEvals> <depth> <fen>            -> opcode stream of a DFS make/unmake walk with evaluate() values
 //   deltas <seed> <count> <dfrc>                     -> per played move the BoardObserver's UpdateContext
+//   adjust <cB> <cW> <oB> <oW> <fen>                 -> "A <staticEvalOnce(contempt)> <adjustEval<false>(optimism, static)>"
 //   add <fen> / bench <threads> <seconds>            -> timing of evaluateOnce over the added positions
 #include <atomic>
 #include <chrono>
@@ -29,6 +30,7 @@
 
 #include "attacks/attacks.h"
 #include "cuckoo.h"
+#include "eval/eval.h"
 #include "eval/nnue.h"
 #include "eval/nnue_state.h"
 #include "movegen.h"
@@ -199,6 +201,23 @@ int main() {
                     }
                 }
             }
+        } else if (cmd == "adjust") {
+            // eval::staticEvalOnce (eval.cpp:109-112: contempt + clamp) and eval::adjustEval<false> (eval.cpp:30-67:
+            // material scaling, optimism, halfmove damping, clamp; no correction history) on one position
+            eval::Contempt contempt{};
+            eval::Optimism optimism{};
+            in >> contempt[0] >> contempt[1] >> optimism[0] >> optimism[1];
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            const auto stat = eval::staticEvalOnce(*pos, contempt);
+            const auto adjusted = eval::adjustEval<false>(*pos, optimism, {}, nullptr, stat);
+            std::printf("A %d %d\n", stat, adjusted);
         } else if (cmd == "playout") {
             u64 seed;
             u32 count, minPly, maxPly, dfrc;

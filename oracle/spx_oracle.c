@@ -629,3 +629,47 @@ void spxo_accumulate_rows(const uint32_t* psqRowsIn, int nPsq, const uint32_t* t
     accumulatePsq(psqRowsIn, nPsq, (uint16_t*)psqOut);
     accumulateThreat(thrRowsIn, nThr, (uint16_t*)thrOut);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Host-scalar post-processing of a raw eval (eval.cpp:24-67):
+ *   adjustStatic  (eval.cpp:24-27)   eval += contempt[stm]; clamp to +-(kScoreWin - 1), kScoreWin = 25000 (core.h:708)
+ *   adjustEval    (eval.cpp:30-67)   material scaling + optimism, halfmove damping, optional correction / 2048, clamp
+ * params: [0..1] contempt (black, white), [2..3] optimism, [4..8] scalingValue{Pawn,Knight,Bishop,Rook,Queen}
+ * (tunable.h:161-165), [9] materialScalingBase, [10] optimismBase, [11] optimismMaterialScale (tunable.h:167-169).
+ * stages: bit 0 = adjustStatic, bit 1 = adjustEval. i32 arithmetic as in the reference (done unsigned where it could
+ * wrap), C division truncating toward zero.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int32_t clampScore(int32_t v) {
+    return v < -24999 ? -24999 : (v > 24999 ? 24999 : v);
+}
+static int32_t wrapMul(int32_t a, int32_t b) {
+    return (int32_t)((uint32_t)a * (uint32_t)b);
+}
+static int32_t wrapAdd(int32_t a, int32_t b) {
+    return (int32_t)((uint32_t)a + (uint32_t)b);
+}
+
+int32_t spxo_adjust(const uint8_t* mailbox, int stm, int halfmove, const int32_t* params, uint32_t stages,
+                    int hasCorrection, int32_t correction, int32_t eval) {
+    if (stages & 1u) {
+        eval = clampScore(wrapAdd(eval, params[stm]));
+    }
+    if (stages & 2u) {
+        int32_t npMaterial = 0;
+        for (int sq = 0; sq < 64; ++sq) {
+            const int piece = mailbox[sq];
+            if (piece != NO_PIECE && (piece >> 1) < 5) {
+                npMaterial += params[4 + (piece >> 1)];
+            }
+        }
+        const int32_t a = wrapMul(eval, wrapAdd(params[9], npMaterial));
+        const int32_t b = wrapMul(params[2 + stm], wrapAdd(params[10], wrapMul(npMaterial, params[11]) / 1024));
+        eval = wrapAdd(a, b) / 32768;
+        eval = wrapMul(eval, 200 - halfmove) / 200;
+        if (hasCorrection) {
+            eval = wrapAdd(eval, correction / 2048);
+        }
+        eval = clampScore(eval);
+    }
+    return eval;
+}

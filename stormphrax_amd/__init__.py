@@ -4,9 +4,12 @@ The product is the C-ABI shared library `libspx_nnue.so` (include/spx_nnue.h; so
 hand-written HIP for gfx950). This package is the Python plumbing the tests and bench.py use.
 """
 from .nnue import (  # noqa: F401
+    ADJUST_EVAL,
+    ADJUST_STATIC,
     PACKED_DTYPE,
     Network,
     NnueState,
+    adjust_params,
     apply_uci,
     count_rows,
     debug_features,

@@ -52,6 +52,14 @@ class MoveDelta(ctypes.Structure):
 
 assert ctypes.sizeof(MoveDelta) == 1080
 
+class AdjustParams(ctypes.Structure):
+    """spx_adjust_params (include/spx_nnue.h): eval::Contempt / Optimism and the scaling tunables of eval.cpp:30-67."""
+    _fields_ = [("contempt", ctypes.c_int32 * 2), ("optimism", ctypes.c_int32 * 2),
+                ("scaling_value", ctypes.c_int32 * 5), ("material_scaling_base", ctypes.c_int32),
+                ("optimism_base", ctypes.c_int32), ("optimism_material_scale", ctypes.c_int32),
+                ("stages", ctypes.c_uint32)]
+
+
 class SelfplayParams(ctypes.Structure):
     _fields_ = [("n_games", ctypes.c_uint32), ("target_games", ctypes.c_uint32), ("max_plies", ctypes.c_uint32),
                 ("opening_plies", ctypes.c_uint32), ("dfrc", ctypes.c_uint32), ("temperature_cp", ctypes.c_int32),
@@ -90,6 +98,9 @@ SYMBOLS = {
     "spx_acc_update_eval_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
+    "spx_adjust_defaults": (None, [_P]),
+    "spx_adjust": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P]),
+    "spx_adjust_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P]),
     "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),

@@ -348,7 +348,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipGetDeviceProperties(&prop, device));
     // persistent-ish grid: workgroups (4 waves) per CU, grid-stride over perspectives. A/B on MI355X: 2 -> 0.72 ms,
     // 4 -> 0.575, 8 -> 0.565, 16 -> 0.557, 64 -> 0.554 (finer-grained tail balancing)
-    uint32_t blocksPerCu = 16;
+    uint32_t blocksPerCu = 32;
     if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
     *out = ctx.release();
@@ -787,6 +787,71 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
         const int rc = spx_eval_full_device(ctx, ctx->dPositions, m, ctx->dOut, ctx->stream);
         if (rc != SPX_OK) return rc;
         SPX_HIP(hipMemcpyAsync(out + lo, ctx->dOut, m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SPX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SPX_OK;
+}
+
+void spx_adjust_defaults(spx_adjust_params* params) {
+    if (!params) return;
+    *params = spx_adjust_params{};
+    const int32_t values[5] = {48, 442, 461, 637, 1223};  // tunable.h:161-165
+    std::copy(values, values + 5, params->scaling_value);
+    params->material_scaling_base = 26000;   // tunable.h:167
+    params->optimism_base = 2024;            // tunable.h:168
+    params->optimism_material_scale = 1005;  // tunable.h:169
+    params->stages = SPX_ADJUST_STATIC | SPX_ADJUST_EVAL;
+}
+
+int spx_adjust_device(spx_ctx* ctx, const void* d_positions, size_t n, const spx_adjust_params* params,
+                      const void* d_corrections, void* d_evals, void* stream) {
+    if (!ctx || !params || (n && (!d_positions || !d_evals)) || n > (1ull << 30)) {
+        setError("spx_adjust_device: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (params->stages == 0 || (params->stages & ~uint32_t(SPX_ADJUST_STATIC | SPX_ADJUST_EVAL))) {
+        setError("spx_adjust_device: stages must be a combination of SPX_ADJUST_STATIC and SPX_ADJUST_EVAL");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (n == 0) return SPX_OK;
+    SPX_HIP(hipSetDevice(ctx->device));
+    AdjustParams ap{};
+    std::copy(params->contempt, params->contempt + 2, ap.contempt);
+    std::copy(params->optimism, params->optimism + 2, ap.optimism);
+    std::copy(params->scaling_value, params->scaling_value + 5, ap.scalingValue);
+    ap.materialScalingBase = params->material_scaling_base;
+    ap.optimismBase = params->optimism_base;
+    ap.optimismMaterialScale = params->optimism_material_scale;
+    ap.stages = params->stages;
+    ap.nPositions = uint32_t(n);
+    ap.positions = static_cast<const uint64_t*>(d_positions);
+    ap.corrections = static_cast<const int32_t*>(d_corrections);
+    ap.evals = static_cast<int32_t*>(d_evals);
+    SPX_HIP(launchAdjust(ap, stream ? static_cast<hipStream_t>(stream) : ctx->stream));
+    return SPX_OK;
+}
+
+int spx_adjust(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const spx_adjust_params* params,
+               const int32_t* corrections, int32_t* evals) {
+    if (!ctx || !params || (n && (!positions || !evals))) {
+        setError("spx_adjust: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (n == 0) return SPX_OK;
+    SPX_HIP(hipSetDevice(ctx->device));
+    for (size_t lo = 0; lo < n; lo += ctx->maxBatch) {  // dSlotsA doubles as the corrections staging buffer
+        const size_t m = std::min(ctx->maxBatch, n - lo);
+        SPX_HIP(hipMemcpyAsync(ctx->dPositions, positions + lo, m * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
+                               ctx->stream));
+        SPX_HIP(hipMemcpyAsync(ctx->dOut, evals + lo, m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (corrections) {
+            SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, corrections + lo, m * sizeof(int32_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        }
+        const int rc = spx_adjust_device(ctx, ctx->dPositions, m, params, corrections ? ctx->dSlotsA : nullptr,
+                                         ctx->dOut, ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipMemcpyAsync(evals + lo, ctx->dOut, m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         SPX_HIP(hipStreamSynchronize(ctx->stream));
     }
     return SPX_OK;

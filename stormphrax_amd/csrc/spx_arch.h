@@ -63,5 +63,6 @@ constexpr uint8_t kActivationId = 0;  // activation.h:99 ClippedReLU
 
 // pieces: type<<1 | colour, black = 0, white = 1 (core.h:336-350); 12 = none
 constexpr uint8_t kNoPiece = 12;
+constexpr int32_t kScoreWin = 25000;  // core.h:708; static evals are clamped to +-(kScoreWin - 1) (eval.cpp:26,63)
 
 }  // namespace spx

@@ -51,6 +51,18 @@ struct SlotActParams {
     uint8_t* stagedRecords;   // [nSlots][32] contiguous copy of the slots' records (input of the bucket sort)
 };
 
+struct AdjustParams {        // spx_adjust_params flattened (include/spx_nnue.h)
+    int32_t contempt[2];
+    int32_t optimism[2];
+    int32_t scalingValue[5];
+    int32_t materialScalingBase, optimismBase, optimismMaterialScale;
+    uint32_t stages;
+    uint32_t nPositions;
+    const uint64_t* positions;    // records as u64[4]
+    const int32_t* corrections;   // nullable
+    int32_t* evals;               // in place
+};
+
 struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
@@ -81,6 +93,7 @@ hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchAdjust(const AdjustParams& p, hipStream_t stream);
 hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();
 

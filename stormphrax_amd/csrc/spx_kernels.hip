@@ -159,6 +159,24 @@ __device__ __forceinline__ uint64_t pawnPartners(bool isPawn, bool own, uint32_t
     return own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane))) : (theirPawns & above & ppMask(int(lane)));
 }
 
+// One piece-square delta row per `active` lane: rows with a compact (u8) copy are appended at the head of `u8List`,
+// the others go to `wideList` (i16 table). Capacities 8 each. Returns the number of compact rows; nWide by reference.
+__device__ __forceinline__ uint32_t emitPsqDeltaRows(bool active, uint32_t row, const uint32_t* lut, uint32_t* wideList,
+                                                     uint32_t* u8List, uint32_t& nWide) {
+    const bool compact = active && ((lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
+    const uint64_t compactMask = __ballot(compact), wideMask = __ballot(active && !compact);
+    const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
+    if (active && slot < 8) {
+        if (compact) {
+            u8List[slot] = (kThreatRows + row) * kL1;
+        } else {
+            wideList[slot] = row * (kL1 * 2);
+        }
+    }
+    nWide = min(uint32_t(popc64(wideMask)), 8u);
+    return min(uint32_t(popc64(compactMask)), 8u);
+}
+
 // Row lists of one perspective of one board (the full-refresh feature set): psqList (capacity kPsqCap) = byte offsets
 // into the i16 piece-square table, thrList (capacity kU8Cap) = byte offsets into the u8 row table; nThr counts both the
 // compact piece-square rows and the threat / pawn-pair rows in it.
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
-    __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];  // incremental: threat rows to SUBTRACT
+    __shared__ uint32_t sSub[kWavesPerBlock][kU8Cap];  // incremental: threat rows to SUBTRACT
     __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];   // incremental: psq rows to subtract / add (<= 4 each)
 
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
@@ -535,20 +553,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
                 const int x = perspXor(c, kingC);  // bucket and mirror half are those of the parent too
                 const int flipColour = (c == 0) ? 1 : 0;
                 // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
-                const uint64_t subMask = __ballot(changedSq && pb.piece != kNoPiece);
-                const uint64_t addMask = __ballot(changedSq && cb.piece != kNoPiece);
-                const uint32_t nPsqSub = min(uint32_t(popc64(subMask)), 8u), nPsqAdd = min(uint32_t(popc64(addMask)), 8u);
-                if (changedSq && pb.piece != kNoPiece) {
-                    const uint32_t slot = prefixCount(subMask);
-                    if (slot < 8) sPsqDelta[wave][0][slot] = psqRow(c, pb.piece, int(lane), kingC) * (kL1 * 2);
-                }
-                if (changedSq && cb.piece != kNoPiece) {
-                    const uint32_t slot = prefixCount(addMask);
-                    if (slot < 8) sPsqDelta[wave][1][slot] = psqRow(c, cb.piece, int(lane), kingC) * (kL1 * 2);
-                }
+                uint32_t nPsqSub, nPsqAdd;
+                const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
+                uint32_t* subList = sSub[wave];
+                uint32_t* addList = sThr[wave];
+                const uint32_t nSubCompact = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC) : 0u,
+                                                              sLut, sPsqDelta[wave][0], subList, nPsqSub);
+                const uint32_t nAddCompact = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC) : 0u,
+                                                              sLut, sPsqDelta[wave][1], addList, nPsqAdd);
+                subList += nSubCompact;
+                addList += nAddCompact;
                 // ---- threat delta ----
-                uint32_t nSub = emitThreatRows(sSub[wave], 0, subTargets, pb.piece, lane, x, flipColour, sLut);
-                uint32_t nAdd = emitThreatRows(sThr[wave], 0, addTargets, cb.piece, lane, x, flipColour, sLut);
+                uint32_t nSub = emitThreatRows(subList, 0, subTargets, pb.piece, lane, x, flipColour, sLut);
+                uint32_t nAdd = emitThreatRows(addList, 0, addTargets, cb.piece, lane, x, flipColour, sLut);
                 // ---- pawn-pair delta (generatePpRows): pairs that exist on one board only ----
                 {
                     const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
@@ -560,13 +577,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
                     // a pair survives iff both pawns are unchanged (same square, same colour) and it is in both sets
                     const uint64_t unchangedPawns = pb.pawnsBb & cb.pawnsBb & ~changed;
                     const uint64_t kept = (pawnP && pawnC && !changedSq) ? (partP & partC & unchangedPawns) : 0;
-                    nSub = emitPawnPairRows(sSub[wave], nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
-                    nAdd = emitPawnPairRows(sThr[wave], nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
+                    nSub = emitPawnPairRows(subList, nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
+                    nAdd = emitPawnPairRows(addList, nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
                 }
                 __builtin_amdgcn_wave_barrier();
 
                 applyDelta(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd,
-                           sThr[wave], nAdd, sSub[wave], nSub, acc);
+                           sThr[wave], nAdd + nAddCompact, sSub[wave], nSub + nSubCompact, acc);
             }
             storeAcc(p.arena, childSlot, c, lane, acc);
             if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_ke
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
-    __shared__ uint32_t sSub[kWavesPerBlock][kThreatCap];
+    __shared__ uint32_t sSub[kWavesPerBlock][kU8Cap];
     __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];
 
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_ke
         const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
         const uint8_t* delta = p.deltas + size_t(it) * kDeltaBytes;
-        const uint32_t nPsqSub = min(uint32_t(delta[0]), 2u), nPsqAdd = min(uint32_t(delta[1]), 2u);
+        const uint32_t nDeltaSub = min(uint32_t(delta[0]), 2u), nDeltaAdd = min(uint32_t(delta[1]), 2u);
         const uint32_t nAdded = min(uint32_t(delta[2]), 128u), nRemoved = min(uint32_t(delta[3]), 128u);
         const uint64_t* pawnBbs = reinterpret_cast<const uint64_t*>(delta + 24);
         const uint64_t blackBefore = pawnBbs[0], whiteBefore = pawnBbs[1], blackAfter = pawnBbs[2], whiteAfter = pawnBbs[3];
@@ -635,16 +652,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_ke
                 const int x = perspXor(c, kingSq);
                 const int flipColour = (c == 0) ? 1 : 0;
                 // updatePsq: <= 2 subs, <= 2 adds
-                if (lane < nPsqSub) sPsqDelta[wave][0][lane] = psqRow(c, delta[4 + lane], delta[6 + lane], kingSq) * (kL1 * 2);
-                if (lane < nPsqAdd) sPsqDelta[wave][1][lane] = psqRow(c, delta[8 + lane], delta[10 + lane], kingSq) * (kL1 * 2);
+                uint32_t nPsqSub, nPsqAdd;
+                const bool subLane = lane < nDeltaSub, addLane = lane < nDeltaAdd;
+                const uint32_t nSubCompact =
+                    emitPsqDeltaRows(subLane, subLane ? psqRow(c, delta[4 + lane] % 12, delta[6 + lane] & 63, kingSq) : 0u,
+                                     sLut, sPsqDelta[wave][0], sSub[wave], nPsqSub);
+                const uint32_t nAddCompact =
+                    emitPsqDeltaRows(addLane, addLane ? psqRow(c, delta[8 + lane] % 12, delta[10 + lane] & 63, kingSq) : 0u,
+                                     sLut, sPsqDelta[wave][1], sThr[wave], nPsqAdd);
                 // applyThreatUpdates: one lane per descriptor, two passes of 64 per list
-                uint32_t nAdd = 0, nSub = 0;
+                uint32_t nAdd = nAddCompact, nSub = nSubCompact;
 #pragma unroll 1
                 for (int list = 0; list < 2; ++list) {
                     const uint8_t* descs = delta + (list == 0 ? 56 : 568);
                     const uint32_t count = list == 0 ? nAdded : nRemoved;
                     uint32_t* out = list == 0 ? sThr[wave] : sSub[wave];
-                    uint32_t n = 0;
+                    uint32_t n = list == 0 ? nAddCompact : nSubCompact;
                     for (uint32_t base = 0; base < count; base += 64) {
                         int32_t row = -1;
                         if (base + lane < count) {
@@ -717,6 +740,54 @@ __global__ __launch_bounds__(256) void spx_slot_act_kernel(SlotActParams p) {
                 reinterpret_cast<const uint32_t*>(rec)[lane];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Post-processing of raw evals: eval::adjustStatic (eval.cpp:24-27) and eval::adjustEval (eval.cpp:30-67) - one thread
+// per position, in place. Piece counts, side to move and the halfmove clock come from the 32-byte record
+// (marlinformat.h:32-84: nibbles at +8, stm bit 7 of byte 24, halfmove byte 25). i32 arithmetic, wrapping where the
+// reference's would overflow; '/' truncates toward zero as in C++.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t clampScore(int32_t v) {
+    return min(max(v, -(kScoreWin - 1)), kScoreWin - 1);
+}
+__device__ __forceinline__ int32_t wrapMul(int32_t a, int32_t b) {
+    return int32_t(uint32_t(a) * uint32_t(b));
+}
+__device__ __forceinline__ int32_t wrapAdd(int32_t a, int32_t b) {
+    return int32_t(uint32_t(a) + uint32_t(b));
+}
+
+__global__ __launch_bounds__(256) void spx_adjust_kernel(AdjustParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nPositions) return;
+    const uint64_t* rec = p.positions + size_t(i) * 4;
+    const uint64_t occ = rec[0], nibLo = rec[1], nibHi = rec[2];
+    const uint32_t tail = uint32_t(rec[3]);  // byte 24 = stm | ep, byte 25 = halfmove clock
+    const int stm = (tail & 0x80u) ? 0 : 1;
+    const int32_t halfmove = int32_t((tail >> 8) & 0xFFu);
+    int32_t eval = p.evals[i];
+    if (p.stages & 1u) {
+        eval = clampScore(wrapAdd(eval, p.contempt[stm]));
+    }
+    if (p.stages & 2u) {
+        int32_t npMaterial = 0;
+        const uint32_t count = min(uint32_t(popc64(occ)), 32u);
+        for (uint32_t k = 0; k < count; ++k) {
+            const int type = nibbleToPiece(int(((k < 16 ? nibLo : nibHi) >> ((k & 15) * 4)) & 0xF)) >> 1;
+            if (type < 5) npMaterial += p.scalingValue[type];
+        }
+        const int32_t scaled = wrapMul(eval, wrapAdd(p.materialScalingBase, npMaterial));
+        const int32_t optimism =
+            wrapMul(p.optimism[stm], wrapAdd(p.optimismBase, wrapMul(npMaterial, p.optimismMaterialScale) / 1024));
+        eval = wrapAdd(scaled, optimism) / 32768;
+        eval = wrapMul(eval, 200 - halfmove) / 200;
+        if (p.corrections) {
+            eval = wrapAdd(eval, p.corrections[i] / 2048);
+        }
+        eval = clampScore(eval);
+    }
+    p.evals[i] = eval;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1004,6 +1075,11 @@ hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t 
 
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream) {
     hipLaunchKernelGGL(spx_update_observed_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchAdjust(const AdjustParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_adjust_kernel, dim3((p.nPositions + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

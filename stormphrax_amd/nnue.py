@@ -38,6 +38,19 @@ def synthetic_net_bytes(preset="tame", seed=DEFAULT_SEED):
     return buf
 
 
+ADJUST_STATIC, ADJUST_EVAL = 1, 2
+
+
+def adjust_params(contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL):
+    """spx_adjust_params with the reference's default tunables (tunable.h:161-169)."""
+    params = _lib.AdjustParams()
+    _lib.load().spx_adjust_defaults(ctypes.byref(params))
+    params.contempt[0], params.contempt[1] = contempt
+    params.optimism[0], params.optimism[1] = optimism
+    params.stages = stages
+    return params
+
+
 class Network:
     """Immutable, shareable network (spx_net). Mirrors eval::init / getNetwork / defaultNetworkName."""
 
@@ -87,6 +100,21 @@ class NnueState:
     def evaluate_once_device(self, d_positions_ptr, n, d_out_ptr, stream_ptr=None):
         """Device-resident variant: raw device pointers (e.g. torch tensors' data_ptr()), enqueued on `stream_ptr`."""
         check(_lib.load().spx_eval_full_device(self._h, d_positions_ptr, n, d_out_ptr, stream_ptr))
+
+    def adjust(self, positions, evals, contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL,
+               corrections=None, params=None):
+        """eval::adjustStatic (+ contempt[stm], clamp) and/or eval::adjustEval (material scaling, optimism, halfmove
+        damping, optional correction / 2048, clamp) of raw evals on the device -> new int32 array.
+        contempt / optimism are indexed by colour (black, white) like eval::Contempt / eval::Optimism."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        out = np.array(evals, dtype=np.int32, copy=True)
+        assert pos.shape[0] == out.shape[0]
+        if params is None:
+            params = adjust_params(contempt, optimism, stages)
+        corr = None if corrections is None else np.ascontiguousarray(corrections, dtype=np.int32)
+        check(_lib.load().spx_adjust(self._h, pos.ctypes.data, pos.shape[0], ctypes.byref(params),
+                                     None if corr is None else corr.ctypes.data, out.ctypes.data))
+        return out
 
     @property
     def compact_psq_rows(self):

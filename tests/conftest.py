@@ -36,7 +36,18 @@ class Oracle:
             ctypes.POINTER(ctypes.c_int)]
         self.lib.spxo_eval_accumulators.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.spxo_eval_accumulators.restype = ctypes.c_int32
+        self.lib.spxo_adjust.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                         ctypes.c_int, ctypes.c_int32, ctypes.c_int32]
+        self.lib.spxo_adjust.restype = ctypes.c_int32
         self._preset = None
+
+    def adjust(self, mailbox, stm, halfmove, raw, contempt=(0, 0), optimism=(0, 0), stages=3, correction=None):
+        """adjustStatic / adjustEval restatement with the reference's default tunables (tunable.h:161-169)."""
+        mailbox = np.ascontiguousarray(mailbox, dtype=np.uint8)
+        params = np.array([*contempt, *optimism, 48, 442, 461, 637, 1223, 26000, 2024, 1005], dtype=np.int32)
+        return int(self.lib.spxo_adjust(mailbox.ctypes.data, int(stm), int(halfmove), params.ctypes.data, stages,
+                                        0 if correction is None else 1, 0 if correction is None else int(correction),
+                                        int(raw)))
 
     def use(self, blob, tag):
         if self._preset != tag:
@@ -87,11 +98,30 @@ def sp():
 _NETS = {}
 
 
+MIXED_WIDE_ROWS = np.arange(11264) % 3 == 0
+
+
+def _mixed_rows_net(sp):
+    """The wild synthetic net with every third piece-square row pushed out of the i8 range (values 128, -129, +-3000,
+    i16 extremes in one column) and the i8 boundary values -128 / 127 planted in the others: exercises the per-row
+    choice between the 1 KiB u8 copy and the 2 KiB i16 row of the feature-transformer kernels."""
+    blob = np.array(sp.synthetic_net_bytes("wild"), copy=True)
+    psq = blob[64 : 64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
+    rng = np.random.default_rng(9)
+    cols = rng.integers(0, 1024, size=11264)
+    vals = rng.choice(np.array([128, -129, 3000, -3000, 32767, -32768], dtype=np.int16), size=11264)
+    wide = np.nonzero(MIXED_WIDE_ROWS)[0]
+    psq[wide, cols[wide]] = vals[wide]
+    narrow = np.nonzero(~MIXED_WIDE_ROWS)[0]
+    psq[narrow, cols[narrow]] = rng.choice(np.array([127, -128], dtype=np.int16), size=narrow.size)
+    return blob
+
+
 @pytest.fixture(scope="session")
 def net_blob(sp):
     def get(preset):
         if preset not in _NETS:
-            _NETS[preset] = sp.synthetic_net_bytes(preset)
+            _NETS[preset] = _mixed_rows_net(sp) if preset == "mixed" else sp.synthetic_net_bytes(preset)
         return _NETS[preset]
 
     return get

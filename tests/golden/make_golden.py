@@ -13,6 +13,9 @@ reference itself computes:
   features.jsonl  {"fen", "bucket", "stm", "psq": [black, white], "thr": [black, white]}: per-perspective row ids in the
                   reference's enumeration order, through its own featureIndex / threatFeatureIndex / ppFeatureIndex
   deltas.txt      per played move of random playouts: the UpdateContext captured by the reference's BoardObserver
+  adjust.jsonl    {"fen", "preset", "contempt", "optimism", "static", "adjusted"}: eval::staticEvalOnce(pos, contempt) and
+                  eval::adjustEval<false>(pos, optimism, {}, nullptr, static) (src/eval/eval.cpp:24-67,109-112);
+                  regenerate alone with `make_golden.py adjust`
   trace_*.txt     PUSH/POP/EVAL opcode streams of a make/unmake walk driven through NnueState::push/evaluate
                   (the lazily-updated incremental path), with the reference's evaluate() at every EVAL
 
@@ -56,7 +59,35 @@ class Probe:
         self.p.wait()
 
 
+def make_adjust():
+    """Post-processing goldens. FENs: every position of evals.jsonl that is not from the big random block, plus 300
+    of those (their halfmove clocks vary), each with three contempt / optimism settings on two presets."""
+    import random
+
+    rng = random.Random(5150)
+    recs = [json.loads(line) for line in open(os.path.join(HERE, "evals.jsonl"))]
+    fens = [r["fen"] for r in recs if r["src"] != "spx_random"][:200]
+    fens += rng.sample([r["fen"] for r in recs if r["src"] == "spx_random"], 300)
+    # halfmove clocks near and beyond the damping range (200 - halfmove goes to zero and negative)
+    fens += ["r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - %d 60" % h for h in (0, 1, 99, 100, 150, 199, 200, 230)]
+    settings = [((0, 0), (0, 0)), ((25, -25), (120, -120)), ((-300, 300), (-87, 87))]
+    with open(os.path.join(HERE, "adjust.jsonl"), "w") as f:
+        for preset in ("tame", "wild"):
+            probe = Probe(PROBES[preset])
+            for fen in fens:
+                for contempt, optimism in settings:
+                    (line,) = probe.cmd("adjust %d %d %d %d %s" % (*contempt, *optimism, fen))
+                    assert line.startswith("A "), (fen, line)
+                    _, stat, adj = line.split()
+                    f.write(json.dumps({"fen": fen, "preset": preset, "contempt": contempt, "optimism": optimism,
+                                        "static": int(stat), "adjusted": int(adj)}) + "\n")
+            probe.close()
+    print("adjust.jsonl written:", 2 * len(fens) * len(settings), "records")
+
+
 def main():
+    if sys.argv[1:] == ["adjust"]:
+        return make_adjust()
     probes = {k: Probe(v) for k, v in PROBES.items()}
     fens = [(STARTPOS, "startpos")]
     fens += [(f.strip(), "bench") for f in open(os.path.join(HERE, "bench_fens.txt")) if f.strip()]
@@ -118,6 +149,7 @@ def main():
     for p in probes.values():
         p.close()
     print("golden vectors written:", len(fens), "positions")
+    make_adjust()
 
 
 if __name__ == "__main__":

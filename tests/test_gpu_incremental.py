@@ -147,6 +147,47 @@ def test_observer_delta_path_matches_reference_traces(sp, states):
         assert np.array_equal(st.evaluate(nodes.astype(np.uint32)), want), name
 
 
+def test_incremental_paths_on_mixed_compact_and_wide_rows(sp, states):
+    """Both incremental kernels route piece-square delta rows through the u8 copy or the i16 table per row: on a net
+    with both kinds of rows (conftest._mixed_rows_net) every update must equal a full refresh, for random games
+    (board-diff kernel) and for a recorded search tree (observer-delta kernel)."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+    from stormphrax_amd.trace import Trace
+
+    st = states("mixed")
+    games = 1024
+    st.reserve_slots(2 * games)
+    pos = sp.random_positions(games, seed=3, min_ply=0, max_ply=30, dfrc_every=3)
+    cur = np.arange(games, dtype=np.uint32)
+    st.reset(pos, cur)
+    for ply in range(60):
+        nxt, moved = sp.random_successors(pos, seed=1000 + ply)
+        idx = np.nonzero(moved)[0]
+        child = (cur[idx] + games) % (2 * games)
+        got = st.update_evaluate(cur[idx], child, nxt[idx])
+        assert np.array_equal(got, st.evaluate_once(nxt[idx])), f"ply {ply}"
+        cur[idx] = child
+        pos[idx] = nxt[idx]
+
+    lib = _lib.load()
+    trace = Trace(os.path.join(GOLDEN, "trace_startpos_tame.txt"))
+    tree = np.zeros(trace.n_nodes, dtype=sp.PACKED_DTYPE)
+    tree[0] = sp.positions_from_fens([trace.root_fen])[0]
+    deltas = (_lib.MoveDelta * trace.n_nodes)()
+    for node in range(1, trace.n_nodes):
+        parent = np.ascontiguousarray(tree[trace.parent[node]]).reshape(1)
+        assert lib.spx_pos_apply_uci_observed(parent.ctypes.data, trace.moves[node].encode(),
+                                              tree[node:node + 1].ctypes.data, ctypes.byref(deltas[node])) == 0
+    st.reserve_slots(trace.n_nodes)
+    st.reset(tree[:1], np.zeros(1, dtype=np.uint32))
+    for parents, children in trace.levels():
+        batch = (_lib.MoveDelta * len(children))(*[deltas[int(c)] for c in children])
+        got = st.update_observed(parents, children, tree[children], batch)
+        assert np.array_equal(got, st.evaluate_once(tree[children]))
+
+
 def test_selfplay_driver_records_are_consistent(sp, states, tmp_path):
     """Config-4 driver in miniature: 96 concurrent games through the fused incremental update+eval path. Every recorded
     score must equal -evaluate_once(position after the move) (the driver's accumulators, maintained incrementally over the

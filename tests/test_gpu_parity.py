@@ -133,30 +133,52 @@ def test_malformed_records_do_not_fault(sp, states):
 
 def test_mixed_compact_and_wide_piece_square_rows(sp, oracle, net_blob, states):
     """Piece-square rows whose weights all fit i8 are served from a 1 KiB u8 copy, the others from the i16 table.
-    A net with both kinds (every third row gets out-of-i8-range weights, boundary values -128/127/128/-129 included)
-    must still equal the oracle bit for bit; per-row classification is checked through the context's count."""
-    blob = np.array(net_blob("wild"), copy=True)
-    psq = blob[64 : 64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
-    rng = np.random.default_rng(9)
-    wide = np.arange(11264) % 3 == 0
-    cols = rng.integers(0, 1024, size=11264)
-    vals = rng.choice(np.array([128, -129, 3000, -3000, 32767, -32768], dtype=np.int16), size=11264)
-    psq[np.nonzero(wide)[0], cols[wide]] = vals[wide]
-    edge = np.nonzero(~wide)[0]
-    psq[edge, cols[edge]] = rng.choice(np.array([127, -128], dtype=np.int16), size=edge.size)  # still compact
-    st = sp.NnueState(sp.Network(blob), device=0, max_batch=4096)
-    try:
-        assert st.compact_psq_rows == int((~wide).sum())
-        assert states("tame").compact_psq_rows == 11264 and states("extreme").compact_psq_rows < 11264
-        pos = sp.random_positions(4096, seed=77, min_ply=0, max_ply=140, dfrc_every=4)
-        mail, stm = sp.positions_to_mailboxes(pos)
-        oracle.use(blob, "mixed-compact")
-        want = oracle.eval_mailboxes(mail, stm)
-        got = st.evaluate_once(pos)
-        assert np.array_equal(got, want)
-        # accumulators written by the refresh path (same lists) feed the incremental path unchanged
-        st.reserve_slots(4096)
-        st.reset(pos, np.arange(4096, dtype=np.uint32))
-        assert np.array_equal(st.evaluate(np.arange(4096, dtype=np.uint32)), want)
-    finally:
-        st.close()
+    A net with both kinds (conftest._mixed_rows_net) must still equal the oracle bit for bit; the per-row
+    classification is checked through the context's count."""
+    from conftest import MIXED_WIDE_ROWS
+
+    st = states("mixed")
+    assert st.compact_psq_rows == int((~MIXED_WIDE_ROWS).sum())
+    assert states("tame").compact_psq_rows == 11264 and states("extreme").compact_psq_rows < 11264
+    pos = sp.random_positions(4096, seed=77, min_ply=0, max_ply=140, dfrc_every=4)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    oracle.use(net_blob("mixed"), "mixed")
+    want = oracle.eval_mailboxes(mail, stm)
+    assert np.array_equal(st.evaluate_once(pos), want)
+    # accumulators written by the refresh path (same lists) feed the arena path unchanged
+    st.reserve_slots(4096)
+    st.reset(pos, np.arange(4096, dtype=np.uint32))
+    assert np.array_equal(st.evaluate(np.arange(4096, dtype=np.uint32)), want)
+
+
+@pytest.mark.parametrize("preset", ["tame", "wild"])
+def test_adjust_on_device_matches_reference_and_oracle(sp, oracle, net_blob, states, preset):
+    """spx_adjust (device post-processing, rows a18 / f-4): golden staticEvalOnce / adjustEval<false> values of the
+    compiled reference, then random positions with random correction-history terms against the oracle."""
+    import json
+    import os
+
+    st = states(preset)
+    golden = os.path.join(os.path.dirname(__file__), "golden", "adjust.jsonl")
+    recs = [r for r in map(json.loads, open(golden)) if r["preset"] == preset]
+    by_setting = {}
+    for r in recs:
+        by_setting.setdefault((tuple(r["contempt"]), tuple(r["optimism"])), []).append(r)
+    for (contempt, optimism), group in by_setting.items():
+        pos = sp.positions_from_fens([r["fen"] for r in group])
+        raw = st.evaluate_once(pos)
+        stat = st.adjust(pos, raw, contempt, optimism, stages=sp.ADJUST_STATIC)
+        assert np.array_equal(stat, np.array([r["static"] for r in group], dtype=np.int32))
+        want = np.array([r["adjusted"] for r in group], dtype=np.int32)
+        assert np.array_equal(st.adjust(pos, stat, contempt, optimism, stages=sp.ADJUST_EVAL), want)
+        assert np.array_equal(st.adjust(pos, raw, contempt, optimism), want)
+
+    pos = sp.random_positions(3000, seed=31, min_ply=0, max_ply=200, dfrc_every=5)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    raw = st.evaluate_once(pos)
+    corr = np.random.default_rng(4).integers(-(1 << 20), 1 << 20, size=len(pos)).astype(np.int32)
+    got = st.adjust(pos, raw, (13, -40), (200, -150), corrections=corr)
+    want = [oracle.adjust(mail[i], stm[i], int(pos[i]["halfmove"]), int(raw[i]), (13, -40), (200, -150), 3, int(corr[i]))
+            for i in range(len(pos))]
+    assert np.array_equal(got, np.array(want, dtype=np.int32))
+    assert st.adjust(pos[:0], raw[:0]).shape == (0,)

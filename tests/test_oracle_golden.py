@@ -50,3 +50,25 @@ def test_golden_covers_king_buckets_and_mirroring():
         for c in (0, 1):
             seen.update(row // 704 for row in r["psq"][c])
     assert seen == set(range(16))
+
+
+@pytest.mark.parametrize("preset", ["tame", "wild"])
+def test_oracle_adjust_matches_reference(oracle, net_blob, sp, preset):
+    """staticEvalOnce (contempt + clamp, eval.cpp:24-27,109-112) and adjustEval<false> (eval.cpp:30-67) of the compiled
+    reference vs the restatement, incl. halfmove clocks beyond 200 and clamped scores."""
+    recs = [r for r in load_jsonl("adjust.jsonl") if r["preset"] == preset]
+    assert len(recs) > 1000
+    oracle.use(net_blob(preset), preset)
+    cache = {}
+    for r in recs:
+        fen = r["fen"]
+        if fen not in cache:
+            pos = sp.positions_from_fens([fen])
+            mail, stm = sp.positions_to_mailboxes(pos)
+            cache[fen] = (mail[0], int(stm[0]), int(fen.split()[4]), oracle.eval_fen(fen))
+        mail, stm, halfmove, raw = cache[fen]
+        stat = oracle.adjust(mail, stm, halfmove, raw, r["contempt"], r["optimism"], stages=1)
+        assert stat == r["static"], r
+        assert oracle.adjust(mail, stm, halfmove, stat, r["contempt"], r["optimism"], stages=2) == r["adjusted"], r
+        # both stages in one call == adjustedStaticEval<false> (eval.cpp:81-91)
+        assert oracle.adjust(mail, stm, halfmove, raw, r["contempt"], r["optimism"], stages=3) == r["adjusted"], r
