@@ -30,11 +30,35 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
+def usable_cpus():
+    """Host threads this process can actually run at once: logical CPUs, capped by the affinity mask and by the
+    container's CPU quota (cgroup v2 cpu.max / v1 cfs quota). The MI355X boxes expose 256 logical CPUs with a quota of
+    16: oversubscribing the quota makes the CPU baseline SLOWER (measured: 2.5e6 evals/s at 16 threads, 1.2e6 at 256)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sp, positions, blob, seconds):
     """Reference CPU path on a bounded sample of the batch (baseline only, never the target)."""
     sample = positions[:4096]
     probe = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame")
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     if os.path.exists(probe):
         try:
             cmds = "".join(f"add {sp.position_to_fen(p)}\n" for p in sample)
@@ -44,7 +68,8 @@ def cpu_baseline(sp, positions, blob, seconds):
             return {
                 "value": float(line[1]), "unit": "evals/s", "cores": cores, "kind": "reference",
                 "sample": f"compiled Stormphrax 8.0.2 (AVX2 build) NnueState::evaluateOnce looped over the first "
-                          f"{len(sample)} positions of the batch for {seconds:.0f} s on {cores} threads",
+                          f"{len(sample)} positions of the batch for {seconds:.0f} s on {cores} threads "
+                          f"(= usable CPUs: {os.cpu_count()} logical, capped by affinity / cgroup quota)",
             }
         except Exception as exc:  # fall through to the port
             print(f"[bench] reference probe failed ({exc}); timing the C restatement instead", file=sys.stderr)

@@ -234,7 +234,7 @@ typedef struct spx_selfplay_params {
     uint32_t opening_plies;  /* random opening plies before play starts (0 = 8, plus a coin flip as datagen.cpp:153) */
     uint32_t dfrc;           /* 1 = double-Chess960 starts */
     int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
-    uint32_t host_threads;   /* move-generation threads (0 = min(32, hardware concurrency)) */
+    uint32_t host_threads;   /* host worker threads (0 = min(16, usable CPUs incl. cgroup quota): phases are short, more only adds hand-off cost) */
     uint32_t reserved;
     uint64_t seed;
 } spx_selfplay_params;

@@ -5,13 +5,24 @@
 // (:153-171), accumulator reset (:179), per move a "search", win/draw adjudication counters with the reference's
 // constants (:74-94,224-252), terminal detection, viriformat game records (src/datagen/viriformat.cpp:28-63). The one
 // deliberate difference: the reference runs a ~24 000-node alpha-beta search per move (out of scope); here
-// the "search" is depth 1 - score(move) = -eval(child) - which is exactly the part that batches. Host work (move
-// generation for every child) is spread over std::threads; games are independent, so multi-GPU = one process per GPU
+// the "search" is depth 1 - score(move) = -eval(child) - which is exactly the part that batches.
+//
+// Host side: a persistent worker pool runs the per-game phases (legal moves, child records, move choice +
+// adjudication) over contiguous game ranges. The games are split into two halves that alternate: while the GPU
+// evaluates the children of one half (fused update+eval batch, issued from a helper thread), the pool prepares the
+// other half - the evaluator and the move generator overlap. Every game owns its RNG stream (seeded when the game
+// starts), so results do not depend on the thread count. Games are independent, so multi-GPU = one process per GPU
 // with its own slice of games and no communication.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <future>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -54,18 +65,37 @@ uint16_t viriMove(const Move& m) {  // viriformat.cpp:37-52
     return uint16_t(m.from | (m.to << 6) | ((m.kind == kPromotion ? m.promo - 1 : 0) << 12) | kTypes[m.kind]);
 }
 
+// CPUs this process may actually use: hardware threads capped by the container's cgroup quota (the MI355X boxes show
+// 256 logical CPUs under a quota of 16 - oversubscribing the quota is slower than respecting it)
+uint32_t usableCpus() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            n = std::min(n, uint32_t(std::max(1l, std::atol(quota) / period)));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 struct Game {
     Board board;
     spx_packed_pos initial;
     std::vector<uint16_t> moves;
     std::vector<int16_t> scores;
     std::vector<uint64_t> history;
+    Rng rng{0};
     uint32_t slot = 0;
     uint32_t winPlies = 0, lossPlies = 0, drawPlies = 0, plies = 0;
     bool active = false;
     // per-step scratch
     std::vector<Move> legal;
     size_t firstChild = 0;
+    uint8_t outcome = 255;   // set by a worker when the game ended this step (255 = still running)
+    bool needsFix = false;   // the chosen child's scratch slot was recycled: re-materialise into the home slot
+    spx_packed_pos fixPos;
 };
 
 void startGame(Game& g, Rng& rng, bool dfrc, uint32_t baseOpeningPlies) {
@@ -86,10 +116,91 @@ void startGame(Game& g, Rng& rng, bool dfrc, uint32_t baseOpeningPlies) {
     g.moves.clear();
     g.scores.clear();
     g.history.clear();
+    g.rng = Rng{rng.next()};
     g.winPlies = g.lossPlies = g.drawPlies = 0;
     g.plies = 0;
+    g.outcome = 255;
+    g.needsFix = false;
     g.active = true;
 }
+
+// Persistent workers; run(fn) executes fn(worker) on every worker and returns when all are done. Phases follow each
+// other within microseconds, so workers first spin on the generation counter and only then sleep on the condition
+// variable (a mutex hand-off per phase per worker costs more than the phases themselves beyond ~32 threads).
+class Pool {
+public:
+    explicit Pool(uint32_t n) : n_(n) {
+        for (uint32_t t = 1; t < n_; ++t) threads_.emplace_back([this, t] { loop(t); });
+    }
+    ~Pool() {
+        stop_.store(true, std::memory_order_release);
+        publish();
+        for (auto& th : threads_) th.join();
+    }
+    uint32_t size() const {
+        return n_;
+    }
+    void run(const std::function<void(uint32_t)>& fn) {
+        job_ = &fn;
+        pending_.store(n_ - 1, std::memory_order_release);
+        publish();
+        fn(0);  // the caller is worker 0
+        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+
+private:
+    void publish() {
+        generation_.fetch_add(1, std::memory_order_acq_rel);
+        if (sleepers_.load(std::memory_order_acquire) != 0) {
+            std::lock_guard<std::mutex> lock(m_);
+            wake_.notify_all();
+        }
+    }
+    void loop(uint32_t t) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint32_t spins = 0;
+            while (generation_.load(std::memory_order_acquire) == seen) {
+                if (++spins < 20000) {  // ~100 us of polling before going to sleep
+                    __builtin_ia32_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lock(m_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                wake_.wait(lock, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            seen = generation_.load(std::memory_order_acquire);
+            if (stop_.load(std::memory_order_acquire)) return;
+            (*job_)(t);
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    uint32_t n_;
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_;
+    const std::function<void(uint32_t)>* job_ = nullptr;
+    std::atomic<uint32_t> pending_{0}, sleepers_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> stop_{false};
+};
+
+// One half of the games: its own child buffers and its own scratch-slot regions, so that its GPU batch can be in
+// flight while the other half is being prepared.
+struct Half {
+    uint32_t begin = 0, end = 0;   // game range
+    uint32_t regionBase = 0;       // first scratch slot (two regions of maxChildren, alternating per step)
+    size_t maxChildren = 0;
+    uint32_t step = 0;
+    size_t total = 0;
+    std::vector<spx_packed_pos> childPos;
+    std::vector<uint32_t> parents, children;
+    std::vector<int32_t> evals;
+    std::vector<uint8_t> slotValid;
+    std::future<int> pending;      // the in-flight GPU batch
+    bool inFlight = false;
+};
 
 }  // namespace
 }  // namespace spx
@@ -103,11 +214,18 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
         return SPX_ERR_INVALID_ARG;
     }
     const uint32_t G = p->n_games;
-    // threads are spawned per ply (no pool): beyond ~32 the spawn cost outweighs the move generation they share
-    const uint32_t threads =
-        std::max(1u, p->host_threads ? p->host_threads : std::min(32u, std::thread::hardware_concurrency()));
-    const size_t maxChildren = size_t(G) * 64;  // scratch slots per step parity (more children are processed in chunks)
-    int rc = spx_acc_reserve(ctx, size_t(G) + 2 * maxChildren);
+    const uint32_t nThreads = std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(16u, usableCpus()), G));
+    const uint32_t nHalves = G >= 2 ? 2 : 1;
+    std::vector<Half> halves(nHalves);
+    uint32_t nextSlot = G;
+    for (uint32_t h = 0; h < nHalves; ++h) {
+        halves[h].begin = uint32_t(uint64_t(G) * h / nHalves);
+        halves[h].end = uint32_t(uint64_t(G) * (h + 1) / nHalves);
+        halves[h].maxChildren = size_t(halves[h].end - halves[h].begin) * 64;  // larger steps are processed in chunks
+        halves[h].regionBase = nextSlot;
+        nextSlot += uint32_t(2 * halves[h].maxChildren);
+    }
+    int rc = spx_acc_reserve(ctx, nextSlot);
     if (rc != SPX_OK) return rc;
     FILE* out = nullptr;
     if (out_path && out_path[0]) {
@@ -120,14 +238,13 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
     std::memset(stats, 0, sizeof(*stats));
     Rng rng{p->seed};
     std::vector<Game> games(G);
-    std::vector<spx_packed_pos> childPos;
-    std::vector<uint32_t> parents, children, refreshSlots;
+    Pool pool(nThreads);
+    std::vector<uint32_t> refreshSlots;
     std::vector<spx_packed_pos> refreshPos;
-    std::vector<int32_t> evals;
     const auto t0 = std::chrono::steady_clock::now();
     double gpuSeconds = 0.0;
     uint64_t started = 0;
-    uint32_t step = 0;
+    std::mutex gpuMutex;  // one context: GPU calls are serialised (the helper thread vs. refreshes on this thread)
 
     auto finishGame = [&](Game& g, uint8_t outcome) {
         g.initial.wdl = outcome;
@@ -144,15 +261,36 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
         stats->positions += g.moves.size();
         stats->outcomes[outcome] += 1;
         g.active = false;
+        g.outcome = 255;
+    };
+    // workers own contiguous slices of a half's game range
+    auto forGames = [&](const Half& h, const std::function<void(Game&, uint32_t)>& fn) {
+        pool.run([&](uint32_t t) {
+            const uint32_t count = h.end - h.begin, per = (count + pool.size() - 1) / pool.size();
+            const uint32_t lo = h.begin + std::min(count, t * per), hi = h.begin + std::min(count, (t + 1) * per);
+            for (uint32_t i = lo; i < hi; ++i) fn(games[i], i);
+        });
+    };
+    auto refresh = [&](const std::vector<spx_packed_pos>& pos, const std::vector<uint32_t>& slots) {
+        std::lock_guard<std::mutex> lock(gpuMutex);
+        const auto g0 = std::chrono::steady_clock::now();
+        int r = SPX_OK;
+        for (size_t lo = 0; lo < slots.size() && r == SPX_OK; lo += ctxMaxBatch(ctx)) {
+            const size_t m = std::min(ctxMaxBatch(ctx), slots.size() - lo);
+            r = spx_acc_refresh(ctx, pos.data() + lo, slots.data() + lo, m);
+        }
+        gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        return r;
     };
 
-    for (;;) {
-        // (re)start games in idle slots and full-refresh their accumulators (NnueState::reset, datagen.cpp:179)
+    // ---- phase 1 of a half's step: (re)start games, legal moves, child records; then launch the GPU batch ----
+    auto prepare = [&](Half& h) -> int {
         refreshSlots.clear();
         refreshPos.clear();
-        for (uint32_t i = 0; i < G; ++i) {
+        for (uint32_t i = h.begin; i < h.end; ++i) {
             Game& g = games[i];
             if (!g.active && started < p->target_games) {
+                // (re)start and full-refresh the accumulators (NnueState::reset, datagen.cpp:179)
                 startGame(g, rng, p->dfrc != 0, p->opening_plies ? p->opening_plies : 8);
                 g.slot = i;
                 ++started;
@@ -163,111 +301,90 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
             }
         }
         if (!refreshSlots.empty()) {
-            const auto g0 = std::chrono::steady_clock::now();
-            for (size_t lo = 0; lo < refreshSlots.size() && rc == SPX_OK; lo += ctxMaxBatch(ctx)) {
-                const size_t m = std::min(ctxMaxBatch(ctx), refreshSlots.size() - lo);
-                rc = spx_acc_refresh(ctx, refreshPos.data() + lo, refreshSlots.data() + lo, m);
-            }
-            gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
-            if (rc != SPX_OK) break;
+            const int r = refresh(refreshPos, refreshSlots);
+            if (r != SPX_OK) return r;
         }
-        bool any = false;
-        for (const Game& g : games) any = any || g.active;
-        if (!any) break;
-
-        // host: legal moves of every active game (threads own contiguous game ranges)
-        {
-            std::vector<std::thread> pool;
-            const uint32_t per = (G + threads - 1) / threads;
-            for (uint32_t t = 0; t < threads; ++t) {
-                pool.emplace_back([&, t] {
-                    for (uint32_t i = t * per; i < std::min(G, (t + 1) * per); ++i) {
-                        if (games[i].active) generateLegal(games[i].board, games[i].legal);
-                    }
-                });
-            }
-            for (auto& th : pool) th.join();
-        }
+        forGames(h, [](Game& g, uint32_t) {
+            if (g.active) generateLegal(g.board, g.legal);
+        });
         // terminal positions: mate / stalemate (datagen.cpp:213-221)
-        size_t total = 0;
-        for (Game& g : games) {
+        h.total = 0;
+        for (uint32_t i = h.begin; i < h.end; ++i) {
+            Game& g = games[i];
             if (!g.active) continue;
             if (g.legal.empty()) {
-                const uint8_t outcome = g.board.inCheck() ? (g.board.stm == 0 ? 2 : 0) : 1;
-                finishGame(g, outcome);
+                finishGame(g, g.board.inCheck() ? (g.board.stm == 0 ? 2 : 0) : 1);
                 continue;
             }
-            g.firstChild = total;
-            total += g.legal.size();
+            g.firstChild = h.total;
+            h.total += g.legal.size();
         }
-        if (total == 0) continue;
-        childPos.resize(total);
-        parents.resize(total);
-        children.resize(total);
-        evals.resize(total);
-        const uint32_t region = uint32_t(G + (step & 1) * maxChildren);
-        {
-            std::vector<std::thread> pool;
-            const uint32_t per = (G + threads - 1) / threads;
-            for (uint32_t t = 0; t < threads; ++t) {
-                pool.emplace_back([&, t] {
-                    for (uint32_t i = t * per; i < std::min(G, (t + 1) * per); ++i) {
-                        Game& g = games[i];
-                        if (!g.active) continue;
-                        for (size_t k = 0; k < g.legal.size(); ++k) {
-                            Board next = g.board;
-                            makeMove(next, g.legal[k]);
-                            packBoard(next, childPos[g.firstChild + k]);
-                            parents[g.firstChild + k] = g.slot;
-                        }
-                    }
-                });
+        if (h.total == 0) return SPX_OK;
+        h.childPos.resize(h.total);
+        h.parents.resize(h.total);
+        h.children.resize(h.total);
+        h.evals.resize(h.total);
+        h.slotValid.assign(h.total, 1);
+        forGames(h, [&h](Game& g, uint32_t) {
+            if (!g.active) return;
+            for (size_t k = 0; k < g.legal.size(); ++k) {
+                Board next = g.board;
+                makeMove(next, g.legal[k]);
+                packBoard(next, h.childPos[g.firstChild + k]);
+                h.parents[g.firstChild + k] = g.slot;
             }
-            for (auto& th : pool) th.join();
+        });
+        // device: one fused update+eval batch per chunk; child slots cycle inside this step's region (only the CHOSEN
+        // child's slot has to survive until the half's next step; a chunk that recycles slots invalidates the earlier
+        // ones and a chosen child among them is re-materialised in finish())
+        const uint32_t region = h.regionBase + uint32_t((h.step & 1) * h.maxChildren);
+        size_t done = 0;
+        while (done < h.total) {
+            const size_t n = std::min(h.total - done, h.maxChildren);
+            for (size_t k = 0; k < n; ++k) h.children[done + k] = region + uint32_t(k);
+            if (done > 0) std::fill(h.slotValid.begin(), h.slotValid.begin() + done, 0);
+            done += n;
         }
-        // device: one update+eval batch per chunk of the context's capacity; child slots cycle inside this step's region
-        // (a chunk never exceeds maxChildren, and only the CHOSEN child's slot has to survive until the next step: when
-        // slots are recycled within a step the chosen child is re-materialised below)
-        std::vector<uint8_t> slotValid(total, 1);
-        {
+        h.pending = std::async(std::launch::async, [&h, &gpuMutex, &gpuSeconds, ctx] {
+            std::lock_guard<std::mutex> lock(gpuMutex);
             const auto g0 = std::chrono::steady_clock::now();
-            size_t done = 0;
-            while (done < total && rc == SPX_OK) {
-                const size_t n = std::min(total - done, maxChildren);
-                for (size_t k = 0; k < n; ++k) children[done + k] = region + uint32_t(k);
-                if (done > 0) std::fill(slotValid.begin(), slotValid.begin() + done, 0);  // earlier chunk overwritten
-                size_t sub = 0;
-                while (sub < n && rc == SPX_OK) {  // respect the context's batch capacity
-                    const size_t m = std::min(n - sub, ctxMaxBatch(ctx));
-                    rc = spx_acc_update_eval(ctx, parents.data() + done + sub, children.data() + done + sub,
-                                             childPos.data() + done + sub, m, evals.data() + done + sub);
-                    sub += m;
-                }
-                done += n;
+            int r = SPX_OK;
+            for (size_t lo = 0; lo < h.total && r == SPX_OK;) {  // chunks of maxChildren, within the batch capacity
+                const size_t chunkEnd = std::min(h.total, lo - lo % h.maxChildren + h.maxChildren);
+                const size_t m = std::min(chunkEnd - lo, ctxMaxBatch(ctx));
+                r = spx_acc_update_eval(ctx, h.parents.data() + lo, h.children.data() + lo, h.childPos.data() + lo, m,
+                                        h.evals.data() + lo);
+                lo += m;
             }
             gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
-            stats->evals += total;
-        }
-        if (rc != SPX_OK) break;
+            return r;
+        });
+        h.inFlight = true;
+        stats->evals += h.total;
+        return SPX_OK;
+    };
 
-        // pick moves, adjudicate (datagen.cpp:224-252), advance
-        std::vector<uint32_t> fixParents, fixChildren;
-        std::vector<spx_packed_pos> fixPos;
-        for (uint32_t i = 0; i < G; ++i) {
-            Game& g = games[i];
-            if (!g.active || g.legal.empty()) continue;
+    // ---- phase 2: wait for the evals, pick moves, adjudicate (datagen.cpp:224-252), advance ----
+    auto finish = [&](Half& h) -> int {
+        if (!h.inFlight) return SPX_OK;
+        h.inFlight = false;
+        const int r = h.pending.get();
+        if (r != SPX_OK) return r;
+        forGames(h, [&](Game& g, uint32_t i) {
+            if (!g.active || g.legal.empty()) return;
+            const int32_t* evals = h.evals.data() + g.firstChild;
             int best = INT32_MIN;
-            for (size_t k = 0; k < g.legal.size(); ++k) best = std::max(best, -evals[g.firstChild + k]);
+            for (size_t k = 0; k < g.legal.size(); ++k) best = std::max(best, -evals[k]);
             // exploration: uniformly among the moves within temperature_cp of the best (0 = greedy, first best)
             size_t pick = 0, seen = 0;
             for (size_t k = 0; k < g.legal.size(); ++k) {
-                if (-evals[g.firstChild + k] >= best - p->temperature_cp) {
+                if (-evals[k] >= best - p->temperature_cp) {
                     ++seen;
-                    if (rng.below(uint32_t(seen)) == 0) pick = k;
+                    if (g.rng.below(uint32_t(seen)) == 0) pick = k;
                     if (p->temperature_cp == 0) break;
                 }
             }
-            const int score = -evals[g.firstChild + pick];
+            const int score = -evals[pick];
             g.moves.push_back(viriMove(g.legal[pick]));
             g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(score) <= 2 ? 0 : score))));
             const int whiteScore = g.board.stm ? score : -score;
@@ -292,32 +409,60 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
             makeMove(g.board, g.legal[pick]);
             ++g.plies;
             const size_t idx = g.firstChild + pick;
-            if (slotValid[idx]) {
-                g.slot = children[idx];
+            if (h.slotValid[idx]) {
+                g.slot = h.children[idx];
             } else {  // its scratch slot was recycled by a later chunk of this step: materialise it again
-                fixParents.push_back(g.slot);
-                fixChildren.push_back(i);  // the game's home slot
-                fixPos.push_back(childPos[idx]);
-                g.slot = i;
+                g.needsFix = true;
+                g.fixPos = h.childPos[idx];
+                g.slot = i;  // the game's home slot
             }
             // draws: 50-move rule, threefold repetition, ply cap (Position::isDrawn analogue, datagen.cpp:264-268)
-            const uint64_t h = boardHash(g.board);
-            const size_t reps = size_t(std::count(g.history.begin(), g.history.end(), h));
+            const uint64_t hash = boardHash(g.board);
+            const size_t reps = size_t(std::count(g.history.begin(), g.history.end(), hash));
             if (outcome == 255 && (g.board.halfmove >= 100 || reps >= 2 || g.plies >= p->max_plies)) outcome = 1;
-            if (outcome != 255) finishGame(g, outcome);
-        }
-        if (!fixParents.empty()) {
-            // parent == child home slot is not allowed inside one batch: go through the record alone (full refresh)
-            for (size_t lo = 0; lo < fixChildren.size() && rc == SPX_OK; lo += ctxMaxBatch(ctx)) {
-                const size_t m = std::min(ctxMaxBatch(ctx), fixChildren.size() - lo);
-                rc = spx_acc_refresh(ctx, fixPos.data() + lo, fixChildren.data() + lo, m);
+            g.outcome = outcome;
+        });
+        refreshSlots.clear();
+        refreshPos.clear();
+        for (uint32_t i = h.begin; i < h.end; ++i) {
+            Game& g = games[i];
+            if (!g.active) continue;
+            if (g.outcome != 255) {
+                finishGame(g, g.outcome);
+            } else if (g.needsFix) {  // through the record alone (full refresh of the home slot)
+                refreshSlots.push_back(i);
+                refreshPos.push_back(g.fixPos);
             }
-            if (rc != SPX_OK) break;
+            g.needsFix = false;
         }
-        ++step;
-        stats->steps = step;
+        ++h.step;
+        stats->steps += 1;
+        return refreshSlots.empty() ? SPX_OK : refresh(refreshPos, refreshSlots);
+    };
+
+    // alternate the halves: prepare(h) runs on the host while the other half's batch is on the GPU
+    for (;;) {
+        bool progress = false;
+        for (Half& h : halves) {
+            if ((rc = finish(h)) != SPX_OK) break;
+            if ((rc = prepare(h)) != SPX_OK) break;
+            progress = progress || h.inFlight;
+        }
+        if (rc != SPX_OK) break;
+        if (!progress) {  // nothing on the GPU: done unless games remain to be started (all of a pass ended in mates)
+            bool idleSlot = false;
+            for (const Game& g : games) idleSlot = idleSlot || !g.active;
+            if (started >= p->target_games || !idleSlot) break;
+        }
+    }
+    for (Half& h : halves) {  // error exit: do not leave a batch in flight
+        if (h.inFlight) {
+            h.pending.wait();
+            h.inFlight = false;
+        }
     }
     if (out) std::fclose(out);
+    stats->steps = (stats->steps + nHalves - 1) / nHalves;  // plies played per game slot
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuSeconds;
     return rc;
