@@ -207,7 +207,8 @@ def main():
                     help="contexts/HIP streams the steps are issued round-robin on (2 lets the small sort/MLP kernels of "
                          "one step overlap the texture-bound gather of the next)")
     ap.add_argument("--distinct", type=int, default=0,
-                    help="diagnostic: tile this many distinct positions to fill the batch (cache-locality ablation)")
+                    help="tile this many distinct positions to fill the batch (cache-locality ablation; also keeps host "
+                         "generation bounded for the HBM-filling batches of BASELINE config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -240,9 +241,9 @@ def main():
     n_ctx = max(1, args.streams)
     states = [sp.NnueState(net, device=local_rank, max_batch=args.batch) for _ in range(n_ctx)]
     state = states[0]
-    positions = sp.random_positions(args.batch, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
-    if args.distinct:
-        positions = np.resize(positions[: args.distinct], args.batch)
+    n_distinct = min(args.distinct or args.batch, args.batch)
+    distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
+    positions = np.resize(distinct, args.batch) if n_distinct < args.batch else distinct
     d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
     d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
     d_out = d_outs[0]
@@ -275,7 +276,9 @@ def main():
     checksum = group.sum_int(int(d_out.to(torch.int64).sum().item()))  # checksum of checksums over all shards
 
     if rank == 0:
-        psq_rows, thr_rows = sp.count_rows(positions)
+        psq_rows, thr_rows = sp.count_rows(distinct)  # host-side count; tiled batches scale the distinct block
+        if n_distinct < args.batch:
+            psq_rows, thr_rows = (int(v * (args.batch / n_distinct)) for v in (psq_rows, thr_rows))
         algo_bytes = 2048 * psq_rows + 1024 * thr_rows + 36 * args.batch  # per launch
         compact_rows = states[0].compact_psq_rows
         psq_bytes = {11264: 1024, 0: 2048}.get(compact_rows)  # mixed nets: not derivable from the row totals
@@ -297,8 +300,9 @@ def main():
             "dtype": "i16 accumulate / i8 MFMA L1 / i32 tail",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: full-refresh NNUE forward on 65536 seeded random legal positions "
-                            "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU",
+                "workload": (f"BASELINE configs[1]: full-refresh NNUE forward on {args.batch} seeded random legal positions "
+                             "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU"
+                             + (f"; batch tiled from {n_distinct} distinct positions" if n_distinct < args.batch else "")),
                 "batch_per_gpu": args.batch,
                 "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path; "

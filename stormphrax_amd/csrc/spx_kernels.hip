@@ -33,6 +33,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_FT_WAVES_PER_SIMD
 #define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
+#ifndef SPX_MLP_WAVES_PER_SIMD
+#define SPX_MLP_WAVES_PER_SIMD 3
+#endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
 constexpr int kU8Cap = kThreatCap + kPsqCap;  // u8-row list: compact piece-square rows first, then <= 256 threat rows
@@ -945,7 +948,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 //   (-2^20, 2^12] the product is one full-rate v_mad_i32_i24; otherwise the exact-but-slow v_mul_lo_u32 path runs.
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kSmallL2W>
-__global__ __launch_bounds__(256) void spx_mlp_kernel(MlpParams p) {
+__global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
     __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
     __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
 

@@ -50,16 +50,10 @@ lib = _lib.load()
 boards = [games]
 import ctypes  # noqa: E402
 
-def random_successors(cur):
-    nxt = cur.copy()
-    for g in range(len(cur)):
-        for _ in range(200):
-            frm, to = int(rng.integers(64)), int(rng.integers(64))
-            uci = "abcdefgh"[frm & 7] + str((frm >> 3) + 1) + "abcdefgh"[to & 7] + str((to >> 3) + 1)
-            o = np.zeros(1, dtype=sp.PACKED_DTYPE)
-            if lib.spx_pos_apply_uci(cur[g:g + 1].ctypes.data, uci.encode(), o.ctypes.data) == 0:
-                nxt[g] = o[0]
-                break
+def random_successors(cur, ply=[0]):
+    ply[0] += 1
+    nxt, moved = sp.random_successors(cur, seed=1000 + ply[0])  # C++ move generation; games without a move stay put
+    nxt[~moved] = cur[~moved]
     return nxt
 
 SUB = 2048  # host move generation through ctypes is slow: build plies for a subset and tile it

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o c -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/g$i.log 2>&1 || echo "FAILED: $grp"
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o c -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/g$i.log 2>&1 || echo "FAILED: $grp"
 done
 python3 - <<PY
 import glob, sqlite3

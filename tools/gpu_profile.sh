@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
 # 1) kernel trace + stats (no counters)
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o t -- $BENCH > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o t -- $BENCH > $OUT/stats.log 2>&1
 # 2) counters, one group per pass (TCC: FETCH_SIZE costs 3 of 4 slots, WRITE_SIZE 2), kernel-trace only
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
@@ -17,7 +17,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmc_$i -o c -- $BENCH > $OUT/pmc_$i.log 2>&1 || echo "pmc group failed: $grp" >> $OUT/errors.log
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmc_$i -o c -- $BENCH > $OUT/pmc_$i.log 2>&1 || echo "pmc group failed: $grp" >> $OUT/errors.log
 done
 python3 - <<PY > $OUT/summary.txt 2>&1
 import glob, sqlite3
