@@ -124,6 +124,12 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream);
 
+/* Page-locked host memory for batch buffers (positions, slots, scores). Optional: every host-buffer entry point accepts
+ * ordinary memory, but copies from/to page-locked buffers run as plain DMA at PCIe speed instead of being staged by the
+ * runtime (the self-play driver builds its child batches in such buffers). Returns NULL on failure. */
+void* spx_host_alloc(size_t nbytes);
+void spx_host_free(void* ptr);
+
 /* ---- post-processing of raw evals on the device -------------------------------------------
  * eval::adjustStatic (src/eval/eval.cpp:24-27: + contempt[stm], clamp to +-24999) and eval::adjustEval
  * (src/eval/eval.cpp:30-67: material scaling + optimism, halfmove damping, optional correction / 2048, clamp) applied

@@ -98,6 +98,8 @@ SYMBOLS = {
     "spx_acc_update_eval_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
+    "spx_host_alloc": (_P, [ctypes.c_size_t]),
+    "spx_host_free": (None, [_P]),
     "spx_adjust_defaults": (None, [_P]),
     "spx_adjust": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P]),
     "spx_adjust_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P]),

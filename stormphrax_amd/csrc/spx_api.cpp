@@ -792,6 +792,19 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
     return SPX_OK;
 }
 
+void* spx_host_alloc(size_t nbytes) {
+    void* ptr = nullptr;
+    if (nbytes == 0 || hipHostMalloc(&ptr, nbytes, hipHostMallocDefault) != hipSuccess) {
+        setError("spx_host_alloc: cannot allocate " + std::to_string(nbytes) + " bytes of page-locked memory");
+        return nullptr;
+    }
+    return ptr;
+}
+
+void spx_host_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 void spx_adjust_defaults(spx_adjust_params* params) {
     if (!params) return;
     *params = spx_adjust_params{};

@@ -186,6 +186,36 @@ private:
     std::atomic<bool> stop_{false};
 };
 
+// Batch buffer in page-locked memory (spx_host_alloc): the GPU batch's copies are plain DMA. Grows geometrically.
+template <typename T>
+class PinnedBuf {
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() {
+        spx_host_free(data_);
+    }
+    bool ensure(size_t n) {  // contents are not preserved
+        if (n <= cap_) return true;
+        spx_host_free(data_);
+        cap_ = std::max(n, cap_ * 2);
+        data_ = static_cast<T*>(spx_host_alloc(cap_ * sizeof(T)));
+        if (!data_) cap_ = 0;
+        return data_ != nullptr;
+    }
+    T* data() {
+        return data_;
+    }
+    T& operator[](size_t i) {
+        return data_[i];
+    }
+
+private:
+    T* data_ = nullptr;
+    size_t cap_ = 0;
+};
+
 // One half of the games: its own child buffers and its own scratch-slot regions, so that its GPU batch can be in
 // flight while the other half is being prepared.
 struct Half {
@@ -194,9 +224,9 @@ struct Half {
     size_t maxChildren = 0;
     uint32_t step = 0;
     size_t total = 0;
-    std::vector<spx_packed_pos> childPos;
-    std::vector<uint32_t> parents, children;
-    std::vector<int32_t> evals;
+    PinnedBuf<spx_packed_pos> childPos;
+    PinnedBuf<uint32_t> parents, children;
+    PinnedBuf<int32_t> evals;
     std::vector<uint8_t> slotValid;
     std::future<int> pending;      // the in-flight GPU batch
     bool inFlight = false;
@@ -320,10 +350,10 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
             h.total += g.legal.size();
         }
         if (h.total == 0) return SPX_OK;
-        h.childPos.resize(h.total);
-        h.parents.resize(h.total);
-        h.children.resize(h.total);
-        h.evals.resize(h.total);
+        if (!h.childPos.ensure(h.total) || !h.parents.ensure(h.total) || !h.children.ensure(h.total) ||
+            !h.evals.ensure(h.total)) {
+            return SPX_ERR_HIP;
+        }
         h.slotValid.assign(h.total, 1);
         forGames(h, [&h](Game& g, uint32_t) {
             if (!g.active) return;
