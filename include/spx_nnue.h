@@ -225,6 +225,25 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 uint64_t spx_perft(const char* fen, int depth);
 
+/* ---- legal move generation + make-move on the device (takes the host out of the self-play loop) ----
+ * For each of the n records: every legal move (viriformat move word, src/datagen/viriformat.cpp:37-52; castling as
+ * "king takes rook") and the 32-byte record of the position after it, byte-identical to what the host chess core
+ * produces (spx_pos_legal_moves below). Children of position i are children[first[i] .. first[i] + count[i]); blocks of
+ * different positions are placed in no particular order. parents[k] = parent_values[i] of the source position (or i
+ * when parent_values is NULL) - pass the positions' accumulator slots to feed spx_acc_update_eval_device directly.
+ * in_check[i] tells mate from stalemate when count[i] == 0. *total receives the number of children generated; if it
+ * exceeds `capacity` nothing beyond capacity was written and the call returns SPX_ERR_CAPACITY.
+ * The _device variant is asynchronous: d_total is a device u32 the caller reads back after the stream. */
+int spx_movegen(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const uint32_t* parent_values,
+                spx_packed_pos* children, uint16_t* moves, uint32_t* parents, uint32_t* first, uint32_t* count,
+                uint8_t* in_check, size_t capacity, size_t* total);
+int spx_movegen_device(spx_ctx* ctx, const void* d_positions, size_t n, const void* d_parent_values, void* d_children,
+                       void* d_moves, void* d_parents, void* d_first, void* d_count, void* d_in_check, size_t capacity,
+                       void* d_total, void* stream);
+/* Host chess core, one position: legal moves (<= 256) in viriformat encoding and, if `children` is not NULL, the
+ * records after them; *in_check = side to move is in check. The parity reference of spx_movegen. */
+int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_pos* children, int* n, int* in_check);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Batched self-play driver (BASELINE config 4 shape; control flow of src/datagen/datagen.cpp:96-318): n_games concurrent
  * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),

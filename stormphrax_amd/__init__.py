@@ -13,6 +13,7 @@ from .nnue import (  # noqa: F401
     apply_uci,
     count_rows,
     debug_features,
+    legal_moves,
     perft,
     position_to_fen,
     positions_from_fens,

@@ -1024,6 +1024,126 @@ int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t
     return SPX_OK;
 }
 
+// ---- move generation ----
+static uint16_t viriMoveWord(const Move& m) {  // viriformat.cpp:37-52
+    static const uint16_t kTypes[4] = {0x0000, 0xC000, 0x8000, 0x4000};  // by MoveKind: normal, promotion, castling, ep
+    return uint16_t(m.from | (m.to << 6) | ((m.kind == kPromotion ? m.promo - 1 : 0) << 12) | kTypes[m.kind]);
+}
+
+int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_pos* children, int* n, int* in_check) {
+    Board b;
+    if (!pos || !moves || !n || !unpackBoard(*pos, b)) {
+        setError("spx_pos_legal_moves: null argument or bad record");
+        return SPX_ERR_BAD_POSITION;
+    }
+    std::vector<Move> legal;
+    generateLegal(b, legal);
+    if (legal.size() > 256) {
+        setError("spx_pos_legal_moves: more than 256 legal moves");
+        return SPX_ERR_CAPACITY;
+    }
+    *n = int(legal.size());
+    if (in_check) *in_check = b.inCheck() ? 1 : 0;
+    for (size_t k = 0; k < legal.size(); ++k) {
+        moves[k] = viriMoveWord(legal[k]);
+        if (children) {
+            Board next = b;
+            makeMove(next, legal[k]);
+            packBoard(next, children[k]);
+        }
+    }
+    return SPX_OK;
+}
+
+int spx_movegen_device(spx_ctx* ctx, const void* d_positions, size_t n, const void* d_parent_values, void* d_children,
+                       void* d_moves, void* d_parents, void* d_first, void* d_count, void* d_in_check, size_t capacity,
+                       void* d_total, void* stream) {
+    if (!ctx || (n && (!d_positions || !d_children || !d_moves || !d_parents || !d_first || !d_count || !d_in_check)) ||
+        !d_total || n > (1ull << 30) || capacity > 0xFFFFFFFFull) {
+        setError("spx_movegen_device: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    SPX_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), s));
+    if (n == 0) return SPX_OK;
+    MovegenParams mp{};
+    mp.positions = static_cast<const uint64_t*>(d_positions);
+    mp.nPositions = uint32_t(n);
+    mp.parentValues = static_cast<const uint32_t*>(d_parent_values);
+    mp.children = static_cast<uint64_t*>(d_children);
+    mp.moves = static_cast<uint16_t*>(d_moves);
+    mp.parents = static_cast<uint32_t*>(d_parents);
+    mp.first = static_cast<uint32_t*>(d_first);
+    mp.count = static_cast<uint32_t*>(d_count);
+    mp.inCheck = static_cast<uint8_t*>(d_in_check);
+    mp.cursor = static_cast<uint32_t*>(d_total);
+    mp.capacity = uint32_t(capacity);
+    uint32_t blocks = uint32_t((n + 3) / 4);
+    if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
+    SPX_HIP(launchMovegen(mp, blocks, s));
+    return SPX_OK;
+}
+
+int spx_movegen(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const uint32_t* parent_values,
+                spx_packed_pos* children, uint16_t* moves, uint32_t* parents, uint32_t* first, uint32_t* count,
+                uint8_t* in_check, size_t capacity, size_t* total) {
+    if (!ctx || !total || (n && (!positions || !children || !moves || !parents || !first || !count || !in_check))) {
+        setError("spx_movegen: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    *total = 0;
+    if (n == 0) return SPX_OK;
+    SPX_HIP(hipSetDevice(ctx->device));
+    // convenience entry point (tests, tools): device scratch lives for the duration of the call
+    struct Scratch {
+        std::vector<void*> ptrs;
+        ~Scratch() {
+            for (void* q : ptrs) (void)hipFree(q);
+        }
+        void* get(size_t bytes) {
+            void* q = nullptr;
+            if (hipMalloc(&q, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+            ptrs.push_back(q);
+            return q;
+        }
+    } scratch;
+    void* dPos = scratch.get(n * 32);
+    void* dPv = parent_values ? scratch.get(n * 4) : nullptr;
+    void* dChildren = scratch.get(capacity * 32);
+    void* dMoves = scratch.get(capacity * 2);
+    void* dParents = scratch.get(capacity * 4);
+    void* dFirst = scratch.get(n * 4);
+    void* dCount = scratch.get(n * 4);
+    void* dCheck = scratch.get(n);
+    void* dTotal = scratch.get(4);
+    if (!dPos || (parent_values && !dPv) || !dChildren || !dMoves || !dParents || !dFirst || !dCount || !dCheck || !dTotal) {
+        setError("spx_movegen: out of device memory");
+        return SPX_ERR_HIP;
+    }
+    hipStream_t s = ctx->stream;
+    SPX_HIP(hipMemcpyAsync(dPos, positions, n * 32, hipMemcpyHostToDevice, s));
+    if (parent_values) SPX_HIP(hipMemcpyAsync(dPv, parent_values, n * 4, hipMemcpyHostToDevice, s));
+    const int rc = spx_movegen_device(ctx, dPos, n, dPv, dChildren, dMoves, dParents, dFirst, dCount, dCheck, capacity,
+                                      dTotal, s);
+    if (rc != SPX_OK) return rc;
+    uint32_t produced = 0;
+    SPX_HIP(hipMemcpyAsync(&produced, dTotal, 4, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipMemcpyAsync(first, dFirst, n * 4, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipMemcpyAsync(count, dCount, n * 4, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipMemcpyAsync(in_check, dCheck, n, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    *total = produced;
+    if (produced > capacity) {
+        setError("spx_movegen: " + std::to_string(produced) + " children exceed the capacity of " + std::to_string(capacity));
+        return SPX_ERR_CAPACITY;
+    }
+    SPX_HIP(hipMemcpy(children, dChildren, size_t(produced) * 32, hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpy(moves, dMoves, size_t(produced) * 2, hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpy(parents, dParents, size_t(produced) * 4, hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
 // ---- viriformat game streams (src/datagen/viriformat.cpp:28-63) ----
 // game = PackedBoard (32 B) + { u16 move, i16 score }* + 4 zero bytes.
 // move: bits 0-5 from, 6-11 to (castling: own rook square), 12-13 promotion (0 = knight .. 3 = queen),

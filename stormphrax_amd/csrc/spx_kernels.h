@@ -63,6 +63,21 @@ struct AdjustParams {        // spx_adjust_params flattened (include/spx_nnue.h)
     int32_t* evals;               // in place
 };
 
+struct MovegenParams {              // spx_movegen_kernel (spx_movegen.hip)
+    const uint64_t* positions;      // records as u64[4]
+    uint32_t nPositions;
+    const uint32_t* parentValues;   // nullable: value recorded for every child of position i (e.g. its accumulator
+                                    // slot); default = i
+    uint64_t* children;             // [capacity] records
+    uint16_t* moves;                // [capacity] viriformat move words
+    uint32_t* parents;              // [capacity]
+    uint32_t* first;                // [nPositions] index of the position's first child
+    uint32_t* count;                // [nPositions] number of legal moves
+    uint8_t* inCheck;               // [nPositions] side to move in check (mate vs stalemate when count == 0)
+    uint32_t* cursor;               // running child count, zero on entry; may end above capacity (= overflow)
+    uint32_t capacity;
+};
+
 struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
@@ -93,6 +108,7 @@ hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchAdjust(const AdjustParams& p, hipStream_t stream);
 hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();

@@ -1,0 +1,321 @@
+// Device-side legal move generation + make-move on packed records, for the batched self-play driver.
+//
+// One wavefront per position, lane = from-square. A lane that holds a piece of the side to move builds its
+// pseudo-legal target set from the same per-lane attack math the feature extractor uses (spx_device_math.h), tests
+// every candidate the way the host core does - make the move, ask whether the own king is attacked
+// (spx_chess.cpp:generateLegal, the reference's Position::isLegal contract, src/position.cpp) - and then writes one
+// child RECORD per legal move: the 32-byte marlinformat PackedBoard of the position after the move, byte-identical to
+// the host's packBoard(makeMove(..)) (spx_chess.cpp:320-367,663-688; format src/datagen/marlinformat.h:32-84), plus
+// the viriformat move word (src/datagen/viriformat.cpp:37-52). Children of one position are contiguous; blocks of
+// different positions are placed with one atomic add per position (their relative order is not deterministic, the
+// content is). Castling follows Chess960 rules with "king takes rook" encoding, as the reference does.
+#include <hip/hip_runtime.h>
+
+#include "spx_arch.h"
+#include "spx_device_math.h"
+#include "spx_kernels.h"
+
+namespace spx {
+
+namespace {
+
+using u128 = unsigned __int128;
+
+__device__ __forceinline__ uint32_t laneId() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint64_t kingAttacksBb(uint64_t b) {
+    const uint64_t row = b | ((b << 1) & ~kFileA) | ((b >> 1) & ~kFileH);
+    return (row | (row << 8) | (row >> 8)) & ~b;
+}
+__device__ __forceinline__ uint64_t below(int sq) {
+    return (1ull << sq) - 1;
+}
+// squares lo..hi inclusive by index (the host's between(), spx_chess.cpp:299-304)
+__device__ __forceinline__ uint64_t spanMask(int a, int c) {
+    const int lo = a < c ? a : c, hi = a < c ? c : a;
+    const uint64_t upTo = hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1);
+    return upTo & ~below(lo);
+}
+
+struct Sets {  // wave-uniform bitboards of the parent position
+    uint64_t occ, pawns, knights, bishops, rooks, queens, kings, white;
+};
+
+// Board::attacked (spx_chess.cpp:67-77) with `removed` squares taken out of the attackers (a captured piece)
+__device__ __forceinline__ bool attackedBy(const Sets& s, int sq, int by, uint64_t occ, uint64_t removed) {
+    const uint64_t bit = 1ull << sq;
+    const uint64_t side = (by ? s.white : ~s.white) & ~removed;
+    if (pawnAttacks(bit, by ^ 1) & s.pawns & side) return true;
+    if (knightAttacks(bit) & s.knights & side) return true;
+    if (kingAttacksBb(bit) & s.kings & side) return true;
+    const uint64_t diag = (s.bishops | s.queens) & side;
+    if (diag && ((lineAttacks(occ, bit, diagMask(sq)) | lineAttacks(occ, bit, antiMask(sq))) & diag)) return true;
+    const uint64_t orth = (s.rooks | s.queens) & side;
+    return orth && ((lineAttacks(occ, bit, fileMask(sq)) | lineAttacks(occ, bit, rankMask(sq))) & orth);
+}
+
+// ---- the 32-nibble piece array (one nibble per occupied square, in square order) as a 128-bit integer ----
+__device__ __forceinline__ u128 nibMask(int idx) {  // the low idx nibbles
+    return idx >= 32 ? ~u128(0) : ((u128(1) << (4 * idx)) - 1);
+}
+__device__ __forceinline__ u128 deleteNibble(u128 x, int idx) {
+    const u128 low = x & nibMask(idx);
+    const u128 high = idx >= 31 ? u128(0) : (x >> (4 * (idx + 1)));
+    return low | (high << (4 * idx));
+}
+__device__ __forceinline__ u128 insertNibble(u128 x, int idx, uint32_t nib) {
+    const u128 low = x & nibMask(idx);
+    const u128 high = idx >= 32 ? u128(0) : (x >> (4 * idx));
+    return low | (u128(nib) << (4 * idx)) | (idx >= 31 ? u128(0) : (high << (4 * (idx + 1))));
+}
+// every nibble equal to `pattern` (6 or 14: an unmoved rook of one colour) loses its castling right: 6 -> 3, 14 -> 11
+__device__ __forceinline__ u128 dropCastlingRights(u128 x, uint32_t pattern) {
+    const u128 ones = (u128(0x1111111111111111ull) << 64) | 0x1111111111111111ull;
+    const u128 y = x ^ (ones * pattern);
+    const u128 nonzero = (y | (y >> 1) | (y >> 2) | (y >> 3)) & ones;
+    return x - (~nonzero & ones) * 3;
+}
+
+struct Parent {
+    uint64_t occ;
+    u128 nibbles;
+    int us;            // side to move, 1 = white
+    int ep;            // en-passant target square or 64
+    uint32_t halfmove, fullmove;
+};
+
+enum ChildKind { kChildNormal = 0, kChildPromotion = 1, kChildCastling = 2, kChildEnPassant = 3 };
+
+// makeMove + packBoard on the record (spx_chess.cpp:320-367,663-688). Castling: from = king square, to = rook square.
+__device__ void writeChild(const Parent& p, const Sets& s, int from, int to, int kind, int promoType, uint64_t* out,
+                           uint16_t* moveOut) {
+    const int us = p.us;
+    const uint32_t colourBit = us ? 0u : 8u;
+    uint64_t occ = p.occ;
+    u128 nib = p.nibbles;
+    const int fromIdx = popc64(occ & below(from));
+    const uint32_t moverNib = uint32_t(nib >> (4 * fromIdx)) & 0xFu;
+    const int moverType = int(moverNib & 7u);  // 6 = rook that still has its castling right
+    bool capture = false;
+    int epOut = 64;
+    if (kind == kChildCastling) {
+        const int base = us ? 0 : 56;
+        const int side = to > from ? 0 : 1;
+        const int kTo = base + (side == 0 ? 6 : 2), rTo = base + (side == 0 ? 5 : 3);
+        // remove king and rook (higher index first so the lower one stays valid), then put them back
+        const int hiSq = from > to ? from : to, loSq = from > to ? to : from;
+        nib = deleteNibble(nib, popc64(occ & below(hiSq)));
+        nib = deleteNibble(nib, popc64(occ & below(loSq)));
+        occ &= ~((1ull << from) | (1ull << to));
+        const int firstSq = kTo < rTo ? kTo : rTo, secondSq = kTo < rTo ? rTo : kTo;
+        const uint32_t firstNib = (firstSq == kTo ? 5u : 3u) | colourBit, secondNib = (secondSq == kTo ? 5u : 3u) | colourBit;
+        nib = insertNibble(nib, popc64(occ & below(firstSq)), firstNib);
+        occ |= 1ull << firstSq;
+        nib = insertNibble(nib, popc64(occ & below(secondSq)), secondNib);
+        occ |= 1ull << secondSq;
+        nib = dropCastlingRights(nib, 6u | colourBit);
+    } else {
+        int capSq = -1;
+        if (kind == kChildEnPassant) {
+            capSq = to + (us ? -8 : 8);
+        } else if ((occ >> to) & 1) {
+            capSq = to;
+        }
+        if (capSq >= 0) {
+            capture = true;
+            nib = deleteNibble(nib, popc64(occ & below(capSq)));
+            occ &= ~(1ull << capSq);
+        }
+        nib = deleteNibble(nib, popc64(occ & below(from)));
+        occ &= ~(1ull << from);
+        uint32_t placed = moverNib;
+        if (kind == kChildPromotion) placed = uint32_t(promoType) | colourBit;
+        if (moverType == 6) placed = 3u | colourBit;  // a rook that moves loses its right
+        nib = insertNibble(nib, popc64(occ & below(to)), placed);
+        occ |= 1ull << to;
+        if (moverType == 5) nib = dropCastlingRights(nib, 6u | colourBit);
+        if (moverType == 0 && (to - from == 16 || from - to == 16)) {
+            // the ep square is recorded only if an enemy pawn could capture there (spx_chess.cpp:347-352)
+            const int epSq = (from + to) / 2;
+            const uint64_t enemyPawns = s.pawns & (us ? ~s.white : s.white);
+            if (pawnAttacks(1ull << epSq, us) & enemyPawns) epOut = epSq;
+        }
+    }
+    const bool pawnMove = moverType == 0 && kind != kChildCastling;
+    const uint32_t halfmove = (capture || pawnMove) ? 0u : min(p.halfmove + 1u, 255u);
+    const uint32_t fullmove = (p.fullmove + (us == 0 ? 1u : 0u)) & 0xFFFFu;
+    const uint32_t stmEp = (us ? 0x80u : 0u) | uint32_t(epOut);  // the child's side to move is the other colour
+    out[0] = occ;
+    out[1] = uint64_t(nib);
+    out[2] = uint64_t(nib >> 64);
+    out[3] = uint64_t(stmEp) | (uint64_t(halfmove) << 8) | (uint64_t(fullmove) << 16);  // eval, wdl, extra = 0
+    static_assert(kChildPromotion == 1 && kChildCastling == 2 && kChildEnPassant == 3, "type bits below");
+    const uint32_t typeBits = kind == kChildPromotion ? 0xC000u : kind == kChildCastling ? 0x8000u
+                              : kind == kChildEnPassant ? 0x4000u : 0u;
+    *moveOut = uint16_t(uint32_t(from) | (uint32_t(to) << 6) |
+                        ((kind == kChildPromotion ? uint32_t(promoType - 1) : 0u) << 12) | typeBits);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x * 4 + wave; it < p.nPositions; it += gridDim.x * 4) {
+        const uint64_t* rec = p.positions + size_t(it) * 4;
+        Parent par;
+        par.occ = rec[0];
+        const uint64_t nibLo = rec[1], nibHi = rec[2];
+        par.nibbles = (u128(nibHi) << 64) | nibLo;
+        const uint32_t tail = uint32_t(rec[3]);
+        par.us = (tail & 0x80u) ? 0 : 1;
+        par.ep = int(tail & 0x7Fu);
+        par.halfmove = (tail >> 8) & 0xFFu;
+        par.fullmove = (tail >> 16) & 0xFFFFu;
+        const int us = par.us, them = us ^ 1;
+
+        const bool occupied = (par.occ >> lane) & 1;
+        const uint32_t idx = min(uint32_t(popc64(par.occ & below(int(lane)))), 31u);
+        const uint32_t nibRaw = occupied ? uint32_t(((idx < 16 ? nibLo : nibHi) >> ((idx & 15) * 4)) & 0xF) : 0u;
+        int type = int(nibRaw & 7u);
+        const bool rights = occupied && type == 6;
+        if (type >= 6) type = (type == 6) ? 3 : 0;  // 7 is not a marlinformat code: treated as a pawn, like the evaluator does
+        const bool isWhite = occupied && !(nibRaw & 8u);
+        Sets s;
+        s.occ = par.occ;
+        s.pawns = __ballot(occupied && type == 0);
+        s.knights = __ballot(occupied && type == 1);
+        s.bishops = __ballot(occupied && type == 2);
+        s.rooks = __ballot(occupied && type == 3);
+        s.queens = __ballot(occupied && type == 4);
+        s.kings = __ballot(occupied && type == 5);
+        s.white = __ballot(isWhite);
+        const uint64_t rightsBb = __ballot(rights);
+        const uint64_t own = us ? s.white : (s.occ & ~s.white), enemy = s.occ & ~own;
+        const uint64_t ownKing = s.kings & own;
+        const int kingSq = ownKing ? ctz64(ownKing) : 0;
+        const bool mine = occupied && (isWhite == (us == 1));
+        const int from = int(lane);
+
+        // ---- pseudo-legal targets of this lane's piece (generatePseudo, spx_chess.cpp:249-318) ----
+        uint64_t targets = 0;
+        bool promo = false;
+        if (mine) {
+            const uint64_t bit = 1ull << from;
+            if (type == 0) {
+                const int fwd = us ? 8 : -8;
+                const int one = from + fwd;
+                if (one >= 0 && one < 64) {
+                    promo = us ? (one >= 56) : (one < 8);
+                    if (!((s.occ >> one) & 1)) {
+                        targets |= 1ull << one;
+                        const bool home = us ? ((from >> 3) == 1) : ((from >> 3) == 6);
+                        if (home && !((s.occ >> (one + fwd)) & 1)) targets |= 1ull << (one + fwd);
+                    }
+                }
+                const uint64_t att = pawnAttacks(bit, us);
+                targets |= att & enemy;
+                if (par.ep < 64 && ((att >> par.ep) & 1)) targets |= 1ull << par.ep;
+            } else if (type == 5) {
+                targets = kingAttacksBb(bit) & ~own;
+            } else {
+                targets = pieceAttacks((type << 1) | us, from, s.occ) & ~own;
+            }
+        }
+        // ---- legality: make the move, the own king must not be attacked (generateLegal, spx_chess.cpp:602-612) ----
+        uint64_t legal = 0;
+        {
+            uint64_t rest = targets;
+            while (rest) {
+                const int to = ctz64(rest);
+                rest &= rest - 1;
+                const bool isEp = type == 0 && to == par.ep && !((s.occ >> to) & 1) && (to & 7) != (from & 7);
+                const uint64_t capBit = isEp ? (1ull << (to + (us ? -8 : 8))) : (s.occ & (1ull << to));
+                const uint64_t occ2 = (s.occ & ~(1ull << from) & ~capBit) | (1ull << to);
+                const int ksq2 = type == 5 ? to : kingSq;
+                if (!attackedBy(s, ksq2, them, occ2, capBit)) legal |= 1ull << to;
+            }
+        }
+        // ---- castling, on the king's lane (spx_chess.cpp:288-317): bit 0 = kingside, bit 1 = queenside ----
+        uint32_t castleOk = 0;
+        int castleRook[2] = {-1, -1};
+        if (mine && type == 5) {
+            const uint64_t myRooks = rightsBb & own;
+            const uint64_t kingside = myRooks & ~below(from) & ~(1ull << from), queenside = myRooks & below(from);
+            // unpackBoard keeps the LAST (highest) flagged rook per side (spx_chess.cpp:708-717)
+            if (kingside) castleRook[0] = 63 - __clzll(kingside);
+            if (queenside) castleRook[1] = 63 - __clzll(queenside);
+            const int base = us ? 0 : 56;
+            for (int side = 0; side < 2; ++side) {
+                const int rsq = castleRook[side];
+                if (rsq < 0) continue;
+                const int kTo = base + (side == 0 ? 6 : 2), rTo = base + (side == 0 ? 5 : 3);
+                const uint64_t span = spanMask(from, kTo) | spanMask(rsq, rTo);
+                const uint64_t others = s.occ & ~(1ull << from) & ~(1ull << rsq);
+                if (span & others) continue;
+                bool safe = true;
+                uint64_t path = spanMask(from, kTo);
+                while (path && safe) {
+                    const int sq = ctz64(path);
+                    path &= path - 1;
+                    safe = !attackedBy(s, sq, them, others | (1ull << rsq), 0);
+                }
+                if (safe && attackedBy(s, kTo, them, others | (1ull << rTo), 0)) safe = false;
+                if (safe) castleOk |= 1u << side;
+            }
+        }
+        // ---- placement: exclusive prefix of the per-lane child counts, one atomic per position ----
+        const uint32_t mineCount = uint32_t(popc64(legal)) * (promo ? 4u : 1u) + uint32_t(__popc(castleOk));
+        uint32_t incl = mineCount;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (int(lane) >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = total ? atomicAdd(p.cursor, total) : 0u;
+            p.first[it] = base;
+            p.count[it] = total;
+            p.inCheck[it] = attackedBy(s, kingSq, them, s.occ, 0) ? 1 : 0;
+        }
+        base = __shfl(base, 0, 64);
+        if (uint64_t(base) + total > p.capacity) continue;  // the host sees cursor > capacity and reports the overflow
+        uint32_t k = base + incl - mineCount;
+        const uint32_t parentValue = p.parentValues ? p.parentValues[it] : it;
+        // ---- children ----
+        uint64_t rest = legal;
+        while (rest) {
+            const int to = ctz64(rest);
+            rest &= rest - 1;
+            const bool isEp = type == 0 && to == par.ep && !((s.occ >> to) & 1) && (to & 7) != (from & 7);
+            if (promo) {
+                for (int pt = 4; pt >= 1; --pt) {
+                    writeChild(par, s, from, to, kChildPromotion, pt, p.children + size_t(k) * 4, p.moves + k);
+                    p.parents[k] = parentValue;
+                    ++k;
+                }
+            } else {
+                writeChild(par, s, from, to, isEp ? kChildEnPassant : kChildNormal, 0, p.children + size_t(k) * 4, p.moves + k);
+                p.parents[k] = parentValue;
+                ++k;
+            }
+        }
+        for (int side = 0; side < 2; ++side) {
+            if (castleOk & (1u << side)) {
+                writeChild(par, s, from, castleRook[side], kChildCastling, 0, p.children + size_t(k) * 4, p.moves + k);
+                p.parents[k] = parentValue;
+                ++k;
+            }
+        }
+    }
+}
+
+hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_movegen_kernel, dim3(gridBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace spx

@@ -116,6 +116,27 @@ class NnueState:
                                      None if corr is None else corr.ctypes.data, out.ctypes.data))
         return out
 
+    def movegen(self, positions, parent_values=None, capacity=None):
+        """Legal moves + child records of every position, generated on the device (spx_movegen).
+        -> dict(children, moves, parents, first, count, in_check)."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        n = pos.shape[0]
+        capacity = capacity if capacity is not None else 64 * n + 256
+        children = np.zeros(capacity, dtype=PACKED_DTYPE)
+        moves = np.zeros(capacity, dtype=np.uint16)
+        parents = np.zeros(capacity, dtype=np.uint32)
+        first = np.zeros(n, dtype=np.uint32)
+        count = np.zeros(n, dtype=np.uint32)
+        in_check = np.zeros(n, dtype=np.uint8)
+        pv = None if parent_values is None else np.ascontiguousarray(parent_values, dtype=np.uint32)
+        total = ctypes.c_size_t()
+        check(_lib.load().spx_movegen(self._h, pos.ctypes.data, n, None if pv is None else pv.ctypes.data,
+                                      children.ctypes.data, moves.ctypes.data, parents.ctypes.data, first.ctypes.data,
+                                      count.ctypes.data, in_check.ctypes.data, capacity, ctypes.byref(total)))
+        t = total.value
+        return {"children": children[:t], "moves": moves[:t], "parents": parents[:t], "first": first, "count": count,
+                "in_check": in_check.astype(bool)}
+
     @property
     def compact_psq_rows(self):
         """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
@@ -291,6 +312,17 @@ def count_rows(positions):
     a, b = ctypes.c_uint64(), ctypes.c_uint64()
     check(_lib.load().spx_count_rows(pos.ctypes.data, pos.shape[0], ctypes.byref(a), ctypes.byref(b)))
     return a.value, b.value
+
+
+def legal_moves(rec):
+    """Host chess core: (viriformat move words, child records, in_check) of one packed record."""
+    rec = np.ascontiguousarray(rec, dtype=PACKED_DTYPE).reshape(1)
+    moves = np.zeros(256, dtype=np.uint16)
+    children = np.zeros(256, dtype=PACKED_DTYPE)
+    n, chk = ctypes.c_int(), ctypes.c_int()
+    check(_lib.load().spx_pos_legal_moves(rec.ctypes.data, moves.ctypes.data, children.ctypes.data, ctypes.byref(n),
+                                          ctypes.byref(chk)))
+    return moves[: n.value].copy(), children[: n.value].copy(), bool(chk.value)
 
 
 def perft(fen, depth):

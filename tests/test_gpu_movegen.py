@@ -1,0 +1,103 @@
+"""Device-side legal move generation + make-move (spx_movegen) against the host chess core, which is itself pinned by
+perft (tests/test_host_logic.py) and by the reference's observer deltas: same legal move sets, byte-identical child
+records, same check flags - on random playouts (standard + DFRC), hand-picked castling / en-passant / promotion / check
+positions, and through the published perft node counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE_FENS = [
+    "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1",
+    "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1",      # kiwipete: both castlings, pins
+    "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R b KQkq - 0 1",
+    "8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1",                                  # ep pin along the rank
+    "8/8/8/8/k2Pp2Q/8/8/3K4 b - d3 0 1",                                          # ep capture would expose the king
+    "rnbqkb1r/ppp1pppp/5n2/3pP3/8/8/PPPP1PPP/RNBQKBNR w KQkq d6 0 3",             # plain ep
+    "4k3/8/8/8/3pP3/8/8/4K3 b - e3 0 1",
+    "r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", "r3k2r/8/8/8/8/8/8/R3K2R b KQkq - 0 1",
+    "r3k2r/8/8/8/8/8/6n1/R3K2R w KQkq - 0 1",                                     # knight attacks f1/e... castling through check
+    "4k3/8/8/8/8/8/8/R3K2R w KQ - 0 1", "r3k2r/8/8/8/8/5b2/8/R3K2R w KQkq - 0 1",
+    "n1n5/PPPk4/8/8/8/8/4Kppp/5N1N b - - 0 1", "n1n5/PPPk4/8/8/8/8/4Kppp/5N1N w - - 0 1",  # promotions incl. captures
+    "4k3/8/8/8/8/8/8/4K2q w - - 0 1", "7k/5Q2/6K1/8/8/8/8/8 b - - 0 1",            # check / stalemate
+    "R6k/6pp/8/8/8/8/8/4K3 b - - 0 1",                                            # back-rank mate
+    "4k3/8/8/8/8/2n5/3b4/4K3 w - - 0 1", "4k3/4r3/8/8/8/2n5/8/4K3 w - - 0 1",      # double check
+    "bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9",          # Chess960 castling rights
+    "1rk3r1/8/8/8/8/8/8/1RK3R1 w GBgb - 0 1", "rk5r/8/8/8/8/8/8/RK5R w HAha - 0 1", "r5kr/8/8/8/8/8/8/R5KR b HAha - 0 1",
+    "2rkr3/8/8/8/8/8/8/2RKR3 w ECec - 0 1", "5rkr/8/8/8/8/8/8/5RKR w HFhf - 0 1",
+    "rnbq1bnr/ppppkppp/8/4p3/4P3/8/PPPPKPPP/RNBQ1BNR w - - 2 3", "8/8/8/8/8/8/8/K6k w - - 0 1",
+]
+
+
+def host_children(sp, rec):
+    moves, children, chk = sp.legal_moves(rec)
+    rows = sorted((int(m), c.tobytes()) for m, c in zip(moves, children))
+    return rows, chk
+
+
+def compare(sp, st, positions):
+    out = st.movegen(positions)
+    assert int(out["count"].sum()) == len(out["children"])
+    for i in range(len(positions)):
+        want, chk = host_children(sp, positions[i])
+        lo, n = int(out["first"][i]), int(out["count"][i])
+        got = sorted((int(m), c.tobytes()) for m, c in zip(out["moves"][lo:lo + n], out["children"][lo:lo + n]))
+        fen = sp.position_to_fen(positions[i])
+        assert n == len(want), (fen, n, len(want))
+        assert got == want, fen
+        assert bool(out["in_check"][i]) == chk, fen
+        assert np.all(out["parents"][lo:lo + n] == i)
+    return out
+
+
+@pytest.fixture(scope="module")
+def st(sp, net_blob):
+    s = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=4096)
+    yield s
+    s.close()
+
+
+def test_edge_positions_match_host_core(sp, st):
+    compare(sp, st, sp.positions_from_fens(EDGE_FENS))
+
+
+def test_random_playouts_match_host_core(sp, st):
+    pos = np.concatenate([
+        sp.random_positions(2500, seed=1, min_ply=0, max_ply=160, dfrc_every=2),
+        sp.random_positions(1500, seed=2, min_ply=0, max_ply=14, dfrc_every=1),   # castling rights still alive
+    ])
+    out = compare(sp, st, pos)
+    kinds = out["moves"] >> 14
+    assert (kinds == 1).any() and (kinds == 2).any() and (kinds == 3).any()       # ep, castling, promotions all occur
+    # parent_values are passed through (e.g. accumulator slots)
+    pv = np.arange(len(pos), dtype=np.uint32)[::-1].copy()
+    out2 = st.movegen(pos, parent_values=pv)
+    for i in (0, 17, len(pos) - 1):
+        lo, n = int(out2["first"][i]), int(out2["count"][i])
+        assert np.all(out2["parents"][lo:lo + n] == pv[i])
+
+
+@pytest.mark.parametrize("fen,depth,nodes", [
+    ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", 4, 197281),
+    ("r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", 3, 97862),
+    ("8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1", 4, 43238),
+    ("r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1", 3, 9467),
+    ("bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9", 3, 12189),
+])
+def test_device_perft(sp, st, fen, depth, nodes):
+    """Published perft counts (chessprogramming.org positions 1-4; the Chess960 one from the FRC perft suite),
+    walked level by level entirely with the device generator."""
+    level = sp.positions_from_fens([fen])
+    for d in range(depth):
+        out = st.movegen(level, capacity=len(level) * 80 + 256)
+        if d == depth - 1:
+            assert int(out["count"].sum()) == nodes
+        level = out["children"]
+
+
+def test_capacity_overflow_is_reported(sp, st):
+    from stormphrax_amd import _lib
+
+    pos = sp.random_positions(64, seed=3)
+    with pytest.raises(_lib.SpxError):
+        st.movegen(pos, capacity=100)
