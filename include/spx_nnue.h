@@ -260,9 +260,10 @@ typedef struct spx_selfplay_params {
     uint32_t dfrc;           /* 1 = double-Chess960 starts */
     int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
     uint32_t host_threads;   /* host worker threads (0 = min(16, usable CPUs incl. cgroup quota): phases are short, more only adds hand-off cost) */
-    uint32_t reserved;
+    uint32_t flags;          /* 0 = moves generated on the device; SPX_SELFPLAY_HOST_MOVEGEN = host chess core instead */
     uint64_t seed;
 } spx_selfplay_params;
+enum { SPX_SELFPLAY_HOST_MOVEGEN = 1 };
 typedef struct spx_selfplay_stats {
     uint64_t games, positions, evals, steps;
     uint64_t outcomes[3];    /* white loss / draw / white win (datagen/common.h:24-28) */

@@ -63,7 +63,7 @@ class AdjustParams(ctypes.Structure):
 class SelfplayParams(ctypes.Structure):
     _fields_ = [("n_games", ctypes.c_uint32), ("target_games", ctypes.c_uint32), ("max_plies", ctypes.c_uint32),
                 ("opening_plies", ctypes.c_uint32), ("dfrc", ctypes.c_uint32), ("temperature_cp", ctypes.c_int32),
-                ("host_threads", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
+                ("host_threads", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
 
 
 class SelfplayStats(ctypes.Structure):

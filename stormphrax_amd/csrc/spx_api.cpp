@@ -81,6 +81,10 @@ struct spx_ctx {
 };
 
 namespace spx {
+int ctxDevice(const spx_ctx* ctx) {
+    return ctx->device;
+}
+
 size_t ctxMaxBatch(const spx_ctx* ctx) {
     return ctx->maxBatch;
 }

@@ -215,4 +215,19 @@ SPX_HD int nibbleToPiece(int nib) {
     return (type << 1) | ((nib & 8) ? 0 : 1);
 }
 
+// 64-bit key of a packed record's position identity (placement incl. castling-right codes, side to move, ep square;
+// not the clocks): repetition detection in the self-play driver, computed on the device for every chosen child and on
+// the host for start positions. Not a Zobrist key - only equality matters.
+SPX_HD uint64_t recordKey(uint64_t occ, uint64_t nibLo, uint64_t nibHi, uint32_t stmEp) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t(stmEp & 0xFFu) * 0xD6E8FEB86659FD93ull);
+    const uint64_t words[3] = {occ, nibLo, nibHi};
+    for (int i = 0; i < 3; ++i) {
+        h ^= words[i];
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+    }
+    return h;
+}
+
 }  // namespace spx

@@ -20,6 +20,7 @@ struct spx_ctx_fwd;
 struct spx_ctx;
 namespace spx {
 size_t ctxMaxBatch(const spx_ctx* ctx);
+int ctxDevice(const spx_ctx* ctx);
 
 // error plumbing (spx_api): thread-local last error string, returned by spx_last_error()
 void setError(const std::string& msg);

@@ -313,6 +313,76 @@ __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Move choice of the depth-1 self-play policy, one thread per game: score(move) = -eval(child); uniformly among the
+// moves within `temperature` of the best (reservoir pick in child order, one RNG draw per candidate - the same rule as
+// the host path of spx_selfplay.cpp); the chosen child's record and accumulator slot become the game's current ones.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.nGames) return;
+    PickResult r{};
+    r.count = p.count[g];
+    r.inCheck = p.inCheck[g];
+    if (r.count != 0) {
+        const uint32_t lo = p.first[g];
+        int32_t best = INT32_MIN;
+        for (uint32_t k = 0; k < r.count; ++k) best = max(best, -p.evals[lo + k]);
+        uint64_t state = p.rng[g];
+        uint32_t pick = 0, seen = 0;
+        for (uint32_t k = 0; k < r.count; ++k) {
+            if (-p.evals[lo + k] >= best - p.temperature) {
+                ++seen;
+                state += 0x9E3779B97F4A7C15ull;
+                uint64_t z = state;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                if (uint32_t(z >> 32) % seen == 0) pick = k;
+                if (p.temperature == 0) break;
+            }
+        }
+        p.rng[g] = state;
+        const uint32_t c = lo + pick;
+        const uint64_t* child = p.children + size_t(c) * 4;
+        const uint64_t w0 = child[0], w1 = child[1], w2 = child[2], w3 = child[3];
+        uint64_t* dst = p.positions + size_t(g) * 4;
+        dst[0] = w0;
+        dst[1] = w1;
+        dst[2] = w2;
+        dst[3] = w3;
+        p.slots[g] = p.childSlots[c];
+        r.key = recordKey(w0, w1, w2, uint32_t(w3));
+        r.score = -p.evals[c];
+        r.move = p.moves[c];
+        r.halfmove = uint8_t((w3 >> 8) & 0xFF);
+    }
+    p.results[g] = r;
+}
+
+__global__ __launch_bounds__(256) void spx_seat_games_kernel(uint32_t n, const uint32_t* seats, const uint64_t* records,
+                                                             const uint64_t* rngStates, uint64_t* positions,
+                                                             uint32_t* slots, uint64_t* rng) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t seat = seats[k];
+    for (int w = 0; w < 4; ++w) positions[size_t(seat) * 4 + w] = records[size_t(k) * 4 + w];
+    slots[seat] = seat;
+    rng[seat] = rngStates[k];
+}
+
+hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,
+                           uint64_t* positions, uint32_t* slots, uint64_t* rng, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_seat_games_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, seats, records, rngStates,
+                       positions, slots, rng);
+    return hipGetLastError();
+}
+
+hipError_t launchPick(const PickParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream) {
     hipLaunchKernelGGL(spx_movegen_kernel, dim3(gridBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -27,9 +27,13 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/spx_nnue.h"
 #include "spx_chess.h"
+#include "spx_device_math.h"
 #include "spx_internal.h"
+#include "spx_kernels.h"
 
 namespace spx {
 
@@ -237,12 +241,10 @@ struct Half {
 
 using namespace spx;
 
-extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path,
-                                spx_selfplay_stats* stats) {
-    if (!ctx || !p || !stats || p->n_games == 0 || p->target_games == 0) {
-        setError("spx_selfplay_run: invalid argument");
-        return SPX_ERR_INVALID_ARG;
-    }
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-movegen path (SPX_SELFPLAY_HOST_MOVEGEN): legal moves and child records from the host chess core.
+// ---------------------------------------------------------------------------------------------------------------------
+static int runHostMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
     const uint32_t G = p->n_games;
     const uint32_t nThreads = std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(16u, usableCpus()), G));
     const uint32_t nHalves = G >= 2 ? 2 : 1;
@@ -496,4 +498,420 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuSeconds;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-movegen path (default): the games live on the GPU. Per ply, for all games at once:
+//   spx_movegen_kernel  legal moves + child records of every game's current position (parents = the games' slots)
+//   fused update+eval   one accumulator update and evaluation per child (spx_acc_update_eval_device)
+//   spx_pick_kernel     the depth-1 policy; the chosen child's record / slot become the game's current ones
+// and 24 bytes per game come back (move, score, key, clocks) for the adjudication counters, repetition detection and
+// the viriformat records, which stay on the host together with the random openings of newly started games.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DeviceBuffers {
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() {
+        for (void* q : ptrs) (void)hipFree(q);
+    }
+    template <typename T>
+    T* get(size_t count) {
+        void* q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) return nullptr;
+        ptrs.push_back(q);
+        return static_cast<T*>(q);
+    }
+};
+
+struct PinnedBuffers {
+    std::vector<void*> ptrs;
+    ~PinnedBuffers() {
+        for (void* q : ptrs) spx_host_free(q);
+    }
+    template <typename T>
+    T* get(size_t count) {
+        void* q = spx_host_alloc(std::max<size_t>(count * sizeof(T), 16));
+        if (q) ptrs.push_back(q);
+        return static_cast<T*>(q);
+    }
+};
+
+struct DeviceGame {
+    spx_packed_pos initial;
+    std::vector<uint16_t> moves;
+    std::vector<int16_t> scores;
+    std::vector<uint64_t> history;  // keys of the positions played through
+    uint64_t key = 0;               // key of the current position
+    uint32_t winPlies = 0, lossPlies = 0, drawPlies = 0, plies = 0;
+    uint8_t stm = 1;
+    bool active = false;
+    bool blank = true;              // the seat's device record is empty (generates no moves)
+    uint8_t outcome = 255;
+};
+
+uint64_t keyOfRecord(const spx_packed_pos& r) {
+    uint64_t lo, hi;
+    std::memcpy(&lo, r.pieces, 8);
+    std::memcpy(&hi, r.pieces + 8, 8);
+    return recordKey(r.occupancy, lo, hi, r.stm_ep);
+}
+
+#define SPX_SP_HIP(call)                                                                      \
+    do {                                                                                      \
+        const hipError_t err_ = (call);                                                       \
+        if (err_ != hipSuccess) {                                                             \
+            setError(std::string("spx_selfplay_run: ") + #call + ": " + hipGetErrorString(err_)); \
+            return SPX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+// One half of the seats: its own child buffers and scratch-slot regions. The halves alternate so that the host's
+// bookkeeping for one half runs while the GPU evaluates the children of the other.
+struct DeviceHalf {
+    uint32_t begin = 0, end = 0;     // seats
+    size_t cap = 0;                  // children per ply
+    uint32_t slotBase = 0;           // first scratch slot; two regions of cap, alternating per ply
+    uint32_t step = 0;
+    uint64_t* dChildren = nullptr;
+    uint16_t* dMoves = nullptr;
+    uint32_t* dParents = nullptr;
+    int32_t* dEvals = nullptr;
+    uint32_t* dChildSlots = nullptr; // [2][cap] slot ids
+    uint32_t* dTotal = nullptr;
+    uint32_t* hTotal = nullptr;      // pinned
+    PickResult* hResults = nullptr;  // pinned, [end - begin]
+    // staging for games that start this ply (pinned host + device)
+    uint32_t* hSeats = nullptr;
+    spx_packed_pos* hRecords = nullptr;
+    uint64_t* hRng = nullptr;
+    uint32_t* dSeats = nullptr;
+    uint64_t* dRecords = nullptr;
+    uint64_t* dRngNew = nullptr;
+};
+
+int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
+    const uint32_t G = p->n_games;
+    const uint32_t nHalves = G >= 2 ? 2 : 1;
+    const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
+    if (size_t(G) * (1 + 2 * perSeat) > 0xFFFFFFFFull) {
+        setError("spx_selfplay_run: too many games for 32-bit slot ids");
+        return SPX_ERR_INVALID_ARG;
+    }
+    int rc = spx_acc_reserve(ctx, size_t(G) * (1 + 2 * perSeat));
+    if (rc != SPX_OK) return rc;
+    SPX_SP_HIP(hipSetDevice(ctxDevice(ctx)));
+    FILE* out = nullptr;
+    if (out_path && out_path[0]) {
+        out = std::fopen(out_path, "wb");
+        if (!out) {
+            setError(std::string("spx_selfplay_run: cannot open ") + out_path);
+            return SPX_ERR_INVALID_ARG;
+        }
+    }
+    struct FileCloser {
+        FILE* f;
+        ~FileCloser() {
+            if (f) std::fclose(f);
+        }
+    } closer{out};
+    std::memset(stats, 0, sizeof(*stats));
+
+    DeviceBuffers dev;
+    PinnedBuffers pinned;
+    auto* dPositions = dev.get<uint64_t>(size_t(G) * 4);
+    auto* dSlots = dev.get<uint32_t>(G);
+    auto* dRng = dev.get<uint64_t>(G);
+    auto* dFirst = dev.get<uint32_t>(G);
+    auto* dCount = dev.get<uint32_t>(G);
+    auto* dInCheck = dev.get<uint8_t>(G);
+    auto* dResults = dev.get<PickResult>(G);
+    bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dResults;
+    std::vector<DeviceHalf> halves(nHalves);
+    uint32_t nextSlot = G;
+    for (uint32_t h = 0; h < nHalves && ok; ++h) {
+        DeviceHalf& hf = halves[h];
+        hf.begin = uint32_t(uint64_t(G) * h / nHalves);
+        hf.end = uint32_t(uint64_t(G) * (h + 1) / nHalves);
+        const uint32_t seats = hf.end - hf.begin;
+        hf.cap = size_t(seats) * perSeat;
+        hf.slotBase = nextSlot;
+        nextSlot += uint32_t(2 * hf.cap);
+        hf.dChildren = dev.get<uint64_t>(hf.cap * 4);
+        hf.dMoves = dev.get<uint16_t>(hf.cap);
+        hf.dParents = dev.get<uint32_t>(hf.cap);
+        hf.dEvals = dev.get<int32_t>(hf.cap);
+        hf.dChildSlots = dev.get<uint32_t>(2 * hf.cap);
+        hf.dTotal = dev.get<uint32_t>(1);
+        hf.dSeats = dev.get<uint32_t>(seats);
+        hf.dRecords = dev.get<uint64_t>(size_t(seats) * 4);
+        hf.dRngNew = dev.get<uint64_t>(seats);
+        hf.hTotal = pinned.get<uint32_t>(1);
+        hf.hResults = pinned.get<PickResult>(seats);
+        hf.hSeats = pinned.get<uint32_t>(seats);
+        hf.hRecords = pinned.get<spx_packed_pos>(seats);
+        hf.hRng = pinned.get<uint64_t>(seats);
+        ok = hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dChildSlots && hf.dTotal && hf.dSeats &&
+             hf.dRecords && hf.dRngNew && hf.hTotal && hf.hResults && hf.hSeats && hf.hRecords && hf.hRng;
+    }
+    if (!ok) {
+        setError("spx_selfplay_run: out of device or page-locked memory");
+        return SPX_ERR_HIP;
+    }
+    hipStream_t stream;
+    SPX_SP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamCloser {
+        hipStream_t s;
+        ~StreamCloser() {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    } streamCloser{stream};
+    for (DeviceHalf& hf : halves) {
+        std::vector<uint32_t> iota(2 * hf.cap);
+        for (size_t k = 0; k < iota.size(); ++k) iota[k] = uint32_t(hf.slotBase + k);
+        SPX_SP_HIP(hipMemcpy(hf.dChildSlots, iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
+    }
+    SPX_SP_HIP(hipMemset(dPositions, 0, size_t(G) * 32));  // empty records generate no moves
+
+    Rng rng{p->seed};
+    std::vector<DeviceGame> games(G);
+    Pool pool(std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(16u, usableCpus()), G)));
+    std::vector<Game> scratch(pool.size());  // random openings reuse the host path's generator, one per worker
+    std::vector<uint64_t> openingSeeds;
+    std::vector<uint8_t> retire;
+    const auto t0 = std::chrono::steady_clock::now();
+    double gpuWait = 0.0;
+    uint64_t started = 0;
+
+    auto finishGame = [&](DeviceGame& g, uint8_t outcome) {
+        g.initial.wdl = outcome;
+        if (out) {
+            std::fwrite(&g.initial, sizeof(g.initial), 1, out);
+            for (size_t i = 0; i < g.moves.size(); ++i) {
+                std::fwrite(&g.moves[i], 2, 1, out);
+                std::fwrite(&g.scores[i], 2, 1, out);
+            }
+            const uint32_t zero = 0;
+            std::fwrite(&zero, 4, 1, out);
+        }
+        stats->games += 1;
+        stats->positions += g.moves.size();
+        stats->outcomes[outcome] += 1;
+        g.active = false;
+        g.outcome = 255;
+    };
+    auto sync = [&]() -> int {
+        const auto g0 = std::chrono::steady_clock::now();
+        SPX_SP_HIP(hipStreamSynchronize(stream));
+        gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        return SPX_OK;
+    };
+
+    // (re)start games in the idle seats of a half (random openings on the host workers, one RNG stream per game,
+    // NnueState::reset of their accumulators) and enqueue the move generation of the half's next ply
+    auto startAndGenerate = [&](DeviceHalf& hf) -> int {
+        uint32_t n = 0;
+        openingSeeds.clear();
+        retire.clear();
+        for (uint32_t i = hf.begin; i < hf.end; ++i) {
+            DeviceGame& g = games[i];
+            if (g.active) continue;
+            if (started < p->target_games) {
+                ++started;
+                hf.hSeats[n++] = i;
+                openingSeeds.push_back(rng.next());
+                retire.push_back(0);
+            } else if (!g.blank) {  // no successor for this seat: blank its record so that it stops generating children
+                g.blank = true;
+                hf.hSeats[n++] = i;
+                openingSeeds.push_back(0);
+                retire.push_back(1);
+            }
+        }
+        if (n) {
+            pool.run([&](uint32_t t) {
+                for (uint32_t k = t; k < n; k += pool.size()) {
+                    DeviceGame& g = games[hf.hSeats[k]];
+                    if (retire[k]) {
+                        std::memset(&hf.hRecords[k], 0, sizeof(spx_packed_pos));
+                        hf.hRng[k] = 0;
+                        continue;
+                    }
+                    Rng local{openingSeeds[k]};
+                    Game& sc = scratch[t];
+                    startGame(sc, local, p->dfrc != 0, p->opening_plies ? p->opening_plies : 8);
+                    g.initial = sc.initial;
+                    g.moves.clear();
+                    g.scores.clear();
+                    g.history.clear();
+                    g.key = keyOfRecord(g.initial);
+                    g.winPlies = g.lossPlies = g.drawPlies = g.plies = 0;
+                    g.stm = sc.board.stm;
+                    g.active = true;
+                    g.blank = false;
+                    hf.hRecords[k] = g.initial;
+                    hf.hRng[k] = sc.rng.s;
+                }
+            });
+            // accumulators of the new games: full refresh into the seats' home slots (blank records of retired seats
+            // are skipped - they never become parents)
+            std::vector<uint32_t> slots;
+            std::vector<spx_packed_pos> recs;
+            for (uint32_t k = 0; k < n; ++k) {
+                if (!retire[k]) {
+                    slots.push_back(hf.hSeats[k]);
+                    recs.push_back(hf.hRecords[k]);
+                }
+            }
+            int r = sync();  // spx_acc_refresh runs on the context's own stream: order it after this one
+            if (r != SPX_OK) return r;
+            for (size_t lo = 0; lo < slots.size(); lo += ctxMaxBatch(ctx)) {
+                const size_t m = std::min(ctxMaxBatch(ctx), slots.size() - lo);
+                if ((r = spx_acc_refresh(ctx, recs.data() + lo, slots.data() + lo, m)) != SPX_OK) return r;
+            }
+            SPX_SP_HIP(hipMemcpyAsync(hf.dSeats, hf.hSeats, size_t(n) * 4, hipMemcpyHostToDevice, stream));
+            SPX_SP_HIP(hipMemcpyAsync(hf.dRecords, hf.hRecords, size_t(n) * 32, hipMemcpyHostToDevice, stream));
+            SPX_SP_HIP(hipMemcpyAsync(hf.dRngNew, hf.hRng, size_t(n) * 8, hipMemcpyHostToDevice, stream));
+            SPX_SP_HIP(launchSeatGames(n, hf.dSeats, hf.dRecords, hf.dRngNew, dPositions, dSlots, dRng, stream));
+        }
+        const uint32_t seats = hf.end - hf.begin;
+        const int r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren,
+                                         hf.dMoves, hf.dParents, dFirst + hf.begin, dCount + hf.begin,
+                                         dInCheck + hf.begin, hf.cap, hf.dTotal, stream);
+        if (r != SPX_OK) return r;
+        SPX_SP_HIP(hipMemcpyAsync(hf.hTotal, hf.dTotal, 4, hipMemcpyDeviceToHost, stream));
+        return SPX_OK;
+    };
+    // fused update+eval of the half's children, the move choice, and the per-game results on their way back
+    auto evaluateAndPick = [&](DeviceHalf& hf) -> int {
+        const size_t total = *hf.hTotal;
+        if (total > hf.cap) {
+            setError("spx_selfplay_run: " + std::to_string(total) + " children in one ply exceed the buffer of " +
+                     std::to_string(hf.cap));
+            return SPX_ERR_CAPACITY;
+        }
+        const uint32_t* childSlots = hf.dChildSlots + size_t(hf.step & 1) * hf.cap;
+        for (size_t lo = 0; lo < total; lo += ctxMaxBatch(ctx)) {
+            const size_t m = std::min(ctxMaxBatch(ctx), total - lo);
+            const int r = spx_acc_update_eval_device(ctx, hf.dParents + lo, childSlots + lo, hf.dChildren + lo * 4, m,
+                                                     hf.dEvals + lo, stream);
+            if (r != SPX_OK) return r;
+        }
+        PickParams pk{};
+        pk.nGames = hf.end - hf.begin;
+        pk.first = dFirst + hf.begin;
+        pk.count = dCount + hf.begin;
+        pk.inCheck = dInCheck + hf.begin;
+        pk.evals = hf.dEvals;
+        pk.moves = hf.dMoves;
+        pk.children = hf.dChildren;
+        pk.childSlots = childSlots;
+        pk.positions = dPositions + size_t(hf.begin) * 4;
+        pk.slots = dSlots + hf.begin;
+        pk.rng = dRng + hf.begin;
+        pk.results = dResults + hf.begin;
+        pk.temperature = p->temperature_cp;
+        SPX_SP_HIP(launchPick(pk, stream));
+        SPX_SP_HIP(hipMemcpyAsync(hf.hResults, dResults + hf.begin, size_t(pk.nGames) * sizeof(PickResult),
+                                  hipMemcpyDeviceToHost, stream));
+        stats->evals += total;
+        ++hf.step;
+        stats->steps += 1;
+        return SPX_OK;
+    };
+    // host bookkeeping of one ply of a half: records, adjudication (datagen.cpp:224-252), draws
+    auto processResults = [&](DeviceHalf& hf) {
+        pool.run([&](uint32_t t) {
+            const uint32_t seats = hf.end - hf.begin, per = (seats + pool.size() - 1) / pool.size();
+            for (uint32_t s = std::min(seats, t * per); s < std::min(seats, (t + 1) * per); ++s) {
+                DeviceGame& g = games[hf.begin + s];
+                if (!g.active) continue;
+                const PickResult& r = hf.hResults[s];
+                if (r.count == 0) {  // mate / stalemate (datagen.cpp:213-221)
+                    g.outcome = r.inCheck ? (g.stm == 0 ? 2 : 0) : 1;
+                    continue;
+                }
+                const int score = r.score;
+                g.moves.push_back(r.move);
+                g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(score) <= 2 ? 0 : score))));
+                const int whiteScore = g.stm ? score : -score;
+                uint8_t outcome = 255;
+                if (whiteScore > kWinAdjMinScore) {
+                    ++g.winPlies;
+                    g.lossPlies = g.drawPlies = 0;
+                } else if (whiteScore < -kWinAdjMinScore) {
+                    ++g.lossPlies;
+                    g.winPlies = g.drawPlies = 0;
+                } else if (g.plies >= kDrawAdjMinPlies && std::abs(score) < kDrawAdjMaxScore) {
+                    ++g.drawPlies;
+                    g.winPlies = g.lossPlies = 0;
+                } else {
+                    g.winPlies = g.lossPlies = g.drawPlies = 0;
+                }
+                if (g.winPlies >= kWinAdjPlyCount) outcome = 2;
+                else if (g.lossPlies >= kWinAdjPlyCount) outcome = 0;
+                else if (g.drawPlies >= kDrawAdjPlyCount) outcome = 1;
+                g.history.push_back(g.key);
+                g.key = r.key;
+                g.stm ^= 1;
+                ++g.plies;
+                // draws: 50-move rule, threefold repetition, ply cap. A repetition can only reach back as far as the
+                // halfmove clock (irreversible moves cut the history).
+                size_t reps = 0;
+                const size_t window = std::min<size_t>(g.history.size(), r.halfmove);
+                for (size_t k = g.history.size() - window; k < g.history.size(); ++k) reps += g.history[k] == g.key;
+                if (outcome == 255 && (r.halfmove >= 100 || reps >= 2 || g.plies >= p->max_plies)) outcome = 1;
+                g.outcome = outcome;
+            }
+        });
+        for (uint32_t i = hf.begin; i < hf.end; ++i) {
+            DeviceGame& g = games[i];
+            if (g.active && g.outcome != 255) {
+                finishGame(g, g.outcome);
+            }
+        }
+    };
+    auto anyActive = [&]() {
+        for (const DeviceGame& g : games) {
+            if (g.active) return true;
+        }
+        return false;
+    };
+
+    // prologue: every half generated; the first half evaluated
+    for (DeviceHalf& hf : halves) {
+        if ((rc = startAndGenerate(hf)) != SPX_OK) return rc;
+    }
+    if ((rc = sync()) != SPX_OK) return rc;
+    if ((rc = evaluateAndPick(halves[0])) != SPX_OK) return rc;
+    if ((rc = sync()) != SPX_OK) return rc;
+    // steady state: `cur` has its results on the host, the other half has its children generated
+    for (uint32_t cur = 0; anyActive(); cur = (cur + 1) % nHalves) {
+        DeviceHalf& hf = halves[cur];
+        if (nHalves > 1 && (rc = evaluateAndPick(halves[1 - cur])) != SPX_OK) break;  // runs while the host works on `cur`
+        processResults(hf);
+        if ((rc = startAndGenerate(hf)) != SPX_OK) break;
+        if ((rc = sync()) != SPX_OK) break;
+        if (nHalves == 1) {
+            if ((rc = evaluateAndPick(hf)) != SPX_OK || (rc = sync()) != SPX_OK) break;
+        }
+    }
+    stats->steps = (stats->steps + nHalves - 1) / nHalves;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stats->gpu_seconds = gpuWait;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path,
+                                spx_selfplay_stats* stats) {
+    if (!ctx || !p || !stats || p->n_games == 0 || p->target_games == 0 ||
+        (p->flags & ~uint32_t(SPX_SELFPLAY_HOST_MOVEGEN))) {
+        setError("spx_selfplay_run: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    return (p->flags & SPX_SELFPLAY_HOST_MOVEGEN) ? runHostMovegen(ctx, p, out_path, stats)
+                                                  : runDeviceMovegen(ctx, p, out_path, stats);
 }

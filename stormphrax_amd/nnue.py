@@ -199,9 +199,11 @@ class NnueState:
         return out
 
     def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1,
-                 host_threads=0):
-        """Batched depth-1 self-play (config 4 shape); returns the stats dict. See spx_selfplay_run."""
-        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, host_threads, 0, seed)
+                 host_threads=0, host_movegen=False):
+        """Batched depth-1 self-play (config 4 shape); returns the stats dict. See spx_selfplay_run.
+        host_movegen=True generates moves with the host chess core instead of the device kernel."""
+        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, host_threads,
+                                     1 if host_movegen else 0, seed)
         stats = _lib.SelfplayStats()
         check(_lib.load().spx_selfplay_run(self._h, ctypes.byref(params), out_path.encode() if out_path else None,
                                            ctypes.byref(stats)))

@@ -188,15 +188,18 @@ def test_incremental_paths_on_mixed_compact_and_wide_rows(sp, states):
         assert np.array_equal(got, st.evaluate_once(tree[children]))
 
 
-def test_selfplay_driver_records_are_consistent(sp, states, tmp_path):
-    """Config-4 driver in miniature: 96 concurrent games through the fused incremental update+eval path. Every recorded
+@pytest.mark.parametrize("host_movegen", [False, True], ids=["device_movegen", "host_movegen"])
+def test_selfplay_driver_records_are_consistent(sp, states, tmp_path, host_movegen):
+    """Config-4 driver in miniature: 96 concurrent games through the fused incremental update+eval path, with the moves
+    generated on the device (default) or by the host chess core. Every recorded
     score must equal -evaluate_once(position after the move) (the driver's accumulators, maintained incrementally over the
     whole game, agree with a from-scratch evaluation - the reference's own datagen assert, datagen.cpp:262), every move
     must be legal (spx_viri_expand re-validates them) and be the best move within the exploration margin."""
     st = states("tame")
     path = str(tmp_path / "games.vf")
     margin = 25
-    stats = st.selfplay(n_games=96, target_games=160, out_path=path, max_plies=120, dfrc=True, temperature_cp=margin, seed=9)
+    stats = st.selfplay(n_games=96, target_games=160, out_path=path, max_plies=120, dfrc=True, temperature_cp=margin, seed=9,
+                        host_movegen=host_movegen)
     assert stats["games"] == 160 and stats["positions"] > 3000 and sum(stats["outcomes"]) == 160
     blob = open(path, "rb").read()
     positions, games = sp.viri_expand(blob)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--temperature", type=int, default=30)
     ap.add_argument("--dfrc", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--host-movegen", action="store_true", help="generate moves with the host chess core instead of on the GPU")
     ap.add_argument("--preset", default="tame")
     ap.add_argument("--net")
     ap.add_argument("--out")
@@ -35,7 +36,8 @@ def main():
     state = sp.NnueState(net, device=group.local_rank, max_batch=args.games * 64)
     out = f"{args.out}.{group.rank}.vf" if args.out else None
     stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
-                           temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads)
+                           temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads,
+                           host_movegen=args.host_movegen)
     slowest = group.max_float(stats["seconds"])
     total = {k: group.sum_int(stats[k]) for k in ("games", "positions", "evals", "steps")}
     gpu_seconds = group.max_float(stats["gpu_seconds"])
@@ -46,6 +48,7 @@ def main():
             "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
             "outcomes_white_loss_draw_win": stats["outcomes"], "host_threads": args.threads or "auto: min(16, usable CPUs)",
+            "move_generation": "host chess core" if args.host_movegen else "device (spx_movegen_kernel)",
             "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
         }))
     group.close()
