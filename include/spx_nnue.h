@@ -249,7 +249,7 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),
  * i.e. a depth-1 "search" - Stormphrax's alpha-beta search is out of scope), random 8-9 ply openings, the reference's
  * adjudication counters, viriformat game records appended to out_path (NULL = discard). Needs spx_ctx with
- * max_batch >= 1; reserves n_games * 129 arena slots. Scores are raw network outputs from the mover's point of view.
+ * max_batch >= 1; reserves n_games * 193 arena slots (129 with host move generation). Scores are raw network outputs from the mover's point of view.
  * Multi-GPU: games are independent - run one process per GPU with its own seed / slice of games.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_selfplay_params {
@@ -259,7 +259,8 @@ typedef struct spx_selfplay_params {
     uint32_t opening_plies;  /* random opening plies before play starts (0 = 8, plus a coin flip as datagen.cpp:153) */
     uint32_t dfrc;           /* 1 = double-Chess960 starts */
     int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
-    uint32_t host_threads;   /* host worker threads (0 = min(16, usable CPUs incl. cgroup quota): phases are short, more only adds hand-off cost) */
+    uint32_t host_threads;   /* host worker threads; 0 = auto: min(4 with device move generation, 16 with host move generation; usable CPUs
+                              * = cgroup quota / LOCAL_WORLD_SIZE). Phases are short: more threads only add hand-off cost */
     uint32_t flags;          /* 0 = moves generated on the device; SPX_SELFPLAY_HOST_MOVEGEN = host chess core instead */
     uint64_t seed;
 } spx_selfplay_params;

@@ -81,6 +81,11 @@ uint32_t usableCpus() {
         }
         std::fclose(f);
     }
+    // one process per GPU (torch.distributed.run exports LOCAL_WORLD_SIZE): the ranks of a node share the CPUs
+    if (const char* env = std::getenv("LOCAL_WORLD_SIZE")) {
+        const long ranks = std::atol(env);
+        if (ranks > 1) n = std::max(1u, n / uint32_t(ranks));
+    }
     return n;
 }
 
@@ -676,7 +681,8 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
 
     Rng rng{p->seed};
     std::vector<DeviceGame> games(G);
-    Pool pool(std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(16u, usableCpus()), G)));
+    // the host only keeps records and adjudication counters here: a few workers are plenty
+    Pool pool(std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(4u, usableCpus()), G)));
     std::vector<Game> scratch(pool.size());  // random openings reuse the host path's generator, one per worker
     std::vector<uint64_t> openingSeeds;
     std::vector<uint8_t> retire;

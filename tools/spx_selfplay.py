@@ -47,7 +47,7 @@ def main():
             "n_gpus": group.world, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
             "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
-            "outcomes_white_loss_draw_win": stats["outcomes"], "host_threads": args.threads or "auto: min(16, usable CPUs)",
+            "outcomes_white_loss_draw_win": stats["outcomes"], "host_threads": args.threads or "auto",
             "move_generation": "host chess core" if args.host_movegen else "device (spx_movegen_kernel)",
             "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
         }))
