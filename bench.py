@@ -57,7 +57,14 @@ def usable_cpus():
 def cpu_baseline(sp, positions, blob, seconds):
     """Reference CPU path on a bounded sample of the batch (baseline only, never the target)."""
     sample = positions[:4096]
-    probe = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame")
+    probe, flavour = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame"), "AVX2-BMI2 build"
+    try:  # the reference's fastest flavour (build.mk:36 "avx512": VNNI + VBMI2) when this host can run it
+        flags = set(next(ln for ln in open("/proc/cpuinfo") if ln.startswith("flags")).split())
+        fast = probe + "_avx512"
+        if {"avx512f", "avx512bw", "avx512vl", "avx512_vnni", "avx512_vbmi2", "avx512vbmi"} <= flags and os.path.exists(fast):
+            probe, flavour = fast, "AVX-512 VNNI/VBMI2 build"
+    except (OSError, StopIteration):
+        pass
     cores = usable_cpus()
     if os.path.exists(probe):
         try:
@@ -67,7 +74,7 @@ def cpu_baseline(sp, positions, blob, seconds):
             line = [ln for ln in out.splitlines() if ln.startswith("B ")][0].split()
             return {
                 "value": float(line[1]), "unit": "evals/s", "cores": cores, "kind": "reference",
-                "sample": f"compiled Stormphrax 8.0.2 (AVX2 build) NnueState::evaluateOnce looped over the first "
+                "sample": f"compiled Stormphrax 8.0.2 ({flavour}) NnueState::evaluateOnce looped over the first "
                           f"{len(sample)} positions of the batch for {seconds:.0f} s on {cores} threads "
                           f"(= usable CPUs: {os.cpu_count()} logical, capped by affinity / cgroup quota)",
             }
@@ -330,7 +337,7 @@ def main():
                                   "2 KiB i16 rows (bit-identical sums); `achieved` stays in algorithmic bytes",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(sp, positions, blob, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     group.close()

@@ -885,6 +885,7 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         return false;
     };
 
+    double phase[3] = {0, 0, 0};  // enqueue, bookkeeping, (re)starts + move generation enqueue
     // prologue: every half generated; the first half evaluated
     for (DeviceHalf& hf : halves) {
         if ((rc = startAndGenerate(hf)) != SPX_OK) return rc;
@@ -895,9 +896,16 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     // steady state: `cur` has its results on the host, the other half has its children generated
     for (uint32_t cur = 0; anyActive(); cur = (cur + 1) % nHalves) {
         DeviceHalf& hf = halves[cur];
+        const auto a0 = std::chrono::steady_clock::now();
         if (nHalves > 1 && (rc = evaluateAndPick(halves[1 - cur])) != SPX_OK) break;  // runs while the host works on `cur`
+        const auto a1 = std::chrono::steady_clock::now();
         processResults(hf);
+        const auto a2 = std::chrono::steady_clock::now();
         if ((rc = startAndGenerate(hf)) != SPX_OK) break;
+        const auto a3 = std::chrono::steady_clock::now();
+        phase[0] += std::chrono::duration<double>(a1 - a0).count();
+        phase[1] += std::chrono::duration<double>(a2 - a1).count();
+        phase[2] += std::chrono::duration<double>(a3 - a2).count();
         if ((rc = sync()) != SPX_OK) break;
         if (nHalves == 1) {
             if ((rc = evaluateAndPick(hf)) != SPX_OK || (rc = sync()) != SPX_OK) break;
@@ -906,6 +914,10 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     stats->steps = (stats->steps + nHalves - 1) / nHalves;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
+    if (std::getenv("SPX_SELFPLAY_TRACE")) {
+        std::fprintf(stderr, "[spx_selfplay] %.3f s: gpu wait %.3f (of which inside start/refresh sync), enqueue %.3f, bookkeeping %.3f, "
+                     "starts+movegen enqueue %.3f\n", stats->seconds, gpuWait, phase[0], phase[1], phase[2]);
+    }
     return rc;
 }
 
