@@ -182,3 +182,40 @@ def test_adjust_on_device_matches_reference_and_oracle(sp, oracle, net_blob, sta
             for i in range(len(pos))]
     assert np.array_equal(got, np.array(want, dtype=np.int32))
     assert st.adjust(pos[:0], raw[:0]).shape == (0,)
+
+
+def test_contexts_are_reentrant_across_threads(sp, oracle, net_blob):
+    """Lazy-SMP analogue (one NnueState per search thread, shared read-only Network - src/thread.h:147): contexts created
+    from one net are used concurrently from different host threads (ctypes releases the GIL) without interfering."""
+    import threading
+
+    net = sp.Network(net_blob("wild"))
+    batches = [sp.random_positions(3000 + 500 * t, seed=900 + t, min_ply=0, max_ply=150, dfrc_every=3) for t in range(4)]
+    oracle.use(net_blob("wild"), "wild")
+    wants = [oracle.eval_mailboxes(*sp.positions_to_mailboxes(b)) for b in batches]
+    errors = []
+
+    def worker(t):
+        try:
+            st = sp.NnueState(net, device=0, max_batch=8192)
+            st.reserve_slots(len(batches[t]))
+            for rep in range(25):
+                got = st.evaluate_once(batches[t])
+                if not np.array_equal(got, wants[t]):
+                    errors.append((t, rep, "full"))
+                    break
+                slots = np.arange(len(batches[t]), dtype=np.uint32)
+                st.reset(batches[t], slots)
+                if not np.array_equal(st.evaluate(slots), wants[t]):
+                    errors.append((t, rep, "arena"))
+                    break
+            st.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
