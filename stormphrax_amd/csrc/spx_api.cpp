@@ -71,6 +71,8 @@ struct spx_ctx {
     int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
                                    // the other one for its successor), [2] belongs to the single-launch small sort
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
+    size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
+    size_t updateSplitMax = 0;     // spx_update_kernel: records up to which the perspectives get separate waves
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
@@ -341,6 +343,13 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
+    // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
+    // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
+    // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
+    ctx->updateSplitMax = 262144;
+    ctx->mlpShareMax = 8192;
+    if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX")) ctx->updateSplitMax = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -408,7 +417,7 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
     mp.l3W = ctx->dL3W;
     mp.l3B = ctx->dL3B;
     mp.out = static_cast<int32_t*>(d_out);
-    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, s));
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, n <= ctx->mlpShareMax, s));
     return SPX_OK;
 }
 
@@ -526,7 +535,10 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
     up.t = tablesOf(ctx);
     up.arena = ctx->dArena;
     up.slotRecords = ctx->dSlotRecords;
-    SPX_HIP(launchUpdate(up, ftGrid(ctx, n), s));
+    {
+        const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
+        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
+    }
     return SPX_OK;
 }
 
@@ -545,7 +557,10 @@ int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const v
     up.slotRecords = ctx->dSlotRecords;
     up.ftOut = ctx->dFtOut;          // activations of the children straight from the update kernel's registers
     up.stagedRecords = ctx->dStaged;
-    SPX_HIP(launchUpdate(up, ftGrid(ctx, n), s));
+    {
+        const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
+        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
+    }
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);

@@ -500,6 +500,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // (the invariant Stormphrax asserts itself, datagen.cpp:262). A perspective whose king changed piece-square bucket or
 // crossed the d/e mirror line (psq.h:264-283, nnue_state.h:118-128) is rebuilt from scratch, as the reference does.
 // ---------------------------------------------------------------------------------------------------------------------
+// kSplit = false: one wavefront per record does both perspectives (board decoding and attack generation shared);
+// kSplit = true: one wavefront per (record, perspective) - twice the waves, half the serial latency - for batches too
+// small to fill the chip (the kernel is latency-bound there: 4 096 records = 36 us unsplit).
+template <bool kSplit>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
@@ -516,7 +520,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
 
-    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < p.nRecords; it += wavesTotal) {
+    const uint32_t nItems = kSplit ? p.nRecords * 2 : p.nRecords;
+    for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < nItems; item += wavesTotal) {
+        const uint32_t it = kSplit ? item >> 1 : item;
+        const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
         const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
         const uint64_t subTargets = tP & ~keep, addTargets = tC & ~keep;
 
 #pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
+        for (int c = cFirst; c < cLast; ++c) {
             const uint64_t kingMaskP = __ballot(pb.piece == (10 | c)), kingMaskC = __ballot(cb.piece == (10 | c));
             const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
             const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(Upda
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
             }
         }
-        if (lane < 8) {
+        if (lane < 8 && cFirst == 0) {
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
             reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
             if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
@@ -947,14 +954,17 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 // kSmallL2W: every |l2W| < 2^23 (checked on the host at context creation), so with the L2 inputs always inside
 //   (-2^20, 2^12] the product is one full-rate v_mad_i32_i24; otherwise the exact-but-slow v_mul_lo_u32 path runs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool kSmallL2W>
+// kShareTile = false: one wavefront per 16-position tile; true: the four waves of a workgroup share ONE tile (each
+// repeats the cheap MFMA part and takes every fourth position of the serial tail) - for batches too small to fill
+// the chip, where the kernel is bound by the latency of a single tile (4 096 positions: 16 us unshared).
+template <bool kSmallL2W, bool kShareTile>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
     __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
     __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x * 4 + wave;
+    const uint32_t tile = kShareTile ? blockIdx.x : blockIdx.x * 4 + wave;
 
     // ---- locate this tile: bucket, first sorted index, number of real positions ----
     uint32_t bucket = 0, sortedBase = 0, count = 0;
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     }
     __builtin_amdgcn_wave_barrier();
 
-    for (uint32_t r = 0; r < count; ++r) {
+    for (uint32_t r = kShareTile ? wave : 0u; r < count; r += kShareTile ? 4u : 1u) {
         const int32_t s = sSum[wave][r][o1];
         const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
         const int32_t ts = int32_t(t);
@@ -1071,8 +1081,12 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) 
     return hipGetLastError();
 }
 
-hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_update_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, hipStream_t stream) {
+    if (splitPerspectives) {
+        hipLaunchKernelGGL(spx_update_kernel<true>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(spx_update_kernel<false>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
@@ -1091,13 +1105,19 @@ hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, hipStream_t stream) {
+hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, bool shareTiles, hipStream_t stream) {
     const uint32_t tiles = (p.nPositions + 15) / 16 + kOutputBuckets;  // worst case: every bucket ends in a partial tile
-    const uint32_t blocks = (tiles + 3) / 4;
+    const uint32_t blocks = shareTiles ? tiles : (tiles + 3) / 4;
     if (smallL2Weights) {
-        hipLaunchKernelGGL(spx_mlp_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+        if (shareTiles) {
+            hipLaunchKernelGGL((spx_mlp_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((spx_mlp_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, p);
+        }
+    } else if (shareTiles) {
+        hipLaunchKernelGGL((spx_mlp_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL(spx_mlp_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((spx_mlp_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }
