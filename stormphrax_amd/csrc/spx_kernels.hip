@@ -33,6 +33,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_FT_WAVES_PER_SIMD
 #define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
+#ifndef SPX_UPDATE_SPLIT_WAVES
+#define SPX_UPDATE_SPLIT_WAVES 4
+#endif
 #ifndef SPX_MLP_WAVES_PER_SIMD
 #define SPX_MLP_WAVES_PER_SIMD 3
 #endif
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // kSplit = true: one wavefront per (record, perspective) - twice the waves, half the serial latency - for batches too
 // small to fill the chip (the kernel is latency-bound there: 4 096 records = 36 us unsplit).
 template <bool kSplit>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
