@@ -23,7 +23,9 @@ class Trace:
         self.moves = [None]
         self.evals = []             # (node, incremental value, evaluateOnce value) as recorded by the reference
         stack = [0]
-        with open(path) as f:
+        import gzip
+
+        with (gzip.open(path, "rt") if str(path).endswith(".gz") else open(path)) as f:
             for line in f:
                 t = line.split()
                 if not t or t[0].startswith("#"):

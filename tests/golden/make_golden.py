@@ -16,6 +16,8 @@ reference itself computes:
   adjust.jsonl    {"fen", "preset", "contempt", "optimism", "static", "adjusted"}: eval::staticEvalOnce(pos, contempt) and
                   eval::adjustEval<false>(pos, optimism, {}, nullptr, static) (src/eval/eval.cpp:24-67,109-112);
                   regenerate alone with `make_golden.py adjust`
+  trace_startpos_tame_64k.txt.gz   the same kind of stream at BASELINE config-3 scale (65 536 EVALs, depth cap 12);
+                  regenerate alone with `make_golden.py bigtrace`
   trace_*.txt     PUSH/POP/EVAL opcode streams of a make/unmake walk driven through NnueState::push/evaluate
                   (the lazily-updated incremental path), with the reference's evaluate() at every EVAL
 
@@ -85,9 +87,24 @@ def make_adjust():
     print("adjust.jsonl written:", 2 * len(fens) * len(settings), "records")
 
 
+def make_big_trace():
+    """BASELINE config 3 scale: a 65 536-EVAL make/unmake walk from the start position (depth cap 12), gzip'd."""
+    import gzip
+
+    probe = Probe(PROBES["tame"])
+    out = probe.cmd(f"trace 11 65536 12 {STARTPOS}")
+    probe.close()
+    with gzip.open(os.path.join(HERE, "trace_startpos_tame_64k.txt.gz"), "wt", compresslevel=9) as f:
+        f.write("# preset tame; produced by oracle/ref_probe.cpp `trace 11 65536 12`\n")
+        f.write("\n".join(out) + "\n")
+    print("big trace written:", sum(1 for ln in out if ln.startswith("EVAL")), "evals")
+
+
 def main():
     if sys.argv[1:] == ["adjust"]:
         return make_adjust()
+    if sys.argv[1:] == ["bigtrace"]:
+        return make_big_trace()
     probes = {k: Probe(v) for k, v in PROBES.items()}
     fens = [(STARTPOS, "startpos")]
     fens += [(f.strip(), "bench") for f in open(os.path.join(HERE, "bench_fens.txt")) if f.strip()]
@@ -150,6 +167,7 @@ def main():
         p.close()
     print("golden vectors written:", len(fens), "positions")
     make_adjust()
+    make_big_trace()
 
 
 if __name__ == "__main__":

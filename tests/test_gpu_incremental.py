@@ -12,7 +12,9 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def preset_of(path):
-    with open(path) as f:
+    import gzip
+
+    with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as f:
         return f.readline().split()[2].rstrip(";")
 
 
@@ -30,8 +32,10 @@ def states(sp, net_blob):
         s.close()
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "trace_*.txt"))), ids=os.path.basename)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "trace_*.txt")) +
+                                        glob.glob(os.path.join(GOLDEN, "trace_*.txt.gz"))), ids=os.path.basename)
 def test_trace_replay_matches_reference(sp, states, path):
+    """Includes the BASELINE config-3 scale trace: 65 536 EVALs of a depth-12 make/unmake walk from the start position."""
     from stormphrax_amd.trace import Trace, replay
 
     trace = Trace(path)
