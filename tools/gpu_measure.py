@@ -100,4 +100,19 @@ full = torch.empty(G, dtype=torch.int32, device="cuda")
 state.evaluate_once_device(d_boards[PLIES].data_ptr(), G, full.data_ptr(), stream)
 torch.cuda.synchronize()
 out["incremental_equals_full_refresh"] = bool(torch.equal(full, d_out))
+# 4) BASELINE config 3: the recorded 65 536-EVAL reference trace, replayed level by level through the arena
+#    (host-buffer entry points; every EVAL is checked against the value the reference recorded)
+from stormphrax_amd.trace import replay  # noqa: E402
+
+trace = Trace(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                           "trace_startpos_tame_64k.txt.gz"))
+tpos = trace.positions()
+replay(state, trace, tpos)
+t0 = time.perf_counter()
+for _ in range(5):
+    got, ref_inc, _ref_once = replay(state, trace, tpos)
+dt = (time.perf_counter() - t0) / 5
+out["trace_64k_replay_ms"] = dt * 1e3
+out["trace_64k_updates_plus_evals_per_s"] = (trace.n_nodes - 1 + len(trace.evals)) / dt
+out["trace_64k_matches_reference"] = bool(np.array_equal(got, ref_inc))
 print(json.dumps(out))
