@@ -154,6 +154,13 @@ int spx_adjust(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const sp
 int spx_adjust_device(spx_ctx* ctx, const void* d_positions, size_t n, const spx_adjust_params* params,
                       const void* d_corrections, void* d_evals, void* stream);
 
+/* As spx_acc_update_eval_device, but the number of records is read on the DEVICE from *d_count (u32, at most `capacity`;
+ * `capacity` sizes the launches and must fit the context): a producer kernel - spx_movegen_device's d_total - feeds the
+ * update without a host round trip. Records beyond *d_count are not touched. */
+int spx_acc_update_eval_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                       const void* d_child_positions, const void* d_count, size_t capacity, void* d_out,
+                                       void* stream);
+
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
  * sort kernels, the feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */

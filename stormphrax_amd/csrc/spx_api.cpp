@@ -384,14 +384,16 @@ void spx_ctx_destroy(spx_ctx* ctx) {
 }
 
 // sort (both keys) on `d_records`, then the MLP over ctx->dFtOut[0..n) -> d_out
-static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp) {
+static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp,
+                         const uint32_t* d_count = nullptr) {
     if (!mlp) {
         SortParams sp{};
         sp.positions = static_cast<const uint64_t*>(d_records);
         sp.nPositions = uint32_t(n);
+        sp.nPositionsPtr = d_count;
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
-        if (n <= 1024) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
+        if (n <= 1024 && !d_count) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
             sp.hist = ctx->dHist + 128;
             sp.histNext = sp.hist;
         } else {
@@ -417,7 +419,7 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
     mp.l3W = ctx->dL3W;
     mp.l3B = ctx->dL3B;
     mp.out = static_cast<int32_t*>(d_out);
-    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, n <= ctx->mlpShareMax, s));
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, n <= ctx->mlpShareMax && !d_count, s));
     return SPX_OK;
 }
 
@@ -542,13 +544,36 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
     return SPX_OK;
 }
 
+static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                            const void* d_child_positions, size_t n, const uint32_t* d_count, void* d_out, void* stream,
+                            const char* who);
+
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream) {
-    int rc = checkAcc(ctx, n, "spx_acc_update_eval_device");
+    return updateEvalDevice(ctx, d_parent_slots, d_child_slots, d_child_positions, n, nullptr, d_out, stream,
+                            "spx_acc_update_eval_device");
+}
+
+int spx_acc_update_eval_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                       const void* d_child_positions, const void* d_count, size_t capacity, void* d_out,
+                                       void* stream) {
+    if (!d_count) {
+        setError("spx_acc_update_eval_device_counted: null count");
+        return SPX_ERR_INVALID_ARG;
+    }
+    return updateEvalDevice(ctx, d_parent_slots, d_child_slots, d_child_positions, capacity,
+                            static_cast<const uint32_t*>(d_count), d_out, stream, "spx_acc_update_eval_device_counted");
+}
+
+static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                            const void* d_child_positions, size_t n, const uint32_t* d_count, void* d_out, void* stream,
+                            const char* who) {
+    int rc = checkAcc(ctx, n, who);
     if (rc != SPX_OK || n == 0) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     UpdateParams up{};
     up.nRecords = uint32_t(n);
+    up.nRecordsPtr = d_count;
     up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
     up.childSlots = static_cast<const uint32_t*>(d_child_slots);
     up.childPositions = d_child_positions;
@@ -561,9 +586,9 @@ int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const v
         const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
         SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
     }
-    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);
     if (rc != SPX_OK) return rc;
-    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
+    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true, d_count);
 }
 
 static_assert(sizeof(spx_move_delta) == 1080, "spx_update_observed_kernel hard-codes the spx_move_delta layout");

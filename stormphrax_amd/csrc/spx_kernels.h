@@ -31,6 +31,8 @@ struct FtParams {
 
 struct UpdateParams {
     uint32_t nRecords;
+    const uint32_t* nRecordsPtr;   // optional: the actual record count lives on the device (<= nRecords, which then
+                                   // only sizes the grid) - lets a producer kernel feed this one without a host sync
     const uint32_t* parentSlots;   // [nRecords] materialised slots
     const uint32_t* childSlots;    // [nRecords] slots to write (distinct from every parent of this batch)
     const void* childPositions;    // spx_packed_pos[nRecords]: the boards after the move
@@ -107,6 +109,7 @@ struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)
 struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
+    const uint32_t* nPositionsPtr;  // optional device-resident count (<= nPositions), as in UpdateParams
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
     uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)

@@ -523,7 +523,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
 
-    const uint32_t nItems = kSplit ? p.nRecords * 2 : p.nRecords;
+    const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
+    const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
     for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < nItems; item += wavesTotal) {
         const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
@@ -821,7 +822,8 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
     if (threadIdx.x < kKingKeys + kOutKeys) sHist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos < p.nPositions) {
+    const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
+    if (pos < nPositions) {
         const uint64_t* rec = p.positions + size_t(pos) * 4;
         uint64_t occ = rec[0];
         const uint64_t nibLo = rec[1], nibHi = rec[2];
@@ -856,7 +858,8 @@ __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uin
     __syncthreads();
     const bool persp = blockIdx.x < perspBlocks;
     const uint32_t id = (persp ? blockIdx.x : blockIdx.x - perspBlocks) * blockDim.x + threadIdx.x;
-    const uint32_t count = persp ? p.nPositions * 2 : p.nPositions;
+    const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
+    const uint32_t count = persp ? nPositions * 2 : nPositions;
     const uint32_t nKeys = persp ? kKingKeys : kOutKeys;
     const uint32_t histOff = persp ? 0 : kHistOut, cursorOff = persp ? kCursorKing : kCursorOut;
     uint32_t key = 0, rank = 0;
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(1024) void spx_sort_small_kernel(SortParams p) {
 // p.hist must be all-zero on entry of the multi-launch path; its scatter kernel clears p.histNext (the buffer the NEXT
 // large sort will use), so no memset launch is ever needed (spx_api alternates two buffers; small sorts use a third).
 hipError_t launchSort(const SortParams& p, hipStream_t stream) {
-    if (p.nPositions <= kSmallSortMax) {
+    if (p.nPositions <= kSmallSortMax && !p.nPositionsPtr) {
         hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
         return hipGetLastError();
     }

@@ -593,6 +593,8 @@ struct DeviceHalf {
     uint32_t* dSeats = nullptr;
     uint64_t* dRecords = nullptr;
     uint64_t* dRngNew = nullptr;
+    hipEvent_t done = nullptr;       // recorded after the ply's results are on their way to the host
+    bool inFlight = false;
 };
 
 int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
@@ -672,7 +674,16 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
             (void)hipStreamDestroy(s);
         }
     } streamCloser{stream};
+    struct EventCloser {
+        std::vector<DeviceHalf>& hs;
+        ~EventCloser() {
+            for (DeviceHalf& hf : hs) {
+                if (hf.done) (void)hipEventDestroy(hf.done);
+            }
+        }
+    } eventCloser{halves};
     for (DeviceHalf& hf : halves) {
+        SPX_SP_HIP(hipEventCreateWithFlags(&hf.done, hipEventDisableTiming));
         std::vector<uint32_t> iota(2 * hf.cap);
         for (size_t k = 0; k < iota.size(); ++k) iota[k] = uint32_t(hf.slotBase + k);
         SPX_SP_HIP(hipMemcpy(hf.dChildSlots, iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
@@ -714,9 +725,15 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         return SPX_OK;
     };
 
-    // (re)start games in the idle seats of a half (random openings on the host workers, one RNG stream per game,
-    // NnueState::reset of their accumulators) and enqueue the move generation of the half's next ply
-    auto startAndGenerate = [&](DeviceHalf& hf) -> int {
+    // With the whole ply's children fitting the context's batch capacity the chain below needs no host round trip: the
+    // update reads its record count on the device (spx_acc_update_eval_device_counted). Otherwise the count is fetched
+    // and the update is issued in chunks.
+    const bool counted = halves[0].cap <= ctxMaxBatch(ctx) && halves[nHalves - 1].cap <= ctxMaxBatch(ctx);
+
+    // One ply of a half, enqueued back to back: (re)start games in its idle seats (random openings on the host workers,
+    // one RNG stream per game; NnueState::reset of their accumulators), move generation, fused update+eval of the
+    // children, move choice, and the per-game results on their way back. Ends with the half's event.
+    auto enqueuePly = [&](DeviceHalf& hf) -> int {
         uint32_t n = 0;
         openingSeeds.clear();
         retire.clear();
@@ -760,52 +777,41 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
                     hf.hRng[k] = sc.rng.s;
                 }
             });
-            // accumulators of the new games: full refresh into the seats' home slots (blank records of retired seats
-            // are skipped - they never become parents)
-            std::vector<uint32_t> slots;
-            std::vector<spx_packed_pos> recs;
-            for (uint32_t k = 0; k < n; ++k) {
-                if (!retire[k]) {
-                    slots.push_back(hf.hSeats[k]);
-                    recs.push_back(hf.hRecords[k]);
-                }
-            }
-            int r = sync();  // spx_acc_refresh runs on the context's own stream: order it after this one
-            if (r != SPX_OK) return r;
-            for (size_t lo = 0; lo < slots.size(); lo += ctxMaxBatch(ctx)) {
-                const size_t m = std::min(ctxMaxBatch(ctx), slots.size() - lo);
-                if ((r = spx_acc_refresh(ctx, recs.data() + lo, slots.data() + lo, m)) != SPX_OK) return r;
-            }
             SPX_SP_HIP(hipMemcpyAsync(hf.dSeats, hf.hSeats, size_t(n) * 4, hipMemcpyHostToDevice, stream));
             SPX_SP_HIP(hipMemcpyAsync(hf.dRecords, hf.hRecords, size_t(n) * 32, hipMemcpyHostToDevice, stream));
             SPX_SP_HIP(hipMemcpyAsync(hf.dRngNew, hf.hRng, size_t(n) * 8, hipMemcpyHostToDevice, stream));
             SPX_SP_HIP(launchSeatGames(n, hf.dSeats, hf.dRecords, hf.dRngNew, dPositions, dSlots, dRng, stream));
+            // accumulators of the new games: full refresh into the seats' home slots (a blanked seat gets the
+            // accumulator of the empty board - never used)
+            for (size_t lo = 0; lo < n; lo += ctxMaxBatch(ctx)) {
+                const size_t m = std::min<size_t>(ctxMaxBatch(ctx), n - lo);
+                const int r = spx_acc_refresh_device(ctx, hf.dRecords + lo * 4, hf.dSeats + lo, m, stream);
+                if (r != SPX_OK) return r;
+            }
         }
         const uint32_t seats = hf.end - hf.begin;
-        const int r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren,
-                                         hf.dMoves, hf.dParents, dFirst + hf.begin, dCount + hf.begin,
-                                         dInCheck + hf.begin, hf.cap, hf.dTotal, stream);
+        int r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren,
+                                   hf.dMoves, hf.dParents, dFirst + hf.begin, dCount + hf.begin, dInCheck + hf.begin,
+                                   hf.cap, hf.dTotal, stream);
         if (r != SPX_OK) return r;
         SPX_SP_HIP(hipMemcpyAsync(hf.hTotal, hf.dTotal, 4, hipMemcpyDeviceToHost, stream));
-        return SPX_OK;
-    };
-    // fused update+eval of the half's children, the move choice, and the per-game results on their way back
-    auto evaluateAndPick = [&](DeviceHalf& hf) -> int {
-        const size_t total = *hf.hTotal;
-        if (total > hf.cap) {
-            setError("spx_selfplay_run: " + std::to_string(total) + " children in one ply exceed the buffer of " +
-                     std::to_string(hf.cap));
-            return SPX_ERR_CAPACITY;
-        }
         const uint32_t* childSlots = hf.dChildSlots + size_t(hf.step & 1) * hf.cap;
-        for (size_t lo = 0; lo < total; lo += ctxMaxBatch(ctx)) {
-            const size_t m = std::min(ctxMaxBatch(ctx), total - lo);
-            const int r = spx_acc_update_eval_device(ctx, hf.dParents + lo, childSlots + lo, hf.dChildren + lo * 4, m,
-                                                     hf.dEvals + lo, stream);
+        if (counted) {
+            r = spx_acc_update_eval_device_counted(ctx, hf.dParents, childSlots, hf.dChildren, hf.dTotal, hf.cap,
+                                                   hf.dEvals, stream);
             if (r != SPX_OK) return r;
+        } else {
+            if ((r = sync()) != SPX_OK) return r;
+            const size_t total = std::min<size_t>(*hf.hTotal, hf.cap);
+            for (size_t lo = 0; lo < total; lo += ctxMaxBatch(ctx)) {
+                const size_t m = std::min(ctxMaxBatch(ctx), total - lo);
+                r = spx_acc_update_eval_device(ctx, hf.dParents + lo, childSlots + lo, hf.dChildren + lo * 4, m,
+                                               hf.dEvals + lo, stream);
+                if (r != SPX_OK) return r;
+            }
         }
         PickParams pk{};
-        pk.nGames = hf.end - hf.begin;
+        pk.nGames = seats;
         pk.first = dFirst + hf.begin;
         pk.count = dCount + hf.begin;
         pk.inCheck = dInCheck + hf.begin;
@@ -819,11 +825,27 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         pk.results = dResults + hf.begin;
         pk.temperature = p->temperature_cp;
         SPX_SP_HIP(launchPick(pk, stream));
-        SPX_SP_HIP(hipMemcpyAsync(hf.hResults, dResults + hf.begin, size_t(pk.nGames) * sizeof(PickResult),
+        SPX_SP_HIP(hipMemcpyAsync(hf.hResults, dResults + hf.begin, size_t(seats) * sizeof(PickResult),
                                   hipMemcpyDeviceToHost, stream));
-        stats->evals += total;
+        SPX_SP_HIP(hipEventRecord(hf.done, stream));
+        hf.inFlight = true;
         ++hf.step;
         stats->steps += 1;
+        return SPX_OK;
+    };
+    // wait for a half's ply; its child count must have fitted the buffers
+    auto awaitPly = [&](DeviceHalf& hf) -> int {
+        const auto g0 = std::chrono::steady_clock::now();
+        SPX_SP_HIP(hipEventSynchronize(hf.done));
+        gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        hf.inFlight = false;
+        const size_t total = *hf.hTotal;
+        if (total > hf.cap) {
+            setError("spx_selfplay_run: " + std::to_string(total) + " children in one ply exceed the buffer of " +
+                     std::to_string(hf.cap));
+            return SPX_ERR_CAPACITY;
+        }
+        stats->evals += total;
         return SPX_OK;
     };
     // host bookkeeping of one ply of a half: records, adjudication (datagen.cpp:224-252), draws
@@ -873,50 +895,45 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         });
         for (uint32_t i = hf.begin; i < hf.end; ++i) {
             DeviceGame& g = games[i];
-            if (g.active && g.outcome != 255) {
-                finishGame(g, g.outcome);
-            }
+            if (g.active && g.outcome != 255) finishGame(g, g.outcome);
         }
     };
-    auto anyActive = [&]() {
-        for (const DeviceGame& g : games) {
-            if (g.active) return true;
+    auto halfHasWork = [&](const DeviceHalf& hf) {
+        for (uint32_t i = hf.begin; i < hf.end; ++i) {
+            if (games[i].active || !games[i].blank) return true;
         }
-        return false;
+        return started < p->target_games;
     };
 
-    double phase[3] = {0, 0, 0};  // enqueue, bookkeeping, (re)starts + move generation enqueue
-    // prologue: every half generated; the first half evaluated
+    // both halves are kept in flight: while the host does the bookkeeping of one, the GPU works on the other
+    double phase[2] = {0, 0};  // bookkeeping, starts + enqueue
     for (DeviceHalf& hf : halves) {
-        if ((rc = startAndGenerate(hf)) != SPX_OK) return rc;
+        if ((rc = enqueuePly(hf)) != SPX_OK) break;
     }
-    if ((rc = sync()) != SPX_OK) return rc;
-    if ((rc = evaluateAndPick(halves[0])) != SPX_OK) return rc;
-    if ((rc = sync()) != SPX_OK) return rc;
-    // steady state: `cur` has its results on the host, the other half has its children generated
-    for (uint32_t cur = 0; anyActive(); cur = (cur + 1) % nHalves) {
+    for (uint32_t cur = 0; rc == SPX_OK; cur = (cur + 1) % nHalves) {
         DeviceHalf& hf = halves[cur];
+        if (!hf.inFlight) {
+            bool any = false;
+            for (const DeviceHalf& other : halves) any = any || other.inFlight;
+            if (!any) break;
+            continue;
+        }
+        if ((rc = awaitPly(hf)) != SPX_OK) break;
         const auto a0 = std::chrono::steady_clock::now();
-        if (nHalves > 1 && (rc = evaluateAndPick(halves[1 - cur])) != SPX_OK) break;  // runs while the host works on `cur`
-        const auto a1 = std::chrono::steady_clock::now();
         processResults(hf);
+        const auto a1 = std::chrono::steady_clock::now();
+        if (halfHasWork(hf)) rc = enqueuePly(hf);
         const auto a2 = std::chrono::steady_clock::now();
-        if ((rc = startAndGenerate(hf)) != SPX_OK) break;
-        const auto a3 = std::chrono::steady_clock::now();
         phase[0] += std::chrono::duration<double>(a1 - a0).count();
         phase[1] += std::chrono::duration<double>(a2 - a1).count();
-        phase[2] += std::chrono::duration<double>(a3 - a2).count();
-        if ((rc = sync()) != SPX_OK) break;
-        if (nHalves == 1) {
-            if ((rc = evaluateAndPick(hf)) != SPX_OK || (rc = sync()) != SPX_OK) break;
-        }
     }
+    (void)hipStreamSynchronize(stream);  // nothing may still reference the staging buffers on an error exit
     stats->steps = (stats->steps + nHalves - 1) / nHalves;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
     if (std::getenv("SPX_SELFPLAY_TRACE")) {
-        std::fprintf(stderr, "[spx_selfplay] %.3f s: gpu wait %.3f (of which inside start/refresh sync), enqueue %.3f, bookkeeping %.3f, "
-                     "starts+movegen enqueue %.3f\n", stats->seconds, gpuWait, phase[0], phase[1], phase[2]);
+        std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, bookkeeping %.3f, starts + enqueue %.3f (%s)\n",
+                     stats->seconds, gpuWait, phase[0], phase[1], counted ? "device-counted update" : "chunked update");
     }
     return rc;
 }
