@@ -192,14 +192,17 @@ def test_incremental_paths_on_mixed_compact_and_wide_rows(sp, states):
         assert np.array_equal(got, st.evaluate_once(tree[children]))
 
 
-@pytest.mark.parametrize("host_movegen", [False, True], ids=["device_movegen", "host_movegen"])
-def test_selfplay_driver_records_are_consistent(sp, states, tmp_path, host_movegen):
+@pytest.mark.parametrize("host_movegen,max_batch", [(False, 8192), (False, 4096), (True, 4096)],
+                         ids=["device_movegen_counted", "device_movegen_chunked", "host_movegen"])
+def test_selfplay_driver_records_are_consistent(sp, net_blob, tmp_path, host_movegen, max_batch):
     """Config-4 driver in miniature: 96 concurrent games through the fused incremental update+eval path, with the moves
     generated on the device (default) or by the host chess core. Every recorded
     score must equal -evaluate_once(position after the move) (the driver's accumulators, maintained incrementally over the
     whole game, agree with a from-scratch evaluation - the reference's own datagen assert, datagen.cpp:262), every move
-    must be legal (spx_viri_expand re-validates them) and be the best move within the exploration margin."""
-    st = states("tame")
+    must be legal (spx_viri_expand re-validates them) and be the best move within the exploration margin.
+    With a context that holds a whole ply's children the update reads its record count on the device
+    (spx_acc_update_eval_device_counted); with a smaller one the driver fetches the count and issues chunks."""
+    st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=max_batch)
     path = str(tmp_path / "games.vf")
     margin = 25
     stats = st.selfplay(n_games=96, target_games=160, out_path=path, max_plies=120, dfrc=True, temperature_cp=margin, seed=9,
@@ -241,3 +244,4 @@ def test_selfplay_driver_records_are_consistent(sp, states, tmp_path, host_moveg
                 succ.append(nxt[0])
         best = max(-int(v) for v in st.evaluate_once(np.array(succ, dtype=sp.PACKED_DTYPE)))
         assert int(positions["eval"][k]) >= min(best, 32000) - margin - 2 or abs(int(positions["eval"][k])) == 0
+    st.close()
