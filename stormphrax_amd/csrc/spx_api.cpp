@@ -71,6 +71,8 @@ struct spx_ctx {
     int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
                                    // the other one for its successor), [2] belongs to the single-launch small sort
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
+    size_t tinyBatchMax = 0;       // spx_eval_full*: batches up to this size skip the sorts (one MLP tile per position)
+    void* hTinyIo = nullptr;       // page-locked, device-mapped staging of the tiny-batch host call: records, then scores
     size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
     size_t updateSplitMax = 0;     // spx_update_kernel: records up to which the perspectives get separate waves
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
@@ -266,6 +268,8 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes) {
     return fnv1a64(data, nbytes);
 }
 
+constexpr size_t kTinyIoRecords = 1024;  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
+
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
     if (!net || !out || max_batch == 0 || max_batch > (1ull << 30)) {
         setError("spx_ctx_create: invalid argument");
@@ -348,6 +352,9 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
     ctx->updateSplitMax = 262144;
     ctx->mlpShareMax = 8192;
+    ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 29, 256: 54 -> 32, 1 024: 68 -> 38
+    if (const char* env = std::getenv("SPX_TINY_BATCH_MAX")) ctx->tinyBatchMax = size_t(std::atoll(env));
+    SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * (sizeof(spx_packed_pos) + sizeof(int32_t)), hipHostMallocMapped));
     if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX")) ctx->updateSplitMax = size_t(std::atoll(env));
     {
@@ -379,6 +386,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         if (p) (void)hipFree(p);
     }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
+    if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -419,7 +427,7 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
     mp.l3W = ctx->dL3W;
     mp.l3B = ctx->dL3B;
     mp.out = static_cast<int32_t*>(d_out);
-    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, n <= ctx->mlpShareMax && !d_count, s));
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, (n <= ctx->mlpShareMax && !d_count) ? kMlpTileShared : kMlpTileSorted, s));
     return SPX_OK;
 }
 
@@ -449,19 +457,35 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         ctx->profUsed += 4;
         SPX_HIP(hipEventRecord(ev[0], s));
     }
-    int rc = runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
+    const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
+    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     FtParams fp{};
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
-    fp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
+    fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
     fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
     SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
-    rc = runSortAndMlp(ctx, d_positions, n, d_out, s, true);
-    if (rc != SPX_OK) return rc;
+    if (tiny) {
+        MlpParams mp{};
+        mp.nPositions = uint32_t(n);
+        mp.records = static_cast<const uint64_t*>(d_positions);
+        mp.ftOut = ctx->dFtOut;
+        mp.l1W = ctx->dL1W;
+        mp.l1B = ctx->dL1B;
+        mp.l2W = ctx->dL2W;
+        mp.l2B = ctx->dL2B;
+        mp.l3W = ctx->dL3W;
+        mp.l3B = ctx->dL3B;
+        mp.out = static_cast<int32_t*>(d_out);
+        SPX_HIP(launchMlp(mp, ctx->smallL2Weights, kMlpTilePerPosition, s));
+    } else {
+        rc = runSortAndMlp(ctx, d_positions, n, d_out, s, true);
+        if (rc != SPX_OK) return rc;
+    }
     if (ev) SPX_HIP(hipEventRecord(ev[3], s));
     return SPX_OK;
 }
@@ -823,6 +847,21 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
     }
     if (n == 0) return SPX_OK;
     SPX_HIP(hipSetDevice(ctx->device));
+    if (n <= ctx->tinyBatchMax && n <= kTinyIoRecords && n <= ctx->maxBatch) {
+        // the one-position drop-in call (NnueState::evaluateOnce): no DMA transfers at all - the kernels read the records
+        // from, and write the scores to, page-locked host memory mapped into the device's address space
+        auto* records = static_cast<spx_packed_pos*>(ctx->hTinyIo);
+        auto* scores = reinterpret_cast<int32_t*>(records + kTinyIoRecords);
+        std::memcpy(records, positions, n * sizeof(spx_packed_pos));
+        void* dRecords = nullptr;
+        SPX_HIP(hipHostGetDevicePointer(&dRecords, records, 0));
+        const int rc = spx_eval_full_device(ctx, dRecords, n, static_cast<char*>(dRecords) + kTinyIoRecords * sizeof(spx_packed_pos),
+                                            ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, scores, n * sizeof(int32_t));
+        return SPX_OK;
+    }
     // host buffers of any length: processed in chunks of the context's capacity (device variants are strict)
     for (size_t lo = 0; lo < n; lo += ctx->maxBatch) {
         const size_t m = std::min(ctx->maxBatch, n - lo);

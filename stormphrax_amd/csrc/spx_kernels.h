@@ -118,10 +118,13 @@ struct SortParams {
     uint32_t* posOrder;         // out: [nPositions] position ids grouped by output bucket
 };
 
+enum MlpTiling { kMlpTileSorted = 0, kMlpTileShared = 1, kMlpTilePerPosition = 2 };
+
 struct MlpParams {
     uint32_t nPositions;
     const uint32_t* posOrder;   // positions grouped by output bucket
     const uint32_t* hist;       // counts per output bucket at hist[16..23]
+    const uint64_t* records;    // kMlpTilePerPosition only: the positions' records (output bucket from the occupancy)
     const uint8_t* ftOut;       // [nPositions][1024]
     const int8_t* l1W;          // device layout [8 buckets][16 ksteps][2 ntiles][64 lanes][16 B]
     const int32_t* l1B;         // [8][32]
@@ -133,7 +136,7 @@ struct MlpParams {
 };
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
-hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, bool shareTiles, hipStream_t stream);
+hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);

@@ -960,11 +960,14 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 // kSmallL2W: every |l2W| < 2^23 (checked on the host at context creation), so with the L2 inputs always inside
 //   (-2^20, 2^12] the product is one full-rate v_mad_i32_i24; otherwise the exact-but-slow v_mul_lo_u32 path runs.
 // ---------------------------------------------------------------------------------------------------------------------
-// kShareTile = false: one wavefront per 16-position tile; true: the four waves of a workgroup share ONE tile (each
-// repeats the cheap MFMA part and takes every fourth position of the serial tail) - for batches too small to fill
-// the chip, where the kernel is bound by the latency of a single tile (4 096 positions: 16 us unshared).
-template <bool kSmallL2W, bool kShareTile>
+// kTiling: kMlpTileSorted = one wavefront per 16-position tile of the bucket-sorted order; kMlpTileShared = the four
+// waves of a workgroup share ONE such tile (each repeats the cheap MFMA part and takes every fourth position of the
+// serial tail) - for batches too small to fill the chip, where the kernel is bound by the latency of a single tile
+// (4 096 positions: 16 us unshared); kMlpTilePerPosition = no sort at all, every position is its own tile and finds
+// its bucket from its record - the handful-of-positions drop-in call, where a sort launch costs more than it saves.
+template <bool kSmallL2W, int kTiling>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
+    constexpr bool kShareTile = kTiling == kMlpTileShared;
     __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
     __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
 
@@ -974,7 +977,14 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 
     // ---- locate this tile: bucket, first sorted index, number of real positions ----
     uint32_t bucket = 0, sortedBase = 0, count = 0;
-    {
+    if constexpr (kTiling == kMlpTilePerPosition) {
+        if (tile < p.nPositions) {
+            const uint32_t pieces = uint32_t(popc64(p.records[size_t(tile) * 4]));
+            bucket = min((pieces - 2u) / 4u, uint32_t(kOutputBuckets - 1));  // MaterialCount<8> (output.h:44-55)
+            sortedBase = tile;
+            count = 1;
+        }
+    } else {
         uint32_t tileStart = 0, posStart = 0;
         bool found = false;
 #pragma unroll
@@ -1004,7 +1014,9 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 
     // ---- L1 on MFMA ----
     const uint32_t rowInTile = lane & 15, kGroup = lane >> 4;
-    const uint32_t myPos = p.posOrder[sortedBase + min(rowInTile, count - 1)];  // rows past `count` replicate the last
+    const uint32_t myPos = kTiling == kMlpTilePerPosition
+                               ? sortedBase
+                               : p.posOrder[sortedBase + min(rowInTile, count - 1)];  // rows past `count` replicate the last
     const uint8_t* aRow = p.ftOut + size_t(myPos) * kL1 + kGroup * 16;
     const int8_t* bBase = p.l1W + size_t(bucket) * (kL1 * kL2) + lane * 16;
     i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -1076,7 +1088,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
         if (lane == 0) {
             const int32_t l3 = int32_t(term + uint32_t(l3Bias));
             const int64_t scaled = int64_t(l3) * kScale / (int64_t(1) << (4 * kQBits));  // truncating division
-            p.out[p.posOrder[sortedBase + r]] = int32_t(scaled);
+            p.out[kTiling == kMlpTilePerPosition ? sortedBase : p.posOrder[sortedBase + r]] = int32_t(scaled);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1111,19 +1123,24 @@ hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, bool shareTiles, hipStream_t stream) {
+template <bool kSmallL2W>
+static void launchMlpTiling(const MlpParams& p, MlpTiling tiling, hipStream_t stream) {
     const uint32_t tiles = (p.nPositions + 15) / 16 + kOutputBuckets;  // worst case: every bucket ends in a partial tile
-    const uint32_t blocks = shareTiles ? tiles : (tiles + 3) / 4;
-    if (smallL2Weights) {
-        if (shareTiles) {
-            hipLaunchKernelGGL((spx_mlp_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, p);
-        } else {
-            hipLaunchKernelGGL((spx_mlp_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, p);
-        }
-    } else if (shareTiles) {
-        hipLaunchKernelGGL((spx_mlp_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, p);
+    if (tiling == kMlpTilePerPosition) {
+        hipLaunchKernelGGL((spx_mlp_kernel<kSmallL2W, kMlpTilePerPosition>), dim3((p.nPositions + 3) / 4), dim3(256), 0,
+                           stream, p);
+    } else if (tiling == kMlpTileShared) {
+        hipLaunchKernelGGL((spx_mlp_kernel<kSmallL2W, kMlpTileShared>), dim3(tiles), dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((spx_mlp_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((spx_mlp_kernel<kSmallL2W, kMlpTileSorted>), dim3((tiles + 3) / 4), dim3(256), 0, stream, p);
+    }
+}
+
+hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream) {
+    if (smallL2Weights) {
+        launchMlpTiling<true>(p, tiling, stream);
+    } else {
+        launchMlpTiling<false>(p, tiling, stream);
     }
     return hipGetLastError();
 }
