@@ -268,7 +268,8 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes) {
     return fnv1a64(data, nbytes);
 }
 
-constexpr size_t kTinyIoRecords = 1024;  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
+constexpr size_t kTinyIoRecords = 1024;
+constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
 
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
     if (!net || !out || max_batch == 0 || max_batch > (1ull << 30)) {
@@ -354,7 +355,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     ctx->mlpShareMax = 8192;
     ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 29, 256: 54 -> 32, 1 024: 68 -> 38
     if (const char* env = std::getenv("SPX_TINY_BATCH_MAX")) ctx->tinyBatchMax = size_t(std::atoll(env));
-    SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * (sizeof(spx_packed_pos) + sizeof(int32_t)), hipHostMallocMapped));
+    SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * kTinyIoBytesPerRecord, hipHostMallocMapped));
     if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX")) ctx->updateSplitMax = size_t(std::atoll(env));
     {
@@ -438,6 +439,23 @@ static uint32_t ftGrid(const spx_ctx* ctx, size_t waves) {
     return (blocks + 7u) & ~7u;  // whole multiples of the 8 XCDs
 }
 
+// MLP of a handful of positions without any sort: every position is its own tile and finds its bucket from its record
+static int runTinyMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s) {
+    MlpParams mp{};
+    mp.nPositions = uint32_t(n);
+    mp.records = static_cast<const uint64_t*>(d_records);
+    mp.ftOut = ctx->dFtOut;
+    mp.l1W = ctx->dL1W;
+    mp.l1B = ctx->dL1B;
+    mp.l2W = ctx->dL2W;
+    mp.l2B = ctx->dL2B;
+    mp.l3W = ctx->dL3W;
+    mp.l3B = ctx->dL3B;
+    mp.out = static_cast<int32_t*>(d_out);
+    SPX_HIP(launchMlp(mp, ctx->smallL2Weights, kMlpTilePerPosition, s));
+    return SPX_OK;
+}
+
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream) {
     if (!ctx || (n && (!d_positions || !d_out))) {
         setError("spx_eval_full_device: null argument");
@@ -469,23 +487,8 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     fp.ftOut = ctx->dFtOut;
     SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
-    if (tiny) {
-        MlpParams mp{};
-        mp.nPositions = uint32_t(n);
-        mp.records = static_cast<const uint64_t*>(d_positions);
-        mp.ftOut = ctx->dFtOut;
-        mp.l1W = ctx->dL1W;
-        mp.l1B = ctx->dL1B;
-        mp.l2W = ctx->dL2W;
-        mp.l2B = ctx->dL2B;
-        mp.l3W = ctx->dL3W;
-        mp.l3B = ctx->dL3B;
-        mp.out = static_cast<int32_t*>(d_out);
-        SPX_HIP(launchMlp(mp, ctx->smallL2Weights, kMlpTilePerPosition, s));
-    } else {
-        rc = runSortAndMlp(ctx, d_positions, n, d_out, s, true);
-        if (rc != SPX_OK) return rc;
-    }
+    rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
+    if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[3], s));
     return SPX_OK;
 }
@@ -610,6 +613,7 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
         const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
         SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
     }
+    if (!d_count && n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true, d_count);
@@ -685,6 +689,7 @@ int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out
     uint32_t blocks = uint32_t((n + 3) / 4);
     if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
     SPX_HIP(launchSlotAct(ap, blocks, s));
+    if (n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
@@ -750,6 +755,26 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
     if ((rc = checkSlots(ctx, parent_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
     if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
     SPX_HIP(hipSetDevice(ctx->device));
+    if (n <= ctx->tinyBatchMax && n <= kTinyIoRecords) {
+        // push + evaluate of a few nodes (the search's own step): all operands through device-mapped page-locked memory
+        auto* records = static_cast<spx_packed_pos*>(ctx->hTinyIo);
+        auto* scores = reinterpret_cast<int32_t*>(records + kTinyIoRecords);
+        uint32_t* parents = reinterpret_cast<uint32_t*>(scores + kTinyIoRecords);
+        uint32_t* children = parents + kTinyIoRecords;
+        std::memcpy(records, child_positions, n * sizeof(spx_packed_pos));
+        std::memcpy(parents, parent_slots, n * sizeof(uint32_t));
+        std::memcpy(children, child_slots, n * sizeof(uint32_t));
+        char* dBase = nullptr;
+        SPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dBase), ctx->hTinyIo, 0));
+        const size_t offScores = kTinyIoRecords * sizeof(spx_packed_pos), offParents = offScores + kTinyIoRecords * 4,
+                     offChildren = offParents + kTinyIoRecords * 4;
+        rc = spx_acc_update_eval_device(ctx, dBase + offParents, dBase + offChildren, dBase, n, dBase + offScores,
+                                        ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, scores, n * sizeof(int32_t));
+        return SPX_OK;
+    }
     SPX_HIP(hipMemcpyAsync(ctx->dPositions, child_positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
                            ctx->stream));
     SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, parent_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -770,6 +795,19 @@ int spx_acc_eval(spx_ctx* ctx, const uint32_t* slots, size_t n, int32_t* out) {
     }
     if ((rc = checkSlots(ctx, slots, n, "spx_acc_eval")) != SPX_OK) return rc;
     SPX_HIP(hipSetDevice(ctx->device));
+    if (n <= ctx->tinyBatchMax && n <= kTinyIoRecords) {  // a few nodes: operands through device-mapped page-locked memory
+        auto* scores = reinterpret_cast<int32_t*>(static_cast<spx_packed_pos*>(ctx->hTinyIo) + kTinyIoRecords);
+        uint32_t* hSlots = reinterpret_cast<uint32_t*>(scores + kTinyIoRecords);
+        std::memcpy(hSlots, slots, n * sizeof(uint32_t));
+        char* dBase = nullptr;
+        SPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dBase), ctx->hTinyIo, 0));
+        const size_t offScores = kTinyIoRecords * sizeof(spx_packed_pos), offSlots = offScores + kTinyIoRecords * 4;
+        rc = spx_acc_eval_device(ctx, dBase + offSlots, n, dBase + offScores, ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, scores, n * sizeof(int32_t));
+        return SPX_OK;
+    }
     SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     rc = spx_acc_eval_device(ctx, ctx->dSlotsA, n, ctx->dOut, ctx->stream);
     if (rc != SPX_OK) return rc;
