@@ -268,7 +268,7 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes) {
     return fnv1a64(data, nbytes);
 }
 
-constexpr size_t kTinyIoRecords = 1024;
+constexpr size_t kTinyIoRecords = 8192;
 constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
 
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
@@ -353,7 +353,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
     ctx->updateSplitMax = 262144;
     ctx->mlpShareMax = 8192;
-    ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 29, 256: 54 -> 32, 1 024: 68 -> 38
+    ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 28, 1 024: 68 -> 37, 2 048: 73 -> 47, 4 096: 93 -> 71, 8 192: 126 -> 117
     if (const char* env = std::getenv("SPX_TINY_BATCH_MAX")) ctx->tinyBatchMax = size_t(std::atoll(env));
     SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * kTinyIoBytesPerRecord, hipHostMallocMapped));
     if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));

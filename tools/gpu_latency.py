@@ -5,7 +5,7 @@ net = sp.Network.synthetic("tame")
 st = sp.NnueState(net, device=0, max_batch=65536)
 pos = sp.random_positions(8192, seed=20260927)
 out = {}
-for n in (1, 64, 256, 512, 1024, 2048):
+for n in (1, 64, 256, 512, 1024, 2048, 4096, 8192):
     for _ in range(20): st.evaluate_once(pos[:n])
     t0 = time.perf_counter()
     for _ in range(500): st.evaluate_once(pos[:n])
