@@ -10,9 +10,13 @@ python bench.py --mode incremental --no-cpu-baseline > $OUT/bench_incremental_n1
 python bench.py --batch 4194304 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_n1_batch4M.json 2> $OUT/bench_4m.err
 python tools/gpu_measure.py > $OUT/secondary.json 2> $OUT/secondary.err
 python tools/spx_selfplay.py --games 4096 --target 8192 > $OUT/selfplay_4096.json 2> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 16384 --target 32768 > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 4096 --target 8192 --host-movegen > $OUT/selfplay_4096_host_movegen.json 2>> $OUT/selfplay.err
+python tools/gpu_latency.py > $OUT/latency.txt 2>&1
 bash tools/gpu_profile.sh $TAG > /dev/null 2>&1
 cp $REPO/gpurun_out/prof_$TAG/summary.txt $OUT/rocprofv3_summary.txt
 # (the TA/TD/TCP counter groups are NOT collected here: on 2026-09-28 rocprofv3 aborted inside hipMemcpy with them and
 #  then hung in its signal handler until the timeout - every rocprofv3 call in tools/ now runs under `timeout 300`)
+bash tools/gpu_stats.sh default_$TAG > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
 bash tools/gpu_stats.sh inc_$TAG --mode incremental > $OUT/rocprofv3_incremental_kernel_stats.txt 2>&1
 ls -la $OUT
