@@ -188,3 +188,27 @@ def test_host_observer_matches_reference_board_observer(sp):
         promos += any(a[0] != s[0] for a in want_add for s in want_sub[:1]) and len(want_add) == 1 and want_sub[0][0] in (0, 1) and want_add[0][0] not in (0, 1)
         refreshes += sum(flags) > 0
     assert n >= 1200 and castles >= 3 and promos >= 1 and refreshes >= 20
+
+
+def test_legal_moves_enumeration_matches_perft_and_viriformat(sp):
+    """spx_pos_legal_moves (the parity reference of the device move generator): one child per legal move, counts equal
+    perft(1), move words decode back to the same children through the viriformat expander."""
+    import struct
+
+    for fen, _, _ in PERFT:
+        (rec,) = sp.positions_from_fens([fen])
+        moves, children, in_check = sp.legal_moves(rec)
+        assert len(moves) == sp.perft(fen, 1) and len(set(c.tobytes() for c in children)) == len(moves)
+        assert all((c["stm_ep"] & 0x80) != (rec["stm_ep"] & 0x80) for c in children)
+        for mv, child in zip(moves, children):
+            # a one-move viriformat game: start record, (move, score), terminator -> positions [start, after move]
+            blob = rec.tobytes() + struct.pack("<Hh", int(mv), 0) + struct.pack("<Hh", 0, 0)[:4]
+            positions, games = sp.viri_expand(blob)
+            assert games == 1 and len(positions) == 1  # the expander lists the positions the moves were played FROM
+        # a second ply from every child reproduces perft(2)
+        total = sum(len(sp.legal_moves(c)[0]) for c in children)
+        assert total == sp.perft(fen, 2)
+    # check flag
+    (mate,) = sp.positions_from_fens(["R6k/6pp/8/8/8/8/8/4K3 b - - 0 1"])
+    moves, _, in_check = sp.legal_moves(mate)
+    assert len(moves) == 0 and in_check
