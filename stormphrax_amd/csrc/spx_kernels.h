@@ -95,12 +95,13 @@ struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)
     const uint32_t* first;          // per game: block of children (spx_movegen_kernel)
     const uint32_t* count;
     const uint8_t* inCheck;
-    const int32_t* evals;           // per child, side to move of the child
+    const int32_t* evals;           // per child, side to move of the child; NULL = all equal (uniformly random move)
+    const uint8_t* enable;          // optional per game: 0 = leave this game alone
     const uint16_t* moves;
     const uint64_t* children;       // records as u64[4]
-    const uint32_t* childSlots;     // per child: the accumulator slot its update was written to
+    const uint32_t* childSlots;     // per child: the accumulator slot its update was written to (NULL with slots)
     uint64_t* positions;            // [nGames] records as u64[4]: replaced by the chosen child
-    uint32_t* slots;                // [nGames] accumulator slot of the game's current position: replaced likewise
+    uint32_t* slots;                // [nGames] accumulator slot of the game's current position: replaced likewise; or NULL
     uint64_t* rng;                  // [nGames] splitmix64 state
     PickResult* results;            // [nGames]
     int32_t temperature;            // pick uniformly among the moves within this margin of the best (0 = first best)

@@ -324,14 +324,14 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
     PickResult r{};
     r.count = p.count[g];
     r.inCheck = p.inCheck[g];
-    if (r.count != 0) {
+    if (r.count != 0 && (!p.enable || p.enable[g])) {
         const uint32_t lo = p.first[g];
         int32_t best = INT32_MIN;
-        for (uint32_t k = 0; k < r.count; ++k) best = max(best, -p.evals[lo + k]);
+        for (uint32_t k = 0; k < r.count; ++k) best = max(best, p.evals ? -p.evals[lo + k] : 0);
         uint64_t state = p.rng[g];
         uint32_t pick = 0, seen = 0;
         for (uint32_t k = 0; k < r.count; ++k) {
-            if (-p.evals[lo + k] >= best - p.temperature) {
+            if ((p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature) {
                 ++seen;
                 state += 0x9E3779B97F4A7C15ull;
                 uint64_t z = state;
@@ -351,13 +351,13 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
         dst[1] = w1;
         dst[2] = w2;
         dst[3] = w3;
-        p.slots[g] = p.childSlots[c];
+        if (p.slots) p.slots[g] = p.childSlots[c];
         r.key = recordKey(w0, w1, w2, uint32_t(w3));
-        r.score = -p.evals[c];
+        r.score = p.evals ? -p.evals[c] : 0;
         r.move = p.moves[c];
         r.halfmove = uint8_t((w3 >> 8) & 0xFF);
     }
-    p.results[g] = r;
+    if (p.results) p.results[g] = r;
 }
 
 __global__ __launch_bounds__(256) void spx_seat_games_kernel(uint32_t n, const uint32_t* seats, const uint64_t* records,

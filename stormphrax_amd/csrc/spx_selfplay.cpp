@@ -571,6 +571,136 @@ uint64_t keyOfRecord(const spx_packed_pos& r) {
         }                                                                                     \
     } while (0)
 
+// Random openings generated in bulk on the device (datagen.cpp:146-171: start position or a double-Chess960 start, then
+// 8 random plies plus one more on a coin flip): the host only places the start pieces; the plies are spx_movegen_kernel +
+// spx_pick_kernel without evaluations (every legal move equally likely), a last generation drops positions that have
+// no legal move. With this the host chess core is out of the device self-play loop altogether - what a rank needs
+// when eight of them share a node's CPUs.
+class OpeningPool {
+public:
+    OpeningPool(spx_ctx* ctx, hipStream_t stream, bool dfrc, uint32_t basePlies)
+        : ctx_(ctx), stream_(stream), dfrc_(dfrc), basePlies_(basePlies) {}
+
+    size_t available() const {
+        return records_.size() - next_;
+    }
+    void pop(spx_packed_pos& rec, uint64_t& gameSeed) {
+        rec = records_[next_];
+        gameSeed = seeds_[next_];
+        ++next_;
+    }
+    // appends at least `want` openings (rounds of up to kRound candidates; a few percent die on the way)
+    int refill(size_t want, Rng& rng) {
+        records_.erase(records_.begin(), records_.begin() + long(next_));
+        seeds_.erase(seeds_.begin(), seeds_.begin() + long(next_));
+        next_ = 0;
+        const size_t target = records_.size() + want;
+        while (records_.size() < target) {
+            const size_t missing = target - records_.size();
+            const int rc = round(std::min(kRound, missing + missing / 8 + 64), rng);
+            if (rc != SPX_OK) return rc;
+        }
+        return SPX_OK;
+    }
+
+private:
+    static constexpr size_t kRound = 16384, kPerSeat = 96;
+
+    int round(size_t b, Rng& rng) {
+        if (!dPositions_) {
+            dPositions_ = dev_.get<uint64_t>(kRound * 4);
+            dRng_ = dev_.get<uint64_t>(kRound);
+            dExtra_ = dev_.get<uint8_t>(kRound);
+            dChildren_ = dev_.get<uint64_t>(kRound * kPerSeat * 4);
+            dMoves_ = dev_.get<uint16_t>(kRound * kPerSeat);
+            dParents_ = dev_.get<uint32_t>(kRound * kPerSeat);
+            dFirst_ = dev_.get<uint32_t>(kRound);
+            dCount_ = dev_.get<uint32_t>(kRound);
+            dInCheck_ = dev_.get<uint8_t>(kRound);
+            dTotal_ = dev_.get<uint32_t>(1);
+            if (!dPositions_ || !dRng_ || !dExtra_ || !dChildren_ || !dMoves_ || !dParents_ || !dFirst_ || !dCount_ ||
+                !dInCheck_ || !dTotal_) {
+                setError("spx_selfplay_run: out of device memory (opening pool)");
+                return SPX_ERR_HIP;
+            }
+        }
+        std::vector<spx_packed_pos> start(b);
+        std::vector<uint64_t> pickSeeds(b), gameSeeds(b);
+        std::vector<uint8_t> extra(b);
+        spx_packed_pos standard;
+        packBoard(startpos(), standard);
+        for (size_t i = 0; i < b; ++i) {
+            if (dfrc_) {
+                const uint32_t w = rng.below(960), k = rng.below(960);
+                packBoard(dfrcStart(w, k), start[i]);
+            } else {
+                start[i] = standard;
+            }
+            extra[i] = uint8_t(rng.next() >> 63);  // 8 + coin flip (datagen.cpp:153)
+            pickSeeds[i] = rng.next();
+            gameSeeds[i] = rng.next();
+        }
+        SPX_SP_HIP(hipMemcpyAsync(dPositions_, start.data(), b * 32, hipMemcpyHostToDevice, stream_));
+        SPX_SP_HIP(hipMemcpyAsync(dRng_, pickSeeds.data(), b * 8, hipMemcpyHostToDevice, stream_));
+        SPX_SP_HIP(hipMemcpyAsync(dExtra_, extra.data(), b, hipMemcpyHostToDevice, stream_));
+        for (uint32_t ply = 0; ply <= basePlies_ + 1; ++ply) {
+            const int rc = spx_movegen_device(ctx_, dPositions_, b, nullptr, dChildren_, dMoves_, dParents_, dFirst_, dCount_,
+                                              dInCheck_, kRound * kPerSeat, dTotal_, stream_);
+            if (rc != SPX_OK) return rc;
+            if (ply == basePlies_ + 1) break;  // the last generation only tells which positions still have a move
+            PickParams pk{};
+            pk.nGames = uint32_t(b);
+            pk.first = dFirst_;
+            pk.count = dCount_;
+            pk.inCheck = dInCheck_;
+            pk.enable = ply == basePlies_ ? dExtra_ : nullptr;
+            pk.moves = dMoves_;
+            pk.children = dChildren_;
+            pk.positions = dPositions_;
+            pk.rng = dRng_;
+            pk.temperature = 0x3FFFFFFF;  // no evaluations: every legal move is within the margin
+            SPX_SP_HIP(launchPick(pk, stream_));
+        }
+        std::vector<spx_packed_pos> done(b);
+        std::vector<uint32_t> counts(b);
+        uint32_t total = 0;
+        SPX_SP_HIP(hipMemcpyAsync(done.data(), dPositions_, b * 32, hipMemcpyDeviceToHost, stream_));
+        SPX_SP_HIP(hipMemcpyAsync(counts.data(), dCount_, b * 4, hipMemcpyDeviceToHost, stream_));
+        SPX_SP_HIP(hipMemcpyAsync(&total, dTotal_, 4, hipMemcpyDeviceToHost, stream_));
+        SPX_SP_HIP(hipStreamSynchronize(stream_));
+        if (total > kRound * kPerSeat) {
+            setError("spx_selfplay_run: opening generation overflowed its child buffer");
+            return SPX_ERR_CAPACITY;
+        }
+        for (size_t i = 0; i < b; ++i) {
+            if (counts[i] != 0) {
+                records_.push_back(done[i]);
+                seeds_.push_back(gameSeeds[i]);
+            }
+        }
+        return SPX_OK;
+    }
+
+    spx_ctx* ctx_;
+    hipStream_t stream_;
+    bool dfrc_;
+    uint32_t basePlies_;
+    DeviceBuffers dev_;
+    uint64_t* dPositions_ = nullptr;
+    uint64_t* dRng_ = nullptr;
+    uint8_t* dExtra_ = nullptr;
+    uint64_t* dChildren_ = nullptr;
+    uint16_t* dMoves_ = nullptr;
+    uint32_t* dParents_ = nullptr;
+    uint32_t* dFirst_ = nullptr;
+    uint32_t* dCount_ = nullptr;
+    uint8_t* dInCheck_ = nullptr;
+    uint32_t* dTotal_ = nullptr;
+    std::vector<spx_packed_pos> records_;
+    std::vector<uint64_t> seeds_;
+    size_t next_ = 0;
+};
+
 // One half of the seats: its own child buffers and scratch-slot regions. The halves alternate so that the host's
 // bookkeeping for one half runs while the GPU evaluates the children of the other.
 struct DeviceHalf {
@@ -694,8 +824,7 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     std::vector<DeviceGame> games(G);
     // the host only keeps records and adjudication counters here: a few workers are plenty
     Pool pool(std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(4u, usableCpus()), G)));
-    std::vector<Game> scratch(pool.size());  // random openings reuse the host path's generator, one per worker
-    std::vector<uint64_t> openingSeeds;
+    OpeningPool openings(ctx, stream, p->dfrc != 0, p->opening_plies ? p->opening_plies : 8);
     std::vector<uint8_t> retire;
     const auto t0 = std::chrono::steady_clock::now();
     double gpuWait = 0.0;
@@ -730,53 +859,50 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     // and the update is issued in chunks.
     const bool counted = halves[0].cap <= ctxMaxBatch(ctx) && halves[nHalves - 1].cap <= ctxMaxBatch(ctx);
 
-    // One ply of a half, enqueued back to back: (re)start games in its idle seats (random openings on the host workers,
-    // one RNG stream per game; NnueState::reset of their accumulators), move generation, fused update+eval of the
+    // One ply of a half, enqueued back to back: (re)start games in its idle seats (openings from the device-generated
+    // pool, one RNG stream per game; NnueState::reset of their accumulators), move generation, fused update+eval of the
     // children, move choice, and the per-game results on their way back. Ends with the half's event.
     auto enqueuePly = [&](DeviceHalf& hf) -> int {
-        uint32_t n = 0;
-        openingSeeds.clear();
+        uint32_t n = 0, fresh = 0;
         retire.clear();
         for (uint32_t i = hf.begin; i < hf.end; ++i) {
             DeviceGame& g = games[i];
             if (g.active) continue;
             if (started < p->target_games) {
                 ++started;
+                ++fresh;
                 hf.hSeats[n++] = i;
-                openingSeeds.push_back(rng.next());
                 retire.push_back(0);
             } else if (!g.blank) {  // no successor for this seat: blank its record so that it stops generating children
                 g.blank = true;
                 hf.hSeats[n++] = i;
-                openingSeeds.push_back(0);
                 retire.push_back(1);
             }
         }
         if (n) {
-            pool.run([&](uint32_t t) {
-                for (uint32_t k = t; k < n; k += pool.size()) {
-                    DeviceGame& g = games[hf.hSeats[k]];
-                    if (retire[k]) {
-                        std::memset(&hf.hRecords[k], 0, sizeof(spx_packed_pos));
-                        hf.hRng[k] = 0;
-                        continue;
-                    }
-                    Rng local{openingSeeds[k]};
-                    Game& sc = scratch[t];
-                    startGame(sc, local, p->dfrc != 0, p->opening_plies ? p->opening_plies : 8);
-                    g.initial = sc.initial;
-                    g.moves.clear();
-                    g.scores.clear();
-                    g.history.clear();
-                    g.key = keyOfRecord(g.initial);
-                    g.winPlies = g.lossPlies = g.drawPlies = g.plies = 0;
-                    g.stm = sc.board.stm;
-                    g.active = true;
-                    g.blank = false;
-                    hf.hRecords[k] = g.initial;
-                    hf.hRng[k] = sc.rng.s;
+            if (openings.available() < fresh) {
+                const size_t ahead = std::min<size_t>(p->target_games - started, 16384);
+                const int r = openings.refill(fresh + ahead, rng);
+                if (r != SPX_OK) return r;
+            }
+            for (uint32_t k = 0; k < n; ++k) {
+                DeviceGame& g = games[hf.hSeats[k]];
+                if (retire[k]) {
+                    std::memset(&hf.hRecords[k], 0, sizeof(spx_packed_pos));
+                    hf.hRng[k] = 0;
+                    continue;
                 }
-            });
+                openings.pop(g.initial, hf.hRng[k]);
+                g.moves.clear();
+                g.scores.clear();
+                g.history.clear();
+                g.key = keyOfRecord(g.initial);
+                g.winPlies = g.lossPlies = g.drawPlies = g.plies = 0;
+                g.stm = (g.initial.stm_ep & 0x80) ? 0 : 1;
+                g.active = true;
+                g.blank = false;
+                hf.hRecords[k] = g.initial;
+            }
             SPX_SP_HIP(hipMemcpyAsync(hf.dSeats, hf.hSeats, size_t(n) * 4, hipMemcpyHostToDevice, stream));
             SPX_SP_HIP(hipMemcpyAsync(hf.dRecords, hf.hRecords, size_t(n) * 32, hipMemcpyHostToDevice, stream));
             SPX_SP_HIP(hipMemcpyAsync(hf.dRngNew, hf.hRng, size_t(n) * 8, hipMemcpyHostToDevice, stream));
