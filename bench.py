@@ -216,6 +216,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=0,
                     help="tile this many distinct positions to fill the batch (cache-locality ablation; also keeps host "
                          "generation bounded for the HBM-filling batches of BASELINE config 5)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="issue the steps with the strictly stream-ordered spx_eval_full_device instead of the pipelined "
+                         "spx_eval_full_device_async (consecutive batches overlap: sorts / MLP of one beside the "
+                         "feature-transformer kernel of the next)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -252,15 +256,19 @@ def main():
     distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
     positions = np.resize(distinct, args.batch) if n_distinct < args.batch else distinct
     d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
-    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
+    pipelined = not args.no_pipeline and n_ctx == 1
+    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(2 if pipelined else n_ctx)]
     d_out = d_outs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_ctx - 1)]
     counter = [0]
 
     def step():
-        k = counter[0] % n_ctx
+        k = counter[0] % len(d_outs)
         counter[0] += 1
-        states[k].evaluate_once_device(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr(), streams[k].cuda_stream)
+        if pipelined:  # returns at once; the library chains the batches on its own two streams
+            state.evaluate_once_device_async(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr())
+        else:
+            states[k].evaluate_once_device(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr(), streams[k].cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -313,7 +321,9 @@ def main():
                 "batch_per_gpu": args.batch,
                 "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path; "
-                               f"steps issued round-robin on {n_ctx} HIP stream(s) per GPU",
+                               + ("steps issued through the pipelined spx_eval_full_device_async (two internal streams: "
+                                  "sorts / MLP of a batch overlap the next batch's feature-transformer kernel)"
+                                  if pipelined else f"steps issued round-robin on {n_ctx} HIP stream(s) per GPU"),
                 "checksum": checksum,
                 "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
             },

@@ -93,6 +93,16 @@ void spx_ctx_destroy(spx_ctx* ctx);
 int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32_t* out);
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream);
 
+/* Pipelined variant for streams of batches (rescoring, throughput runs): the call returns at once and consecutive
+ * calls overlap - the context alternates two internal streams and scratch sets so that the sorts and the MLP of one
+ * batch run beside the feature-transformer kernel of the next (the FT kernels themselves are chained). The inputs must
+ * be valid when the call is made and stay untouched, like d_out, until the batch is done: *done_event (a hipEvent_t,
+ * owned by the context, valid until two more async calls) or spx_ctx_synchronize(ctx). Results are bit-identical to
+ * spx_eval_full_device. Allocates the second scratch set on first use (~1.1 KB per position of max_batch, twice). */
+int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event);
+/* waits for everything the context has enqueued on its own streams */
+int spx_ctx_synchronize(spx_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Incremental path: an arena of accumulator "slots" resident in HBM (4 KiB of i16 accumulators + the 32-byte record
  * per slot) replaces NnueState's accumulator stack (src/eval/nnue_state.h:47-83,87-116). A caller that used to do

@@ -41,6 +41,8 @@ struct spx_net {
     const int8_t* l1W() const { return reinterpret_cast<const int8_t*>(blob.data() + kOffL1W); }
 };
 
+constexpr size_t kProfEventsPerCall = 5;
+
 struct spx_ctx {
     int device = 0;
     size_t maxBatch = 0;
@@ -71,6 +73,20 @@ struct spx_ctx {
     int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
                                    // the other one for its successor), [2] belongs to the single-launch small sort
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
+    // spx_eval_full_device_async: two scratch sets ("lanes") with their own streams alternate, so that the sorts and
+    // the MLP of one batch run beside the feature-transformer kernel of the next; the FT kernels themselves are
+    // chained by events (they never overlap each other - two of them thrash the caches)
+    struct EvalLane {
+        uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr;
+        uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *histUsed = nullptr;
+        int histCur = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t ftDone = nullptr, done = nullptr;
+        bool ftRecorded = false;
+    } lanes[2];
+    bool lanesReady = false;
+    unsigned laneNext = 0;
+    hipEvent_t ftGateWait = nullptr, ftGateRecord = nullptr;  // set around a lane's call: FT waits / signals
     size_t tinyBatchMax = 0;       // spx_eval_full*: batches up to this size skip the sorts (one MLP tile per position)
     void* hTinyIo = nullptr;       // page-locked, device-mapped staging of the tiny-batch host call: records, then scores
     size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
@@ -80,7 +96,8 @@ struct spx_ctx {
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
-    std::vector<hipEvent_t> profEvents;  // 3 per recorded call: before ft, between, after mlp
+    std::vector<hipEvent_t> profEvents;  // kProfEventsPerCall per recorded call: [0] start, [1] after the sorts, [4] before
+                                         // the FT kernel (after a pipelined call's wait), [2] after it, [3] after the MLP
     size_t profUsed = 0;
 };
 
@@ -372,6 +389,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     uint32_t blocksPerCu = 32;
     if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
+    SPX_HIP(hipDeviceSynchronize());  // the hist memset ran on the null stream, the context's stream does not wait for it
     *out = ctx.release();
     return SPX_OK;
 }
@@ -388,6 +406,16 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
+    for (auto& lane : ctx->lanes) {
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+        void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dHist, lane.dPerspOrder, lane.dPosOrder};
+        for (void* q : lanePtrs) {
+            if (q) (void)hipFree(q);
+        }
+        if (lane.ftDone) (void)hipEventDestroy(lane.ftDone);
+        if (lane.done) (void)hipEventDestroy(lane.done);
+        if (lane.stream) (void)hipStreamDestroy(lane.stream);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -470,15 +498,17 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipEvent_t* ev = nullptr;
-    if (ctx->profUsed + 4 <= ctx->profEvents.size()) {
+    if (ctx->profUsed + kProfEventsPerCall <= ctx->profEvents.size()) {
         ev = &ctx->profEvents[ctx->profUsed];
-        ctx->profUsed += 4;
+        ctx->profUsed += kProfEventsPerCall;
         SPX_HIP(hipEventRecord(ev[0], s));
     }
     const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
     int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
+    if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
+    if (ev) SPX_HIP(hipEventRecord(ev[4], s));  // after the wait: the FT interval is the kernel alone
     FtParams fp{};
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
@@ -486,10 +516,79 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
     SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
+    if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    return SPX_OK;
+}
+
+// ---- pipelined full-refresh evaluation ----
+static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
+    std::swap(ctx->dFtOut, lane.dFtOut);
+    std::swap(ctx->dKingKeys, lane.dKingKeys);
+    std::swap(ctx->dOutKeys, lane.dOutKeys);
+    std::swap(ctx->dHist, lane.dHist);
+    std::swap(ctx->dPerspOrder, lane.dPerspOrder);
+    std::swap(ctx->dPosOrder, lane.dPosOrder);
+    std::swap(ctx->histUsed, lane.histUsed);
+    std::swap(ctx->histCur, lane.histCur);
+}
+
+static int ensureLanes(spx_ctx* ctx) {
+    if (ctx->lanesReady) return SPX_OK;
+    for (auto& lane : ctx->lanes) {
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dFtOut), ctx->maxBatch * size_t(kL1)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dKingKeys), ctx->maxBatch * 2));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dOutKeys), ctx->maxBatch));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), 3 * 64 * sizeof(uint32_t)));
+        SPX_HIP(hipMemset(lane.dHist, 0, 3 * 64 * sizeof(uint32_t)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
+        SPX_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        SPX_HIP(hipEventCreateWithFlags(&lane.ftDone, hipEventDisableTiming));
+        SPX_HIP(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+    }
+    SPX_HIP(hipDeviceSynchronize());  // the memsets ran on the null stream, the lanes' streams do not wait for it
+    ctx->lanesReady = true;
+    return SPX_OK;
+}
+
+int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event) {
+    if (!ctx) {
+        setError("spx_eval_full_device_async: null context");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    int rc = ensureLanes(ctx);
+    if (rc != SPX_OK) return rc;
+    spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
+    spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
+    ++ctx->laneNext;
+    swapLane(ctx, lane);
+    ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
+    ctx->ftGateRecord = lane.ftDone;
+    rc = spx_eval_full_device(ctx, d_positions, n, d_out, lane.stream);
+    ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+    swapLane(ctx, lane);
+    if (rc != SPX_OK) return rc;
+    if (n) lane.ftRecorded = true;
+    SPX_HIP(hipEventRecord(lane.done, lane.stream));
+    if (done_event) *done_event = lane.done;
+    return SPX_OK;
+}
+
+int spx_ctx_synchronize(spx_ctx* ctx) {
+    if (!ctx) {
+        setError("spx_ctx_synchronize: null context");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->lanesReady) {
+        for (auto& lane : ctx->lanes) SPX_HIP(hipStreamSynchronize(lane.stream));
+    }
     return SPX_OK;
 }
 
@@ -510,6 +609,7 @@ int spx_acc_reserve(spx_ctx* ctx, size_t n_slots) {
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dArena), n_slots * kAccSlotBytes));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotRecords), n_slots * 32));
     SPX_HIP(hipMemset(ctx->dSlotRecords, 0, n_slots * 32));
+    SPX_HIP(hipDeviceSynchronize());  // null-stream memset vs. the non-blocking streams that use the arena next
     ctx->nSlots = n_slots;
     return SPX_OK;
 }
@@ -822,7 +922,7 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
         return SPX_ERR_INVALID_ARG;
     }
     SPX_HIP(hipSetDevice(ctx->device));
-    while (ctx->profEvents.size() < max_calls * 4) {
+    while (ctx->profEvents.size() < max_calls * kProfEventsPerCall) {
         hipEvent_t e;
         SPX_HIP(hipEventCreate(&e));
         ctx->profEvents.push_back(e);
@@ -842,12 +942,12 @@ int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms
     }
     SPX_HIP(hipSetDevice(ctx->device));
     *sort_ms = *ft_ms = *mlp_ms = 0.0;
-    *calls = ctx->profUsed / 4;
-    for (size_t i = 0; i + 3 < ctx->profUsed; i += 4) {
+    *calls = ctx->profUsed / kProfEventsPerCall;
+    for (size_t i = 0; i + kProfEventsPerCall - 1 < ctx->profUsed; i += kProfEventsPerCall) {
         float a = 0.f, b = 0.f, c = 0.f;
         SPX_HIP(hipEventSynchronize(ctx->profEvents[i + 3]));
         SPX_HIP(hipEventElapsedTime(&a, ctx->profEvents[i], ctx->profEvents[i + 1]));
-        SPX_HIP(hipEventElapsedTime(&b, ctx->profEvents[i + 1], ctx->profEvents[i + 2]));
+        SPX_HIP(hipEventElapsedTime(&b, ctx->profEvents[i + 4], ctx->profEvents[i + 2]));
         SPX_HIP(hipEventElapsedTime(&c, ctx->profEvents[i + 2], ctx->profEvents[i + 3]));
         *sort_ms += a;
         *ft_ms += b;

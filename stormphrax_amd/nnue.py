@@ -142,6 +142,15 @@ class NnueState:
         """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
         return int(_lib.load().spx_ctx_compact_psq_rows(self._h))
 
+    def evaluate_once_device_async(self, d_positions_ptr, n, d_out_ptr):
+        """Pipelined variant (spx_eval_full_device_async): returns the hipEvent_t handle that marks the batch done."""
+        ev = ctypes.c_void_p()
+        check(_lib.load().spx_eval_full_device_async(self._h, d_positions_ptr, n, d_out_ptr, ctypes.byref(ev)))
+        return ev.value
+
+    def synchronize(self):
+        check(_lib.load().spx_ctx_synchronize(self._h))
+
     def profile_begin(self, max_calls):
         check(_lib.load().spx_profile_begin(self._h, max_calls))
 

@@ -219,3 +219,45 @@ def test_contexts_are_reentrant_across_threads(sp, oracle, net_blob):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_pipelined_async_calls_equal_the_synchronous_path(sp, oracle, net_blob):
+    """spx_eval_full_device_async: several batches in flight on the context's two internal lanes (different inputs and
+    sizes per call, incl. sort-free small ones) give exactly the results of the stream-ordered call. Inputs and outputs
+    live in page-locked host memory (spx_host_alloc), which the device addresses directly."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=20000)
+    sizes = [20000, 777, 12345, 1, 20000, 9000, 4096, 15000]
+    batches = [sp.random_positions(n, seed=500 + i, min_ply=0, max_ply=150, dfrc_every=3) for i, n in enumerate(sizes)]
+    wants = [st.evaluate_once(b) for b in batches]
+    oracle.use(net_blob("wild"), "wild")
+    assert np.array_equal(wants[1], oracle.eval_mailboxes(*sp.positions_to_mailboxes(batches[1])))
+    ptrs, d_in, d_out = [], [], []
+    try:
+        for b in batches:
+            pin, pout = lib.spx_host_alloc(len(b) * 32), lib.spx_host_alloc(len(b) * 4)
+            assert pin and pout
+            ptrs += [pin, pout]
+            src = np.ctypeslib.as_array((ctypes.c_uint8 * (len(b) * 32)).from_address(pin))
+            src[:] = b.view(np.uint8).reshape(-1)
+            d_in.append(pin)
+            d_out.append(np.ctypeslib.as_array((ctypes.c_int32 * len(b)).from_address(pout)))
+        for rep in range(3):
+            for out in d_out:
+                out[:] = -1
+            events = [st.evaluate_once_device_async(d_in[i], len(batches[i]), d_out[i].ctypes.data)
+                      for i in range(len(batches))]
+            assert all(events)
+            st.synchronize()
+            for i in range(len(batches)):
+                assert np.array_equal(d_out[i], wants[i]), (rep, i)
+        # the synchronous entry points still work on the same context afterwards
+        assert np.array_equal(st.evaluate_once(batches[2]), wants[2])
+    finally:
+        st.close()
+        for q in ptrs:
+            lib.spx_host_free(q)
