@@ -77,7 +77,7 @@ struct spx_ctx {
     // the MLP of one batch run beside the feature-transformer kernel of the next; the FT kernels themselves are
     // chained by events (they never overlap each other - two of them thrash the caches)
     struct EvalLane {
-        uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr;
+        uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr, *dStaged = nullptr;
         uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *histUsed = nullptr;
         int histCur = 0;
         hipStream_t stream = nullptr;
@@ -408,7 +408,8 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
-        void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dHist, lane.dPerspOrder, lane.dPosOrder};
+        void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
+                            lane.dPosOrder};
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
@@ -529,6 +530,7 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
     std::swap(ctx->dFtOut, lane.dFtOut);
     std::swap(ctx->dKingKeys, lane.dKingKeys);
     std::swap(ctx->dOutKeys, lane.dOutKeys);
+    std::swap(ctx->dStaged, lane.dStaged);
     std::swap(ctx->dHist, lane.dHist);
     std::swap(ctx->dPerspOrder, lane.dPerspOrder);
     std::swap(ctx->dPosOrder, lane.dPosOrder);
@@ -538,15 +540,22 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
 
 static int ensureLanes(spx_ctx* ctx) {
     if (ctx->lanesReady) return SPX_OK;
+    // The two lanes must sit on different hardware queues or their kernels serialise: HIP spreads streams of one
+    // priority round-robin over a small pool of queues (two lanes were seen sharing one), but never mixes priorities.
+    int leastPriority = 0, greatestPriority = 0;
+    SPX_HIP(hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority));
+    int laneIndex = 0;
     for (auto& lane : ctx->lanes) {
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dFtOut), ctx->maxBatch * size_t(kL1)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dKingKeys), ctx->maxBatch * 2));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dOutKeys), ctx->maxBatch));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dStaged), ctx->maxBatch * 32));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), 3 * 64 * sizeof(uint32_t)));
         SPX_HIP(hipMemset(lane.dHist, 0, 3 * 64 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
-        SPX_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking,
+                                            laneIndex++ == 0 ? leastPriority : greatestPriority));
         SPX_HIP(hipEventCreateWithFlags(&lane.ftDone, hipEventDisableTiming));
         SPX_HIP(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
     }
@@ -591,6 +600,33 @@ int spx_ctx_synchronize(spx_ctx* ctx) {
     }
     return SPX_OK;
 }
+
+}  // extern "C"
+
+namespace spx {
+// Internal (spx_internal.h): run a sequence of *_device calls of this context on one of its two lanes - the lane's
+// scratch set and stream - so that two independent sequences (the two halves of the self-play seats) overlap. The
+// lane's big kernel (FT / update) first waits for the other lane's latest one.
+int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream) {
+    const int rc = ensureLanes(ctx);
+    if (rc != SPX_OK) return rc;
+    spx_ctx::EvalLane& lane = ctx->lanes[laneIndex & 1];
+    spx_ctx::EvalLane& other = ctx->lanes[(laneIndex & 1) ^ 1];
+    swapLane(ctx, lane);
+    ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
+    ctx->ftGateRecord = lane.ftDone;
+    lane.ftRecorded = true;  // conservatively: an unrecorded event counts as complete for hipStreamWaitEvent
+    *stream = lane.stream;
+    return SPX_OK;
+}
+
+void ctxLaneEnd(spx_ctx* ctx, int laneIndex) {
+    ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+    swapLane(ctx, ctx->lanes[laneIndex & 1]);
+}
+}  // namespace spx
+
+extern "C" {
 
 // ---- incremental path: accumulator arena ----
 int spx_acc_reserve(spx_ctx* ctx, size_t n_slots) {
@@ -711,7 +747,9 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
     up.stagedRecords = ctx->dStaged;
     {
         const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
+        if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // lanes: the big kernels are chained
         SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
+        if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     }
     if (!d_count && n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);

@@ -21,6 +21,9 @@ struct spx_ctx;
 namespace spx {
 size_t ctxMaxBatch(const spx_ctx* ctx);
 int ctxDevice(const spx_ctx* ctx);
+// lanes: see spx_api.cpp (two scratch sets + streams; big kernels chained by events)
+int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream);
+void ctxLaneEnd(spx_ctx* ctx, int laneIndex);
 
 // error plumbing (spx_api): thread-local last error string, returned by spx_last_error()
 void setError(const std::string& msg);

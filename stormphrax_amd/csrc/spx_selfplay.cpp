@@ -725,6 +725,7 @@ struct DeviceHalf {
     uint64_t* dRngNew = nullptr;
     hipEvent_t done = nullptr;       // recorded after the ply's results are on their way to the host
     bool inFlight = false;
+    uint32_t index = 0;              // which lane of the context this half runs on
 };
 
 int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
@@ -768,6 +769,7 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     uint32_t nextSlot = G;
     for (uint32_t h = 0; h < nHalves && ok; ++h) {
         DeviceHalf& hf = halves[h];
+        hf.index = h;
         hf.begin = uint32_t(uint64_t(G) * h / nHalves);
         hf.end = uint32_t(uint64_t(G) * (h + 1) / nHalves);
         const uint32_t seats = hf.end - hf.begin;
@@ -847,12 +849,6 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         g.active = false;
         g.outcome = 255;
     };
-    auto sync = [&]() -> int {
-        const auto g0 = std::chrono::steady_clock::now();
-        SPX_SP_HIP(hipStreamSynchronize(stream));
-        gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
-        return SPX_OK;
-    };
 
     // With the whole ply's children fitting the context's batch capacity the chain below needs no host round trip: the
     // update reads its record count on the device (spx_acc_update_eval_device_counted). Otherwise the count is fetched
@@ -863,6 +859,19 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     // pool, one RNG stream per game; NnueState::reset of their accumulators), move generation, fused update+eval of the
     // children, move choice, and the per-game results on their way back. Ends with the half's event.
     auto enqueuePly = [&](DeviceHalf& hf) -> int {
+        // everything of this half runs on its own lane of the context (scratch set + stream): the small kernels of one
+        // half's chain overlap the other half's update kernel, the update kernels themselves are chained
+        void* laneStream = nullptr;
+        int lr = ctxLaneBegin(ctx, int(hf.index), &laneStream);
+        if (lr != SPX_OK) return lr;
+        struct LaneGuard {
+            spx_ctx* c;
+            int i;
+            ~LaneGuard() {
+                ctxLaneEnd(c, i);
+            }
+        } laneGuard{ctx, int(hf.index)};
+        hipStream_t stream = static_cast<hipStream_t>(laneStream);  // shadows the driver's own stream inside this ply
         uint32_t n = 0, fresh = 0;
         retire.clear();
         for (uint32_t i = hf.begin; i < hf.end; ++i) {
@@ -927,7 +936,7 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
                                                    hf.dEvals, stream);
             if (r != SPX_OK) return r;
         } else {
-            if ((r = sync()) != SPX_OK) return r;
+            SPX_SP_HIP(hipStreamSynchronize(stream));
             const size_t total = std::min<size_t>(*hf.hTotal, hf.cap);
             for (size_t lo = 0; lo < total; lo += ctxMaxBatch(ctx)) {
                 const size_t m = std::min(ctxMaxBatch(ctx), total - lo);
@@ -1053,7 +1062,7 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
         phase[0] += std::chrono::duration<double>(a1 - a0).count();
         phase[1] += std::chrono::duration<double>(a2 - a1).count();
     }
-    (void)hipStreamSynchronize(stream);  // nothing may still reference the staging buffers on an error exit
+    (void)spx_ctx_synchronize(ctx);  // nothing may still reference the staging buffers on an error exit
     stats->steps = (stats->steps + nHalves - 1) / nHalves;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
