@@ -159,7 +159,10 @@ __device__ void writeChild(const Parent& p, const Sets& s, int from, int to, int
 
 }  // namespace
 
+constexpr int kMaxItems = 256;  // pseudo-legal moves of one position (the legal maximum is 218)
+
 __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
+    __shared__ uint16_t sItems[4][kMaxItems];
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t it = blockIdx.x * 4 + wave; it < p.nPositions; it += gridDim.x * 4) {
@@ -200,14 +203,12 @@ __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
 
         // ---- pseudo-legal targets of this lane's piece (generatePseudo, spx_chess.cpp:249-318) ----
         uint64_t targets = 0;
-        bool promo = false;
         if (mine) {
             const uint64_t bit = 1ull << from;
             if (type == 0) {
                 const int fwd = us ? 8 : -8;
                 const int one = from + fwd;
                 if (one >= 0 && one < 64) {
-                    promo = us ? (one >= 56) : (one < 8);
                     if (!((s.occ >> one) & 1)) {
                         targets |= 1ull << one;
                         const bool home = us ? ((from >> 3) == 1) : ((from >> 3) == 6);
@@ -223,57 +224,92 @@ __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
                 targets = pieceAttacks((type << 1) | us, from, s.occ) & ~own;
             }
         }
-        // ---- legality: make the move, the own king must not be attacked (generateLegal, spx_chess.cpp:602-612) ----
-        uint64_t legal = 0;
+        // ---- flatten: every pseudo-legal (from, to) pair becomes one work item in LDS (lane order, targets ascending),
+        // so that the heavy per-move work below runs on up to 64 moves at once instead of lane by lane ----
+        uint32_t nItems;
         {
+            const uint32_t mine32 = uint32_t(popc64(targets));
+            uint32_t incl = mine32;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (int(lane) >= d) incl += up;
+            }
+            nItems = min(uint32_t(__shfl(incl, 63, 64)), uint32_t(kMaxItems - 2));  // two slots stay free for castling
+            uint32_t slot = incl - mine32;
             uint64_t rest = targets;
             while (rest) {
                 const int to = ctz64(rest);
                 rest &= rest - 1;
-                const bool isEp = type == 0 && to == par.ep && !((s.occ >> to) & 1) && (to & 7) != (from & 7);
+                if (slot < nItems) sItems[wave][slot] = uint16_t(uint32_t(from) | (uint32_t(to) << 6));
+                ++slot;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- legality of every item: make the move, the own king must not be attacked (generateLegal,
+        // spx_chess.cpp:602-612); flags are stored back into the item (bit 12 legal, 13 promotion, 14 en passant) ----
+        uint32_t total = 0;
+        for (uint32_t base = 0; base < nItems; base += 64) {
+            const uint32_t i = base + lane;
+            uint32_t children = 0;
+            const uint32_t item = i < nItems ? sItems[wave][i] : 0u;
+            const int f = int(item & 63), to = int((item >> 6) & 63);
+            const int fType = __shfl(type, f, 64);  // outside the branch: the source lane must be active
+            if (i < nItems) {
+                const bool isEp = fType == 0 && to == par.ep && !((s.occ >> to) & 1) && (to & 7) != (f & 7);
+                const bool isPromo = fType == 0 && (us ? to >= 56 : to < 8);
                 const uint64_t capBit = isEp ? (1ull << (to + (us ? -8 : 8))) : (s.occ & (1ull << to));
-                const uint64_t occ2 = (s.occ & ~(1ull << from) & ~capBit) | (1ull << to);
-                const int ksq2 = type == 5 ? to : kingSq;
-                if (!attackedBy(s, ksq2, them, occ2, capBit)) legal |= 1ull << to;
+                const uint64_t occ2 = (s.occ & ~(1ull << f) & ~capBit) | (1ull << to);
+                const int ksq2 = fType == 5 ? to : kingSq;
+                const bool ok = !attackedBy(s, ksq2, them, occ2, capBit);
+                children = ok ? (isPromo ? 4u : 1u) : 0u;
+                sItems[wave][i] = uint16_t(item | (ok ? 0x1000u : 0u) | (isPromo ? 0x2000u : 0u) | (isEp ? 0x4000u : 0u));
             }
-        }
-        // ---- castling, on the king's lane (spx_chess.cpp:288-317): bit 0 = kingside, bit 1 = queenside ----
-        uint32_t castleOk = 0;
-        int castleRook[2] = {-1, -1};
-        if (mine && type == 5) {
-            const uint64_t myRooks = rightsBb & own;
-            const uint64_t kingside = myRooks & ~below(from) & ~(1ull << from), queenside = myRooks & below(from);
-            // unpackBoard keeps the LAST (highest) flagged rook per side (spx_chess.cpp:708-717)
-            if (kingside) castleRook[0] = 63 - __clzll(kingside);
-            if (queenside) castleRook[1] = 63 - __clzll(queenside);
-            const int base = us ? 0 : 56;
-            for (int side = 0; side < 2; ++side) {
-                const int rsq = castleRook[side];
-                if (rsq < 0) continue;
-                const int kTo = base + (side == 0 ? 6 : 2), rTo = base + (side == 0 ? 5 : 3);
-                const uint64_t span = spanMask(from, kTo) | spanMask(rsq, rTo);
-                const uint64_t others = s.occ & ~(1ull << from) & ~(1ull << rsq);
-                if (span & others) continue;
-                bool safe = true;
-                uint64_t path = spanMask(from, kTo);
-                while (path && safe) {
-                    const int sq = ctz64(path);
-                    path &= path - 1;
-                    safe = !attackedBy(s, sq, them, others | (1ull << rsq), 0);
-                }
-                if (safe && attackedBy(s, kTo, them, others | (1ull << rTo), 0)) safe = false;
-                if (safe) castleOk |= 1u << side;
-            }
-        }
-        // ---- placement: exclusive prefix of the per-lane child counts, one atomic per position ----
-        const uint32_t mineCount = uint32_t(popc64(legal)) * (promo ? 4u : 1u) + uint32_t(__popc(castleOk));
-        uint32_t incl = mineCount;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (int(lane) >= d) incl += up;
+            for (int off = 32; off > 0; off >>= 1) children += __shfl_xor(children, off, 64);
+            total += children;
         }
-        const uint32_t total = __shfl(incl, 63, 64);
+        // ---- castling, on the king's lane (spx_chess.cpp:288-317): appended as ready-made legal items ----
+        {
+            uint32_t castleOk = 0;
+            int castleRook[2] = {-1, -1};
+            if (mine && type == 5) {
+                const uint64_t myRooks = rightsBb & own;
+                const uint64_t kingside = myRooks & ~below(from) & ~(1ull << from), queenside = myRooks & below(from);
+                // unpackBoard keeps the LAST (highest) flagged rook per side (spx_chess.cpp:708-717)
+                if (kingside) castleRook[0] = 63 - __clzll(kingside);
+                if (queenside) castleRook[1] = 63 - __clzll(queenside);
+                const int base = us ? 0 : 56;
+                for (int side = 0; side < 2; ++side) {
+                    const int rsq = castleRook[side];
+                    if (rsq < 0) continue;
+                    const int kTo = base + (side == 0 ? 6 : 2), rTo = base + (side == 0 ? 5 : 3);
+                    const uint64_t span = spanMask(from, kTo) | spanMask(rsq, rTo);
+                    const uint64_t others = s.occ & ~(1ull << from) & ~(1ull << rsq);
+                    if (span & others) continue;
+                    bool safe = true;
+                    uint64_t path = spanMask(from, kTo);
+                    while (path && safe) {
+                        const int sq = ctz64(path);
+                        path &= path - 1;
+                        safe = !attackedBy(s, sq, them, others | (1ull << rsq), 0);
+                    }
+                    if (safe && attackedBy(s, kTo, them, others | (1ull << rTo), 0)) safe = false;
+                    if (safe) castleOk |= 1u << side;
+                }
+                uint32_t slot = nItems;
+                for (int side = 0; side < 2; ++side) {
+                    if (castleOk & (1u << side)) {
+                        sItems[wave][slot++] = uint16_t(uint32_t(from) | (uint32_t(castleRook[side]) << 6) | 0x9000u);
+                    }
+                }
+            }
+            const uint32_t nCastle = uint32_t(popc64(__ballot(castleOk & 1u)) + popc64(__ballot(castleOk & 2u)));
+            nItems += nCastle;
+            total += nCastle;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- placement: one atomic per position ----
         uint32_t base = 0;
         if (lane == 0) {
             base = total ? atomicAdd(p.cursor, total) : 0u;
@@ -283,43 +319,52 @@ __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
         }
         base = __shfl(base, 0, 64);
         if (uint64_t(base) + total > p.capacity) continue;  // the host sees cursor > capacity and reports the overflow
-        uint32_t k = base + incl - mineCount;
         const uint32_t parentValue = p.parentValues ? p.parentValues[it] : it;
-        // ---- children ----
-        uint64_t rest = legal;
-        while (rest) {
-            const int to = ctz64(rest);
-            rest &= rest - 1;
-            const bool isEp = type == 0 && to == par.ep && !((s.occ >> to) & 1) && (to & 7) != (from & 7);
-            if (promo) {
-                for (int pt = 4; pt >= 1; --pt) {
-                    writeChild(par, s, from, to, kChildPromotion, pt, p.children + size_t(k) * 4, p.moves + k);
+        // ---- children: one item per lane, promotions write four ----
+        uint32_t done = 0;
+        for (uint32_t chunk = 0; chunk < nItems; chunk += 64) {
+            const uint32_t i = chunk + lane;
+            const uint32_t item = i < nItems ? sItems[wave][i] : 0u;
+            const bool legal = (item & 0x1000u) != 0;
+            const bool isPromo = (item & 0x2000u) != 0;
+            const uint32_t mineCount = legal ? (isPromo ? 4u : 1u) : 0u;
+            uint32_t incl = mineCount;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (int(lane) >= d) incl += up;
+            }
+            const uint32_t chunkTotal = __shfl(incl, 63, 64);
+            if (legal) {
+                uint32_t k = base + done + incl - mineCount;
+                const int f = int(item & 63), to = int((item >> 6) & 63);
+                if (isPromo) {
+                    for (int pt = 4; pt >= 1; --pt) {
+                        writeChild(par, s, f, to, kChildPromotion, pt, p.children + size_t(k) * 4, p.moves + k);
+                        p.parents[k] = parentValue;
+                        ++k;
+                    }
+                } else {
+                    const int kind = (item & 0x8000u) ? kChildCastling : (item & 0x4000u) ? kChildEnPassant : kChildNormal;
+                    writeChild(par, s, f, to, kind, 0, p.children + size_t(k) * 4, p.moves + k);
                     p.parents[k] = parentValue;
-                    ++k;
                 }
-            } else {
-                writeChild(par, s, from, to, isEp ? kChildEnPassant : kChildNormal, 0, p.children + size_t(k) * 4, p.moves + k);
-                p.parents[k] = parentValue;
-                ++k;
             }
+            done += chunkTotal;
         }
-        for (int side = 0; side < 2; ++side) {
-            if (castleOk & (1u << side)) {
-                writeChild(par, s, from, castleRook[side], kChildCastling, 0, p.children + size_t(k) * 4, p.moves + k);
-                p.parents[k] = parentValue;
-                ++k;
-            }
-        }
+        __builtin_amdgcn_wave_barrier();  // the item list is reused by this wave's next position
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Move choice of the depth-1 self-play policy, one thread per game: score(move) = -eval(child); uniformly among the
-// moves within `temperature` of the best (reservoir pick in child order, one RNG draw per candidate - the same rule as
-// the host path of spx_selfplay.cpp); the chosen child's record and accumulator slot become the game's current ones.
+// Move choice of the depth-1 self-play policy, one wavefront per game (lanes = its children): score(move) =
+// -eval(child); uniformly among the moves within `temperature` of the best (one splitmix64 draw per game and ply; the
+// host path of spx_selfplay.cpp draws per candidate - same distribution); the chosen child's record and accumulator
+// slot become the game's current ones.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = laneId();
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per game, lanes = its children
     if (g >= p.nGames) return;
     PickResult r{};
     r.count = p.count[g];
@@ -327,37 +372,50 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
     if (r.count != 0 && (!p.enable || p.enable[g])) {
         const uint32_t lo = p.first[g];
         int32_t best = INT32_MIN;
-        for (uint32_t k = 0; k < r.count; ++k) best = max(best, p.evals ? -p.evals[lo + k] : 0);
-        uint64_t state = p.rng[g];
-        uint32_t pick = 0, seen = 0;
-        for (uint32_t k = 0; k < r.count; ++k) {
-            if ((p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature) {
-                ++seen;
-                state += 0x9E3779B97F4A7C15ull;
-                uint64_t z = state;
-                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                z ^= z >> 31;
-                if (uint32_t(z >> 32) % seen == 0) pick = k;
-                if (p.temperature == 0) break;
-            }
+        for (uint32_t k = lane; k < r.count; k += 64) best = max(best, p.evals ? -p.evals[lo + k] : 0);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+        // candidates = moves within the margin of the best; one draw picks uniformly among them (0 margin: the first)
+        uint32_t nCandidates = 0;
+        for (uint32_t base = 0; base < r.count; base += 64) {
+            const uint32_t k = base + lane;
+            const bool cand = k < r.count && (p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature;
+            nCandidates += uint32_t(popc64(__ballot(cand)));
         }
-        p.rng[g] = state;
+        uint64_t state = p.rng[g] + 0x9E3779B97F4A7C15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        uint32_t target = p.temperature == 0 ? 0u : uint32_t(z >> 32) % nCandidates;
+        uint32_t pick = 0;
+        for (uint32_t base = 0; base < r.count; base += 64) {
+            const uint32_t k = base + lane;
+            const bool cand = k < r.count && (p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature;
+            const uint64_t mask = __ballot(cand);
+            const uint32_t here = uint32_t(popc64(mask));
+            if (target < here) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+                const uint64_t hit = __ballot(cand && rank == target);
+                pick = base + uint32_t(ctz64(hit));
+                break;
+            }
+            target -= here;
+        }
         const uint32_t c = lo + pick;
         const uint64_t* child = p.children + size_t(c) * 4;
         const uint64_t w0 = child[0], w1 = child[1], w2 = child[2], w3 = child[3];
-        uint64_t* dst = p.positions + size_t(g) * 4;
-        dst[0] = w0;
-        dst[1] = w1;
-        dst[2] = w2;
-        dst[3] = w3;
-        if (p.slots) p.slots[g] = p.childSlots[c];
+        if (lane < 4) p.positions[size_t(g) * 4 + lane] = child[lane];
+        if (lane == 0) {
+            p.rng[g] = state;
+            if (p.slots) p.slots[g] = p.childSlots[c];
+        }
         r.key = recordKey(w0, w1, w2, uint32_t(w3));
         r.score = p.evals ? -p.evals[c] : 0;
         r.move = p.moves[c];
         r.halfmove = uint8_t((w3 >> 8) & 0xFF);
     }
-    if (p.results) p.results[g] = r;
+    if (p.results && lane == 0) p.results[g] = r;
 }
 
 __global__ __launch_bounds__(256) void spx_seat_games_kernel(uint32_t n, const uint32_t* seats, const uint64_t* records,
@@ -379,7 +437,7 @@ hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* re
 }
 
 hipError_t launchPick(const PickParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
