@@ -83,6 +83,9 @@ struct spx_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t ftDone = nullptr, done = nullptr;
         bool ftRecorded = false;
+        // staging of the chunked host-buffer call (allocated on its first use): device in/out + page-locked mirrors
+        void *dIn = nullptr, *hIn = nullptr;
+        int32_t *dOutStage = nullptr, *hOut = nullptr;
     } lanes[2];
     bool lanesReady = false;
     unsigned laneNext = 0;
@@ -409,7 +412,9 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
-                            lane.dPosOrder};
+                            lane.dPosOrder, lane.dIn, lane.dOutStage};
+        if (lane.hIn) (void)hipHostFree(lane.hIn);
+        if (lane.hOut) (void)hipHostFree(lane.hOut);
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
@@ -1037,6 +1042,55 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
         SPX_HIP(hipStreamSynchronize(ctx->stream));
         std::memcpy(out, scores, n * sizeof(int32_t));
         return SPX_OK;
+    }
+    if (n > ctx->maxBatch) {
+        // More than one chunk of the context's capacity (rescoring a data set): the chunks alternate between the two
+        // lanes - while one chunk is evaluated, the next is copied into page-locked staging and sent over PCIe and the
+        // previous one's scores come back; FT kernels chained as in spx_eval_full_device_async.
+        int rc = ensureLanes(ctx);
+        if (rc != SPX_OK) return rc;
+        for (auto& lane : ctx->lanes) {
+            if (lane.dIn) continue;
+            SPX_HIP(hipMalloc(&lane.dIn, ctx->maxBatch * sizeof(spx_packed_pos)));
+            SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dOutStage), ctx->maxBatch * sizeof(int32_t)));
+            SPX_HIP(hipHostMalloc(&lane.hIn, ctx->maxBatch * sizeof(spx_packed_pos), hipHostMallocDefault));
+            SPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&lane.hOut), ctx->maxBatch * sizeof(int32_t), hipHostMallocDefault));
+        }
+        struct Pending {
+            size_t lo = 0, m = 0;
+            bool active = false;
+        } pending[2];
+        auto drain = [&](int li) -> int {
+            if (!pending[li].active) return SPX_OK;
+            SPX_HIP(hipEventSynchronize(ctx->lanes[li].done));
+            std::memcpy(out + pending[li].lo, ctx->lanes[li].hOut, pending[li].m * sizeof(int32_t));
+            pending[li].active = false;
+            return SPX_OK;
+        };
+        int li = 0;
+        for (size_t lo = 0; lo < n; lo += ctx->maxBatch, li ^= 1) {
+            const size_t m = std::min(ctx->maxBatch, n - lo);
+            if ((rc = drain(li)) != SPX_OK) return rc;
+            spx_ctx::EvalLane& lane = ctx->lanes[li];
+            spx_ctx::EvalLane& other = ctx->lanes[li ^ 1];
+            std::memcpy(lane.hIn, positions + lo, m * sizeof(spx_packed_pos));
+            SPX_HIP(hipMemcpyAsync(lane.dIn, lane.hIn, m * sizeof(spx_packed_pos), hipMemcpyHostToDevice, lane.stream));
+            swapLane(ctx, lane);
+            ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
+            ctx->ftGateRecord = lane.ftDone;
+            rc = spx_eval_full_device(ctx, lane.dIn, m, lane.dOutStage, lane.stream);
+            ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+            swapLane(ctx, lane);
+            if (rc != SPX_OK) return rc;
+            lane.ftRecorded = true;
+            SPX_HIP(hipMemcpyAsync(lane.hOut, lane.dOutStage, m * sizeof(int32_t), hipMemcpyDeviceToHost, lane.stream));
+            SPX_HIP(hipEventRecord(lane.done, lane.stream));
+            pending[li].lo = lo;
+            pending[li].m = m;
+            pending[li].active = true;
+        }
+        if ((rc = drain(0)) != SPX_OK) return rc;
+        return drain(1);
     }
     // host buffers of any length: processed in chunks of the context's capacity (device variants are strict)
     for (size_t lo = 0; lo < n; lo += ctx->maxBatch) {

@@ -257,6 +257,11 @@ def test_pipelined_async_calls_equal_the_synchronous_path(sp, oracle, net_blob):
                 assert np.array_equal(d_out[i], wants[i]), (rep, i)
         # the synchronous entry points still work on the same context afterwards
         assert np.array_equal(st.evaluate_once(batches[2]), wants[2])
+        # a host buffer larger than the context's capacity is chunked over the same two lanes (copies of one chunk
+        # overlap the evaluation of its neighbours)
+        big = np.concatenate(batches * 2)
+        assert len(big) > 4 * 20000
+        assert np.array_equal(st.evaluate_once(big), np.concatenate(wants * 2))
     finally:
         st.close()
         for q in ptrs:

@@ -30,6 +30,14 @@ for _ in range(reps):
 dt = time.perf_counter() - t0
 out["host_buffer_evals_per_s"] = N * reps / dt
 
+# 1b) a host buffer of 16 chunks: the library pipelines the chunks over its two lanes (copies overlap evaluation)
+big = np.tile(pos, 16)
+state.evaluate_once(big)
+t0 = time.perf_counter()
+for _ in range(3):
+    state.evaluate_once(big)
+out["host_buffer_16_chunks_evals_per_s"] = len(big) * 3 / (time.perf_counter() - t0)
+
 # 2) small batches (latency of one synchronous call)
 for n in (1, 64, 1024, 4096, 8192):
     for _ in range(5):
