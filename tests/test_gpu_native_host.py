@@ -13,6 +13,13 @@ EXE = os.path.join(ROOT, "stormphrax_amd", "spx_raweval")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def native_program():
+    if not os.path.exists(EXE):  # normally built by __graft_entry__.build(); hipcc is on the GPU box too
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "stormphrax_amd", "csrc")], stdout=subprocess.DEVNULL)
+    assert os.path.exists(EXE)
+
+
 @pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
 def test_raweval_matches_reference_goldens(preset):
     recs = [json.loads(line) for line in open(os.path.join(GOLDEN, "evals.jsonl"))]
