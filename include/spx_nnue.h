@@ -265,8 +265,14 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * Batched self-play driver (BASELINE config 4 shape; control flow of src/datagen/datagen.cpp:96-318): n_games concurrent
  * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),
  * i.e. a depth-1 "search" - Stormphrax's alpha-beta search is out of scope), random 8-9 ply openings, the reference's
- * adjudication counters, viriformat game records appended to out_path (NULL = discard). Needs spx_ctx with
- * max_batch >= 1; reserves n_games * 193 arena slots (129 with host move generation). Scores are raw network outputs from the mover's point of view.
+ * adjudication counters, viriformat game records appended to out_path (NULL = discard). Scores are raw network outputs
+ * from the mover's point of view.
+ * Default: the games live on the GPU - legal moves and child records from spx_movegen, openings generated in bulk by the
+ * same kernels, the move choice on the device, the two halves of the seats on the context's two lanes; the host keeps
+ * the adjudication counters and the records (24 bytes per game and ply come back). SPX_SELFPLAY_HOST_MOVEGEN selects
+ * the host chess core for moves and openings instead. Needs a context whose max_batch holds a ply's children
+ * (48 * n_games is always enough; smaller contexts fall back to chunked updates); reserves n_games * 193 arena slots
+ * (129 with host move generation).
  * Multi-GPU: games are independent - run one process per GPU with its own seed / slice of games.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_selfplay_params {

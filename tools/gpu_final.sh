@@ -6,11 +6,14 @@ OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $REPO
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+python bench.py --no-pipeline --no-cpu-baseline > $OUT/bench_n1_strict_stream_order.json 2> $OUT/bench_strict.err
 python bench.py --mode incremental --no-cpu-baseline > $OUT/bench_incremental_n1.json 2> $OUT/bench_incremental_n1.err
 python bench.py --batch 4194304 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_n1_batch4M.json 2> $OUT/bench_4m.err
 python tools/gpu_measure.py > $OUT/secondary.json 2> $OUT/secondary.err
 python tools/spx_selfplay.py --games 4096 --target 8192 > $OUT/selfplay_4096.json 2> $OUT/selfplay.err
 python tools/spx_selfplay.py --games 16384 --target 32768 > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 1024 --target 2048 > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
+python tools/gpu_movegen_rate.py > $OUT/movegen_rate.json 2>> $OUT/selfplay.err
 python tools/spx_selfplay.py --games 4096 --target 8192 --host-movegen > $OUT/selfplay_4096_host_movegen.json 2>> $OUT/selfplay.err
 python tools/gpu_latency.py > $OUT/latency.txt 2>&1
 bash tools/gpu_profile.sh $TAG > /dev/null 2>&1
