@@ -49,3 +49,28 @@ def test_product_never_references_the_oracle():
                     text = open(os.path.join(dirpath, name), errors="replace").read()
                     assert "libspx_oracle" not in text and "spxo_" not in text and "oracle/" not in text.replace(
                         "the CPU oracle lives in oracle/", ""), os.path.join(dirpath, name)
+
+
+def test_cpp_mirror_header_compiles_standalone():
+    """include/spx_nnue.hpp (the C++ mirror of eval::NnueState) is self-contained: it compiles with a plain host
+    compiler, without HIP headers, against the C ABI header alone."""
+    import subprocess
+
+    src = '#include "spx_nnue.hpp"\nint main() { return sizeof(spx_nnue::NnueState) > 0 ? 0 : 1; }\n'
+    out = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I",
+                          os.path.join(ROOT, "include"), "-x", "c++", "-"], input=src, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """The evaluator has no CPU path: on a box without a HIP device bench.py says so instead of measuring something else."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
