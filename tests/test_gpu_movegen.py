@@ -101,3 +101,46 @@ def test_capacity_overflow_is_reported(sp, st):
     pos = sp.random_positions(64, seed=3)
     with pytest.raises(_lib.SpxError):
         st.movegen(pos, capacity=100)
+
+
+def test_garbage_records_do_not_fault(sp, st):
+    """Random bytes instead of records (no kings, 64 occupied squares, codes 7 / 15): the generator and the incremental
+    kernels stay inside their buffers - results for such records are unspecified, results for the valid ones around them
+    are not disturbed (hot calls never validate per position, like the reference, which only asserts)."""
+    good = sp.random_positions(512, seed=8, min_ply=0, max_ply=100, dfrc_every=3)
+    bad = good.copy()
+    rng = np.random.default_rng(6)
+    raw = bad.view(np.uint8).reshape(-1, 32)
+    for i in range(0, 512, 4):
+        raw[i] = rng.integers(0, 256, 32, dtype=np.uint8)
+    raw[8] = 0xFF
+    raw[12] = 0
+    want = st.movegen(good, capacity=512 * 256)
+    try:
+        got = st.movegen(bad, capacity=512 * 256)
+    except Exception:  # a capacity overflow from nonsense positions is a legitimate answer
+        got = None
+    if got is not None:
+        for i in range(512):
+            if i % 4 == 0:
+                continue
+            lo, n = int(got["first"][i]), int(got["count"][i])
+            wlo, wn = int(want["first"][i]), int(want["count"][i])
+            assert n == wn
+            a = sorted((int(m), c.tobytes()) for m, c in zip(got["moves"][lo:lo + n], got["children"][lo:lo + n]))
+            b = sorted((int(m), c.tobytes()) for m, c in zip(want["moves"][wlo:wlo + wn], want["children"][wlo:wlo + wn]))
+            assert a == b
+    # incremental kernels: garbage parents / children among valid pairs
+    st.reserve_slots(2048)
+    slots = np.arange(512, dtype=np.uint32)
+    st.reset(bad, slots)                                  # refresh from garbage records
+    nxt, moved = sp.random_successors(good, seed=2)
+    mixed = nxt.copy()
+    mixed[1::4] = bad[0::4]                               # garbage children for valid parents
+    out = st.update_evaluate(slots, slots + 1024, mixed)  # parents 0,4,8.. hold garbage records themselves
+    full = st.evaluate_once(nxt)
+    ok = np.ones(512, dtype=bool)
+    ok[0::4] = False
+    ok[1::4] = False
+    assert np.array_equal(out[ok], full[ok])
+    assert np.array_equal(st.evaluate_once(good), st.evaluate_once(good.copy()))  # the context is still healthy
