@@ -58,13 +58,17 @@ typedef struct spx_packed_pos {
 /* ------------------------------------------------------------------------------------------------------------------
  * Network (replaces eval::init / eval::getNetwork / eval::shutdown, src/eval/nnue.h:38-44, nnue.cpp:200-321).
  * `blob` is a CBNF file image: 64-byte header (src/eval/header.h:38-52) + arrays in the order of
- * preprocess/permute.cpp:33-56, in LOGICAL (unpermuted) column order, uncompressed. Validation mirrors
- * nnue.cpp:85-185. The blob is copied; the caller may free it after the call.
+ * preprocess/permute.cpp:33-56, in LOGICAL (unpermuted) column order - either plain, or with header flag 0x0001 and
+ * the payload as one zstd frame (the form Stormphrax's release nets ship in, nnue.cpp:213-247; inflated through the
+ * system's libzstd.so.1, loaded on demand). Validation mirrors nnue.cpp:85-185. The blob is copied; the caller may
+ * free it after the call.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_net spx_net;
 int spx_net_load(const void* blob, size_t nbytes, spx_net** out);
 void spx_net_free(spx_net* net);
 const char* spx_net_name(const spx_net* net); /* eval::defaultNetworkName, nnue.h:44 */
+/* FNV-1a 64 of the logical (uncompressed) payload: the same for a net loaded from its plain and from its zstd image */
+uint64_t spx_net_digest(const spx_net* net);
 
 /* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
  * 2 extreme (i16 accumulator wraps too). Writes spx_synth_net_bytes() bytes. */

@@ -3,6 +3,8 @@
 // SPX_ERR_NO_DEVICE (the CPU oracle lives in oracle/ and is test infrastructure only).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -177,13 +179,34 @@ int validateHeader(const unsigned char* h, std::string& name) {
         setError("wrong number of output buckets " + std::to_string(outputBuckets) + " (expected: 8)");
         return SPX_ERR_BAD_NET;
     }
-    if (flags & kFlagZstd) {
-        // the reference inflates these with its vendored zstd decoder (nnue.cpp:219-247); no decoder is linked here
-        setError("zstd-compressed network: decompress to the raw CBNF image first");
-        return SPX_ERR_BAD_NET;
-    }
     name.assign(reinterpret_cast<const char*>(h + 16), nameLen < 48 ? nameLen : 48);
     return SPX_OK;
+}
+
+// zstd-compressed nets (header flag 0x0001, nnue.cpp:213-247): the 64-byte header stays plain, the payload is one zstd
+// frame of the logical (unpermuted) arrays. The reference inflates it with its vendored decoder; here the system's
+// libzstd is loaded on first need (no link-time dependency, no headers: three functions with a stable C ABI).
+struct ZstdApi {
+    size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+    unsigned (*isError)(size_t) = nullptr;
+    const char* (*getErrorName)(size_t) = nullptr;
+};
+
+const ZstdApi* zstdApi() {
+    static const ZstdApi api = [] {
+        ZstdApi z;
+        for (const char* lib : {"libzstd.so.1", "libzstd.so"}) {
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_LOCAL)) {
+                z.decompress = reinterpret_cast<decltype(z.decompress)>(dlsym(h, "ZSTD_decompress"));
+                z.isError = reinterpret_cast<decltype(z.isError)>(dlsym(h, "ZSTD_isError"));
+                z.getErrorName = reinterpret_cast<decltype(z.getErrorName)>(dlsym(h, "ZSTD_getErrorName"));
+                if (z.decompress && z.isError && z.getErrorName) break;
+                z = ZstdApi{};
+            }
+        }
+        return z;
+    }();
+    return api.decompress ? &api : nullptr;
 }
 
 // Threat table relayout: +128 bias (so widening is a zero-extend) and per-lane column interleave: the 16 bytes lane
@@ -252,13 +275,38 @@ int spx_net_load(const void* blob, size_t nbytes, spx_net** out) {
     if (rc != SPX_OK) {
         return rc;
     }
-    if (nbytes < kNetFileBytes) {
-        setError("Default network too small? " + std::to_string(nbytes - kHeaderBytes) + " < " +
-                 std::to_string(kNetFileBytes - kHeaderBytes));  // nnue.cpp:252-255
-        return SPX_ERR_BAD_NET;
-    }
     auto net = std::make_unique<spx_net>();
-    net->blob.assign(static_cast<const unsigned char*>(blob), static_cast<const unsigned char*>(blob) + kNetFileBytes);
+    const auto* bytes = static_cast<const unsigned char*>(blob);
+    uint16_t flags;
+    std::memcpy(&flags, bytes + 6, 2);
+    if (flags & kFlagZstd) {
+        const ZstdApi* z = zstdApi();
+        if (!z) {
+            setError("zstd-compressed network, and libzstd.so.1 could not be loaded: decompress to the raw CBNF image first");
+            return SPX_ERR_BAD_NET;
+        }
+        net->blob.resize(kNetFileBytes);
+        std::memcpy(net->blob.data(), bytes, kHeaderBytes);
+        net->blob[6] = static_cast<unsigned char>(flags & ~kFlagZstd);  // the image kept in memory is the plain one
+        const size_t got = z->decompress(net->blob.data() + kHeaderBytes, kNetFileBytes - kHeaderBytes,
+                                         bytes + kHeaderBytes, nbytes - kHeaderBytes);
+        if (z->isError(got)) {
+            setError(std::string("Failed to decompress default network: ") + z->getErrorName(got));  // nnue.cpp:236-239
+            return SPX_ERR_BAD_NET;
+        }
+        if (got < kNetFileBytes - kHeaderBytes) {
+            setError("Decompressed default network too small? " + std::to_string(got) + " < " +
+                     std::to_string(kNetFileBytes - kHeaderBytes));  // nnue.cpp:241-244
+            return SPX_ERR_BAD_NET;
+        }
+    } else {
+        if (nbytes < kNetFileBytes) {
+            setError("Default network too small? " + std::to_string(nbytes - kHeaderBytes) + " < " +
+                     std::to_string(kNetFileBytes - kHeaderBytes));  // nnue.cpp:252-255
+            return SPX_ERR_BAD_NET;
+        }
+        net->blob.assign(bytes, bytes + kNetFileBytes);
+    }
     net->name = name;
     *out = net.release();
     return SPX_OK;
@@ -270,6 +318,10 @@ void spx_net_free(spx_net* net) {
 
 const char* spx_net_name(const spx_net* net) {
     return net ? net->name.c_str() : "";
+}
+
+uint64_t spx_net_digest(const spx_net* net) {
+    return net ? fnv1a64(net->blob.data() + kHeaderBytes, net->blob.size() - kHeaderBytes) : 0;
 }
 
 size_t spx_synth_net_bytes(void) {

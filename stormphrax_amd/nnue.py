@@ -70,6 +70,11 @@ class Network:
     def name(self):
         return _lib.load().spx_net_name(self._h).decode()
 
+    @property
+    def digest(self):
+        """FNV-1a 64 of the logical payload (identical for the plain and the zstd-compressed image of a net)."""
+        return int(_lib.load().spx_net_digest(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

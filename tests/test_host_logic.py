@@ -117,7 +117,7 @@ def test_net_validation_mirrors_reference(sp, net_blob):
     expect(lambda b: b.__setitem__(13, 16), "threat inputs")
     expect(lambda b: b.__setitem__(13, 0x80 | 8), "wrong number of input buckets")
     expect(lambda b: b.__setitem__(14, 4), "wrong number of output buckets")
-    expect(lambda b: b.__setitem__(6, 0x0F), "zstd")
+    expect(lambda b: b.__setitem__(6, 0x0F), "Failed to decompress")  # flagged as zstd but the payload is not a frame
     with pytest.raises(_lib.SpxError) as err:
         sp.Network(good[: good.size - 64])
     assert "too small" in str(err.value)
@@ -212,3 +212,33 @@ def test_legal_moves_enumeration_matches_perft_and_viriformat(sp):
     (mate,) = sp.positions_from_fens(["R6k/6pp/8/8/8/8/8/4K3 b - - 0 1"])
     moves, _, in_check = sp.legal_moves(mate)
     assert len(moves) == 0 and in_check
+
+
+def test_zstd_compressed_net_image_loads_like_the_plain_one(sp):
+    """Release nets ship zstd-compressed: header flag 0x0001, plain 64-byte header, payload = one zstd frame of the
+    logical arrays (nnue.cpp:213-247). Compressed here with the system's libzstd through ctypes."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        pytest.skip("no libzstd.so.1 on this box")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    plain = sp.synthetic_net_bytes("wild")
+    payload = np.ascontiguousarray(plain[64:])
+    cap = z.ZSTD_compressBound(payload.size)
+    comp = np.empty(cap, dtype=np.uint8)
+    n = z.ZSTD_compress(comp.ctypes.data, cap, payload.ctypes.data, payload.size, 1)
+    assert 0 < n < cap
+    packed = np.concatenate([plain[:64], comp[:n]])
+    packed[6] |= 0x01
+    a, b = sp.Network(plain), sp.Network(packed)
+    assert a.name == b.name and a.digest == b.digest != 0
+    with pytest.raises(_lib.SpxError) as err:          # truncated frame
+        sp.Network(packed[: 64 + n // 2])
+    assert "decompress" in str(err.value).lower()
