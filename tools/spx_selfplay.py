@@ -33,7 +33,9 @@ def main():
     args = ap.parse_args()
     group = Group(backend="gloo")
     net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
-    state = sp.NnueState(net, device=group.local_rank, max_batch=args.games * 64)
+    # SPX_BENCH_SHARE_GPU=1 (debug, as in bench.py): every rank on GPU 0, to exercise the N > 1 control flow on one GPU
+    device = 0 if os.environ.get("SPX_BENCH_SHARE_GPU") == "1" else group.local_rank
+    state = sp.NnueState(net, device=device, max_batch=args.games * 64)
     out = f"{args.out}.{group.rank}.vf" if args.out else None
     stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
                            temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads,
@@ -41,13 +43,14 @@ def main():
     slowest = group.max_float(stats["seconds"])
     total = {k: group.sum_int(stats[k]) for k in ("games", "positions", "evals", "steps")}
     gpu_seconds = group.max_float(stats["gpu_seconds"])
+    outcomes = [group.sum_int(v) for v in stats["outcomes"]]
     if group.rank == 0:
         print(json.dumps({
             "metric": "selfplay_leaf_evals_per_sec", "value": total["evals"] / slowest, "unit": "evals/s",
             "n_gpus": group.world, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
             "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
-            "outcomes_white_loss_draw_win": stats["outcomes"], "host_threads": args.threads or "auto",
+            "outcomes_white_loss_draw_win": outcomes, "host_threads": args.threads or "auto",
             "move_generation": "host chess core" if args.host_movegen else "device (spx_movegen_kernel)",
             "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
         }))
