@@ -90,6 +90,8 @@ struct spx_ctx {
         int32_t *dOutStage = nullptr, *hOut = nullptr;
     } lanes[2];
     bool lanesReady = false;
+    bool lanesUnavailable = false;   // the lanes did not fit into the device memory: async calls run stream-ordered
+    hipEvent_t fallbackDone = nullptr;
     unsigned laneNext = 0;
     hipEvent_t ftGateWait = nullptr, ftGateRecord = nullptr;  // set around a lane's call: FT waits / signals
     size_t tinyBatchMax = 0;       // spx_eval_full*: batches up to this size skip the sorts (one MLP tile per position)
@@ -461,6 +463,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
+    if (ctx->fallbackDone) (void)hipEventDestroy(ctx->fallbackDone);
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
@@ -621,14 +624,46 @@ static int ensureLanes(spx_ctx* ctx) {
     return SPX_OK;
 }
 
+static void releaseLanes(spx_ctx* ctx) {
+    for (auto& lane : ctx->lanes) {
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+        void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
+                            lane.dPosOrder, lane.dIn, lane.dOutStage};
+        for (void* q : lanePtrs) {
+            if (q) (void)hipFree(q);
+        }
+        if (lane.hIn) (void)hipHostFree(lane.hIn);
+        if (lane.hOut) (void)hipHostFree(lane.hOut);
+        if (lane.ftDone) (void)hipEventDestroy(lane.ftDone);
+        if (lane.done) (void)hipEventDestroy(lane.done);
+        if (lane.stream) (void)hipStreamDestroy(lane.stream);
+        lane = spx_ctx::EvalLane{};
+    }
+    ctx->lanesReady = false;
+}
+
 int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event) {
     if (!ctx) {
         setError("spx_eval_full_device_async: null context");
         return SPX_ERR_INVALID_ARG;
     }
     SPX_HIP(hipSetDevice(ctx->device));
-    int rc = ensureLanes(ctx);
-    if (rc != SPX_OK) return rc;
+    int rc = ctx->lanesUnavailable ? SPX_ERR_HIP : ensureLanes(ctx);
+    if (rc != SPX_OK) {
+        // no room for a second scratch set (a context sized to fill the HBM): same results, stream-ordered on the
+        // context's own stream
+        if (!ctx->lanesUnavailable) {
+            (void)hipGetLastError();
+            releaseLanes(ctx);
+            ctx->lanesUnavailable = true;
+            if (!ctx->fallbackDone) SPX_HIP(hipEventCreateWithFlags(&ctx->fallbackDone, hipEventDisableTiming));
+        }
+        rc = spx_eval_full_device(ctx, d_positions, n, d_out, ctx->stream);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipEventRecord(ctx->fallbackDone, ctx->stream));
+        if (done_event) *done_event = ctx->fallbackDone;
+        return SPX_OK;
+    }
     spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
     spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
     ++ctx->laneNext;
@@ -1095,12 +1130,16 @@ int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32
         std::memcpy(out, scores, n * sizeof(int32_t));
         return SPX_OK;
     }
-    if (n > ctx->maxBatch) {
+    if (n > ctx->maxBatch && !ctx->lanesUnavailable && ensureLanes(ctx) != SPX_OK) {
+        (void)hipGetLastError();  // no room for the lanes: plain chunk loop below
+        releaseLanes(ctx);
+        ctx->lanesUnavailable = true;
+    }
+    if (n > ctx->maxBatch && !ctx->lanesUnavailable) {
         // More than one chunk of the context's capacity (rescoring a data set): the chunks alternate between the two
         // lanes - while one chunk is evaluated, the next is copied into page-locked staging and sent over PCIe and the
         // previous one's scores come back; FT kernels chained as in spx_eval_full_device_async.
-        int rc = ensureLanes(ctx);
-        if (rc != SPX_OK) return rc;
+        int rc = SPX_OK;
         for (auto& lane : ctx->lanes) {
             if (lane.dIn) continue;
             SPX_HIP(hipMalloc(&lane.dIn, ctx->maxBatch * sizeof(spx_packed_pos)));
