@@ -243,6 +243,13 @@ int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t
  * spx_viri_random_game writes one random game (test / demo input; scores are random). */
 int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, size_t capacity,
                     size_t* n_positions, size_t* n_games);
+/* The same expansion on the device (one thread per game replays the moves on the packed records): byte-identical output
+ * for well-formed streams, two to three orders of magnitude faster than the host replay, which validates every move
+ * against the legal-move generator - this one trusts the stream as the reference's own reader does; *bad_games counts
+ * games that hit a move whose from-square holds no piece of the side to move (the rest of such a game repeats the
+ * last position). `bad_games` may be NULL. */
+int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity,
+                        size_t* n_positions, size_t* n_games, size_t* bad_games);
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 uint64_t spx_perft(const char* fen, int depth);
 

@@ -102,6 +102,8 @@ SYMBOLS = {
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_eval_full_device_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_ctx_synchronize": (ctypes.c_int, [_P]),
+    "spx_viri_expand_gpu": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                           ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_movegen": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_movegen_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_pos_legal_moves": (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -1628,6 +1628,89 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
     return SPX_OK;
 }
 
+// viriformat expansion on the device: the host only finds the game boundaries (one linear scan for the 4-byte null
+// terminators), a thread per game replays the moves (spx_viri_expand_kernel)
+int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity,
+                        size_t* n_positions, size_t* n_games, size_t* bad_games) {
+    if (!ctx || !data || !n_positions) {
+        setError("spx_viri_expand_gpu: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const auto* p = static_cast<const unsigned char*>(data);
+    std::vector<uint64_t> gameOffset, outOffset;
+    size_t off = 0, count = 0;
+    while (off + sizeof(spx_packed_pos) + 4 <= nbytes) {
+        gameOffset.push_back(off);
+        outOffset.push_back(count);
+        off += sizeof(spx_packed_pos);
+        for (;;) {
+            if (off + 4 > nbytes) {
+                setError("spx_viri_expand_gpu: truncated game " + std::to_string(gameOffset.size() - 1));
+                return SPX_ERR_INVALID_ARG;
+            }
+            uint32_t word;
+            std::memcpy(&word, p + off, 4);
+            off += 4;
+            if (word == 0) break;  // null move + null score
+            ++count;
+        }
+    }
+    outOffset.push_back(count);
+    *n_positions = count;
+    if (n_games) *n_games = gameOffset.size();
+    if (bad_games) *bad_games = 0;
+    if (!out || count == 0) return SPX_OK;
+    if (count > capacity) {
+        setError("spx_viri_expand_gpu: output capacity exceeded");
+        return SPX_ERR_CAPACITY;
+    }
+    if (gameOffset.size() > 0xFFFFFFFFull) {
+        setError("spx_viri_expand_gpu: too many games in one call");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    struct Scratch {
+        std::vector<void*> ptrs;
+        ~Scratch() {
+            for (void* q : ptrs) (void)hipFree(q);
+        }
+        void* get(size_t bytes) {
+            void* q = nullptr;
+            if (hipMalloc(&q, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+            ptrs.push_back(q);
+            return q;
+        }
+    } scratch;
+    void* dData = scratch.get(off);
+    void* dGameOffset = scratch.get(gameOffset.size() * 8);
+    void* dOutOffset = scratch.get(outOffset.size() * 8);
+    void* dOut = scratch.get(count * sizeof(spx_packed_pos));
+    void* dBad = scratch.get(4);
+    if (!dData || !dGameOffset || !dOutOffset || !dOut || !dBad) {
+        setError("spx_viri_expand_gpu: out of device memory");
+        return SPX_ERR_HIP;
+    }
+    hipStream_t s = ctx->stream;
+    SPX_HIP(hipMemcpyAsync(dData, data, off, hipMemcpyHostToDevice, s));
+    SPX_HIP(hipMemcpyAsync(dGameOffset, gameOffset.data(), gameOffset.size() * 8, hipMemcpyHostToDevice, s));
+    SPX_HIP(hipMemcpyAsync(dOutOffset, outOffset.data(), outOffset.size() * 8, hipMemcpyHostToDevice, s));
+    SPX_HIP(hipMemsetAsync(dBad, 0, 4, s));
+    ViriExpandParams vp{};
+    vp.data = static_cast<const uint8_t*>(dData);
+    vp.nGames = uint32_t(gameOffset.size());
+    vp.gameOffset = static_cast<const uint64_t*>(dGameOffset);
+    vp.outOffset = static_cast<const uint64_t*>(dOutOffset);
+    vp.out = static_cast<uint64_t*>(dOut);
+    vp.badGames = static_cast<uint32_t*>(dBad);
+    SPX_HIP(launchViriExpand(vp, s));
+    uint32_t bad = 0;
+    SPX_HIP(hipMemcpyAsync(out, dOut, count * sizeof(spx_packed_pos), hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    if (bad_games) *bad_games = bad;
+    return SPX_OK;
+}
+
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes) {
     if (!buf || !nbytes || plies < 0) {
         setError("spx_viri_random_game: invalid argument");

@@ -107,6 +107,15 @@ struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)
     int32_t temperature;            // pick uniformly among the moves within this margin of the best (0 = first best)
 };
 
+struct ViriExpandParams {          // spx_viri_expand_kernel (spx_movegen.hip)
+    const uint8_t* data;            // the viriformat stream
+    uint32_t nGames;
+    const uint64_t* gameOffset;     // [nGames] byte offset of each game's 32-byte start record
+    const uint64_t* outOffset;      // [nGames + 1] index of each game's first output record (prefix sum of its moves)
+    uint64_t* out;                  // records as u64[4]
+    uint32_t* badGames;             // counter: games with a move whose from-square holds no piece of the side to move
+};
+
 struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
@@ -142,6 +151,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);
 // seats[k] of the self-play state receive record k, slot = seat id, RNG state k (games that start this ply)
 hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,

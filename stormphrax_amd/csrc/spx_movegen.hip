@@ -436,6 +436,87 @@ hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* re
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// viriformat game streams -> one record per played move, on the device (src/datagen/viriformat.cpp:28-63; what
+// Marlinformat::push would have stored, marlinformat.cpp:31-36): one THREAD per game replays its moves on the packed
+// record itself (writeChild = makeMove + packBoard) and stores the position BEFORE every move with eval = the recorded
+// score and wdl = the game's outcome. The stream is trusted like the reference's own reader trusts it; only a
+// from-square without a piece of the side to move is counted (badGames) and ends that game's replay.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spx_viri_expand_kernel(ViriExpandParams p) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.nGames) return;
+    const uint8_t* game = p.data + p.gameOffset[g];
+    uint64_t rec[4];
+    for (int w = 0; w < 4; ++w) {  // byte-wise: games start at 4-byte, not 8-byte, boundaries
+        uint64_t v = 0;
+        for (int b = 0; b < 8; ++b) v |= uint64_t(game[8 * w + b]) << (8 * b);
+        rec[w] = v;
+    }
+    const uint64_t wdlBits = rec[3] & (0xFFull << 48);  // byte 30: the game's outcome
+    const uint64_t first = p.outOffset[g], count = p.outOffset[g + 1] - first;
+    const uint8_t* moves = game + 32;
+    for (uint64_t k = 0; k < count; ++k) {
+        const uint32_t mv = uint32_t(moves[4 * k]) | (uint32_t(moves[4 * k + 1]) << 8);
+        const uint32_t score = uint32_t(moves[4 * k + 2]) | (uint32_t(moves[4 * k + 3]) << 8);
+        uint64_t* dst = p.out + (first + k) * 4;
+        dst[0] = rec[0];
+        dst[1] = rec[1];
+        dst[2] = rec[2];
+        dst[3] = (rec[3] & 0x00000000FFFFFFFFull) | (uint64_t(score) << 32) | wdlBits;  // eval = score, wdl, extra = 0
+        // the position after the move
+        Parent par;
+        par.occ = rec[0];
+        par.nibbles = (u128(rec[2]) << 64) | rec[1];
+        const uint32_t tail = uint32_t(rec[3]);
+        par.us = (tail & 0x80u) ? 0 : 1;
+        par.ep = int(tail & 0x7Fu);
+        par.halfmove = (tail >> 8) & 0xFFu;
+        par.fullmove = (tail >> 16) & 0xFFFFu;
+        Sets s{};  // writeChild only looks at the pawns and the colours (the en-passant square of a double push)
+        s.occ = par.occ;
+        {
+            uint64_t occ = par.occ;
+            u128 nib = par.nibbles;
+            while (occ) {
+                const int sq = ctz64(occ);
+                occ &= occ - 1;
+                const uint32_t n = uint32_t(nib) & 0xFu;
+                nib >>= 4;
+                if ((n & 7u) == 0u) s.pawns |= 1ull << sq;
+                if (!(n & 8u)) s.white |= 1ull << sq;
+            }
+        }
+        const int from = int(mv & 63u), to = int((mv >> 6) & 63u);
+        const uint32_t type = mv >> 14;  // 0 normal, 1 en passant, 2 castling, 3 promotion (viriformat.cpp:37-52)
+        const int kind = type == 0 ? kChildNormal : type == 1 ? kChildEnPassant : type == 2 ? kChildCastling : kChildPromotion;
+        const bool ownPiece = ((par.occ >> from) & 1) && (((s.white >> from) & 1) == uint64_t(par.us));
+        if (!ownPiece) {
+            atomicAdd(p.badGames, 1u);
+            for (uint64_t r = k + 1; r < count; ++r) {  // keep the output defined: the rest of the game repeats this position
+                uint64_t* rest = p.out + (first + r) * 4;
+                rest[0] = dst[0];
+                rest[1] = dst[1];
+                rest[2] = dst[2];
+                rest[3] = dst[3];
+            }
+            return;
+        }
+        uint64_t next[4];
+        uint16_t ignored;
+        writeChild(par, s, from, to, kind, int((mv >> 12) & 3u) + 1, next, &ignored);
+        rec[0] = next[0];
+        rec[1] = next[1];
+        rec[2] = next[2];
+        rec[3] = next[3];
+    }
+}
+
+hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_viri_expand_kernel, dim3((p.nGames + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launchPick(const PickParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();

@@ -121,6 +121,19 @@ class NnueState:
                                      None if corr is None else corr.ctypes.data, out.ctypes.data))
         return out
 
+    def viri_expand(self, blob):
+        """viriformat game stream -> one record per played move, replayed on the device (spx_viri_expand_gpu).
+        -> (records, games, bad_games)."""
+        data = np.frombuffer(blob, dtype=np.uint8)
+        n, games, bad = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        lib = _lib.load()
+        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, None, 0, ctypes.byref(n), ctypes.byref(games),
+                                      ctypes.byref(bad)))
+        out = np.zeros(n.value, dtype=PACKED_DTYPE)
+        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, out.ctypes.data, n.value, ctypes.byref(n),
+                                      ctypes.byref(games), ctypes.byref(bad)))
+        return out, games.value, bad.value
+
     def movegen(self, positions, parent_values=None, capacity=None):
         """Legal moves + child records of every position, generated on the device (spx_movegen).
         -> dict(children, moves, parents, first, count, in_check)."""
@@ -228,6 +241,12 @@ class NnueState:
         out = np.empty((n, 1024), dtype=np.uint8)
         check(_lib.load().spx_debug_copy_ft(self._h, n, out.ctypes.data))
         return out
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -144,3 +144,36 @@ def test_garbage_records_do_not_fault(sp, st):
     ok[1::4] = False
     assert np.array_equal(out[ok], full[ok])
     assert np.array_equal(st.evaluate_once(good), st.evaluate_once(good.copy()))  # the context is still healthy
+
+
+def test_viriformat_expansion_on_the_device_matches_the_host_replay(sp, st):
+    """spx_viri_expand_gpu (one thread per game replays the moves on the packed records) against the host expander,
+    which validates every move with the legal-move generator: byte-identical records over random games with castling
+    (standard and Chess960), en passant and promotions; self-play output of the driver goes through the same check."""
+    import time
+
+    blob = b"".join(sp.viri_random_game(3000 + seed, plies=180, dfrc=(seed % 3 == 0)) for seed in range(300))
+    t0 = time.perf_counter()
+    want, games = sp.viri_expand(blob)
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    got, games_gpu, bad = st.viri_expand(blob)
+    t_gpu = time.perf_counter() - t0
+    assert games_gpu == games == 300 and bad == 0 and len(got) == len(want) > 20000
+    assert got.tobytes() == want.tobytes()
+    kinds = set()
+    off = 0
+    while off < len(blob):   # every move type occurs in the input
+        off += 32
+        while blob[off:off + 4] != b"\x00\x00\x00\x00":
+            kinds.add(blob[off + 1] >> 6)
+            off += 4
+        off += 4
+    assert kinds == {0, 1, 2, 3}
+    print(f"viri expand: host {len(want) / t_host:.3e} positions/s, device path {len(got) / t_gpu:.3e} (incl. copies)")
+    # a corrupted move (from-square without a piece of the side to move) is counted, not followed
+    broken = bytearray(blob)
+    broken[32] = 27 | (broken[32] & 0xC0)  # first move of the first game now starts on d4 - empty in every start position
+    broken[33] &= 0xF0
+    _, _, bad = st.viri_expand(bytes(broken))
+    assert bad == 1

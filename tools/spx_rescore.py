@@ -25,14 +25,23 @@ def main():
     ap.add_argument("--preset", default="tame")
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--validate", action="store_true",
+                    help=".vf input: replay the games on the host and check every move against the legal-move generator "
+                         "(~5e5 positions/s) instead of the device replay, which trusts the stream")
     args = ap.parse_args()
     raw = open(args.src, "rb").read()
+    net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
     if args.src.endswith(".vf"):
-        positions, games = sp.viri_expand(raw)
+        if args.validate:
+            positions, games = sp.viri_expand(raw)
+        else:
+            with sp.NnueState(net, device=args.device, max_batch=1) as expander:
+                positions, games, bad = expander.viri_expand(raw)
+            if bad:
+                print(f"warning: {bad} games contain a move from a square without a piece of the side to move", file=sys.stderr)
         print(f"{games} games -> {len(positions)} positions")
     else:
         positions = np.frombuffer(raw, dtype=sp.PACKED_DTYPE).copy()
-    net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
     state = sp.NnueState(net, device=args.device, max_batch=min(args.batch, max(len(positions), 1)))
     evals = state.evaluate_once(positions)  # chunked internally
     positions["eval"] = np.clip(evals, -32768, 32767).astype(np.int16)
