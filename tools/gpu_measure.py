@@ -123,4 +123,15 @@ dt = (time.perf_counter() - t0) / 5
 out["trace_64k_replay_ms"] = dt * 1e3
 out["trace_64k_updates_plus_evals_per_s"] = (trace.n_nodes - 1 + len(trace.evals)) / dt
 out["trace_64k_matches_reference"] = bool(np.array_equal(got, ref_inc))
+# 5) viriformat -> records: host replay (validating) vs device replay (incl. the copies both ways)
+blob = b"".join(sp.viri_random_game(7000 + s, plies=160, dfrc=(s % 4 == 0)) for s in range(2000))
+t0 = time.perf_counter()
+host_pos, _ = sp.viri_expand(blob)
+out["viri_expand_host_positions_per_s"] = len(host_pos) / (time.perf_counter() - t0)
+state.viri_expand(blob)
+t0 = time.perf_counter()
+for _ in range(5):
+    dev_pos, _, _ = state.viri_expand(blob)
+out["viri_expand_device_positions_per_s"] = len(dev_pos) * 5 / (time.perf_counter() - t0)
+out["viri_expand_identical"] = bool(dev_pos.tobytes() == host_pos.tobytes())
 print(json.dumps(out))
