@@ -239,17 +239,20 @@ int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, 
 int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);
 /* viriformat game streams (src/datagen/viriformat.cpp:28-63: PackedBoard + {u16 move, i16 score}* + 4 zero bytes per
  * game) -> one record per played move (the position BEFORE the move, `eval` = the recorded score, `wdl` = the game's
- * outcome), i.e. what Marlinformat::push would have stored (marlinformat.cpp:31-36). Pass out = NULL to count only.
- * spx_viri_random_game writes one random game (test / demo input; scores are random). */
-int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, size_t capacity,
-                    size_t* n_positions, size_t* n_games);
+ * outcome). `unfiltered` (optional, one byte per record) tells which of them the reference's marlinformat output keeps:
+ * Marlinformat::push drops a position when the side to move is in check or the played move is noisy - a capture, an
+ * en passant or a queen promotion (datagen.cpp:254, position.cpp:683-689, marlinformat.cpp:31-36): 1 = stored, 0 =
+ * filtered. Pass out = NULL to count only. spx_viri_random_game writes one random game (test / demo input; scores are
+ * random). */
+int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, uint8_t* unfiltered,
+                    size_t capacity, size_t* n_positions, size_t* n_games);
 /* The same expansion on the device (one thread per game replays the moves on the packed records): byte-identical output
  * for well-formed streams, two to three orders of magnitude faster than the host replay, which validates every move
  * against the legal-move generator - this one trusts the stream as the reference's own reader does; *bad_games counts
  * games that hit a move whose from-square holds no piece of the side to move (the rest of such a game repeats the
  * last position). `bad_games` may be NULL. */
-int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity,
-                        size_t* n_positions, size_t* n_games, size_t* bad_games);
+int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, uint8_t* unfiltered,
+                        size_t capacity, size_t* n_positions, size_t* n_games, size_t* bad_games);
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 uint64_t spx_perft(const char* fen, int depth);
 

@@ -102,7 +102,7 @@ SYMBOLS = {
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_eval_full_device_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_ctx_synchronize": (ctypes.c_int, [_P]),
-    "spx_viri_expand_gpu": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+    "spx_viri_expand_gpu": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                            ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_movegen": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_movegen_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
@@ -123,7 +123,7 @@ SYMBOLS = {
     "spx_acc_update_observed_device": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_random_successors": (ctypes.c_int, [ctypes.c_uint64, _P, ctypes.c_size_t, _P, _P]),
-    "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),

@@ -1575,8 +1575,8 @@ static uint16_t viriEncodeMove(const Move& m) {
     return uint16_t(m.from | (m.to << 6) | ((m.kind == kPromotion ? m.promo - 1 : 0) << 12) | kTypes[m.kind]);
 }
 
-int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, size_t capacity,
-                    size_t* n_positions, size_t* n_games) {
+int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, uint8_t* unfiltered,
+                    size_t capacity, size_t* n_positions, size_t* n_games) {
     if (!data || !n_positions) {
         setError("spx_viri_expand: null argument");
         return SPX_ERR_INVALID_ARG;
@@ -1617,6 +1617,11 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
                 out[count].eval = score;
                 out[count].wdl = initial.wdl;
                 if (scores) scores[count] = score;
+                if (unfiltered) {  // datagen.cpp:254: filtered = pos.isCheck() || pos.isNoisy(move) (position.cpp:683-689)
+                    const bool noisy = m.kind != kCastling && (m.kind == kEnPassant || (m.kind == kPromotion && m.promo == 4) ||
+                                                                b.mailbox[m.to] != kNoPiece);
+                    unfiltered[count] = (b.inCheck() || noisy) ? 0 : 1;
+                }
             }
             ++count;
             makeMove(b, m);
@@ -1630,8 +1635,8 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
 
 // viriformat expansion on the device: the host only finds the game boundaries (one linear scan for the 4-byte null
 // terminators), a thread per game replays the moves (spx_viri_expand_kernel)
-int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity,
-                        size_t* n_positions, size_t* n_games, size_t* bad_games) {
+int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, uint8_t* unfiltered,
+                        size_t capacity, size_t* n_positions, size_t* n_games, size_t* bad_games) {
     if (!ctx || !data || !n_positions) {
         setError("spx_viri_expand_gpu: null argument");
         return SPX_ERR_INVALID_ARG;
@@ -1686,7 +1691,8 @@ int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packe
     void* dOutOffset = scratch.get(outOffset.size() * 8);
     void* dOut = scratch.get(count * sizeof(spx_packed_pos));
     void* dBad = scratch.get(4);
-    if (!dData || !dGameOffset || !dOutOffset || !dOut || !dBad) {
+    void* dKeep = unfiltered ? scratch.get(count) : nullptr;
+    if (!dData || !dGameOffset || !dOutOffset || !dOut || !dBad || (unfiltered && !dKeep)) {
         setError("spx_viri_expand_gpu: out of device memory");
         return SPX_ERR_HIP;
     }
@@ -1701,11 +1707,13 @@ int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packe
     vp.gameOffset = static_cast<const uint64_t*>(dGameOffset);
     vp.outOffset = static_cast<const uint64_t*>(dOutOffset);
     vp.out = static_cast<uint64_t*>(dOut);
+    vp.unfiltered = static_cast<uint8_t*>(dKeep);
     vp.badGames = static_cast<uint32_t*>(dBad);
     SPX_HIP(launchViriExpand(vp, s));
     uint32_t bad = 0;
     SPX_HIP(hipMemcpyAsync(out, dOut, count * sizeof(spx_packed_pos), hipMemcpyDeviceToHost, s));
     SPX_HIP(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, s));
+    if (unfiltered) SPX_HIP(hipMemcpyAsync(unfiltered, dKeep, count, hipMemcpyDeviceToHost, s));
     SPX_HIP(hipStreamSynchronize(s));
     if (bad_games) *bad_games = bad;
     return SPX_OK;

@@ -113,6 +113,8 @@ struct ViriExpandParams {          // spx_viri_expand_kernel (spx_movegen.hip)
     const uint64_t* gameOffset;     // [nGames] byte offset of each game's 32-byte start record
     const uint64_t* outOffset;      // [nGames + 1] index of each game's first output record (prefix sum of its moves)
     uint64_t* out;                  // records as u64[4]
+    uint8_t* unfiltered;            // optional, per record: 1 = Marlinformat::push would store it (not in check, the
+                                    // played move not noisy: datagen.cpp:254, marlinformat.cpp:31-36), 0 = filtered
     uint32_t* badGames;             // counter: games with a move whose from-square holds no piece of the side to move
 };
 

@@ -473,23 +473,37 @@ __global__ __launch_bounds__(256) void spx_viri_expand_kernel(ViriExpandParams p
         par.ep = int(tail & 0x7Fu);
         par.halfmove = (tail >> 8) & 0xFFu;
         par.fullmove = (tail >> 16) & 0xFFFFu;
-        Sets s{};  // writeChild only looks at the pawns and the colours (the en-passant square of a double push)
+        Sets s{};
         s.occ = par.occ;
         {
             uint64_t occ = par.occ;
             u128 nib = par.nibbles;
             while (occ) {
-                const int sq = ctz64(occ);
+                const uint64_t bit = occ & (~occ + 1);
                 occ &= occ - 1;
                 const uint32_t n = uint32_t(nib) & 0xFu;
                 nib >>= 4;
-                if ((n & 7u) == 0u) s.pawns |= 1ull << sq;
-                if (!(n & 8u)) s.white |= 1ull << sq;
+                const uint32_t t = n & 7u;
+                if (t == 0u) s.pawns |= bit;
+                else if (t == 1u) s.knights |= bit;
+                else if (t == 2u) s.bishops |= bit;
+                else if (t == 3u || t == 6u) s.rooks |= bit;
+                else if (t == 4u) s.queens |= bit;
+                else if (t == 5u) s.kings |= bit;
+                if (!(n & 8u)) s.white |= bit;
             }
         }
         const int from = int(mv & 63u), to = int((mv >> 6) & 63u);
         const uint32_t type = mv >> 14;  // 0 normal, 1 en passant, 2 castling, 3 promotion (viriformat.cpp:37-52)
         const int kind = type == 0 ? kChildNormal : type == 1 ? kChildEnPassant : type == 2 ? kChildCastling : kChildPromotion;
+        if (p.unfiltered) {  // datagen.cpp:254: filtered = pos.isCheck() || pos.isNoisy(move) (position.cpp:683-689)
+            const uint64_t ownKing = s.kings & (par.us ? s.white : ~s.white);
+            const bool inCheck = ownKing && attackedBy(s, ctz64(ownKing), par.us ^ 1, par.occ, 0);
+            const bool noisy = kind != kChildCastling &&
+                               (kind == kChildEnPassant || (kind == kChildPromotion && ((mv >> 12) & 3u) == 3u) ||
+                                ((par.occ >> to) & 1));
+            p.unfiltered[first + k] = (inCheck || noisy) ? 0 : 1;
+        }
         const bool ownPiece = ((par.occ >> from) & 1) && (((s.white >> from) & 1) == uint64_t(par.us));
         if (!ownPiece) {
             atomicAdd(p.badGames, 1u);
@@ -499,6 +513,7 @@ __global__ __launch_bounds__(256) void spx_viri_expand_kernel(ViriExpandParams p
                 rest[1] = dst[1];
                 rest[2] = dst[2];
                 rest[3] = dst[3];
+                if (p.unfiltered) p.unfiltered[first + r] = 0;
             }
             return;
         }

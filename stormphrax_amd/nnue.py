@@ -121,18 +121,20 @@ class NnueState:
                                      None if corr is None else corr.ctypes.data, out.ctypes.data))
         return out
 
-    def viri_expand(self, blob):
+    def viri_expand(self, blob, with_filter=False):
         """viriformat game stream -> one record per played move, replayed on the device (spx_viri_expand_gpu).
-        -> (records, games, bad_games)."""
+        -> (records, games, bad_games[, unfiltered mask: what the reference's marlinformat output would keep])."""
         data = np.frombuffer(blob, dtype=np.uint8)
         n, games, bad = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         lib = _lib.load()
-        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, None, 0, ctypes.byref(n), ctypes.byref(games),
-                                      ctypes.byref(bad)))
-        out = np.zeros(n.value, dtype=PACKED_DTYPE)
-        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, out.ctypes.data, n.value, ctypes.byref(n),
+        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, None, None, 0, ctypes.byref(n),
                                       ctypes.byref(games), ctypes.byref(bad)))
-        return out, games.value, bad.value
+        out = np.zeros(n.value, dtype=PACKED_DTYPE)
+        keep = np.zeros(n.value, dtype=np.uint8) if with_filter else None
+        check(lib.spx_viri_expand_gpu(self._h, data.ctypes.data, data.size, out.ctypes.data,
+                                      None if keep is None else keep.ctypes.data, n.value, ctypes.byref(n),
+                                      ctypes.byref(games), ctypes.byref(bad)))
+        return (out, games.value, bad.value, keep.astype(bool)) if with_filter else (out, games.value, bad.value)
 
     def movegen(self, positions, parent_values=None, capacity=None):
         """Legal moves + child records of every position, generated on the device (spx_movegen).
@@ -312,15 +314,18 @@ def random_successors(positions, seed=1):
     return out, moved.astype(bool)
 
 
-def viri_expand(data):
-    """viriformat game stream (bytes) -> (positions before each played move with eval/wdl filled, n_games)."""
+def viri_expand(data, with_filter=False):
+    """viriformat game stream (bytes) -> (positions before each played move with eval/wdl filled, n_games[, unfiltered
+    mask: the positions the reference's marlinformat output would keep])."""
     lib = _lib.load()
     buf = np.frombuffer(data, dtype=np.uint8)
     n, g = ctypes.c_size_t(), ctypes.c_size_t()
-    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, None, None, 0, ctypes.byref(n), ctypes.byref(g)))
+    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, None, None, None, 0, ctypes.byref(n), ctypes.byref(g)))
     out = np.zeros(n.value, dtype=PACKED_DTYPE)
-    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, out.ctypes.data, None, n.value, ctypes.byref(n), ctypes.byref(g)))
-    return out, g.value
+    keep = np.zeros(n.value, dtype=np.uint8) if with_filter else None
+    check(lib.spx_viri_expand(buf.ctypes.data, buf.size, out.ctypes.data, None, None if keep is None else keep.ctypes.data,
+                              n.value, ctypes.byref(n), ctypes.byref(g)))
+    return (out, g.value, keep.astype(bool)) if with_filter else (out, g.value)
 
 
 def viri_random_game(seed, plies=80, dfrc=False):

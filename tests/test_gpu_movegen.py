@@ -161,6 +161,10 @@ def test_viriformat_expansion_on_the_device_matches_the_host_replay(sp, st):
     t_gpu = time.perf_counter() - t0
     assert games_gpu == games == 300 and bad == 0 and len(got) == len(want) > 20000
     assert got.tobytes() == want.tobytes()
+    # the marlinformat filter (in check / noisy move) computed on the device equals the host's
+    _, _, keep_host = sp.viri_expand(blob, with_filter=True)
+    _, _, _, keep_gpu = st.viri_expand(blob, with_filter=True)
+    assert np.array_equal(keep_gpu, keep_host) and 0.3 < keep_host.mean() < 0.95
     kinds = set()
     off = 0
     while off < len(blob):   # every move type occurs in the input

@@ -242,3 +242,37 @@ def test_zstd_compressed_net_image_loads_like_the_plain_one(sp):
     with pytest.raises(_lib.SpxError) as err:          # truncated frame
         sp.Network(packed[: 64 + n // 2])
     assert "decompress" in str(err.value).lower()
+
+
+def test_marlinformat_filter_flags(sp):
+    """`unfiltered` of the viriformat expander = the positions Marlinformat::push keeps (datagen.cpp:254,
+    position.cpp:683-689): side to move not in check, played move not a capture / en passant / queen promotion."""
+    import struct
+
+    blob = b"".join(sp.viri_random_game(50 + s, plies=150, dfrc=(s % 2 == 0)) for s in range(12))
+    positions, games, keep = sp.viri_expand(blob, with_filter=True)
+    assert games == 12 and len(keep) == len(positions)
+    # recompute from the stream: the move words in order, the position records in order
+    words, off = [], 0
+    while off < len(blob):
+        off += 32
+        while blob[off:off + 4] != b"\x00\x00\x00\x00":
+            words.append(struct.unpack_from("<H", blob, off)[0])
+            off += 4
+        off += 4
+    assert len(words) == len(positions)
+    seen = {"check": 0, "capture": 0, "ep": 0, "queen_promo": 0, "under_promo": 0, "castle": 0, "quiet": 0}
+    for rec, mv, kept in zip(positions, words, keep):
+        kind, to, promo = mv >> 14, (mv >> 6) & 63, (mv >> 12) & 3
+        _, _, in_check = sp.legal_moves(rec)
+        occupied = (int(rec["occupancy"]) >> to) & 1
+        noisy = kind != 2 and (kind == 1 or (kind == 3 and promo == 3) or occupied)
+        assert bool(kept) == (not (in_check or noisy))
+        seen["check"] += in_check
+        seen["ep"] += kind == 1
+        seen["castle"] += kind == 2
+        seen["queen_promo"] += kind == 3 and promo == 3
+        seen["under_promo"] += kind == 3 and promo != 3
+        seen["capture"] += bool(kind in (0, 3) and occupied)
+        seen["quiet"] += bool(kept)
+    assert seen["check"] > 0 and seen["capture"] > 0 and seen["quiet"] > 0, seen

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--preset", default="tame")
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--filter", action="store_true",
+                    help=".vf input: keep only the positions the reference's marlinformat output keeps (side to move not in "
+                         "check, played move not a capture / en passant / queen promotion: datagen.cpp:254)")
     ap.add_argument("--validate", action="store_true",
                     help=".vf input: replay the games on the host and check every move against the legal-move generator "
                          "(~5e5 positions/s) instead of the device replay, which trusts the stream")
@@ -33,13 +36,16 @@ def main():
     net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
     if args.src.endswith(".vf"):
         if args.validate:
-            positions, games = sp.viri_expand(raw)
+            positions, games, keep = sp.viri_expand(raw, with_filter=True)
         else:
             with sp.NnueState(net, device=args.device, max_batch=1) as expander:
-                positions, games, bad = expander.viri_expand(raw)
+                positions, games, bad, keep = expander.viri_expand(raw, with_filter=True)
             if bad:
                 print(f"warning: {bad} games contain a move from a square without a piece of the side to move", file=sys.stderr)
-        print(f"{games} games -> {len(positions)} positions")
+        total = len(positions)
+        if args.filter:
+            positions = positions[keep]
+        print(f"{games} games -> {total} positions" + (f", {len(positions)} after filtering" if args.filter else ""))
     else:
         positions = np.frombuffer(raw, dtype=sp.PACKED_DTYPE).copy()
     state = sp.NnueState(net, device=args.device, max_batch=min(args.batch, max(len(positions), 1)))
