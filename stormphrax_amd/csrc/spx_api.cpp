@@ -97,6 +97,7 @@ struct spx_ctx {
     size_t tinyBatchMax = 0;       // spx_eval_full*: batches up to this size skip the sorts (one MLP tile per position)
     void* hTinyIo = nullptr;       // page-locked, device-mapped staging of the tiny-batch host call: records, then scores
     size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
+    size_t streamAccMin = 0;       // spx_update_kernel: records from which the arena is accessed non-temporally
     size_t updateSplitMax = 0;     // spx_update_kernel: records up to which the perspectives get separate waves
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
@@ -426,6 +427,8 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
     ctx->updateSplitMax = 262144;
+    ctx->streamAccMin = 32768;
+    if (const char* env = std::getenv("SPX_STREAM_ACC_MIN")) ctx->streamAccMin = size_t(std::atoll(env));
     ctx->mlpShareMax = 8192;
     ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 28, 1 024: 68 -> 37, 2 048: 73 -> 47, 4 096: 93 -> 71, 8 192: 126 -> 117
     if (const char* env = std::getenv("SPX_TINY_BATCH_MAX")) ctx->tinyBatchMax = size_t(std::atoll(env));
@@ -794,7 +797,7 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
     up.slotRecords = ctx->dSlotRecords;
     {
         const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
-        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
+        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, s));
     }
     return SPX_OK;
 }
@@ -840,7 +843,7 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
     {
         const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
         if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // lanes: the big kernels are chained
-        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, s));
+        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, s));
         if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     }
     if (!d_count && n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);

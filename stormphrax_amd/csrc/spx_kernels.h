@@ -150,7 +150,8 @@ struct MlpParams {
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
-hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, hipStream_t stream);
+hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
+                        hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);

@@ -33,6 +33,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_FT_WAVES_PER_SIMD
 #define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
+#ifndef SPX_STREAM_LOADS
+#define SPX_STREAM_LOADS 0
+#endif
 #ifndef SPX_UPDATE_SPLIT_WAVES
 #define SPX_UPDATE_SPLIT_WAVES 4
 #endif
@@ -355,6 +358,13 @@ __device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
 
 // Accumulator arena slot: [colour 0: i16[1024]][colour 1: i16[1024]] = 4 KiB, natural column order. Lane l owns
 // columns {8l..8l+7} (16 B at 16l) and {512+8l..} (16 B at 1024+16l) - the same split as a piece-square row.
+// kStream: child accumulators of a big batch are written once and, if at all, read much later - non-temporal stores
+// keep those 4 KiB per update from evicting the weight rows out of L2 (65 536 updates: 454 -> 444 us per ply, self-play
+// +3-4 %); small batches (<= 16 384: -4 %) are better off with their slots cached. The parent loads stay cached
+// (SPX_STREAM_LOADS=1 would stream them too: +5 % when every parent has one child, -15 % in self-play where ~35
+// siblings share a parent). Compile-time, because the hint does not survive a run-time select between the two kinds
+// of access.
+template <bool kStream = false>
 __device__ __forceinline__ void storeAcc(uint8_t* arena, uint32_t slot, int c, uint32_t lane, const uint32_t (&acc)[8]) {
     uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
     u32x4 lo, hi;
@@ -363,13 +373,25 @@ __device__ __forceinline__ void storeAcc(uint8_t* arena, uint32_t slot, int c, u
         lo[r] = acc[r];
         hi[r] = acc[4 + r];
     }
-    *reinterpret_cast<u32x4*>(base) = lo;
-    *reinterpret_cast<u32x4*>(base + 1024) = hi;
+    if constexpr (kStream) {
+        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4*>(base));
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4*>(base + 1024));
+    } else {
+        *reinterpret_cast<u32x4*>(base) = lo;
+        *reinterpret_cast<u32x4*>(base + 1024) = hi;
+    }
 }
+template <bool kStream = false>
 __device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int c, uint32_t lane, uint32_t (&acc)[8]) {
     const uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
-    const u32x4 lo = *reinterpret_cast<const u32x4*>(base);
-    const u32x4 hi = *reinterpret_cast<const u32x4*>(base + 1024);
+    u32x4 lo, hi;
+    if constexpr (kStream) {
+        lo = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base));
+        hi = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + 1024));
+    } else {
+        lo = *reinterpret_cast<const u32x4*>(base);
+        hi = *reinterpret_cast<const u32x4*>(base + 1024);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         acc[r] = lo[r];
@@ -379,11 +401,12 @@ __device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int
 
 // child accumulator = parent accumulator - removed rows + added rows (updatePsq, nnue_state.cpp:34-87;
 // applyThreatRows, :89-145). Lists hold byte offsets; wrapping i16; threat sums kept in non-overflowing 32-bit fields.
+template <bool kStream = false>
 __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* arena, uint32_t parentSlot, int c,
                                            uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
                                            const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
                                            uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]) {
-    loadAcc(arena, parentSlot, c, lane, acc);
+    loadAcc<kStream && SPX_STREAM_LOADS>(arena, parentSlot, c, lane, acc);
     const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
     for (uint32_t i = 0; i < nPsqSub; ++i) {
         const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqSub[i]);
@@ -506,7 +529,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // kSplit = false: one wavefront per record does both perspectives (board decoding and attack generation shared);
 // kSplit = true: one wavefront per (record, perspective) - twice the waves, half the serial latency - for batches too
 // small to fill the chip (the kernel is latency-bound there: 4 096 records = 36 us unsplit).
-template <bool kSplit>
+template <bool kSplit, bool kStream>
 __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
@@ -596,10 +619,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
                 }
                 __builtin_amdgcn_wave_barrier();
 
-                applyDelta(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd,
-                           sThr[wave], nAdd + nAddCompact, sSub[wave], nSub + nSubCompact, acc);
+                applyDelta<kStream>(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1],
+                                    nPsqAdd, sThr[wave], nAdd + nAddCompact, sSub[wave], nSub + nSubCompact, acc);
             }
-            storeAcc(p.arena, childSlot, c, lane, acc);
+            storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
             if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
                 const uint32_t half = (c == cb.stm) ? 0u : 1u;
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
@@ -1099,11 +1122,17 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) 
     return hipGetLastError();
 }
 
-hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, hipStream_t stream) {
-    if (splitPerspectives) {
-        hipLaunchKernelGGL(spx_update_kernel<true>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
+                        hipStream_t stream) {
+    const dim3 grid(gridBlocks), block(64 * kWavesPerBlock);
+    if (splitPerspectives && streamAccumulators) {
+        hipLaunchKernelGGL((spx_update_kernel<true, true>), grid, block, 0, stream, p);
+    } else if (splitPerspectives) {
+        hipLaunchKernelGGL((spx_update_kernel<true, false>), grid, block, 0, stream, p);
+    } else if (streamAccumulators) {
+        hipLaunchKernelGGL((spx_update_kernel<false, true>), grid, block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL(spx_update_kernel<false>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((spx_update_kernel<false, false>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
