@@ -245,3 +245,23 @@ def test_selfplay_driver_records_are_consistent(sp, net_blob, tmp_path, host_mov
         best = max(-int(v) for v in st.evaluate_once(np.array(succ, dtype=sp.PACKED_DTYPE)))
         assert int(positions["eval"][k]) >= min(best, 32000) - margin - 2 or abs(int(positions["eval"][k])) == 0
     st.close()
+
+
+def test_big_update_batches_take_the_streaming_store_variant(sp, net_blob):
+    """From 32 768 records on the update kernel writes the child accumulators with non-temporal stores (and one wave per
+    perspective): same bits as a full refresh, for the children and for grandchildren updated from them."""
+    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=40000)
+    try:
+        n = 40000
+        pos = sp.random_positions(n, seed=21, min_ply=0, max_ply=120, dfrc_every=4)
+        st.reserve_slots(3 * n)
+        slots = np.arange(n, dtype=np.uint32)
+        st.reset(pos, slots)
+        child, _ = sp.random_successors(pos, seed=5)
+        got = st.update_evaluate(slots, slots + n, child)
+        assert np.array_equal(got, st.evaluate_once(child))
+        grand, _ = sp.random_successors(child, seed=6)
+        got = st.update_evaluate(slots + n, slots + 2 * n, grand)
+        assert np.array_equal(got, st.evaluate_once(grand))
+    finally:
+        st.close()
