@@ -74,3 +74,26 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
+
+
+def test_cpp_mirror_reports_the_missing_device_as_an_exception(tmp_path):
+    """spx_nnue::NnueState on a box without a GPU: the library's SPX_ERR_NO_DEVICE surfaces as spx_nnue::Error (the
+    reference's calls cannot fail; the mirror must not pretend to evaluate)."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "spx_nnue.hpp"\n#include <cstdio>\n'
+                   'int main() { try { auto net = spx_nnue::Network::synthetic(0); spx_nnue::NnueState st(net); }\n'
+                   '  catch (const spx_nnue::Error& e) { std::printf("%d %s\\n", e.status, e.what()); return 0; }\n'
+                   '  return 1; }\n')
+    exe = tmp_path / "t"
+    lib_dir = os.path.join(ROOT, "stormphrax_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-lspx_nnue", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("4 "), out.stdout + out.stderr
+    assert "no CPU fallback" in out.stdout
