@@ -873,7 +873,7 @@ int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, con
         up.ftOut = ctx->dFtOut;
         up.stagedRecords = ctx->dStaged;
     }
-    SPX_HIP(launchUpdateObserved(up, ftGrid(ctx, n), s));
+    SPX_HIP(launchUpdateObserved(up, ftGrid(ctx, 2 * n), s));  // one wave per (record, perspective)
     if (!d_out) return SPX_OK;
     rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
