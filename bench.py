@@ -10,9 +10,20 @@ no data-path collective), weak scaling; value = all ranks' positions / max-over-
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 200 --warmup 20
 
-Rank 0 prints ONE JSON line. Extra objects: `roofline` (feature-transformer kernel, algorithmic gather bytes / HIP-event
-kernel time vs the 8 TB/s HBM peak) and `cpu_baseline` (the compiled reference `oracle/_ref/sp_ref_probe_tame` when
-present, else the C restatement, timed on a bounded sample of the same batch on this box's host cores).
+Rank 0 prints ONE JSON line. Extra objects:
+  `roofline`      the feature-transformer kernel against the roof that BINDS it. The 100 MB of weight rows are resident in
+                  L2 / Infinity Cache, so the gather is bound by the L2 -> CU path and VALU issue, not by HBM: `bound` =
+                  "l2", `achieved` = bytes the kernel's loads request per launch / its HIP-event duration, `peak` = the
+                  34.5 TB/s aggregate L2 bandwidth. The SURVEY 8(d) algorithmic-bytes figure and the measured HBM/fabric
+                  traffic (rocprofv3 PMC pass committed under profiles/) are reported beside it under `hbm`, the VALU issue
+                  utilisation from the same PMC passes under `valu`. Every `frac` is <= 1 and recomputable from profiles/.
+  `wide_psq_rows` the same timed run on a context with SPX_CTX_WIDE_PSQ_ROWS (no 1 KiB u8 copies of piece-square rows):
+                  the figure a net whose piece-square weights do not fit i8 would get.
+  `cpu_baseline`  the compiled reference (`oracle/_ref/sp_ref_probe_tame[_avx512]`) timed on a bounded sample of the same
+                  batch on this box's host cores. Its absence is an error (--allow-port-baseline times the scalar C
+                  restatement instead).
+Before the W warm-up steps the loop is additionally run untimed until the chip's clocks have settled (>= 1 s and three
+consecutive 10-step chunks within 2 %), so a short `--steps 20 --warmup 5` run measures the same steady state as a long one.
 """
 import argparse
 import ctypes
@@ -28,6 +39,76 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
+N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
+PMC_FILES = {"full": "r02_pmc_full_refresh.json", "incremental": "r02_pmc_incremental.json"}
+
+
+def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):
+    """Untimed clock / cache warm-up: run `chunk`-step groups until >= min_seconds have passed AND the last three group
+    times agree within 2 % (DVFS has settled), or max_seconds. Returns the number of steps issued."""
+    times, total, steps = [], 0.0, 0
+    while total < max_seconds:
+        t0 = time.perf_counter()
+        for _ in range(chunk):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        total += dt
+        steps += chunk
+        if total >= min_seconds and len(times) >= 3 and max(times[-3:]) <= 1.02 * min(times[-3:]):
+            break
+    return steps
+
+
+def load_pmc(mode, **match):
+    """Counters of the committed rocprofv3 PMC passes of this command (profiles/r02_pmc_*.json, written by
+    tools/pmc_to_json.py from the passes of tools/gpu_profile.sh). None when this run's configuration was not profiled."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[mode])))
+    except (OSError, ValueError):
+        return None
+    if any(rec.get("config", {}).get(k) != v for k, v in match.items()):
+        return None
+    return rec
+
+
+def kernel_pmc(rec, name):
+    if not rec:
+        return None
+    for k, v in rec.get("kernels", {}).items():
+        if name in k:
+            return v
+    return None
+
+
+def valu_block(kp, cycles_per_instr):
+    """VALU issue utilisation of one kernel from its PMC pass: wave-level VALU instructions x SIMD cycles per instruction
+    / (SIMDs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8."""
+    if not kp or "SQ_INSTS_VALU" not in kp.get("counters", {}) or "GRBM_GUI_ACTIVE" not in kp["counters"]:
+        return None
+    c = kp["counters"]
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+    return {"insts_per_launch": c["SQ_INSTS_VALU"], "kernel_cycles": cycles, "cycles_per_wave_instr": cycles_per_instr,
+            "util": c["SQ_INSTS_VALU"] * cycles_per_instr / (N_SIMDS * cycles),
+            "source": "profiles/ (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes of this command)"}
+
+
+def oracle_sample_check(sp, blob, positions, got):
+    """Parity inside the bench, outside the timed region: the scalar C restatement (oracle/, test infrastructure) on a
+    sample of the batch vs the GPU's scores for the same positions."""
+    so = os.path.join(ROOT, "oracle", "libspx_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"], stdout=subprocess.DEVNULL)
+    oracle = ctypes.CDLL(so)
+    oracle.spxo_init.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    oracle.spxo_eval_mailboxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    assert oracle.spxo_init(blob.ctypes.data, blob.size) == 0
+    mail, stm = sp.positions_to_mailboxes(positions)
+    want = np.empty(len(positions), dtype=np.int32)
+    assert oracle.spxo_eval_mailboxes(mail.ctypes.data, stm.ctypes.data, len(positions), want.ctypes.data) == 0
+    return bool(np.array_equal(want, np.asarray(got, dtype=np.int32)))
 
 
 def usable_cpus():
@@ -54,7 +135,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(sp, positions, blob, seconds):
+def cpu_baseline(sp, positions, blob, seconds, allow_port=False):
     """Reference CPU path on a bounded sample of the batch (baseline only, never the target)."""
     sample = positions[:4096]
     probe, flavour = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame"), "AVX2-BMI2 build"
@@ -66,6 +147,11 @@ def cpu_baseline(sp, positions, blob, seconds):
     except (OSError, StopIteration):
         pass
     cores = usable_cpus()
+    if not os.path.exists(probe) and not allow_port:
+        raise SystemExit(f"bench.py: {probe} is missing - the cpu_baseline leg times the COMPILED REFERENCE, which is built "
+                         "in the authoring container (`make -C oracle ref ref512`, needs /root/reference) and travels "
+                         "untracked in oracle/_ref/. Re-run with --allow-port-baseline to time the scalar C restatement "
+                         "(kind 'port', 1 thread) instead, or with --no-cpu-baseline.")
     if os.path.exists(probe):
         try:
             cmds = "".join(f"add {sp.position_to_fen(p)}\n" for p in sample)
@@ -78,7 +164,10 @@ def cpu_baseline(sp, positions, blob, seconds):
                           f"{len(sample)} positions of the batch for {seconds:.0f} s on {cores} threads "
                           f"(= usable CPUs: {os.cpu_count()} logical, capped by affinity / cgroup quota)",
             }
-        except Exception as exc:  # fall through to the port
+        except Exception as exc:
+            if not allow_port:
+                raise SystemExit(f"bench.py: the reference probe {probe} failed ({exc}); --allow-port-baseline would time "
+                                 "the scalar C restatement instead")
             print(f"[bench] reference probe failed ({exc}); timing the C restatement instead", file=sys.stderr)
     so = os.path.join(ROOT, "oracle", "libspx_oracle.so")
     if not os.path.exists(so):
@@ -96,20 +185,6 @@ def cpu_baseline(sp, positions, blob, seconds):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"scalar C restatement (oracle/spx_oracle.c) over the first {len(sample)} positions, {dt:.1f} s, 1 thread"}
-
-
-def pmc_traffic(args):
-    """HBM/fabric bytes per launch of the FT kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/ft_traffic_pmc.json; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE).
-    bench.py cannot collect counters on itself; null when the run's configuration differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "ft_traffic_pmc.json")
-    try:
-        rec = json.load(open(path))
-    except OSError:
-        return None
-    if rec.get("batch") != args.batch or rec.get("preset") != args.preset:
-        return None
-    return rec["traffic_bytes_per_launch"] / 1e9 / rec["ft_kernel_ms"] * 1e3  # GB/s, comparable with `achieved`
 
 
 def delta_rows_sample(sp, parents, children, sample=256):
@@ -162,11 +237,13 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
                                                   G, d_out.data_ptr(), stream))
         step_no[0] = s + 1
 
+    settle_steps = 0 if args.no_settle else settle(step, torch.cuda.synchronize)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     group.barrier()
     torch.cuda.synchronize()
+    state.profile_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -174,6 +251,7 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
     group.barrier()
     torch.cuda.synchronize()
     elapsed = group.max_float(time.perf_counter() - t0)
+    _, update_ms, mlp_ms, calls = state.profile_end()
     # parity inside the bench: the incrementally maintained evals equal a full refresh of the final boards
     full = torch.empty(G, dtype=torch.int32, device="cuda")
     state.evaluate_once_device(d_boards[board_index(step_no[0])].data_ptr(), G, full.data_ptr(), stream)
@@ -181,8 +259,28 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
     exact = group.sum_int(int(torch.equal(full, d_out))) == world
     if rank == 0:
         psq_d, thr_d = delta_rows_sample(sp, chain[3], chain[4])
-        algo = 2048 * psq_d + 1024 * thr_d + 2 * 4096 + 72
+        compulsory = 2 * 4096 + 72  # parent accumulators read + child accumulators written + the two records
+        update_s = update_ms / max(calls, 1) / 1e3
         value = world * G * args.steps / elapsed
+        pmc = load_pmc("incremental", batch=G, preset=args.preset)
+        kp = kernel_pmc(pmc, "spx_update_kernel<")
+        roofline = {
+            "kernel": "spx_update_kernel (+ its rebuild pass)", "bound": "hbm",
+            "achieved": compulsory * G / update_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": compulsory * G / update_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "update_kernel_ms": update_s * 1e3, "sort_mlp_ms": mlp_ms / max(calls, 1),
+            "compulsory_bytes_per_update": compulsory,
+            "note": "achieved = the bytes an update MUST move through HBM (parent accumulators 4 KiB in, child "
+                    "accumulators 4 KiB out, records) x records / the HIP-event duration of the update kernel and its "
+                    "rebuild pass; the delta rows (mean_delta_rows_per_update x 1-2 KiB) come from L2 / Infinity Cache "
+                    "and are reported as gather_bytes_per_update, not counted against the HBM roof. traffic = measured "
+                    "fabric+HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE of the committed PMC pass)",
+            "gather_bytes_per_update": 2048 * psq_d + 1024 * thr_d, "valu": None,
+        }
+        if kp and "FETCH_SIZE" in kp["counters"] and "WRITE_SIZE" in kp["counters"]:
+            roofline["traffic"] = (2 * kp["counters"]["FETCH_SIZE"] + kp["counters"]["WRITE_SIZE"]) * 1024
+        if pmc:
+            roofline["valu"] = valu_block(kp, pmc.get("valu_cycles_per_wave_instr", 4))
         print(json.dumps({
             "metric": "nnue_incremental_updates_per_sec", "value": value, "unit": "updates+evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -190,14 +288,48 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
             "dtype": "i16 accumulate / i8 MFMA L1 / i32 tail", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3] shape: per step one ply of incremental accumulator updates "
                                    "(device-derived add/sub deltas) + evaluation for every one of the concurrent games",
-                       "games_per_gpu": G, "bit_exact_vs_full_refresh": bool(exact),
+                       "games_per_gpu": G, "bit_exact_vs_full_refresh": bool(exact), "settle_steps": settle_steps,
                        "mean_delta_rows_per_update": {"psq": psq_d, "threat": thr_d}},
-            "roofline": {"kernel": "spx_update_kernel + spx_slot_act_kernel + spx_mlp_kernel", "bound": "hbm",
-                         "achieved": algo * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo * value / world / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_update": algo},
+            "roofline": roofline,
         }), flush=True)
     group.close()
+
+
+def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
+    """Settle, W warm-up steps, then exactly K timed steps of the full-refresh path on `state`.
+    -> (elapsed max over ranks, per-kernel ms (sort, ft, mlp, calls), settle steps, the output tensor of the last step)."""
+    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(n_outs if pipelined else 1)]
+    stream = torch.cuda.current_stream().cuda_stream
+    counter = [0]
+
+    def step():
+        k = counter[0] % len(d_outs)
+        counter[0] += 1
+        if pipelined:  # returns at once; the library chains the batches on its own two streams
+            state.evaluate_once_device_async(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr())
+        else:
+            state.evaluate_once_device(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr(), stream)
+
+    def sync():
+        state.synchronize()
+        torch.cuda.synchronize()
+
+    settle_steps = 0 if args.no_settle else settle(step, sync)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    group.barrier()
+    sync()
+    state.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    group.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = state.profile_end()
+    return group.max_float(elapsed), prof, settle_steps, d_outs[(counter[0] - 1) % len(d_outs)]
 
 
 def main():
@@ -207,12 +339,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="positions per GPU per step")
     ap.add_argument("--preset", default="tame", choices=["tame", "wild", "extreme"])
+    ap.add_argument("--net", default=None,
+                    help="CBNF net file (plain or zstd-compressed, e.g. Stormphrax's net093_255_128_q6.nnue) instead of the "
+                         "synthetic preset; the compiled-reference CPU leg embeds the synthetic net, so it is skipped")
     ap.add_argument("--mode", default="full", choices=["full", "incremental"],
                     help="full = BASELINE configs[1] (headline); incremental = configs[2]/[3] shape: one ply of "
                          "parent->child accumulator updates + evaluation for --batch concurrent games per step")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="contexts/HIP streams the steps are issued round-robin on (2 lets the small sort/MLP kernels of "
-                         "one step overlap the texture-bound gather of the next)")
     ap.add_argument("--distinct", type=int, default=0,
                     help="tile this many distinct positions to fill the batch (cache-locality ablation; also keeps host "
                          "generation bounded for the HBM-filling batches of BASELINE config 5)")
@@ -220,8 +352,16 @@ def main():
                     help="issue the steps with the strictly stream-ordered spx_eval_full_device instead of the pipelined "
                          "spx_eval_full_device_async (consecutive batches overlap: sorts / MLP of one beside the "
                          "feature-transformer kernel of the next)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the time-based clock warm-up before the W warm-up steps")
+    ap.add_argument("--no-wide", action="store_true", help="skip the second timed run with SPX_CTX_WIDE_PSQ_ROWS")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: all_gather the per-rank scores of the last step (RCCL) and check the gathered array "
+                         "against each rank's own shard checksum (SURVEY 8e's optional result gather; outside the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-port-baseline", action="store_true",
+                    help="time the scalar C restatement when the compiled reference probe (oracle/_ref) is missing, "
+                         "instead of failing")
     args = ap.parse_args()
 
     import torch
@@ -246,61 +386,97 @@ def main():
     if args.mode == "incremental":
         return incremental_bench(args, sp, torch, group, rank, local_rank, world)
 
-    # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
-    blob = sp.synthetic_net_bytes(args.preset)
+    # ---- network: rank 0 owns the blob; the other ranks receive it over RCCL ----
+    t_net = time.perf_counter()
+    if rank == 0 or world == 1:
+        blob = np.fromfile(args.net, dtype=np.uint8) if args.net else sp.synthetic_net_bytes(args.preset)
+    else:
+        blob = None
+    blob = group.broadcast_bytes(blob)
+    net_bcast_s = time.perf_counter() - t_net
     net = sp.Network(blob)
-    n_ctx = max(1, args.streams)
-    states = [sp.NnueState(net, device=local_rank, max_batch=args.batch) for _ in range(n_ctx)]
-    state = states[0]
+    state = sp.NnueState(net, device=local_rank, max_batch=args.batch)
+
+    # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     n_distinct = min(args.distinct or args.batch, args.batch)
     distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
     positions = np.resize(distinct, args.batch) if n_distinct < args.batch else distinct
     d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
-    pipelined = not args.no_pipeline and n_ctx == 1
-    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(2 if pipelined else n_ctx)]
-    d_out = d_outs[0]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_ctx - 1)]
-    counter = [0]
+    pipelined = not args.no_pipeline
 
-    def step():
-        k = counter[0] % len(d_outs)
-        counter[0] += 1
-        if pipelined:  # returns at once; the library chains the batches on its own two streams
-            state.evaluate_once_device_async(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr())
-        else:
-            states[k].evaluate_once_device(d_pos.data_ptr(), args.batch, d_outs[k].data_ptr(), streams[k].cuda_stream)
+    elapsed, (sort_ms, ft_ms, mlp_ms, calls), settle_steps, d_last = timed_full_run(args, torch, group, state, d_pos, pipelined)
+    checksum = group.sum_int(int(d_last.to(torch.int64).sum().item()))  # checksum of checksums over all shards
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    group.barrier()
-    torch.cuda.synchronize()
-    for st in states:
-        st.profile_begin(args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    group.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = [st.profile_end() for st in states]
-    sort_ms, ft_ms, mlp_ms, calls = (sum(p[i] for p in prof) for i in range(4))
+    # ---- parity inside the bench (outside the timed region): oracle on a sample of every rank's shard ----
+    n_sample = min(4096, args.batch)
+    got = d_last[:n_sample].cpu().numpy()
+    exact = group.sum_int(int(oracle_sample_check(sp, blob, positions[:n_sample], got))) == world
 
-    elapsed = group.max_float(elapsed)  # slowest rank defines the step time
-    checksum = group.sum_int(int(d_out.to(torch.int64).sum().item()))  # checksum of checksums over all shards
+    # ---- optional result gather over RCCL (not on the data path; outside the timed region) ----
+    gathered_ok = None
+    if args.gather and world > 1:
+        full = group.gather_scores(d_last.cpu().numpy(), args.batch * world)
+        lo = rank * args.batch
+        mine_ok = np.array_equal(full[lo:lo + args.batch], d_last.cpu().numpy())
+        gathered_ok = group.sum_int(int(mine_ok and int(full.astype(np.int64).sum()) == checksum)) == world
+
+    # ---- second headline: the same run without compact piece-square rows ----
+    wide = None
+    if not args.no_wide and state.compact_psq_rows:
+        wstate = sp.NnueState(net, device=local_rank, max_batch=args.batch, wide_psq_rows=True)
+        w_elapsed, (_, w_ft, _, w_calls), _, w_last = timed_full_run(args, torch, group, wstate, d_pos, pipelined)
+        w_same = group.sum_int(int(torch.equal(w_last, d_last))) == world
+        wide = {"value": world * args.batch * args.steps / w_elapsed, "unit": "evals/s",
+                "ms_per_step": w_elapsed / args.steps * 1e3, "ft_kernel_ms": w_ft / max(w_calls, 1),
+                "identical_scores": bool(w_same),
+                "note": "same timed run on a context created with SPX_CTX_WIDE_PSQ_ROWS: every piece-square row fetched "
+                        "as its 2 KiB i16 row (what a net whose piece-square weights do not fit i8 gets)"}
+        wstate.close()
 
     if rank == 0:
-        psq_rows, thr_rows = sp.count_rows(distinct)  # host-side count; tiled batches scale the distinct block
+        wide_rows, compact_rows, thr_rows = state.count_rows(distinct)  # host-side count; tiled batches scale the distinct block
         if n_distinct < args.batch:
-            psq_rows, thr_rows = (int(v * (args.batch / n_distinct)) for v in (psq_rows, thr_rows))
+            wide_rows, compact_rows, thr_rows = (int(v * (args.batch / n_distinct)) for v in (wide_rows, compact_rows, thr_rows))
+        psq_rows = wide_rows + compact_rows
         algo_bytes = 2048 * psq_rows + 1024 * thr_rows + 36 * args.batch  # per launch
-        compact_rows = states[0].compact_psq_rows
-        psq_bytes = {11264: 1024, 0: 2048}.get(compact_rows)  # mixed nets: not derivable from the row totals
-        requested = None if psq_bytes is None else psq_bytes * psq_rows + 1024 * thr_rows + 36 * args.batch
+        requested = 2048 * wide_rows + 1024 * (compact_rows + thr_rows) + 36 * args.batch  # what the loads ask for
         ft_avg_s = ft_ms / max(calls, 1) / 1e3
-        achieved = algo_bytes / ft_avg_s / 1e9
         value = world * args.batch * args.steps / elapsed
+        pmc = load_pmc("full", batch=args.batch, preset=args.preset, net=args.net) if n_distinct == args.batch else None
+        kp = kernel_pmc(pmc, "spx_ft_kernel")
+        hbm = {
+            "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_position": algo_bytes / args.batch,
+            "algorithmic_gbs": algo_bytes / ft_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+            "algorithmic_over_peak": algo_bytes / ft_avg_s / 1e9 / HBM_PEAK_GBS,
+            "note": "cache-resident gather; HBM not binding: the 100 MB of row tables stay in L2 / Infinity Cache, so the "
+                    "SURVEY 8(d) algorithmic-byte rate exceeds the HBM peak (algorithmic_over_peak is NOT a roofline "
+                    "fraction). traffic_* = measured fabric+HBM bytes per launch (rocprofv3 FETCH_SIZE x2 per the gfx950 "
+                    "correction + WRITE_SIZE, committed PMC passes; Infinity-Cache hits are included, so an upper bound "
+                    "on HBM bytes), null if this configuration was not profiled",
+            "traffic_bytes_per_launch": None, "traffic_gbs": None, "frac": None,
+        }
+        if kp and "FETCH_SIZE" in kp["counters"] and "WRITE_SIZE" in kp["counters"]:
+            tb = (2 * kp["counters"]["FETCH_SIZE"] + kp["counters"]["WRITE_SIZE"]) * 1024
+            hbm.update(traffic_bytes_per_launch=tb, traffic_gbs=tb / ft_avg_s / 1e9, frac=tb / ft_avg_s / 1e9 / HBM_PEAK_GBS)
+        l2_gbs = requested / ft_avg_s / 1e9
+        roofline = {
+            "kernel": "spx_ft_kernel", "bound": "l2", "achieved": l2_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s",
+            "frac": l2_gbs / L2_PEAK_GBS, "traffic": hbm["traffic_bytes_per_launch"],
+            "requested_bytes_per_launch": requested, "ft_kernel_ms": ft_avg_s * 1e3,
+            "rows_per_launch": {"psq_wide_2KiB": wide_rows, "psq_compact_1KiB": compact_rows, "threat_1KiB": thr_rows},
+            "note": "achieved = bytes requested by the kernel's row loads (2 KiB per wide piece-square row, 1 KiB per "
+                    "compact piece-square / threat / pawn-pair row, + record and score) / the FT kernel's HIP-event "
+                    "duration, against the aggregate L2 bandwidth; the committed PMC pass counts the same bytes as "
+                    "TCC_REQ x 128 B (l2_pmc)",
+            "l2_pmc": None, "hbm": hbm, "valu": None,
+        }
+        if kp and "TCC_REQ_sum" in kp["counters"]:
+            c = kp["counters"]
+            roofline["l2_pmc"] = {"tcc_req_bytes_per_launch": c["TCC_REQ_sum"] * 128,
+                                  "hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)),
+                                  "kernel_us_under_rocprofv3": kp.get("avg_us")}
+        if pmc:
+            roofline["valu"] = valu_block(kp, pmc.get("valu_cycles_per_wave_instr", 4))
         line = {
             "metric": "nnue_position_evals_per_sec",
             "value": value,
@@ -314,41 +490,34 @@ def main():
             "vs_baseline": None,
             "dtype": "i16 accumulate / i8 MFMA L1 / i32 tail",
             "data": "synthetic",
+            "bit_exact_sample": bool(exact),
             "config": {
                 "workload": (f"BASELINE configs[1]: full-refresh NNUE forward on {args.batch} seeded random legal positions "
                              "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU"
                              + (f"; batch tiled from {n_distinct} distinct positions" if n_distinct < args.batch else "")),
                 "batch_per_gpu": args.batch,
-                "net": f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8",
+                "net": (f"file {os.path.basename(args.net)} '{net.name}'" if args.net else
+                        f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8"),
+                "compact_psq_rows": f"{state.compact_psq_rows} of 11264 piece-square rows fit i8 and are served as 1 KiB copies",
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path; "
                                + ("steps issued through the pipelined spx_eval_full_device_async (two internal streams: "
                                   "sorts / MLP of a batch overlap the next batch's feature-transformer kernel)"
-                                  if pipelined else f"steps issued round-robin on {n_ctx} HIP stream(s) per GPU"),
+                                  if pipelined else "steps issued stream-ordered on one HIP stream per GPU"),
+                "net_distribution": (f"rank 0's {blob.size} B net image broadcast to the other ranks over "
+                                     f"{backend} in {net_bcast_s * 1e3:.1f} ms (init only)" if world > 1 else "single rank"),
+                "settle_steps": settle_steps,
+                "bit_exact_sample": f"{n_sample} positions of every rank's shard checked against the CPU oracle "
+                                    "(oracle/spx_oracle.c) after the timed region",
+                "gathered_scores_ok": gathered_ok,
                 "checksum": checksum,
                 "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
             },
-            "roofline": {
-                "kernel": "spx_ft_kernel",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args),
-                "traffic_note": "fabric+HBM GB/s of the FT kernel from the committed rocprofv3 PMC passes "
-                                "(profiles/ft_traffic_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); null if "
-                                "this run's configuration was not profiled",
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_position": algo_bytes / args.batch,
-                "compact_psq_rows": compact_rows,
-                "requested_bytes_per_launch": requested,
-                "requested_note": "bytes the kernel's loads ask for: piece-square rows whose weights all fit i8 "
-                                  f"({compact_rows} of 11264 in this net) are fetched as 1 KiB u8 copies instead of "
-                                  "2 KiB i16 rows (bit-identical sums); `achieved` stays in algorithmic bytes",
-            },
+            "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(sp, positions, blob, args.cpu_seconds)
+        if wide:
+            line["wide_psq_rows"] = wide
+        if not args.no_cpu_baseline and world == 1 and not args.net:  # the CPU leg is timed on rank 0 of the single-GPU run only
+            line["cpu_baseline"] = cpu_baseline(sp, positions, blob, args.cpu_seconds, args.allow_port_baseline)
         print(json.dumps(line), flush=True)
     group.close()
 

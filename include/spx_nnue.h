@@ -83,6 +83,11 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes);
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_ctx spx_ctx;
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out);
+/* As spx_ctx_create, with option flags. SPX_CTX_WIDE_PSQ_ROWS: every piece-square row is gathered from the 2 KiB i16
+ * table, i.e. the lossless "compact row" optimisation (1 KiB u8 copies of rows whose weights all fit i8) is off - what a
+ * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
+enum { SPX_CTX_WIDE_PSQ_ROWS = 1 };
+int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
 void spx_ctx_destroy(spx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -152,7 +157,16 @@ void spx_host_free(void* ptr);
  * eval::adjustedStaticEval. The correction-history table itself stays with the search on the host: pass its
  * per-position `correction(pos, keyHistory)` values, or NULL for adjustEval<false>. i32 arithmetic wraps where the
  * reference's would overflow (undefined there). */
-enum { SPX_ADJUST_STATIC = 1, SPX_ADJUST_EVAL = 2 };
+enum {
+    SPX_ADJUST_STATIC = 1,
+    SPX_ADJUST_EVAL = 2,
+    /* datagen's view of a score (Searcher::runDatagenSearch, src/search.cpp:237-238), applied after the stages above:
+     * WHITE_POV negates the evals of positions with black to move; WDL maps the score through wdl::normalizeScore
+     * (src/wdl.cpp:28-79: f64 cubic in Position::classicalMaterial of the record, std::round; zero and decisive scores
+     * pass through) - the value the reference's adjudication counters compare (src/datagen/datagen.cpp:224-252). */
+    SPX_ADJUST_WHITE_POV = 4,
+    SPX_ADJUST_WDL = 8
+};
 typedef struct spx_adjust_params {
     int32_t contempt[2];             /* eval::Contempt, by colour: [0] black, [1] white (eval.h:31) */
     int32_t optimism[2];             /* eval::Optimism (eval.h:32) */
@@ -184,6 +198,12 @@ int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms
 /* Active feature rows of a batch, both perspectives summed (what a full refresh gathers): algorithmic bytes =
  * 2048 * psq_rows + 1024 * threat_rows (+ 36 B per position of record and score). Host-side count. */
 int spx_count_rows(const spx_packed_pos* positions, size_t n, uint64_t* psq_rows, uint64_t* threat_rows);
+
+/* The same count split by what THIS context's kernels fetch: piece-square rows served from the 2 KiB i16 table
+ * (psq_wide_rows), from their 1 KiB u8 copy (psq_compact_rows), and the 1 KiB threat / pawn-pair rows. Requested bytes
+ * of a full refresh = 2048 * wide + 1024 * (compact + threat). */
+int spx_ctx_count_rows(const spx_ctx* ctx, const spx_packed_pos* positions, size_t n, uint64_t* psq_wide_rows,
+                       uint64_t* psq_compact_rows, uint64_t* threat_rows);
 
 /* Number of piece-square rows (of 11264) whose weights all fit i8: the context keeps a 1 KiB u8 copy of those and the
  * full-refresh kernel fetches it instead of the 2 KiB i16 row (identical sums, fewer bytes). Net dependent; 0 when
@@ -313,6 +333,14 @@ int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* params, const char
  * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */
 int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows, int* n_psq, uint32_t* threat_rows,
                        int* n_threat);
+
+/* Host emulation of the update kernel's DELTA derivation (same SPX_HD code, lane by lane): the rows perspective `colour`
+ * loses (sub) and gains (add) between two boards one move apart - piece-square rows (capacity 8 each) and threat /
+ * pawn-pair rows (capacity 288 each). *refresh = 1 (and empty lists) when the perspective is rebuilt instead: its king
+ * changed bucket or mirror half (psq.h:264-283, nnue_state.h:118-128) or more than four squares differ. Test-only. */
+int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, int colour, uint32_t* psq_sub,
+                    int* n_psq_sub, uint32_t* psq_add, int* n_psq_add, uint32_t* threat_sub, int* n_threat_sub,
+                    uint32_t* threat_add, int* n_threat_add, int* refresh);
 
 #ifdef __cplusplus
 }

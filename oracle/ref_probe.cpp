@@ -19,6 +19,11 @@
 //   deltas <seed> <count> <dfrc>                     -> per played move the BoardObserver's UpdateContext
 //   adjust <cB> <cW> <oB> <oW> <fen>                 -> "A <staticEvalOnce(contempt)> <adjustEval<false>(optimism, static)>"
 //   add <fen> / bench <threads> <seconds>            -> timing of evaluateOnce over the added positions
+//   pack <fen>                 -> "K <64 hex digits>": the 32 bytes of datagen::marlinformat::PackedBoard::pack(pos, 0)
+//   viri <seed> <plies> <dfrc> -> a random game pushed through datagen::Viriformat: per ply "M <fen before> | <uci> |
+//                                 <score> | <filtered> | <pack hex of the position before>", then "V <hex of the stream
+//                                 writeAllWithOutcome wrote>" (marlinformat.h:32-84, viriformat.cpp:28-63)
+//   wdl <score> <fen>          -> "W <classicalMaterial> <wdl::normalizeScore(score, material)>" (wdl.cpp:28-79)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -30,6 +35,8 @@
 
 #include "attacks/attacks.h"
 #include "cuckoo.h"
+#include "datagen/marlinformat.h"
+#include "datagen/viriformat.h"
 #include "eval/eval.h"
 #include "eval/nnue.h"
 #include "eval/nnue_state.h"
@@ -38,6 +45,7 @@
 #include "position.h"
 #include "tunable.h"
 #include "util/numa/numa.h"
+#include "wdl.h"
 
 using namespace stormphrax;
 
@@ -54,6 +62,17 @@ namespace {
             return static_cast<u32>((next() >> 32) % n);
         }
     };
+
+    std::string hexOf(const void* data, usize n) {
+        static const char* kDigits = "0123456789abcdef";
+        std::string out;
+        const auto* bytes = static_cast<const unsigned char*>(data);
+        for (usize i = 0; i < n; ++i) {
+            out += kDigits[bytes[i] >> 4];
+            out += kDigits[bytes[i] & 15];
+        }
+        return out;
+    }
 
     std::vector<Move> legalMoves(const Position& pos) {
         ScoredMoveList moves{};
@@ -218,6 +237,64 @@ int main() {
             const auto stat = eval::staticEvalOnce(*pos, contempt);
             const auto adjusted = eval::adjustEval<false>(*pos, optimism, {}, nullptr, stat);
             std::printf("A %d %d\n", stat, adjusted);
+        } else if (cmd == "pack") {
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            const auto packed = datagen::marlinformat::PackedBoard::pack(*pos, 0);
+            std::printf("K %s\n", hexOf(&packed, sizeof(packed)).c_str());
+        } else if (cmd == "wdl") {
+            i32 score;
+            in >> score;
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            const auto material = pos->classicalMaterial();
+            std::printf("W %d %d\n", material, wdl::normalizeScore(score, material));
+        } else if (cmd == "viri") {
+            u64 seed;
+            u32 plies, dfrc;
+            in >> seed >> plies >> dfrc;
+            SplitMix64 rng{seed};
+            auto pos = dfrc ? *Position::fromDfrcIndex(rng.below(960 * 960)) : Position::startpos();
+            datagen::Viriformat format{};
+            format.start(pos);
+            for (u32 ply = 0; ply < plies; ++ply) {
+                const auto moves = legalMoves(pos);
+                if (moves.empty()) {
+                    break;
+                }
+                std::vector<Move> special;
+                for (const auto mv : moves) {
+                    if (mv.type() != MoveType::kStandard) {
+                        special.push_back(mv);
+                    }
+                }
+                const auto& pool = (!special.empty() && rng.below(2) == 0) ? special : moves;
+                const auto move = pool[rng.below(static_cast<u32>(pool.size()))];
+                const auto score = static_cast<Score>(rng.below(4001)) - 2000;
+                const bool filtered = pos.isCheck() || pos.isNoisy(move);  // datagen.cpp:254
+                const auto packed = datagen::marlinformat::PackedBoard::pack(pos, static_cast<i16>(score));
+                std::printf("M %s | %s | %d | %d | %s\n", pos.toFen().c_str(), fmt::format("{}", move).c_str(), score,
+                            filtered ? 1 : 0, hexOf(&packed, sizeof(packed)).c_str());
+                format.push(filtered, move, score);
+                pos = pos.applyMove(move);
+            }
+            std::ostringstream stream;
+            const auto outcome = static_cast<datagen::Outcome>(rng.below(3));
+            format.writeAllWithOutcome(stream, outcome);
+            const auto bytes = stream.str();
+            std::printf("V %s\n", hexOf(bytes.data(), bytes.size()).c_str());
         } else if (cmd == "playout") {
             u64 seed;
             u32 count, minPly, maxPly, dfrc;

@@ -15,6 +15,7 @@
  * All arithmetic that wraps in the reference is done on unsigned types here (no signed-overflow UB).
  */
 #include <limits.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -672,4 +673,28 @@ int32_t spxo_adjust(const uint8_t* mailbox, int stm, int halfmove, const int32_t
         eval = clampScore(eval);
     }
     return eval;
+}
+
+/* wdl::normalizeScore<false> (src/wdl.cpp:28-79; wdlParams :29-40): score / a(material) * 100, rounded half away from
+ * zero; zero and decisive scores (|score| > kScoreWin = 25000, core.h:708,722-724) pass through. `material` =
+ * Position::classicalMaterial (position.h:515-521). Plain double arithmetic in the reference's expression order. */
+int32_t spxo_wdl_normalize(int32_t score, int32_t material) {
+    if (score == 0 || score > 25000 || score < -25000) {
+        return score;
+    }
+    const double m = (double)(material < 17 ? 17 : (material > 78 ? 78 : material)) / 58.0;
+    const double a = ((-244.97139595 * m + 687.39969858) * m + -654.38002091) * m + 608.47087786;
+    return (int32_t)round(100.0 * ((double)score / a));
+}
+
+/* Position::classicalMaterial (position.h:515-521) of a 64-square mailbox */
+int32_t spxo_classical_material(const uint8_t* mailbox) {
+    static const int kValue[6] = {1, 3, 3, 5, 9, 0};
+    int32_t material = 0;
+    for (int sq = 0; sq < 64; ++sq) {
+        if (mailbox[sq] != NO_PIECE) {
+            material += kValue[mailbox[sq] >> 1];
+        }
+    }
+    return material;
 }

@@ -6,12 +6,15 @@ hand-written HIP for gfx950). This package is the Python plumbing the tests and 
 from .nnue import (  # noqa: F401
     ADJUST_EVAL,
     ADJUST_STATIC,
+    ADJUST_WDL,
+    ADJUST_WHITE_POV,
     PACKED_DTYPE,
     Network,
     NnueState,
     adjust_params,
     apply_uci,
     count_rows,
+    debug_delta,
     debug_features,
     legal_moves,
     perft,

@@ -83,6 +83,7 @@ SYMBOLS = {
     "spx_synth_net": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, _P, ctypes.c_size_t]),
     "spx_fnv1a64": (ctypes.c_uint64, [_P, ctypes.c_size_t]),
     "spx_ctx_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_P)]),
+    "spx_ctx_create_ex": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
     "spx_ctx_destroy": (None, [_P]),
     "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
@@ -113,6 +114,7 @@ SYMBOLS = {
     "spx_adjust": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P]),
     "spx_adjust_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P]),
     "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "spx_ctx_count_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
@@ -127,6 +129,7 @@ SYMBOLS = {
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
+    "spx_debug_delta": (ctypes.c_int, [_P, _P, ctypes.c_int] + [_P, ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int)]),
     "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),
 }
 

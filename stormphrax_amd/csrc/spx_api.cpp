@@ -29,6 +29,7 @@ void setError(const std::string& msg) {
 }
 
 int buildThreatLut(uint32_t* lut);  // spx_luts.cpp
+void buildDeltaTables(uint64_t* tab);  // spx_luts.cpp
 
 }  // namespace spx
 
@@ -56,6 +57,7 @@ struct spx_ctx {
     int8_t* dL1W = nullptr;
     int32_t *dL1B = nullptr, *dL2W = nullptr, *dL2B = nullptr, *dL3W = nullptr, *dL3B = nullptr;
     uint32_t* dLut = nullptr;
+    uint64_t* dDeltaTab = nullptr;  // ray / knight masks + pseudo-attack sets of the threat-delta derivation
     // scratch
     void* dPositions = nullptr;  // staging for the host-buffer entry point
     int32_t* dOut = nullptr;
@@ -72,8 +74,10 @@ struct spx_ctx {
     uint32_t *dSlotsA = nullptr, *dSlotsB = nullptr;  // staging for the host-buffer entry points [max_batch]
     uint8_t* dStaged = nullptr;                        // [max_batch][32] records of the slots being evaluated
     uint8_t* dDeltas = nullptr;                        // [max_batch] spx_move_delta staging (allocated on first use)
-    int histCur = 0;               // dHist holds 3 x 64 words: [0],[1] alternate between large sorts (each sort clears
-                                   // the other one for its successor), [2] belongs to the single-launch small sort
+    int histCur = 0;               // dHist holds 4 x 64 words: [0],[1] alternate between large sorts (each sort clears
+                                   // the other one for its successor), [2] belongs to the single-launch small sort,
+                                   // [3] words 0,1: alternating counters of the update kernel's deferred-refresh list
+    int refreshCur = 0;            // which of the two counters the next update uses (its refresh pass clears the other)
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
     // spx_eval_full_device_async: two scratch sets ("lanes") with their own streams alternate, so that the sorts and
     // the MLP of one batch run beside the feature-transformer kernel of the next; the FT kernels themselves are
@@ -81,7 +85,7 @@ struct spx_ctx {
     struct EvalLane {
         uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr, *dStaged = nullptr;
         uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *histUsed = nullptr;
-        int histCur = 0;
+        int histCur = 0, refreshCur = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ftDone = nullptr, done = nullptr;
         bool ftRecorded = false;
@@ -99,7 +103,11 @@ struct spx_ctx {
     size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
     size_t streamAccMin = 0;       // spx_update_kernel: records from which the arena is accessed non-temporally
     size_t updateSplitMax = 0;     // spx_update_kernel: records up to which the perspectives get separate waves
+    bool updateLegacy = false;     // the round-1 update kernel (two full attack generations, rebuilds inline: ONE launch) serves
+    bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
+    size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
+    uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
@@ -245,6 +253,7 @@ FtTables tablesOf(const spx_ctx* ctx) {
     t.thrW = ctx->dThrW;
     t.ftBias = ctx->dFtBias;
     t.lut = ctx->dLut;
+    t.deltaTab = ctx->dDeltaTab;
     return t;
 }
 
@@ -347,7 +356,17 @@ constexpr size_t kTinyIoRecords = 8192;
 constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
 
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
-    if (!net || !out || max_batch == 0 || max_batch > (1ull << 30)) {
+    return spx_ctx_create_ex(net, device, max_batch, 0u, out);
+}
+
+namespace {
+struct CtxDeleter {  // a context that fails half-way through its creation releases what it already holds
+    void operator()(spx_ctx* c) const { spx_ctx_destroy(c); }
+};
+}  // namespace
+
+int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out) {
+    if (!net || !out || max_batch == 0 || max_batch > (1ull << 30) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS))) {
         setError("spx_ctx_create: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -358,7 +377,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
         return SPX_ERR_NO_DEVICE;
     }
     SPX_HIP(hipSetDevice(device));
-    auto ctx = std::make_unique<spx_ctx>();
+    std::unique_ptr<spx_ctx, CtxDeleter> ctx(new spx_ctx());
     ctx->device = device;
     ctx->maxBatch = max_batch;
     SPX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -374,8 +393,8 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
         for (uint32_t r = 0; r < kThreatRows; ++r) {
             relayoutThreatRow(net->threatW() + size_t(r) * kL1, thr.data() + size_t(r) * kL1);
         }
-        bool useCompact = true;
-        if (const char* env = std::getenv("SPX_NO_COMPACT")) useCompact = env[0] == '0';
+        bool useCompact = !(flags & SPX_CTX_WIDE_PSQ_ROWS);
+        if (const char* env = std::getenv("SPX_NO_COMPACT")) useCompact = useCompact && env[0] == '0';
         const int16_t* psq = reinterpret_cast<const int16_t*>(b + kOffPsqW);
         for (uint32_t r = 0; r < kPsqRows && useCompact; ++r) {
             const int16_t* row = psq + size_t(r) * kL1;
@@ -408,15 +427,19 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
             return SPX_ERR_BAD_NET;
         }
         std::memcpy(lut + kLutCompactBase, compactBits, sizeof(compactBits));
+        std::memcpy(ctx->compactBits, compactBits, sizeof(compactBits));
         if ((rc = uploadArray(ctx->dLut, lut, sizeof(lut), ctx->stream)) != SPX_OK) return rc;
+        std::vector<uint64_t> tab(kDeltaTabWords);
+        buildDeltaTables(tab.data());
+        if ((rc = uploadArray(ctx->dDeltaTab, tab.data(), tab.size() * sizeof(uint64_t), ctx->stream)) != SPX_OK) return rc;
     }
     SPX_HIP(hipMalloc(&ctx->dPositions, max_batch * sizeof(spx_packed_pos)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOut), max_batch * sizeof(int32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dFtOut), max_batch * size_t(kL1)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKingKeys), max_batch * 2));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOutKeys), max_batch));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 3 * 64 * sizeof(uint32_t)));
-    SPX_HIP(hipMemset(ctx->dHist, 0, 3 * 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 4 * 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMemset(ctx->dHist, 0, 4 * 64 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
@@ -435,6 +458,12 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
     SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * kTinyIoBytesPerRecord, hipHostMallocMapped));
     if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX")) ctx->updateSplitMax = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_UPDATE_V1")) {
+        ctx->updateLegacyForced = true;
+        ctx->updateLegacy = env[0] == '1';
+    }
+    ctx->updateSplitMaxV2 = 16384;
+    if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -458,7 +487,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
-                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dPositions, ctx->dOut, ctx->dFtOut,
+                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
                     ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
@@ -560,6 +589,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     if (n == 0) {
         return SPX_OK;
     }
+    SPX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipEvent_t* ev = nullptr;
     if (ctx->profUsed + kProfEventsPerCall <= ctx->profEvents.size()) {
@@ -599,6 +629,7 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
     std::swap(ctx->dPosOrder, lane.dPosOrder);
     std::swap(ctx->histUsed, lane.histUsed);
     std::swap(ctx->histCur, lane.histCur);
+    std::swap(ctx->refreshCur, lane.refreshCur);
 }
 
 static int ensureLanes(spx_ctx* ctx) {
@@ -613,8 +644,8 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dKingKeys), ctx->maxBatch * 2));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dOutKeys), ctx->maxBatch));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dStaged), ctx->maxBatch * 32));
-        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), 3 * 64 * sizeof(uint32_t)));
-        SPX_HIP(hipMemset(lane.dHist, 0, 3 * 64 * sizeof(uint32_t)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), 4 * 64 * sizeof(uint32_t)));
+        SPX_HIP(hipMemset(lane.dHist, 0, 4 * 64 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
         SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking,
@@ -760,6 +791,7 @@ static int checkAcc(spx_ctx* ctx, size_t n, const char* who) {
         setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->maxBatch));
         return SPX_ERR_CAPACITY;
     }
+    SPX_HIP(hipSetDevice(ctx->device));  // every arena entry point passes through here: contexts on other GPUs stay independent
     return SPX_OK;
 }
 
@@ -782,6 +814,8 @@ int spx_acc_refresh_device(spx_ctx* ctx, const void* d_positions, const void* d_
     return SPX_OK;
 }
 
+static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipStream_t s);
+
 int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                           const void* d_child_positions, size_t n, void* stream) {
     int rc = checkAcc(ctx, n, "spx_acc_update_device");
@@ -795,16 +829,39 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
     up.t = tablesOf(ctx);
     up.arena = ctx->dArena;
     up.slotRecords = ctx->dSlotRecords;
-    {
-        const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
-        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, s));
-    }
-    return SPX_OK;
+    return launchUpdateAndRefresh(ctx, up, n, s);
 }
 
 static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                             const void* d_child_positions, size_t n, const uint32_t* d_count, void* d_out, void* stream,
                             const char* who);
+
+// The update kernel proper, followed (second-generation kernel) by the pass that rebuilds the perspectives it deferred:
+// the feature-transformer kernel over the refresh list (ids in dPerspOrder - free until the MLP's sort - and the count in
+// one of two alternating device words; the pass clears the other one for the next update).
+static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipStream_t s) {
+    const bool legacy = ctx->updateLegacyForced ? ctx->updateLegacy : (n <= ctx->tinyBatchMax && !up.nRecordsPtr);
+    const bool split = n <= (legacy ? ctx->updateSplitMax : ctx->updateSplitMaxV2);  // one wave per (record, perspective)
+    uint32_t* counters = ctx->dHist + 192;
+    up.refreshList = ctx->dPerspOrder;
+    up.refreshCount = counters + ctx->refreshCur;
+    SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));
+    if (legacy) return SPX_OK;
+    FtParams fp{};
+    fp.positions = up.childPositions;
+    fp.nPositions = uint32_t(n);
+    fp.order = up.refreshList;
+    fp.nPerspPtr = up.refreshCount;
+    fp.clearWord = counters + (ctx->refreshCur ^ 1);
+    fp.t = up.t;
+    fp.ftOut = up.ftOut;
+    fp.accOut = up.arena;
+    fp.slots = up.childSlots;
+    fp.slotRecords = up.slotRecords;
+    ctx->refreshCur ^= 1;
+    SPX_HIP(launchFt(fp, ftGrid(ctx, std::max<size_t>(256, n / 4)), s));
+    return SPX_OK;
+}
 
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream) {
@@ -840,16 +897,30 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
     up.slotRecords = ctx->dSlotRecords;
     up.ftOut = ctx->dFtOut;          // activations of the children straight from the update kernel's registers
     up.stagedRecords = ctx->dStaged;
-    {
-        const bool split = n <= ctx->updateSplitMax;  // small batches: one wave per (record, perspective)
-        if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // lanes: the big kernels are chained
-        SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, s));
-        if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
+    if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // lanes: the big kernels are chained
+    // spx_profile_*: the "ft" interval is the update kernel + its rebuild pass, the "mlp" interval the sort + MLP
+    hipEvent_t* ev = nullptr;
+    if (ctx->profUsed + kProfEventsPerCall <= ctx->profEvents.size()) {
+        ev = &ctx->profEvents[ctx->profUsed];
+        ctx->profUsed += kProfEventsPerCall;
+        SPX_HIP(hipEventRecord(ev[0], s));
+        SPX_HIP(hipEventRecord(ev[1], s));
+        SPX_HIP(hipEventRecord(ev[4], s));
     }
-    if (!d_count && n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
-    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);
+    rc = launchUpdateAndRefresh(ctx, up, n, s);
     if (rc != SPX_OK) return rc;
-    return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true, d_count);
+    if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
+    if (ev) SPX_HIP(hipEventRecord(ev[2], s));
+    if (!d_count && n <= ctx->tinyBatchMax) {
+        rc = runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
+    } else {
+        rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);
+        if (rc != SPX_OK) return rc;
+        rc = runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true, d_count);
+    }
+    if (rc != SPX_OK) return rc;
+    if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    return SPX_OK;
 }
 
 static_assert(sizeof(spx_move_delta) == 1080, "spx_update_observed_kernel hard-codes the spx_move_delta layout");
@@ -1111,6 +1182,32 @@ int spx_count_rows(const spx_packed_pos* positions, size_t n, uint64_t* psq_rows
     return SPX_OK;
 }
 
+int spx_ctx_count_rows(const spx_ctx* ctx, const spx_packed_pos* positions, size_t n, uint64_t* psq_wide_rows,
+                       uint64_t* psq_compact_rows, uint64_t* threat_rows) {
+    if (!ctx || (n && !positions) || !psq_wide_rows || !psq_compact_rows || !threat_rows) {
+        setError("spx_ctx_count_rows: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    uint64_t nw = 0, nc = 0, nt = 0;
+    uint32_t psq[32], thr[256];
+    for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 2; ++c) {
+            int a = 0, b = 0;
+            const int rc = spx_debug_features(&positions[i], c, psq, &a, thr, &b);
+            if (rc != SPX_OK) return rc;
+            for (int k = 0; k < a; ++k) {
+                const bool compact = (ctx->compactBits[psq[k] >> 5] >> (psq[k] & 31)) & 1u;
+                (compact ? nc : nw) += 1;
+            }
+            nt += uint64_t(b);
+        }
+    }
+    *psq_wide_rows = nw;
+    *psq_compact_rows = nc;
+    *threat_rows = nt;
+    return SPX_OK;
+}
+
 int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32_t* out) {
     if (!ctx || (n && (!positions || !out))) {
         setError("spx_eval_full: null argument");
@@ -1229,8 +1326,9 @@ int spx_adjust_device(spx_ctx* ctx, const void* d_positions, size_t n, const spx
         setError("spx_adjust_device: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
-    if (params->stages == 0 || (params->stages & ~uint32_t(SPX_ADJUST_STATIC | SPX_ADJUST_EVAL))) {
-        setError("spx_adjust_device: stages must be a combination of SPX_ADJUST_STATIC and SPX_ADJUST_EVAL");
+    if (params->stages == 0 ||
+        (params->stages & ~uint32_t(SPX_ADJUST_STATIC | SPX_ADJUST_EVAL | SPX_ADJUST_WHITE_POV | SPX_ADJUST_WDL))) {
+        setError("spx_adjust_device: stages must be a combination of the SPX_ADJUST_* flags");
         return SPX_ERR_INVALID_ARG;
     }
     if (n == 0) return SPX_OK;
@@ -1842,6 +1940,114 @@ int spx_debug_features(const spx_packed_pos* pos, int c, uint32_t* psqRows, int*
     }
     *nPsq = np;
     *nThr = nt;
+    return SPX_OK;
+}
+
+
+// Host emulation of spx_update_kernel's delta derivation: the same SPX_HD per-lane code (deltaCandidates, descRow,
+// pawn-pair partner sets), run lane by lane. Capacities: 8 piece-square rows, 288 threat / pawn-pair rows per list.
+int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, int c, uint32_t* psqSub, int* nPsqSub,
+                    uint32_t* psqAdd, int* nPsqAdd, uint32_t* thrSub, int* nThrSub, uint32_t* thrAdd, int* nThrAdd,
+                    int* refresh) {
+    if (!parent || !child || !psqSub || !nPsqSub || !psqAdd || !nPsqAdd || !thrSub || !nThrSub || !thrAdd || !nThrAdd ||
+        !refresh || (c != 0 && c != 1)) {
+        setError("spx_debug_delta: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    static const std::vector<uint32_t> lutStorage = [] {
+        std::vector<uint32_t> v(kLutWords);
+        buildThreatLut(v.data());
+        return v;
+    }();
+    static const std::vector<uint64_t> tabStorage = [] {
+        std::vector<uint64_t> v(kDeltaTabWords);
+        buildDeltaTables(v.data());
+        return v;
+    }();
+    const uint32_t* lut = lutStorage.data();
+    const uint64_t* tab = tabStorage.data();
+    struct Side {
+        uint64_t occ = 0, white = 0, pawns = 0;
+        uint8_t mail[64];
+        int king[2] = {-1, -1};
+    } side[2];
+    const spx_packed_pos* recs[2] = {parent, child};
+    for (int b = 0; b < 2; ++b) {
+        Side& sd = side[b];
+        sd.occ = recs[b]->occupancy;
+        if (popc64(sd.occ) > 32) {
+            setError("spx_debug_delta: more than 32 pieces");
+            return SPX_ERR_BAD_POSITION;
+        }
+        for (int sq = 0; sq < 64; ++sq) {
+            sd.mail[sq] = kNoPiece;
+            if (!((sd.occ >> sq) & 1)) continue;
+            const int idx = popc64(sd.occ & ((1ull << sq) - 1));
+            const int pc = nibbleToPiece((recs[b]->pieces[idx >> 1] >> ((idx & 1) * 4)) & 0xF);
+            sd.mail[sq] = uint8_t(pc);
+            if (pc & 1) sd.white |= 1ull << sq;
+            if ((pc >> 1) == 0 && sq >= 8 && sq < 56) sd.pawns |= 1ull << sq;
+            if ((pc >> 1) == 5) sd.king[pc & 1] = sq;
+        }
+        if (sd.king[0] < 0 || sd.king[1] < 0) {
+            setError("spx_debug_delta: no king");
+            return SPX_ERR_BAD_POSITION;
+        }
+    }
+    uint64_t changed = 0;
+    for (int sq = 0; sq < 64; ++sq) {
+        if (side[0].mail[sq] != side[1].mail[sq]) changed |= 1ull << sq;
+    }
+    const int kingP = side[0].king[c], kingC = side[1].king[c];
+    const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
+    *nPsqSub = *nPsqAdd = *nThrSub = *nThrAdd = 0;
+    *refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) || popc64(changed) > 4;
+    if (*refresh) return SPX_OK;
+    const int x = perspXor(c, kingC), flipColour = c == 0;
+    // piece-square rows of the changed squares
+    int squares[4], nS = 0;
+    for (uint64_t m = changed; m; m &= m - 1) squares[nS++] = ctz64(m);
+    for (int k = 0; k < nS; ++k) {
+        const int f = squares[k];
+        if (side[0].mail[f] != kNoPiece) psqSub[(*nPsqSub)++] = psqRow(c, side[0].mail[f], f, kingC);
+        if (side[1].mail[f] != kNoPiece) psqAdd[(*nPsqAdd)++] = psqRow(c, side[1].mail[f], f, kingC);
+    }
+    // threat rows: passes of 64 lanes, lane = board << 5 | f index << 4 | slot
+    for (int pass = 0; 2 * pass < nS; ++pass) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int b = lane >> 5, fi = 2 * pass + ((lane >> 4) & 1), slot = lane & 15;
+            if (fi >= nS) continue;
+            uint32_t d[2];
+            deltaCandidates(tab, side[b].mail, side[b].occ, changed, squares[fi], slot, d[0], d[1]);
+            for (uint32_t desc : d) {
+                if (desc == kNoDesc) continue;
+                const int32_t row = descRow(lut, tab, desc, x, flipColour);
+                if (row < 0) continue;
+                if (b == 0 && *nThrSub < 288) thrSub[(*nThrSub)++] = uint32_t(row);
+                if (b == 1 && *nThrAdd < 288) thrAdd[(*nThrAdd)++] = uint32_t(row);
+            }
+        }
+    }
+    // pawn-pair rows: every pair that involves a pawn that left (parent board) or arrived (child board)
+    for (int b = 0; b < 2; ++b) {
+        const Side &self = side[b], &other = side[b ^ 1];
+        const uint64_t own = self.pawns & (c ? self.white : ~self.white);
+        const uint64_t otherOwn = other.pawns & (c ? other.white : ~other.white);
+        // pawns of this board that the other board does not have (same square AND same colour)
+        uint64_t moved = (own & ~otherOwn) | ((self.pawns & ~own) & ~(other.pawns & ~otherOwn));
+        uint64_t done = 0;
+        for (; moved; moved &= moved - 1) {
+            const int a = ctz64(moved);
+            done |= 1ull << a;
+            const uint32_t idA = ppId(a ^ x, !((own >> a) & 1));
+            for (uint64_t partners = self.pawns & ppMask(a) & ~done; partners; partners &= partners - 1) {
+                const int q = ctz64(partners);
+                const uint32_t row = ppRow(idA, ppId(q ^ x, !((own >> q) & 1)));
+                if (b == 0 && *nThrSub < 288) thrSub[(*nThrSub)++] = row;
+                if (b == 1 && *nThrAdd < 288) thrAdd[(*nThrAdd)++] = row;
+            }
+        }
+    }
     return SPX_OK;
 }
 

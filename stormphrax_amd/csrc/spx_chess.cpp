@@ -76,6 +76,24 @@ bool Board::attacked(int sq, int by, uint64_t occupancy) const {
     return (orth & (pieces[6 | by] | pieces[8 | by])) != 0;
 }
 
+// Position::filterEp (position.cpp:1608-1683): the en-passant square survives only while an en passant capture is LEGAL
+// (capturer not pinned, no discovered check along the rank, no other checker). Here: make each of the <= 2 candidate
+// captures and test the king, the way generateLegal() decides legality.
+static void filterEp(Board& b) {
+    if (b.ep < 0) return;
+    const int us = b.stm, them = us ^ 1;
+    uint64_t capturers = pawnAttacks(1ull << b.ep, them) & b.pieces[0 | us];
+    bool legal = false;
+    while (capturers && !legal) {
+        const int from = ctz64(capturers);
+        capturers &= capturers - 1;
+        Board next = b;
+        makeMove(next, Move{uint8_t(from), uint8_t(b.ep), kEnPassant, 0});
+        legal = !next.attacked(next.kingSq[us], them, next.occ);
+    }
+    if (!legal) b.ep = -1;
+}
+
 bool boardFromFen(const char* fen, Board& b) {
     b.clear();
     if (!fen) return false;
@@ -89,6 +107,7 @@ bool boardFromFen(const char* fen, Board& b) {
             file = 0;
         } else if (ch >= '1' && ch <= '8') {
             file += ch - '0';
+            if (file > 8) return false;
         } else {
             const char* at = std::strchr(kPieceChars, ch);
             if (!at || rank < 0 || file > 7) return false;
@@ -96,6 +115,8 @@ bool boardFromFen(const char* fen, Board& b) {
             ++file;
         }
     }
+    // a packed record holds 32 pieces (marlinformat.h:36) and the evaluator expects exactly one king per colour
+    if (popc64(b.occ) > 32 || popc64(b.pieces[10]) != 1 || popc64(b.pieces[11]) != 1) return false;
     if (b.kingSq[0] < 0 || b.kingSq[1] < 0) return false;
     while (*p == ' ') ++p;
     if (*p != 'w' && *p != 'b') return false;
@@ -134,6 +155,10 @@ bool boardFromFen(const char* fen, Board& b) {
     if (*p && *p != '-') {
         if (p[0] >= 'a' && p[0] <= 'h' && p[1] >= '1' && p[1] <= '8') {
             b.ep = int8_t((p[1] - '1') * 8 + (p[0] - 'a'));
+            // only a double-pushed enemy pawn in front of an empty target square can be captured en passant
+            const int rank = b.ep >> 3, pushed = b.ep + (b.stm ? -8 : 8);
+            if (rank != (b.stm ? 5 : 2) || b.mailbox[b.ep] != kNoPiece || b.mailbox[pushed] != (0 | (b.stm ^ 1))) b.ep = -1;
+            filterEp(b);
         }
     }
     while (*p && *p != ' ') ++p;
@@ -345,8 +370,8 @@ void makeMove(Board& b, const Move& m) {
         b.remove(m.from);
         b.put(m.kind == kPromotion ? ((m.promo << 1) | us) : moving, m.to);
         if (movingType == 0 && std::abs(int(m.to) - int(m.from)) == 16) {
-            // ep square only if an enemy pawn could actually capture (filterEp in the reference is stricter about
-            // legality; for evaluation purposes the field is unused)
+            // the ep square is kept only if an enemy pawn can LEGALLY capture there (filterEp below, run once the side to
+            // move has flipped) - as the reference's Position::filterEp: records and repetition keys then agree with it
             const int epSq = (m.from + m.to) / 2;
             if (pawnAttacks(1ull << epSq, us) & b.pieces[0 | them]) b.ep = int8_t(epSq);
         }
@@ -364,6 +389,7 @@ void makeMove(Board& b, const Move& m) {
     b.halfmove = (captured == kNoPiece && movingType != 0) ? uint16_t(b.halfmove + 1) : uint16_t(0);
     if (us == 0) ++b.fullmove;
     b.stm = uint8_t(them);
+    filterEp(b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -665,7 +691,7 @@ void packBoard(const Board& b, spx_packed_pos& out) {
     out.occupancy = b.occ;
     uint64_t occ = b.occ;
     int i = 0;
-    while (occ) {
+    while (occ && i < 32) {  // never beyond the 16 nibble bytes (boards with more pieces are rejected at parse time)
         const int sq = ctz64(occ);
         occ &= occ - 1;
         const int pc = b.mailbox[sq];

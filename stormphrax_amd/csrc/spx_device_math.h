@@ -44,6 +44,13 @@ SPX_HD int ctz64(uint64_t x) {
     return __builtin_ctzll(x);
 #endif
 }
+SPX_HD int clz64(uint64_t x) {  // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll(static_cast<long long>(x));
+#else
+    return __builtin_clzll(x);
+#endif
+}
 SPX_HD uint64_t brev64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __brevll(x);
@@ -202,6 +209,78 @@ SPX_HD uint32_t ppRow(uint32_t a, uint32_t b) {
     return hi * (hi - 1) / 2 + lo;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Threat DELTA between two boards that differ on a small set S of squares (one move: |S| <= 4).
+//
+// The reference captures the delta while the move is made (BoardObserver + geometry ray walks, nnue.cpp:380-599,
+// geometry.h:44-141). Here it is derived from the two boards, but with the same ray geometry instead of two full attack
+// generations: a threat pair (attacker a on x -> victim v on y) differs between the boards only if it TOUCHES S - x in S,
+// y in S, or a square of S strictly between x and y. For each board B the pairs that touch S are enumerated exactly once
+// from the squares f of S, one (f, slot) per lane, slot = one of 8 rays or 8 knight jumps:
+//   (A) attacker on f:  f -> nearest piece X on the slot, if the piece on f attacks along it        [owned by x = f]
+//   (B) victim on f:    X -> f, if X attacks towards f and X is NOT in S (else (A) from X has it)   [owned by y = f]
+//   (C) f empty in B:   slider X on the ray -> nearest piece V on the opposite ray, if neither end is in S and no other
+//                       square of S lies between X and f (the S-square nearest the attacker owns the pair)
+// sub = pairs of the parent board, add = pairs of the child board; pairs present in both cancel in the accumulator
+// (sums mod 2^16), pairs that do not touch S are identical on both boards. Kings neither attack nor are attacked in
+// the threat features (nnue_state.cpp:319-323), so they only matter as blockers.
+//
+// Slots: 0 N(+8) 1 NE(+9) 2 E(+1) 3 NW(+7) 4 S 5 SW 6 W 7 SE (slot ^ 4 = opposite ray); 8..15 knight jumps.
+// Tables (u64 words, built by spx_luts.cpp:buildDeltaTables, staged in LDS by the update kernel):
+//   [0, 1024)     ray[slot][sq]: the squares of the ray from sq (exclusive) to the edge / the one knight target (or 0)
+//   [1024, 1408)  pseudo[k][sq]: piecePseudoAttacks, k = 0 black pawn, 1 white pawn, 2 knight, 3 bishop, 4 rook, 5 queen
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kDeltaRayWords = 16 * 64;
+constexpr int kDeltaPseudoWords = 6 * 64;
+constexpr int kDeltaTabWords = kDeltaRayWords + kDeltaPseudoWords;
+constexpr uint32_t kNoDesc = 0xFFFFFFFFu;
+
+SPX_HD int nearestOnSlot(const uint64_t* tab, uint64_t occ, int f, int slot) {  // -1: nothing there
+    const uint64_t blockers = occ & tab[slot * 64 + f];
+    const uint64_t safe = blockers | (blockers ? 0 : 1);
+    const int sq = (slot & 12) == 4 ? 63 - clz64(safe) : ctz64(safe);  // rays 4..7 run towards lower squares
+    return blockers ? sq : -1;
+}
+
+// does `piece` standing at one end of a ray attack the other end? dir = ray direction FROM the piece, adjacent = the two
+// squares touch. Straight-line (this runs divergently per lane): direction sets as byte masks indexed by piece type -
+// sliders at any distance (bishop 1,3,5,7; rook 0,2,4,6; queen all), pawns only next to it (white NE, NW; black SW, SE).
+SPX_HD bool attacksOnRay(int piece, int dir, bool adjacent) {
+    const uint32_t type = uint32_t(piece) >> 1;  // 6 = empty square
+    const uint32_t far = uint32_t(0x000000FF55AA0000ull >> (type * 8)) & 0xFFu;
+    const uint32_t near = (piece < 2 && adjacent) ? ((0x0AA0u >> (piece * 8)) & 0xFFu) : 0u;
+    return ((far | near) >> dir) & 1u;
+}
+
+SPX_HD uint32_t packDesc(int attacker, int asq, int victim, int vsq) {  // ThreatDescriptor byte order (psq.h:30-35)
+    return uint32_t(attacker) | (uint32_t(asq) << 8) | (uint32_t(victim) << 16) | (uint32_t(vsq) << 24);
+}
+
+// One lane of the candidate pass on board B (mail = its 64 piece bytes, occ = its occupancy); f in S.
+SPX_HD void deltaCandidates(const uint64_t* tab, const uint8_t* mail, uint64_t occ, uint64_t changed, int f, int slot,
+                            uint32_t& d1, uint32_t& d2) {
+    const bool isRay = slot < 8;
+    const int dir = slot & 7;
+    const int xRaw = nearestOnSlot(tab, occ, f, slot), vRaw = nearestOnSlot(tab, occ, f, slot ^ 4);
+    const bool hasX = xRaw >= 0, hasV = vRaw >= 0;
+    const int x = hasX ? xRaw : 0, v = hasV ? vRaw : 0;
+    const int pf = mail[f], px = mail[x], pv = mail[v];
+    const int gap = x > f ? x - f : f - x;
+    const bool adjacent = gap == ((0x07010908 >> ((dir & 3) * 8)) & 0xFF);  // |step| of N, NE, E, NW (rays only)
+    const bool xChanged = (changed >> x) & 1, vChanged = (changed >> v) & 1;
+    const bool fOccupied = pf != kNoPiece, fKing = (pf >> 1) == 5;
+    // piece on one end attacks the other end: knights on the jump slots, everything else along rays
+    const bool fAttacksX = isRay ? attacksOnRay(pf, dir, adjacent) : (pf >> 1) == 1;
+    const bool xAttacksF = isRay ? attacksOnRay(px, dir ^ 4, adjacent) : (px >> 1) == 1;
+    const uint64_t between = tab[slot * 64 + f] & ~tab[slot * 64 + x] & ~(1ull << x);
+    const bool a = hasX & fOccupied & !fKing & ((px >> 1) != 5) & fAttacksX;                                  // (A)
+    const bool b = hasX & fOccupied & !fKing & !xChanged & xAttacksF;                                         // (B)
+    const bool c = hasX & !fOccupied & isRay & !xChanged & attacksOnRay(px, dir ^ 4, false) & hasV & !vChanged &
+                   ((pv >> 1) != 5) & !(between & changed);                                                  // (C)
+    d1 = a ? packDesc(pf, f, px, x) : (c ? packDesc(px, x, pv, v) : kNoDesc);
+    d2 = b ? packDesc(px, x, pf, f) : kNoDesc;
+}
+
 // marlinformat nibble -> piece id (type<<1|colour, white = 1). Nibble: type | colour<<3 with black = 8 and
 // type 6 = "unmoved rook" (marlinformat.h:39,52-58).
 SPX_HD int nibbleToPiece(int nib) {
@@ -213,6 +292,32 @@ SPX_HD int nibbleToPiece(int nib) {
         type = 0;  // not a marlinformat code: malformed record. Any valid piece keeps every table index in range.
     }
     return (type << 1) | ((nib & 8) ? 0 : 1);
+}
+
+// row of a packed threat descriptor for the perspective with transform (x, flipColour); < 0 = not a feature
+SPX_HD int32_t descRow(const uint32_t* lut, const uint64_t* tab, uint32_t desc, int x, int flipColour) {
+    const int attackerRel = int(desc & 0xFF) ^ flipColour, asqRel = int((desc >> 8) & 0xFF) ^ x;
+    const int victimRel = int((desc >> 16) & 0xFF) ^ flipColour, vsqRel = int(desc >> 24) ^ x;
+    const int k = attackerRel >= 2 ? (attackerRel >> 1) + 1 : attackerRel;
+    return threatRow(lut, attackerRel, asqRel, tab[kDeltaRayWords + k * 64 + asqRel], victimRel, vsqRel);
+}
+
+// wdl::normalizeScore<false> (wdl.cpp:28-79; the <true> flavour is identical at the default evalSharpness of 100): a score
+// in internal units -> "centipawns" such that 100 = 50 % win probability at this material; zero and decisive scores
+// (|score| > kScoreWin, core.h:722-724) pass through. f64 cubic in material / 58, evaluated with fused multiply-adds (the
+// reference's x86-64 builds contract the same expression), rounding half away from zero like std::round.
+SPX_HD int32_t wdlNormalize(int32_t score, int32_t material) {
+    if (score == 0 || score > kScoreWin || score < -kScoreWin) return score;
+    const int32_t clamped = material < 17 ? 17 : (material > 78 ? 78 : material);
+    const double m = double(clamped) / 58.0;
+    const double a = __builtin_fma(__builtin_fma(__builtin_fma(-244.97139595, m, 687.39969858), m, -654.38002091), m, 608.47087786);
+    return int32_t(__builtin_round(100.0 * (double(score) / a)));
+}
+
+// Position::classicalMaterial (position.h:515-521) from a record's nibble array: pawn 1, knight 3, bishop 3, rook 5
+// (code 6 = rook with castling rights), queen 9
+SPX_HD int32_t classicalMaterialOfNibble(int nib) {
+    return int32_t((0x05095331u >> ((nib & 7) * 4)) & 0xFu);  // types 0..7: 1, 3, 3, 5, 9, 0 (king), 5, 0
 }
 
 // 64-bit key of a packed record's position identity (placement incl. castling-right codes, side to move, ep square;

@@ -16,6 +16,7 @@ struct FtTables {
     const uint8_t* thrW;     // [64368][1024] u8: value+128, columns interleaved per lane (see relayout in spx_api)
     const int16_t* ftBias;   // [1024]
     const uint32_t* lut;     // kLutWords threat LUT
+    const uint64_t* deltaTab;  // kDeltaTabWords ray / knight masks + pseudo-attack sets (threat-delta derivation)
 };
 
 struct FtParams {
@@ -25,7 +26,9 @@ struct FtParams {
     FtTables t;
     uint8_t* ftOut;          // mode A: [nPositions][1024] u8 activations (stm half, then nstm half)
     uint8_t* accOut;         // mode B (ftOut == nullptr): accumulator arena ...
-    const uint32_t* slots;   //         ... slot of each position
+    const uint32_t* slots;   //         ... slot of each position   (both outputs may be set)
+    const uint32_t* nPerspPtr;  // optional: number of entries of `order` lives on the device (deferred refresh list)
+    uint32_t* clearWord;        // optional: a device word this launch zeroes (the refresh counter of the NEXT update)
     uint8_t* slotRecords;    //         ... and the per-slot record store [nSlots][32]
 };
 
@@ -42,6 +45,8 @@ struct UpdateParams {
     const uint8_t* deltas;         // spx_update_observed_kernel only: spx_move_delta[nRecords] (1080 B each)
     uint8_t* ftOut;                // optional fused evaluation: [nRecords][1024] activations of the children ...
     uint8_t* stagedRecords;        // ... and [nRecords][32] their records (input of the MLP's bucket sort)
+    uint32_t* refreshList;         // spx_update_kernel: ids (2 * record + colour) of the perspectives to rebuild ...
+    uint32_t* refreshCount;        // ... and their number (zero on entry); the FT kernel launched next consumes both
 };
 
 struct SlotActParams {
@@ -151,7 +156,7 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
-                        hipStream_t stream);
+                        bool legacy, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);

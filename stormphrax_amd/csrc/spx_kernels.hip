@@ -45,6 +45,8 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
 constexpr int kU8Cap = kThreatCap + kPsqCap;  // u8-row list: compact piece-square rows first, then <= 256 threat rows
+constexpr int kDeltaCap = 96;  // rows per delta list of the update kernel; a legal move stays far below (<= 64 threat rows
+                               // per board for two changed squares, + pawn pairs); a list that would overflow is rebuilt
 
 __device__ __forceinline__ uint32_t laneId() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -470,6 +472,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
 
+    if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
+    if (p.nPerspPtr && *p.nPerspPtr == 0) return;  // nothing was deferred: the refresh pass costs one empty launch
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
         sLut[i] = p.t.lut[i];
     }
@@ -477,7 +481,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t nPersp = p.nPositions * 2;
+    // nPerspPtr: the list in `order` was produced on the device (deferred refreshes of the update kernel) and so was its length
+    const uint32_t nPersp = p.nPerspPtr ? min(*p.nPerspPtr, p.nPositions * 2) : p.nPositions * 2;
     // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch order; affects speed only). Each XCD walks
     // one contiguous eighth of the (king-bucket sorted) perspective order, so its private 4 MiB L2 only ever holds
     // the 1.4 MiB piece-square slab of the bucket(s) in its slice plus the hot threat rows.
@@ -505,7 +510,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
                 reinterpret_cast<uint32_t*>(p.slotRecords + size_t(slot) * 32)[lane] =
                     reinterpret_cast<const uint32_t*>(rec)[lane];
             }
-        } else {
+        }
+        if (p.ftOut) {
             const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
             *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
         }
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // kSplit = true: one wavefront per (record, perspective) - twice the waves, half the serial latency - for batches too
 // small to fill the chip (the kernel is latency-bound there: 4 096 records = 36 us unsplit).
 template <bool kSplit, bool kStream>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel(UpdateParams p) {  // ~120 VGPRs: two boards live
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel_v1(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
@@ -628,6 +634,285 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
             }
         }
+        if (lane < 8 && cFirst == 0) {
+            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Incremental update kernel, second generation (round 2): same contract as spx_update_kernel_v1 above - child
+// accumulator = parent accumulator + added rows - removed rows, delta derived on the device from the two boards - but
+// the threat delta comes from RAY WALKS around the changed squares (deltaCandidates, spx_device_math.h: one lane per
+// (board, changed square, ray / knight slot), no loops) instead of two full attack generations and per-lane victim
+// loops; pawn pairs only from the pawns that left or arrived; the parent accumulator is requested before the delta is
+// derived and the delta rows are fetched four at a time. PMC of v1 at 65 536 records (profiles/r02_pmc_incremental_v1.txt):
+// 1 065 VALU instructions per (record, perspective) wave and 64 % of the wave cycles parked on memory (one row load at a
+// time); this kernel: see DESIGN.md 4.3.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// u8 delta rows: `nAdd` rows are added, `nSub` rows subtracted. A subtracted row is accumulated as its byte-wise
+// complement (255 - b per column), so ONE non-overflowing accumulator serves both signs:
+// sum = sum(add) + 255 * nSub - sum(sub); with the +128 storage bias of the table the correction is
+// 128 * nAdd + 127 * nSub per column (mod 2^16). nAdd + nSub <= 256 (16-bit fields: 256 * 255 < 2^16).
+// Rows are fetched kN at a time - the round-1 kernel waited for every row before asking for the next.
+template <int kN>
+__device__ __forceinline__ void loadAddRows(const uint8_t* thrW, uint32_t laneOff, const uint32_t* list, uint32_t flip,
+                                            uint32_t (&tacc)[8]) {
+    u32x4 w[kN];
+#pragma unroll
+    for (int u = 0; u < kN; ++u) {  // uniform row base + 32-bit lane offset: the saddr form of global_load, no 64-bit VALU add
+        const uint8_t* row = thrW + __builtin_amdgcn_readfirstlane(list[u]);
+        w[u] = *reinterpret_cast<const u32x4*>(row + laneOff);
+    }
+#pragma unroll
+    for (int u = 0; u < kN; ++u) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t v = w[u][d] ^ flip;
+            tacc[2 * d] += unpackLo(v);
+            tacc[2 * d + 1] += unpackHi(v);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // consume row by row: hoisting all 8 * kN widenings costs 32 VGPRs
+    }
+}
+
+__device__ __forceinline__ void accumulateRows(const uint8_t* thrW, uint32_t laneOff, const uint32_t* list, uint32_t n,
+                                               uint32_t flip, uint32_t (&tacc)[8]) {
+    uint32_t i = 0;
+#pragma unroll 1
+    for (; i + 4 <= n; i += 4) loadAddRows<4>(thrW, laneOff, list + i, flip, tacc);
+    const uint32_t rest = n - i;  // wave-uniform
+    if (rest == 3) {
+        loadAddRows<3>(thrW, laneOff, list + i, flip, tacc);
+    } else if (rest == 2) {
+        loadAddRows<2>(thrW, laneOff, list + i, flip, tacc);
+    } else if (rest == 1) {
+        loadAddRows<1>(thrW, laneOff, list + i, flip, tacc);
+    }
+}
+
+__device__ __forceinline__ void applyU8Delta(const FtTables& t, uint32_t lane, const uint32_t* addList, uint32_t nAdd,
+                                             const uint32_t* subList, uint32_t nSub, uint32_t (&acc)[8]) {
+    uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    accumulateRows(t.thrW, 16 * lane, addList, nAdd, 0u, tacc);
+    accumulateRows(t.thrW, 16 * lane, subList, nSub, 0xFFFFFFFFu, tacc);
+    const uint32_t corr = (nAdd * 128u + nSub * 127u) & 0xFFFFu;
+    const uint32_t corr2 = corr | (corr << 16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
+    }
+}
+
+// wide (i16) piece-square delta rows - only nets whose piece-square rows do not all fit i8 have any
+__device__ __forceinline__ void applyWidePsqDelta(const FtTables& t, uint32_t lane, const uint32_t* subList, uint32_t nSub,
+                                                  const uint32_t* addList, uint32_t nAdd, uint32_t (&acc)[8]) {
+    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
+#pragma unroll 1
+    for (uint32_t i = 0; i < nSub; ++i) {
+        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(subList[i]);
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = pkSub16(acc[r], lo[r]);
+            acc[4 + r] = pkSub16(acc[4 + r], hi[r]);
+        }
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < nAdd; ++i) {
+        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(addList[i]);
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = pkAdd16(acc[r], lo[r]);
+            acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
+        }
+    }
+}
+
+// Appends the pawn-pair rows that involve the pawns in `moved` (pawns of this board the other board lacks) to `list`:
+// lane = partner square. All masks are wave-uniform, so positions come from popcounts, not ballots.
+__device__ __forceinline__ uint32_t emitPawnPairDelta(uint32_t* list, uint32_t n, uint64_t moved, uint64_t pawns,
+                                                      uint64_t ownPawns, uint32_t lane, int x) {
+    uint64_t done = 0;
+    while (moved) {
+        const int a = ctz64(moved);
+        moved &= moved - 1;
+        done |= 1ull << a;
+        const uint64_t partners = pawns & ppMask(a) & ~done;
+        const uint32_t idA = ppId(a ^ x, !((ownPawns >> a) & 1));
+        if ((partners >> lane) & 1) {
+            const uint32_t slot = n + uint32_t(popc64(partners & ((1ull << lane) - 1)));
+            if (slot < uint32_t(kDeltaCap)) list[slot] = ppRow(idA, ppId(int(lane) ^ x, !((ownPawns >> lane) & 1))) * kL1;
+        }
+        n += uint32_t(popc64(partners));  // may exceed the capacity: the caller then rebuilds the perspective
+    }
+    return n;
+}
+
+}  // namespace
+
+#ifndef SPX_UPDATE_WAVES
+#define SPX_UPDATE_WAVES 5  // 96 VGPRs: no spills (6 -> 80 VGPRs spills 14-25)
+#endif
+
+// kSplit = false: one wavefront per record does both perspectives (board decoding and the ray walks shared);
+// kSplit = true: one wavefront per (record, perspective) - twice the waves for batches too small to fill the chip.
+// Perspectives that must be REBUILT (king changed bucket / mirror half, boards more than one move apart) are not
+// handled here: their ids (2 * record + colour) are appended to p.refreshList and the feature-transformer kernel,
+// launched right behind this one on the same stream, rebuilds exactly those (3-4 % of the perspectives in play).
+template <bool kSplit, bool kStream>
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_update_kernel(UpdateParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint64_t sTab[kDeltaTabWords];                  // ray / knight masks + pseudo-attack sets (11 KiB)
+    __shared__ uint32_t sAdd[kWavesPerBlock][2][kDeltaCap];    // per perspective: u8 rows to add ...
+    __shared__ uint32_t sSub[kWavesPerBlock][2][kDeltaCap];    // ... and to subtract (compact piece-square rows first)
+    __shared__ uint32_t sWide[kWavesPerBlock][2][2][8];        // per perspective: wide piece-square rows to subtract / add
+    __shared__ uint8_t sMail[kWavesPerBlock][2][64];           // piece per square of the parent / child board
+
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    for (int i = threadIdx.x; i < kDeltaTabWords; i += blockDim.x) {
+        sTab[i] = p.t.deltaTab[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
+
+    const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
+    const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
+    for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < nItems; item += wavesTotal) {
+        const uint32_t it = kSplit ? item >> 1 : item;
+        const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
+        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
+        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
+        const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
+
+        // ================= phase 1: the delta row lists of the perspective(s), into LDS =================
+        uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
+        bool refresh[2] = {false, false};
+        int childStm;
+        {
+            const LaneBoard pb = decodeBoard(parentRec, lane);
+            const LaneBoard cb = decodeBoard(childRec, lane);
+            childStm = cb.stm;
+            sMail[wave][0][lane] = uint8_t(pb.piece);
+            sMail[wave][1][lane] = uint8_t(cb.piece);
+            const bool changedSq = pb.piece != cb.piece;
+            const uint64_t changed = __ballot(changedSq);
+            const uint32_t nChanged = uint32_t(popc64(changed));
+            __builtin_amdgcn_wave_barrier();
+
+            int x[2], kingC[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint64_t kingMaskP = pb.kingsBb & (c ? pb.whiteBb : ~pb.whiteBb);
+                const uint64_t kingMaskC = cb.kingsBb & (c ? cb.whiteBb : ~cb.whiteBb);
+                const int kingP = kingMaskP ? ctz64(kingMaskP) : 0;
+                kingC[c] = kingMaskC ? ctz64(kingMaskC) : 0;
+                const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC[c] ^ 56) : kingC[c];
+                // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the
+                // caller paired unrelated boards) and is rebuilt, like a king that changed bucket or mirror half
+                refresh[c] = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC[c] & 7) >= 4) ||
+                             nChanged > 4;
+                x[c] = perspXor(c, kingC[c]);  // bucket and mirror half are those of the parent too
+            }
+
+            // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
+            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c < cFirst || c >= cLast || refresh[c]) continue;
+                nSub[c] = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC[c]) : 0u, sLut,
+                                           sWide[wave][c][0], sSub[wave][c], nWideSub[c]);
+                nAdd[c] = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC[c]) : 0u, sLut,
+                                           sWide[wave][c][1], sAdd[wave][c], nWideAdd[c]);
+            }
+
+            // ---- threat delta: ray walks around the changed squares, lane = board << 5 | square index << 4 | slot;
+            //      two changed squares per pass, so a second pass only for castling / en passant ----
+            {
+                uint64_t m = nChanged <= 4 ? changed : 0;
+                const int b = int(lane >> 5);
+                const uint64_t occB = b ? cb.occ : pb.occ;
+#pragma unroll 1
+                while (m) {
+                    const int fA = ctz64(m);
+                    m &= m - 1;
+                    const int fB = m ? ctz64(m) : -1;
+                    m &= m - 1;
+                    const int f = (lane & 16) ? fB : fA;
+                    uint32_t desc[2];
+                    deltaCandidates(sTab, sMail[wave][b], occB, changed, max(f, 0), int(lane & 15), desc[0], desc[1]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c < cFirst || c >= cLast || refresh[c]) continue;
+                        const int flipColour = (c == 0) ? 1 : 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const bool have = f >= 0 && desc[j] != kNoDesc;
+                            const int32_t row = descRow(sLut, sTab, have ? desc[j] : 0u, x[c], flipColour);
+                            const uint64_t valid = __ballot(have && row >= 0);
+                            const uint32_t lo = uint32_t(valid), hi = uint32_t(valid >> 32);
+                            // parent-board lanes (0..31) -> rows to subtract, child-board lanes (32..63) -> rows to add
+                            const uint32_t slot = lane < 32 ? nSub[c] + __builtin_amdgcn_mbcnt_lo(lo, 0u)
+                                                            : nAdd[c] + __builtin_amdgcn_mbcnt_hi(hi, 0u);
+                            if (((valid >> lane) & 1) && slot < uint32_t(kDeltaCap)) {
+                                (lane < 32 ? sSub[wave][c] : sAdd[wave][c])[slot] = uint32_t(row) * kL1;
+                            }
+                            nSub[c] += uint32_t(__builtin_popcount(lo));
+                            nAdd[c] += uint32_t(__builtin_popcount(hi));
+                        }
+                    }
+                }
+            }
+
+            // ---- pawn-pair delta (generatePpRows): pairs of the pawns that left / arrived ----
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c < cFirst || c >= cLast || refresh[c]) continue;
+                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
+                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
+                nSub[c] = emitPawnPairDelta(sSub[wave][c], nSub[c], (ownP & ~ownC) | (theirP & ~theirC), pb.pawnsBb, ownP,
+                                            lane, x[c]);
+                nAdd[c] = emitPawnPairDelta(sAdd[wave][c], nAdd[c], (ownC & ~ownP) | (theirC & ~theirP), cb.pawnsBb, ownC,
+                                            lane, x[c]);
+                if (nSub[c] > uint32_t(kDeltaCap) || nAdd[c] > uint32_t(kDeltaCap)) refresh[c] = true;  // never in legal play
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ================= phase 2: child = parent - removed rows + added rows =================
+#pragma unroll 1
+        for (int c = cFirst; c < cLast; ++c) {
+            // (selects, not indexing: a dynamically indexed register array would live in scratch memory)
+            if (c ? refresh[1] : refresh[0]) {
+                if (lane == 0) p.refreshList[atomicAdd(p.refreshCount, 1u)] = 2 * it + uint32_t(c);
+                continue;
+            }
+            const uint32_t na = c ? nAdd[1] : nAdd[0], ns = c ? nSub[1] : nSub[0];
+            const uint32_t nws = c ? nWideSub[1] : nWideSub[0], nwa = c ? nWideAdd[1] : nWideAdd[0];
+            uint32_t acc[8];
+            loadAcc<kStream && SPX_STREAM_LOADS>(p.arena, parentSlot, c, lane, acc);
+            applyWidePsqDelta(p.t, lane, sWide[wave][c][0], nws, sWide[wave][c][1], nwa, acc);
+            applyU8Delta(p.t, lane, sAdd[wave][c], na, sSub[wave][c], ns, acc);
+            storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
+            if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
+                const uint32_t half = (c == childStm) ? 0u : 1u;
+                *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // this record's lists are dead before the next record's are written
         if (lane < 8 && cFirst == 0) {
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
             reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
@@ -810,9 +1095,9 @@ __global__ __launch_bounds__(256) void spx_adjust_kernel(AdjustParams p) {
     if (p.stages & 1u) {
         eval = clampScore(wrapAdd(eval, p.contempt[stm]));
     }
+    const uint32_t count = min(uint32_t(popc64(occ)), 32u);
     if (p.stages & 2u) {
         int32_t npMaterial = 0;
-        const uint32_t count = min(uint32_t(popc64(occ)), 32u);
         for (uint32_t k = 0; k < count; ++k) {
             const int type = nibbleToPiece(int(((k < 16 ? nibLo : nibHi) >> ((k & 15) * 4)) & 0xF)) >> 1;
             if (type < 5) npMaterial += p.scalingValue[type];
@@ -826,6 +1111,16 @@ __global__ __launch_bounds__(256) void spx_adjust_kernel(AdjustParams p) {
             eval = wrapAdd(eval, p.corrections[i] / 2048);
         }
         eval = clampScore(eval);
+    }
+    if (p.stages & 12u) {  // SPX_ADJUST_WHITE_POV, SPX_ADJUST_WDL: what runDatagenSearch returns (search.cpp:237-238)
+        if ((p.stages & 4u) && stm == 0) eval = int32_t(0u - uint32_t(eval));
+        if (p.stages & 8u) {
+            int32_t material = 0;
+            for (uint32_t k = 0; k < count; ++k) {
+                material += classicalMaterialOfNibble(int(((k < 16 ? nibLo : nibHi) >> ((k & 15) * 4)) & 0xF));
+            }
+            eval = wdlNormalize(eval, material);
+        }
     }
     p.evals[i] = eval;
 }
@@ -1126,8 +1421,20 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) 
 }
 
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
-                        hipStream_t stream) {
+                        bool legacy, hipStream_t stream) {
     const dim3 grid(gridBlocks), block(64 * kWavesPerBlock);
+    if (legacy) {  // round-1 kernel, kept for A/B runs (SPX_UPDATE_V1=1)
+        if (splitPerspectives && streamAccumulators) {
+            hipLaunchKernelGGL((spx_update_kernel_v1<true, true>), grid, block, 0, stream, p);
+        } else if (splitPerspectives) {
+            hipLaunchKernelGGL((spx_update_kernel_v1<true, false>), grid, block, 0, stream, p);
+        } else if (streamAccumulators) {
+            hipLaunchKernelGGL((spx_update_kernel_v1<false, true>), grid, block, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((spx_update_kernel_v1<false, false>), grid, block, 0, stream, p);
+        }
+        return hipGetLastError();
+    }
     if (splitPerspectives && streamAccumulators) {
         hipLaunchKernelGGL((spx_update_kernel<true, true>), grid, block, 0, stream, p);
     } else if (splitPerspectives) {

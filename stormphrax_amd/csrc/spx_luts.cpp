@@ -75,4 +75,30 @@ int buildThreatLut(uint32_t* lut) {
     return offset;
 }
 
+// Fills tab[kDeltaTabWords]: ray / knight-jump masks per (slot, square) and the pseudo-attack sets per (piece kind,
+// square) of the threat-delta derivation (layout in spx_device_math.h).
+void buildDeltaTables(uint64_t* tab) {
+    static const int kRayStep[8][2] = {{0, 1}, {1, 1}, {1, 0}, {-1, 1}, {0, -1}, {-1, -1}, {-1, 0}, {1, -1}};  // (df, dr)
+    static const int kJump[8][2] = {{1, 2}, {2, 1}, {2, -1}, {1, -2}, {-1, -2}, {-2, -1}, {-2, 1}, {-1, 2}};
+    for (int sq = 0; sq < 64; ++sq) {
+        const int file = sq & 7, rank = sq >> 3;
+        for (int d = 0; d < 8; ++d) {
+            uint64_t m = 0;
+            for (int f = file + kRayStep[d][0], r = rank + kRayStep[d][1]; f >= 0 && f < 8 && r >= 0 && r < 8;
+                 f += kRayStep[d][0], r += kRayStep[d][1]) {
+                m |= 1ull << (r * 8 + f);
+            }
+            tab[d * 64 + sq] = m;
+        }
+        for (int j = 0; j < 8; ++j) {
+            const int f = file + kJump[j][0], r = rank + kJump[j][1];
+            tab[(8 + j) * 64 + sq] = (f >= 0 && f < 8 && r >= 0 && r < 8) ? 1ull << (r * 8 + f) : 0;
+        }
+        for (int k = 0; k < 6; ++k) {
+            const int piece = k < 2 ? k : ((k - 1) << 1);  // 0 black pawn, 1 white pawn, then knight .. queen
+            tab[kDeltaRayWords + k * 64 + sq] = piecePseudoAttacks(piece, sq);
+        }
+    }
+}
+
 }  // namespace spx

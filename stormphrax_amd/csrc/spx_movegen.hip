@@ -136,10 +136,20 @@ __device__ void writeChild(const Parent& p, const Sets& s, int from, int to, int
         occ |= 1ull << to;
         if (moverType == 5) nib = dropCastlingRights(nib, 6u | colourBit);
         if (moverType == 0 && (to - from == 16 || from - to == 16)) {
-            // the ep square is recorded only if an enemy pawn could capture there (spx_chess.cpp:347-352)
+            // the ep square is recorded only if an enemy pawn can LEGALLY capture there (Position::filterEp,
+            // position.cpp:1608-1683; spx_chess.cpp:filterEp): make each of the <= 2 candidate captures - capturer to the
+            // ep square, the pushed pawn gone - and test the capturing side's king against our pieces (`s` still has the
+            // pushed pawn on `from`: taken out of the attackers)
             const int epSq = (from + to) / 2;
-            const uint64_t enemyPawns = s.pawns & (us ? ~s.white : s.white);
-            if (pawnAttacks(1ull << epSq, us) & enemyPawns) epOut = epSq;
+            const uint64_t enemy = us ? ~s.white : s.white;
+            uint64_t capturers = pawnAttacks(1ull << epSq, us) & s.pawns & enemy;
+            const uint64_t enemyKing = s.kings & enemy;
+            while (capturers && epOut == 64) {
+                const int cf = ctz64(capturers);
+                capturers &= capturers - 1;
+                const uint64_t occ2 = (occ & ~((1ull << cf) | (1ull << to))) | (1ull << epSq);
+                if (enemyKing && !attackedBy(s, ctz64(enemyKing), us, occ2, 1ull << from)) epOut = epSq;
+            }
         }
     }
     const bool pawnMove = moverType == 0 && kind != kChildCastling;

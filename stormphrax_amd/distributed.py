@@ -67,6 +67,25 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def broadcast_bytes(self, data, src=0):
+        """Rank `src`'s uint8 array on every rank (the 89 MB net image at start-up: SURVEY 8e's ncclBroadcast of the
+        weight blob; over RCCL the payload travels GPU to GPU across xGMI). Ranks other than `src` pass None."""
+        if not self.dist:
+            return np.ascontiguousarray(data, dtype=np.uint8)
+        import torch
+
+        size = self._tensor([0 if data is None else int(np.asarray(data).size)], torch.int64)
+        self.dist.broadcast(size, src=src)
+        n = int(size.item())
+        if self.rank == src:
+            t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.uint8).copy())
+        else:
+            t = torch.empty(n, dtype=torch.uint8)
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
     def gather_scores(self, local_scores, n_total):
         """all_gather of per-rank int32 score shards (contiguous sharding) -> full array on every rank."""
         local = np.ascontiguousarray(local_scores, dtype=np.int32)

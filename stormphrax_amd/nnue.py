@@ -38,7 +38,8 @@ def synthetic_net_bytes(preset="tame", seed=DEFAULT_SEED):
     return buf
 
 
-ADJUST_STATIC, ADJUST_EVAL = 1, 2
+ADJUST_STATIC, ADJUST_EVAL, ADJUST_WHITE_POV, ADJUST_WDL = 1, 2, 4, 8
+CTX_WIDE_PSQ_ROWS = 1  # spx_ctx_create_ex flag: no compact (u8) copies of piece-square rows
 
 
 def adjust_params(contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL):
@@ -87,10 +88,11 @@ class Network:
 class NnueState:
     """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
 
-    def __init__(self, network, device=0, max_batch=65536):
+    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False):
         lib = _lib.load()
         handle = ctypes.c_void_p()
-        check(lib.spx_ctx_create(network._h, device, max_batch, ctypes.byref(handle)))
+        flags = CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0
+        check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
         self._h = handle
         self._net = network
         self.max_batch = max_batch
@@ -161,6 +163,15 @@ class NnueState:
     def compact_psq_rows(self):
         """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
         return int(_lib.load().spx_ctx_compact_psq_rows(self._h))
+
+    def count_rows(self, positions):
+        """(psq rows fetched wide (2 KiB), psq rows fetched compact (1 KiB), threat / pawn-pair rows (1 KiB)) a full
+        refresh of the batch gathers through THIS context, both perspectives summed. Host-side count."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(_lib.load().spx_ctx_count_rows(self._h, pos.ctypes.data, pos.shape[0], ctypes.byref(a), ctypes.byref(b),
+                                             ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def evaluate_once_device_async(self, d_positions_ptr, n, d_out_ptr):
         """Pipelined variant (spx_eval_full_device_async): returns the hipEvent_t handle that marks the batch done."""
@@ -344,6 +355,23 @@ def debug_features(rec, colour):
     n1, n2 = ctypes.c_int(), ctypes.c_int()
     check(lib.spx_debug_features(rec.ctypes.data, colour, psq.ctypes.data, ctypes.byref(n1), thr.ctypes.data, ctypes.byref(n2)))
     return psq[: n1.value].copy(), thr[: n2.value].copy()
+
+
+def debug_delta(parent, child, colour):
+    """Host emulation of the update kernel's delta derivation -> dict(psq_sub, psq_add, thr_sub, thr_add, refresh)."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(parent, dtype=PACKED_DTYPE).reshape(1)
+    b = np.ascontiguousarray(child, dtype=PACKED_DTYPE).reshape(1)
+    bufs = [np.empty(n, dtype=np.uint32) for n in (8, 8, 288, 288)]
+    counts = [ctypes.c_int() for _ in range(4)]
+    refresh = ctypes.c_int()
+    args = []
+    for buf, cnt in zip(bufs, counts):
+        args += [buf.ctypes.data, ctypes.byref(cnt)]
+    check(lib.spx_debug_delta(a.ctypes.data, b.ctypes.data, colour, *args, ctypes.byref(refresh)))
+    out = {k: buf[: cnt.value].copy() for k, buf, cnt in zip(("psq_sub", "psq_add", "thr_sub", "thr_add"), bufs, counts)}
+    out["refresh"] = bool(refresh.value)
+    return out
 
 
 def count_rows(positions):

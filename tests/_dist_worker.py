@@ -22,7 +22,10 @@ def main():
     positions = sp.random_positions(n, seed=77)          # every rank derives the same global batch...
     lo, hi = shard_bounds(n, group.rank, group.world)     # ...and evaluates only its contiguous shard
     oracle = Oracle()
-    oracle.use(sp.synthetic_net_bytes("tame"), "tame")
+    # the net image travels from rank 0 to the others (bench.py: RCCL broadcast at start-up), as SURVEY 8e lists
+    blob = group.broadcast_bytes(sp.synthetic_net_bytes("tame") if group.rank == 0 else None)
+    assert np.array_equal(blob, sp.synthetic_net_bytes("tame")), "broadcast net image differs from rank 0's"
+    oracle.use(blob, "tame")
     mail, stm = sp.positions_to_mailboxes(positions[lo:hi])
     local = oracle.eval_mailboxes(mail, stm)
     full = group.gather_scores(local, n)

@@ -18,6 +18,15 @@ reference itself computes:
                   regenerate alone with `make_golden.py adjust`
   trace_startpos_tame_64k.txt.gz   the same kind of stream at BASELINE config-3 scale (65 536 EVALs, depth cap 12);
                   regenerate alone with `make_golden.py bigtrace`
+  pack.txt        "<fen> | <64 hex>": the 32 bytes of datagen::marlinformat::PackedBoard::pack(pos, 0)
+                  (src/datagen/marlinformat.h:32-84) - castling-rook code 6, relative ep square (only when an en passant
+                  capture is legal: Position::filterEp), clocks, zero eval / wdl / extra
+  viri_games.txt  random games pushed through the reference's datagen::Viriformat (src/datagen/viriformat.cpp:28-63): per
+                  ply "M <fen before> | <uci> | <score> | <filtered> | <pack hex incl. the score>", then "V <hex>" = the
+                  byte stream writeAllWithOutcome wrote (start record with the outcome byte, {u16 move, i16 score}*, 4 zero
+                  bytes)
+  wdl.txt         "<score> <classicalMaterial> <wdl::normalizeScore(score, material)>" (src/wdl.cpp:28-79)
+                  regenerate these three alone with `make_golden.py wire`
   trace_*.txt     PUSH/POP/EVAL opcode streams of a make/unmake walk driven through NnueState::push/evaluate
                   (the lazily-updated incremental path), with the reference's evaluate() at every EVAL
 
@@ -100,7 +109,53 @@ def make_big_trace():
     print("big trace written:", sum(1 for ln in out if ln.startswith("EVAL")), "evals")
 
 
+def make_wire():
+    """Wire-format and WDL goldens: bytes written by the reference's own marlinformat / viriformat code."""
+    import random
+
+    rng = random.Random(777)
+    probe = Probe(PROBES["tame"])
+    recs = [json.loads(line) for line in open(os.path.join(HERE, "evals.jsonl"))]
+    fens = [r["fen"] for r in recs if r["src"] in ("startpos", "bench", "edge", "ref_playout")]
+    fens += rng.sample([r["fen"] for r in recs if r["src"] == "spx_random"], 400)
+    # en-passant squares: legal capture, no capturer, capturer pinned on the file / on the diagonal / the capture would
+    # discover a rook check along the rank, and in check by another piece (Position::filterEp keeps only the legal ones)
+    fens += [
+        "4k3/8/8/3pP3/8/8/8/4K3 w - d6 0 2", "4k3/8/8/3p4/8/8/8/4K3 w - d6 0 2", "4k3/4r3/8/3pP3/8/8/8/4K3 w - d6 0 2",
+        "4k3/8/8/KPp4r/8/8/8/8 w - c6 0 2", "7k/8/8/8/1pP4R/8/8/K7 b - c3 0 2", "4k3/8/8/2pP4/8/8/8/4K2b w - c6 0 2",
+        "8/8/8/1k6/2Pp4/8/8/4K2B b - c3 0 2", "rnbqkbnr/ppp1pppp/8/8/3pP3/8/PPPP1PPP/RNBQKBNR b KQkq e3 0 3",
+        "r3k2r/8/8/8/8/8/8/R3K2R w Kq - 5 40", "1rk4r/8/8/8/8/8/8/1RK4R w Hb - 0 9",
+    ]
+    with open(os.path.join(HERE, "pack.txt"), "w") as f:
+        f.write("# <fen> | PackedBoard::pack(pos, 0) as hex; oracle/ref_probe.cpp `pack`\n")
+        for fen in fens:
+            (line,) = probe.cmd("pack " + fen)
+            assert line.startswith("K "), (fen, line)
+            f.write(f"{fen} | {line.split()[1]}\n")
+    with open(os.path.join(HERE, "viri_games.txt"), "w") as f:
+        f.write("# oracle/ref_probe.cpp `viri <seed> <plies> <dfrc>`\n")
+        games = [(seed, 40 + 7 * (seed % 23), seed % 2) for seed in range(1, 41)]
+        for seed, plies, dfrc in games:
+            f.write(f"GAME {seed} {plies} {dfrc}\n")
+            for line in probe.cmd(f"viri {seed} {plies} {dfrc}"):
+                f.write(line + "\n")
+    with open(os.path.join(HERE, "wdl.txt"), "w") as f:
+        f.write("# <score> <classicalMaterial> <wdl::normalizeScore(score, material)>; oracle/ref_probe.cpp `wdl`\n")
+        sample = rng.sample(fens, 120)
+        scores = [0, 1, -1, 2, 9, 10, 11, -10, 100, -100, 396, 1000, -1249, 1250, 1251, -1251, 5000, 24999, -24999, 25000,
+                  25001, -25001, 31000, -32000]
+        for fen in sample:
+            for score in scores + [rng.randint(-3000, 3000) for _ in range(6)]:
+                (line,) = probe.cmd(f"wdl {score} {fen}")
+                _, material, norm = line.split()
+                f.write(f"{score} {material} {norm}\n")
+    probe.close()
+    print("wire goldens written:", len(fens), "packs,", len(games), "games")
+
+
 def main():
+    if sys.argv[1:] == ["wire"]:
+        return make_wire()
     if sys.argv[1:] == ["adjust"]:
         return make_adjust()
     if sys.argv[1:] == ["bigtrace"]:
@@ -168,6 +223,7 @@ def main():
     print("golden vectors written:", len(fens), "positions")
     make_adjust()
     make_big_trace()
+    make_wire()
 
 
 if __name__ == "__main__":

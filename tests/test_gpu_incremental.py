@@ -18,13 +18,25 @@ def preset_of(path):
         return f.readline().split()[2].rstrip(";")
 
 
-@pytest.fixture(scope="module")
-def states(sp, net_blob):
+@pytest.fixture(scope="module", params=["default-kernels", "ray-walk-kernel"])
+def states(sp, net_blob, request):
+    """Every test of this module runs twice: with the library's own choice of update kernel (batches this small take the
+    single-launch round-1 kernel) and with the second-generation kernel forced (SPX_UPDATE_V1=0, read when the context is
+    created): ray-walk threat deltas + deferred rebuild pass, what batches above 8 192 records get."""
     cache = {}
 
     def get(preset):
         if preset not in cache:
-            cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
+            old = os.environ.get("SPX_UPDATE_V1")
+            if request.param == "ray-walk-kernel":
+                os.environ["SPX_UPDATE_V1"] = "0"
+            try:
+                cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
+            finally:
+                if old is None:
+                    os.environ.pop("SPX_UPDATE_V1", None)
+                else:
+                    os.environ["SPX_UPDATE_V1"] = old
         return cache[preset]
 
     yield get

@@ -276,3 +276,70 @@ def test_marlinformat_filter_flags(sp):
         seen["capture"] += bool(kind in (0, 3) and occupied)
         seen["quiet"] += bool(kept)
     assert seen["check"] > 0 and seen["capture"] > 0 and seen["quiet"] > 0, seen
+
+
+def _delta_is_exact(sp, parent, child):
+    """features(child) == features(parent) - sub + add, as multisets, for both perspectives (or the perspective is rebuilt)."""
+    from collections import Counter
+
+    rebuilt = 0
+    for c in (0, 1):
+        d = sp.debug_delta(parent, child, c)
+        if d["refresh"]:
+            rebuilt += 1
+            continue
+        p0, t0 = sp.debug_features(parent, c)
+        p1, t1 = sp.debug_features(child, c)
+        for before, after, sub, add in ((p0, p1, d["psq_sub"], d["psq_add"]), (t0, t1, d["thr_sub"], d["thr_add"])):
+            rows = Counter(before.tolist())
+            rows.subtract(sub.tolist())
+            assert all(v >= 0 for v in rows.values()), "a row was subtracted that the parent does not have"
+            rows.update(add.tolist())
+            assert +rows == Counter(after.tolist()), (sp.position_to_fen(parent), sp.position_to_fen(child), c)
+    return rebuilt
+
+
+def test_update_kernel_delta_derivation_is_an_exact_feature_difference(sp):
+    """The second-generation update kernel derives a move's threat delta from ray walks around the changed squares
+    (spx_device_math.h:deltaCandidates) and its pawn-pair delta from the pawns that left / arrived. spx_debug_delta runs
+    that same per-lane code on the host: applied to the parent's feature lists (the extractor pinned against the
+    reference's row lists in features.jsonl) it must give exactly the child's lists - the reference's own invariant
+    evaluate() == evaluateOnce() (datagen.cpp:262) at the level of feature rows."""
+    # hand-picked geometry: en passant opening a rank for a rook (two empty changed squares on one line), king-takes-rook
+    # castling incl. overlapping Chess960 squares, capture-promotion, discovered x-rays through the vacated square,
+    # a pawn capturing a pawn (colour flip on the landing square of the pawn-pair sets)
+    cases = [
+        ("8/8/8/Q2pP2r/8/8/8/K6k w - d6 0 1", "e5d6"),
+        ("r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", "e1h1"),
+        ("r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", "e1a1"),
+        ("r3k2r/pppq1ppp/8/8/8/8/PPPQ1PPP/R3K2R b KQkq - 0 1", "e8a8"),
+        ("1k6/8/8/8/8/8/8/RK5R w KQ - 0 1", "b1a1"),
+        ("1k6/8/8/8/8/8/8/RK5R w KQ - 0 1", "b1h1"),
+        ("1n2k3/P7/8/8/8/8/8/4K3 w - - 0 1", "a7b8q"),
+        ("1n2k3/P7/8/8/8/8/8/4K3 w - - 0 1", "a7a8n"),
+        ("4k3/8/8/r2N3Q/8/8/8/4K3 w - - 0 1", "d5f6"),
+        ("4k3/8/2p1p3/3P4/8/8/8/4K3 w - - 0 1", "d5c6"),
+        ("4k3/8/8/3pP3/8/8/8/4K3 w - d6 0 1", "e5d6"),
+        ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", "g1f3"),
+        ("r1bqkbnr/pppp1ppp/2n5/4p3/2B1P3/5N2/PPPP1PPP/RNBQK2R w KQkq - 2 3", "e1h1"),
+    ]
+    for fen, uci in cases:
+        parent = sp.positions_from_fens([fen])[0]
+        _delta_is_exact(sp, parent, sp.apply_uci(parent, uci))
+    # random play, every 3rd game double-Chess960: quiet moves, captures, promotions, castling, king walks
+    pos = sp.random_positions(1500, seed=41, min_ply=0, max_ply=160, dfrc_every=3)
+    rebuilt = checked = 0
+    for ply in range(3):
+        nxt, moved = sp.random_successors(pos, seed=900 + ply)
+        for i in np.nonzero(moved)[0]:
+            rebuilt += _delta_is_exact(sp, pos[i], nxt[i])
+            checked += 2
+        pos = nxt
+    assert checked > 8000 and 0 < rebuilt < checked // 10  # king-bucket / mirror changes are rebuilt, the rest is a delta
+    # a null move (only the side to move flips) is an empty delta; unrelated boards are rebuilt
+    a, b = sp.random_positions(2, seed=3)
+    flipped = a.copy()
+    flipped["stm_ep"] ^= 0x80
+    d = sp.debug_delta(a, flipped, 1)
+    assert not d["refresh"] and all(len(d[k]) == 0 for k in ("psq_sub", "psq_add", "thr_sub", "thr_add"))
+    assert sp.debug_delta(a, b, 0)["refresh"]
