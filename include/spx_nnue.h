@@ -299,8 +299,10 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * Batched self-play driver (BASELINE config 4 shape; control flow of src/datagen/datagen.cpp:96-318): n_games concurrent
  * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),
  * i.e. a depth-1 "search" - Stormphrax's alpha-beta search is out of scope), random 8-9 ply openings, the reference's
- * adjudication counters, viriformat game records appended to out_path (NULL = discard). Scores are raw network outputs
- * from the mover's point of view.
+ * adjudication counters, viriformat game records appended to out_path (NULL = discard). As in the reference the recorded
+ * scores are from WHITE's point of view (Searcher::runDatagenSearch, src/search.cpp:237; clamped like datagen.cpp:283) and
+ * the adjudication counters compare their WDL-normalised form (wdl::normalizeScore at the material of the position the
+ * move was played from, src/search.cpp:238, src/datagen/datagen.cpp:224-252); the scores are raw network outputs.
  * Default: the games live on the GPU - legal moves and child records from spx_movegen, openings generated in bulk by the
  * same kernels, the move choice on the device, the two halves of the seats on the context's two lanes; the host keeps
  * the adjudication counters and the records (24 bytes per game and ply come back). SPX_SELFPLAY_HOST_MOVEGEN selects
@@ -341,6 +343,10 @@ int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows
 int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, int colour, uint32_t* psq_sub,
                     int* n_psq_sub, uint32_t* psq_add, int* n_psq_add, uint32_t* threat_sub, int* n_threat_sub,
                     uint32_t* threat_add, int* n_threat_add, int* refresh);
+
+/* Host evaluation of what SPX_ADJUST_WDL computes per position (same source as the kernel): Position::classicalMaterial
+ * (src/position.h:515-521) of the record and wdl::normalizeScore (src/wdl.cpp:28-79) of `score` at it. Test-only. */
+int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, int32_t* normalized);
 
 #ifdef __cplusplus
 }

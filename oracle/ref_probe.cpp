@@ -23,7 +23,8 @@
 //   viri <seed> <plies> <dfrc> -> a random game pushed through datagen::Viriformat: per ply "M <fen before> | <uci> |
 //                                 <score> | <filtered> | <pack hex of the position before>", then "V <hex of the stream
 //                                 writeAllWithOutcome wrote>" (marlinformat.h:32-84, viriformat.cpp:28-63)
-//   wdl <score> <fen>          -> "W <classicalMaterial> <wdl::normalizeScore(score, material)>" (wdl.cpp:28-79)
+//   wdl <score> <fen>          -> "W <classicalMaterial> <wdl::normalizeScore(score, material)>" (wdl.cpp:28-79) at
+//                                 datagen's evalSharpness of 100 (datagen.cpp:353)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -260,7 +261,16 @@ int main() {
                 continue;
             }
             const auto material = pos->classicalMaterial();
-            std::printf("W %d %d\n", material, wdl::normalizeScore(score, material));
+            // datagen runs with evalSharpness = 100 (datagen.cpp:353: no sharpening), which makes the default
+            // normalizeScore<true> that runDatagenSearch calls (search.cpp:238) equal to normalizeScore<false>
+            opts::mutableOpts().evalSharpness = 100;
+            const auto norm = wdl::normalizeScore(score, material);
+            if (norm != wdl::normalizeScore<false>(score, material)) {
+                std::printf("ERR sharpened and plain normalisation differ at sharpness 100\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            std::printf("W %d %d\n", material, norm);
         } else if (cmd == "viri") {
             u64 seed;
             u32 plies, dfrc;

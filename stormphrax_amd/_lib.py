@@ -130,6 +130,7 @@ SYMBOLS = {
     "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
     "spx_debug_delta": (ctypes.c_int, [_P, _P, ctypes.c_int] + [_P, ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int)]),
+    "spx_debug_wdl": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),
 }
 

@@ -106,6 +106,7 @@ struct spx_ctx {
     bool updateLegacy = false;     // the round-1 update kernel (two full attack generations, rebuilds inline: ONE launch) serves
     bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
+    size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = records / 4)
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
@@ -464,6 +465,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     }
     ctx->updateSplitMaxV2 = 16384;
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -859,7 +861,7 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     fp.slots = up.childSlots;
     fp.slotRecords = up.slotRecords;
     ctx->refreshCur ^= 1;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, std::max<size_t>(256, n / 4)), s));
+    SPX_HIP(launchFt(fp, ftGrid(ctx, ctx->refreshWaves ? ctx->refreshWaves : std::max<size_t>(256, n / 4)), s));
     return SPX_OK;
 }
 
@@ -2048,6 +2050,22 @@ int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, i
             }
         }
     }
+    return SPX_OK;
+}
+
+
+// Host evaluation of the SPX_HD functions behind SPX_ADJUST_WDL (the device runs the same source): Position::classicalMaterial
+// of a record and wdl::normalizeScore of a score at that material. Test-only.
+int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, int32_t* normalized) {
+    if (!pos || !material || !normalized) {
+        setError("spx_debug_wdl: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const int n = std::min(popc64(pos->occupancy), 32);
+    int32_t m = 0;
+    for (int k = 0; k < n; ++k) m += classicalMaterialOfNibble((pos->pieces[k >> 1] >> ((k & 1) * 4)) & 0xF);
+    *material = m;
+    *normalized = wdlNormalize(score, m);
     return SPX_OK;
 }
 

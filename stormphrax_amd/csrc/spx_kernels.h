@@ -92,7 +92,8 @@ struct PickResult {   // per game, read back by the self-play driver after every
     uint16_t move;    // viriformat word of the chosen move
     uint8_t inCheck;
     uint8_t halfmove; // halfmove clock after the move
-    uint32_t pad;
+    int32_t normScore; // wdl::normalizeScore of the WHITE-point-of-view score at the material of the position the move was
+                       // played from: what datagen's adjudication counters compare (search.cpp:237-238, datagen.cpp:224-252)
 };
 
 struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)

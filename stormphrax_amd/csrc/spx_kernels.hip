@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t unpackHi(uint32_t x) {
 }
 
 // pairwise clipped ReLU of one column pair (multilayer.h:108-145): a = column j, b = column j+512 (i16, wrapped)
-__device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
+[[maybe_unused]] __device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
     const int32_t i1 = min(max(a, 0), 255);
     const int32_t i2 = min(b, 255);              // NOT clamped at zero
     const int32_t p = ((i1 << 7) * i2) >> 16;    // mulhi_epi16(i1 << 7, i2): arithmetic shift (floor)
@@ -90,8 +90,24 @@ struct LaneBoard {
     int stm;                                  // side to move, 1 = white
 };
 
+#ifndef SPX_OPT_DECODE
+#define SPX_OPT_DECODE 1
+#endif
 __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
     LaneBoard b;
+#if SPX_OPT_DECODE
+    // ONE coalesced load for the whole 32-byte record (lane l fetches dword l & 7); the wave-uniform fields come out of
+    // v_readlane into SGPRs - so every mask derived from the occupancy is scalar arithmetic - and a lane's nibble comes
+    // from the lane that holds its dword (ds_bpermute) instead of a second, dependent global load
+    const uint32_t w = reinterpret_cast<const uint32_t*>(rec)[lane & 7];
+    b.occ = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(w), 1))) << 32) | uint32_t(__builtin_amdgcn_readlane(int(w), 0));
+    b.stm = (uint32_t(__builtin_amdgcn_readlane(int(w), 6)) & 0x80u) ? 0 : 1;
+    const bool occupied = (b.occ >> lane) & 1;
+    // malformed records (> 32 pieces) must not index past the 16 nibble bytes: results are unspecified, accesses are not
+    const uint32_t nibIdx = min(prefixCount(b.occ), 31u);
+    const uint32_t word = uint32_t(__shfl(int(w), int(2 + (nibIdx >> 3)), 64));
+    b.piece = occupied ? nibbleToPiece(int((word >> ((nibIdx & 7) * 4)) & 0xF)) : int(kNoPiece);
+#else
     b.occ = *reinterpret_cast<const uint64_t*>(rec);
     b.stm = (rec[24] & 0x80) ? 0 : 1;
     const bool occupied = (b.occ >> lane) & 1;
@@ -102,6 +118,7 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
         const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
         b.piece = nibbleToPiece(nib);
     }
+#endif
     const int type = b.piece >> 1;  // 6 for empty
     b.kingsBb = __ballot(type == 5);
     b.whiteBb = __ballot(occupied && (b.piece & 1) == 1);
@@ -339,7 +356,30 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
 }
 
 // pairwise activation of one perspective's accumulator -> 8 bytes per lane (columns 8l..8l+7 of the 512 outputs)
+#ifndef SPX_OPT_PKACT
+#define SPX_OPT_PKACT 1
+#endif
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
+#if SPX_OPT_PKACT
+    // Two columns per instruction on the packed-16-bit pipe (multilayer.h:108-145): i1 = clamp(a, 0, 255),
+    // i2 = min(b, 255); ((i1 << 7) * i2) >> 16 floors i1 * i2 / 512 and negatives saturate to 0 - and since i1 >= 0 the
+    // product is negative exactly when i2 is, so clamping i2 at 0 first gives the same byte. Then both factors are
+    // 0..255, the product fits 16 bits: v_pk_max/min_i16, v_pk_mul_lo_u16, v_pk_lshrrev_b16.
+    const i16x2 zero = {0, 0}, top = {255, 255};
+    uint32_t q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const i16x2 a = __builtin_bit_cast(i16x2, acc[r]), b = __builtin_bit_cast(i16x2, acc[4 + r]);
+        const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(a, zero), top));
+        const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top));
+        q[r] = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));  // [col 2r | col 2r + 1 << 16], each 0..127
+    }
+    u32x2 o;  // bytes 0, 2 of each pair of dwords
+    o[0] = __builtin_amdgcn_perm(q[1], q[0], 0x06040200u);
+    o[1] = __builtin_amdgcn_perm(q[3], q[2], 0x06040200u);
+    return o;
+#else
     uint32_t outLo = 0, outHi = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -356,6 +396,7 @@ __device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
     o[0] = outLo;
     o[1] = outHi;
     return o;
+#endif
 }
 
 // Accumulator arena slot: [colour 0: i16[1024]][colour 1: i16[1024]] = 4 KiB, natural column order. Lane l owns
@@ -758,6 +799,9 @@ __device__ __forceinline__ uint32_t emitPawnPairDelta(uint32_t* list, uint32_t n
 
 }  // namespace
 
+#ifndef SPX_OPT_PREFETCH
+#define SPX_OPT_PREFETCH 1
+#endif
 #ifndef SPX_UPDATE_WAVES
 #define SPX_UPDATE_WAVES 5  // 96 VGPRs: no spills (6 -> 80 VGPRs spills 14-25)
 #endif
@@ -798,6 +842,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
         const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
 
+#if SPX_OPT_PREFETCH
+        // the parent accumulators are the one HBM-latency read of an update: one dword per 64 bytes pulls the whole slot
+        // (4 KiB, or this perspective's 2 KiB) towards the CU while phase 1 runs; the value itself is never used
+        const uint32_t warm = *reinterpret_cast<const uint32_t*>(p.arena + size_t(parentSlot) * kAccSlotBytes +
+                                                                 (kSplit ? size_t(cFirst) * (kL1 * 2) + 32 * lane : 64 * lane));
+#endif
         // ================= phase 1: the delta row lists of the perspective(s), into LDS =================
         uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
         bool refresh[2] = {false, false};
@@ -893,6 +943,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         }
 
         // ================= phase 2: child = parent - removed rows + added rows =================
+#if SPX_OPT_PREFETCH
+        asm volatile("" ::"v"(warm));  // keeps the warming load alive (and waited for) up to here
+#endif
 #pragma unroll 1
         for (int c = cFirst; c < cLast; ++c) {
             // (selects, not indexing: a dynamically indexed register array would live in scratch memory)

@@ -415,6 +415,18 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
         const uint32_t c = lo + pick;
         const uint64_t* child = p.children + size_t(c) * 4;
         const uint64_t w0 = child[0], w1 = child[1], w2 = child[2], w3 = child[3];
+        // Position::classicalMaterial of the position the move is played FROM (lane k sums nibble k), before it is replaced
+        int32_t material = 0;
+        {
+            const uint64_t* parent = p.positions + size_t(g) * 4;
+            const uint32_t pieces = min(uint32_t(popc64(parent[0])), 32u);
+            if (lane < pieces) {
+                material = classicalMaterialOfNibble(int((parent[1 + (lane >> 4)] >> ((lane & 15) * 4)) & 0xF));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) material += __shfl_xor(material, off, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
         if (lane < 4) p.positions[size_t(g) * 4 + lane] = child[lane];
         if (lane == 0) {
             p.rng[g] = state;
@@ -422,6 +434,9 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
         }
         r.key = recordKey(w0, w1, w2, uint32_t(w3));
         r.score = p.evals ? -p.evals[c] : 0;
+        // the child has the OTHER side to move: bit 7 of its stm byte set = black to move = white made this move
+        const bool whiteMoved = (w3 & 0x80u) != 0;
+        r.normScore = wdlNormalize(whiteMoved ? r.score : -r.score, material);
         r.move = p.moves[c];
         r.halfmove = uint8_t((w3 >> 8) & 0xFF);
     }

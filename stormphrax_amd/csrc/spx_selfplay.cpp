@@ -423,16 +423,24 @@ static int runHostMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char
             }
             const int score = -evals[pick];
             g.moves.push_back(viriMove(g.legal[pick]));
-            g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(score) <= 2 ? 0 : score))));
+            // white-point-of-view score (what the reference records) and its WDL-normalised form (what its adjudication
+            // counters compare): search.cpp:237-238, datagen.cpp:224-252,283-284
             const int whiteScore = g.board.stm ? score : -score;
+            int material = 0;
+            for (int sq = 0; sq < 64; ++sq) {
+                static const int kValue[7] = {1, 3, 3, 5, 9, 0, 0};
+                if (g.board.mailbox[sq] != kNoPiece) material += kValue[g.board.mailbox[sq] >> 1];
+            }
+            const int normScore = wdlNormalize(whiteScore, material);
+            g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(whiteScore) <= 2 ? 0 : whiteScore))));
             uint8_t outcome = 255;
-            if (whiteScore > kWinAdjMinScore) {
+            if (normScore > kWinAdjMinScore) {
                 ++g.winPlies;
                 g.lossPlies = g.drawPlies = 0;
-            } else if (whiteScore < -kWinAdjMinScore) {
+            } else if (normScore < -kWinAdjMinScore) {
                 ++g.lossPlies;
                 g.winPlies = g.drawPlies = 0;
-            } else if (g.plies >= kDrawAdjMinPlies && std::abs(score) < kDrawAdjMaxScore) {
+            } else if (g.plies >= kDrawAdjMinPlies && std::abs(normScore) < kDrawAdjMaxScore) {
                 ++g.drawPlies;
                 g.winPlies = g.lossPlies = 0;
             } else {
@@ -995,18 +1003,21 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
                     g.outcome = r.inCheck ? (g.stm == 0 ? 2 : 0) : 1;
                     continue;
                 }
-                const int score = r.score;
+                // what runDatagenSearch hands to datagen (search.cpp:237-238): the score from WHITE's point of view - this
+                // is what the reference records (datagen.cpp:283-284) - and its WDL-normalised form, which the
+                // adjudication counters compare (datagen.cpp:224-252)
+                const int whiteScore = g.stm ? r.score : -r.score;
+                const int normScore = r.normScore;
                 g.moves.push_back(r.move);
-                g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(score) <= 2 ? 0 : score))));
-                const int whiteScore = g.stm ? score : -score;
+                g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(whiteScore) <= 2 ? 0 : whiteScore))));
                 uint8_t outcome = 255;
-                if (whiteScore > kWinAdjMinScore) {
+                if (normScore > kWinAdjMinScore) {
                     ++g.winPlies;
                     g.lossPlies = g.drawPlies = 0;
-                } else if (whiteScore < -kWinAdjMinScore) {
+                } else if (normScore < -kWinAdjMinScore) {
                     ++g.lossPlies;
                     g.winPlies = g.drawPlies = 0;
-                } else if (g.plies >= kDrawAdjMinPlies && std::abs(score) < kDrawAdjMaxScore) {
+                } else if (g.plies >= kDrawAdjMinPlies && std::abs(normScore) < kDrawAdjMaxScore) {
                     ++g.drawPlies;
                     g.winPlies = g.lossPlies = 0;
                 } else {

@@ -25,7 +25,7 @@ reference itself computes:
                   ply "M <fen before> | <uci> | <score> | <filtered> | <pack hex incl. the score>", then "V <hex>" = the
                   byte stream writeAllWithOutcome wrote (start record with the outcome byte, {u16 move, i16 score}*, 4 zero
                   bytes)
-  wdl.txt         "<score> <classicalMaterial> <wdl::normalizeScore(score, material)>" (src/wdl.cpp:28-79)
+  wdl.txt         "<score> <classicalMaterial> <wdl::normalizeScore(score, material)> | <fen>" (src/wdl.cpp:28-79)
                   regenerate these three alone with `make_golden.py wire`
   trace_*.txt     PUSH/POP/EVAL opcode streams of a make/unmake walk driven through NnueState::push/evaluate
                   (the lazily-updated incremental path), with the reference's evaluate() at every EVAL
@@ -140,7 +140,7 @@ def make_wire():
             for line in probe.cmd(f"viri {seed} {plies} {dfrc}"):
                 f.write(line + "\n")
     with open(os.path.join(HERE, "wdl.txt"), "w") as f:
-        f.write("# <score> <classicalMaterial> <wdl::normalizeScore(score, material)>; oracle/ref_probe.cpp `wdl`\n")
+        f.write("# <score> <classicalMaterial> <wdl::normalizeScore(score, material)> | <fen>; oracle/ref_probe.cpp `wdl`\n")
         sample = rng.sample(fens, 120)
         scores = [0, 1, -1, 2, 9, 10, 11, -10, 100, -100, 396, 1000, -1249, 1250, 1251, -1251, 5000, 24999, -24999, 25000,
                   25001, -25001, 31000, -32000]
@@ -148,7 +148,7 @@ def make_wire():
             for score in scores + [rng.randint(-3000, 3000) for _ in range(6)]:
                 (line,) = probe.cmd(f"wdl {score} {fen}")
                 _, material, norm = line.split()
-                f.write(f"{score} {material} {norm}\n")
+                f.write(f"{score} {material} {norm} | {fen}\n")
     probe.close()
     print("wire goldens written:", len(fens), "packs,", len(games), "games")
 

@@ -239,7 +239,9 @@ def test_selfplay_driver_records_are_consistent(sp, net_blob, tmp_path, host_mov
     checked = 0
     for n in lengths:
         for k in range(start, start + n - 1):
-            want = -int(full[k + 1])
+            want = -int(full[k + 1])                       # the mover's view of the position it reached ...
+            if positions["stm_ep"][k] & 0x80:              # ... recorded from WHITE's point of view (search.cpp:237)
+                want = -want
             want = 0 if abs(want) <= 2 else max(-32000, min(32000, want))
             assert int(positions["eval"][k]) == want, (k, sp.position_to_fen(positions[k]))
             checked += 1
@@ -255,7 +257,8 @@ def test_selfplay_driver_records_are_consistent(sp, net_blob, tmp_path, host_mov
             if moved[0]:
                 succ.append(nxt[0])
         best = max(-int(v) for v in st.evaluate_once(np.array(succ, dtype=sp.PACKED_DTYPE)))
-        assert int(positions["eval"][k]) >= min(best, 32000) - margin - 2 or abs(int(positions["eval"][k])) == 0
+        mover_view = -int(positions["eval"][k]) if positions["stm_ep"][k] & 0x80 else int(positions["eval"][k])
+        assert mover_view >= min(best, 32000) - margin - 2 or mover_view == 0
     st.close()
 
 

@@ -5,8 +5,10 @@
 
 Input: marlinformat `.bin` (32-byte PackedBoard records, src/datagen/marlinformat.h:32-84) or viriformat `.vf` game
 streams (src/datagen/viriformat.cpp:28-63, expanded to one record per played move). Output: marlinformat records whose
-`eval` field holds the raw network output of the position (clamped to i16), everything else unchanged - the same 32-byte
-records bullet/marlinflow-style trainers consume."""
+`eval` field holds the raw network output of the position from WHITE's point of view (clamped to i16) - the convention of
+the reference's own data files (Searcher::runDatagenSearch returns the white-relative score, src/search.cpp:237, and
+Marlinformat / Viriformat store it, datagen.cpp:283-284) - everything else unchanged: the same 32-byte records
+bullet/marlinflow-style trainers consume. --pov stm keeps the side-to-move-relative value instead."""
 import argparse
 import os
 import sys
@@ -28,6 +30,8 @@ def main():
     ap.add_argument("--filter", action="store_true",
                     help=".vf input: keep only the positions the reference's marlinformat output keeps (side to move not in "
                          "check, played move not a capture / en passant / queen promotion: datagen.cpp:254)")
+    ap.add_argument("--pov", default="white", choices=["white", "stm"],
+                    help="point of view of the written evals: white (the reference's data convention) or the side to move")
     ap.add_argument("--validate", action="store_true",
                     help=".vf input: replay the games on the host and check every move against the legal-move generator "
                          "(~5e5 positions/s) instead of the device replay, which trusts the stream")
@@ -49,7 +53,9 @@ def main():
     else:
         positions = np.frombuffer(raw, dtype=sp.PACKED_DTYPE).copy()
     state = sp.NnueState(net, device=args.device, max_batch=min(args.batch, max(len(positions), 1)))
-    evals = state.evaluate_once(positions)  # chunked internally
+    evals = state.evaluate_once(positions)  # chunked internally; relative to the side to move
+    if args.pov == "white":
+        evals = np.where(positions["stm_ep"] & 0x80, -evals, evals)  # bit 7 = black to move
     positions["eval"] = np.clip(evals, -32768, 32767).astype(np.int16)
     positions.tofile(args.dst)
     print(f"wrote {len(positions)} records to {args.dst} (net '{net.name}')")
