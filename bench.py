@@ -54,6 +54,10 @@ def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):
             step()
         sync()
         dt = time.perf_counter() - t0
+        if dt > 2.0 * min_seconds:  # steps that take seconds themselves (HBM-filling batches): one group is warm-up enough
+            return steps + chunk
+        if dt > 0.25 and chunk > 1:
+            chunk = 1
         times.append(dt)
         total += dt
         steps += chunk
@@ -230,33 +234,45 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
 
     step_no = [0]
 
+    pipelined = not args.no_pipeline
+    d_outs = [d_out, torch.empty(G, dtype=torch.int32, device="cuda")]
+
     def step():
         s = step_no[0]
         cur, nxt = slots[s & 1], slots[(s + 1) & 1]
-        _lib.check(lib.spx_acc_update_eval_device(h, cur.data_ptr(), nxt.data_ptr(), d_boards[board_index(s + 1)].data_ptr(),
-                                                  G, d_out.data_ptr(), stream))
+        boards = d_boards[board_index(s + 1)].data_ptr()
+        if pipelined:  # update kernels chained in call order, sort + MLP of a ply beside the next ply's update
+            _lib.check(lib.spx_acc_update_eval_device_async(h, cur.data_ptr(), nxt.data_ptr(), boards, G,
+                                                            d_outs[s & 1].data_ptr(), None))
+        else:
+            _lib.check(lib.spx_acc_update_eval_device(h, cur.data_ptr(), nxt.data_ptr(), boards, G,
+                                                      d_outs[s & 1].data_ptr(), stream))
         step_no[0] = s + 1
 
-    settle_steps = 0 if args.no_settle else settle(step, torch.cuda.synchronize)
+    def sync():
+        state.synchronize()
+        torch.cuda.synchronize()
+
+    settle_steps = 0 if args.no_settle else settle(step, sync)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     group.barrier()
-    torch.cuda.synchronize()
+    sync()
     state.profile_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     group.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = group.max_float(time.perf_counter() - t0)
     _, update_ms, mlp_ms, calls = state.profile_end()
     # parity inside the bench: the incrementally maintained evals equal a full refresh of the final boards
     full = torch.empty(G, dtype=torch.int32, device="cuda")
     state.evaluate_once_device(d_boards[board_index(step_no[0])].data_ptr(), G, full.data_ptr(), stream)
     torch.cuda.synchronize()
-    exact = group.sum_int(int(torch.equal(full, d_out))) == world
+    exact = group.sum_int(int(torch.equal(full, d_outs[(step_no[0] - 1) & 1]))) == world
     if rank == 0:
         psq_d, thr_d = delta_rows_sample(sp, chain[3], chain[4])
         compulsory = 2 * 4096 + 72  # parent accumulators read + child accumulators written + the two records
@@ -289,6 +305,8 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
             "config": {"workload": "BASELINE configs[2]/[3] shape: per step one ply of incremental accumulator updates "
                                    "(device-derived add/sub deltas) + evaluation for every one of the concurrent games",
                        "games_per_gpu": G, "bit_exact_vs_full_refresh": bool(exact), "settle_steps": settle_steps,
+                       "issue": ("pipelined spx_acc_update_eval_device_async: update kernels in call order, sort + MLP of a "
+                                 "ply beside the next ply's update kernel" if pipelined else "stream-ordered calls"),
                        "mean_delta_rows_per_update": {"psq": psq_d, "threat": thr_d}},
             "roofline": roofline,
         }), flush=True)
@@ -314,13 +332,14 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
         state.synchronize()
         torch.cuda.synchronize()
 
-    settle_steps = 0 if args.no_settle else settle(step, sync)
+    settle_steps = 0 if args.no_settle else settle(step, sync, chunk=10 if args.batch <= (1 << 22) else 1)
     for _ in range(args.warmup):
         step()
     sync()
     group.barrier()
     sync()
-    state.profile_begin(args.steps)
+    chunks = -(-args.batch // state.scratch_batch)  # calls above the scratch capacity run as several launch sequences
+    state.profile_begin(args.steps * chunks)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -328,7 +347,8 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
     group.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    prof = state.profile_end()
+    sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
+    prof = (sort_ms, ft_ms, mlp_ms, calls / chunks)  # per-kernel times per STEP (= per batch), as the byte counts are
     return group.max_float(elapsed), prof, settle_steps, d_outs[(counter[0] - 1) % len(d_outs)]
 
 
@@ -400,15 +420,20 @@ def main():
     # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     n_distinct = min(args.distinct or args.batch, args.batch)
     distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
-    positions = np.resize(distinct, args.batch) if n_distinct < args.batch else distinct
-    d_pos = torch.from_numpy(positions.view(np.uint8).reshape(-1, 32)).cuda()
+    d_distinct = torch.from_numpy(distinct.view(np.uint8).reshape(-1, 32)).cuda()
+    if n_distinct < args.batch:  # tiled ON THE DEVICE: an HBM-filling batch (config 5) never exists in host memory
+        reps = -(-args.batch // n_distinct)
+        d_pos = d_distinct.repeat(reps, 1)[: args.batch].contiguous()
+        positions = distinct  # the sample checks below look at the first n_sample <= n_distinct positions
+    else:
+        d_pos, positions = d_distinct, distinct
     pipelined = not args.no_pipeline
 
     elapsed, (sort_ms, ft_ms, mlp_ms, calls), settle_steps, d_last = timed_full_run(args, torch, group, state, d_pos, pipelined)
     checksum = group.sum_int(int(d_last.to(torch.int64).sum().item()))  # checksum of checksums over all shards
 
     # ---- parity inside the bench (outside the timed region): oracle on a sample of every rank's shard ----
-    n_sample = min(4096, args.batch)
+    n_sample = min(4096, n_distinct)
     got = d_last[:n_sample].cpu().numpy()
     exact = group.sum_int(int(oracle_sample_check(sp, blob, positions[:n_sample], got))) == world
 
@@ -496,6 +521,8 @@ def main():
                              "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU"
                              + (f"; batch tiled from {n_distinct} distinct positions" if n_distinct < args.batch else "")),
                 "batch_per_gpu": args.batch,
+                "resident_bytes": int(torch.cuda.max_memory_allocated()) if hasattr(torch.cuda, "max_memory_allocated") else None,
+                "chunks_per_step": -(-args.batch // state.scratch_batch),
                 "net": (f"file {os.path.basename(args.net)} '{net.name}'" if args.net else
                         f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8"),
                 "compact_psq_rows": f"{state.compact_psq_rows} of 11264 piece-square rows fit i8 and are served as 1 KiB copies",
@@ -517,7 +544,7 @@ def main():
         if wide:
             line["wide_psq_rows"] = wide
         if not args.no_cpu_baseline and world == 1 and not args.net:  # the CPU leg is timed on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(sp, positions, blob, args.cpu_seconds, args.allow_port_baseline)
+            line["cpu_baseline"] = cpu_baseline(sp, distinct, blob, args.cpu_seconds, args.allow_port_baseline)
         print(json.dumps(line), flush=True)
     group.close()
 

@@ -88,6 +88,11 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
  * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
 enum { SPX_CTX_WIDE_PSQ_ROWS = 1 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
+/* Positions the context keeps intermediates for at once: min(max_batch, SPX_SCRATCH_CAP = 4 Mi by default). The
+ * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an
+ * HBM-filling batch costs 36 bytes per resident position: record in, score out); the arena entry points (spx_acc_*) and
+ * spx_movegen take at most this many records per call. */
+size_t spx_ctx_scratch_batch(const spx_ctx* ctx);
 void spx_ctx_destroy(spx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -127,6 +132,8 @@ int spx_ctx_synchronize(spx_ctx* ctx);
  *   spx_acc_eval     == evaluateNetwork on materialised slots (nnue_state.cpp:396-438); stm comes from the slot's record
  * Host-buffer variants synchronise; *_device variants take device pointers and enqueue on `stream` (NULL = context's).
  * ---------------------------------------------------------------------------------------------------------------- */
+/* spx_acc_reserve sizes the arena (never shrinks). Growing it keeps every materialised slot: accumulators and records are
+ * copied into the new allocation (both arenas exist for the duration of the call). */
 int spx_acc_reserve(spx_ctx* ctx, size_t n_slots);
 int spx_acc_refresh(spx_ctx* ctx, const spx_packed_pos* positions, const uint32_t* slots, size_t n);
 int spx_acc_update(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
@@ -142,6 +149,14 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
                         const spx_packed_pos* child_positions, size_t n, int32_t* out);
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream);
+
+/* Pipelined variant for chains of plies (self-play style loops, trace replays level by level): returns at once; the
+ * update kernels of consecutive calls run in call order (a ply's parents may be the previous call's children), while the
+ * sort and the MLP of one call overlap the update kernel of the next on the context's second internal stream. Inputs and
+ * d_out must stay untouched until *done_event (a hipEvent_t owned by the context, valid until two more async calls) or
+ * spx_ctx_synchronize(ctx). Results are bit-identical to spx_acc_update_eval_device. */
+int spx_acc_update_eval_device_async(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                     const void* d_child_positions, size_t n, void* d_out, void** done_event);
 
 /* Page-locked host memory for batch buffers (positions, slots, scores). Optional: every host-buffer entry point accepts
  * ordinary memory, but copies from/to page-locked buffers run as plain DMA at PCIe speed instead of being staged by the

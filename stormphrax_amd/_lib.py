@@ -84,6 +84,7 @@ SYMBOLS = {
     "spx_fnv1a64": (ctypes.c_uint64, [_P, ctypes.c_size_t]),
     "spx_ctx_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_P)]),
     "spx_ctx_create_ex": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    "spx_ctx_scratch_batch": (ctypes.c_size_t, [_P]),
     "spx_ctx_destroy": (None, [_P]),
     "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
@@ -97,6 +98,7 @@ SYMBOLS = {
     "spx_acc_update_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_eval": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_eval_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
+    "spx_acc_update_eval_device_async": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_net_digest": (ctypes.c_uint64, [_P]),
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),

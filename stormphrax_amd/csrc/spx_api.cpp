@@ -48,7 +48,9 @@ constexpr size_t kProfEventsPerCall = 5;
 
 struct spx_ctx {
     int device = 0;
-    size_t maxBatch = 0;
+    size_t maxBatch = 0;       // scratch capacity: positions one launch sequence can hold intermediates for
+    size_t callLimit = 0;      // spx_eval_full_device[_async] accept up to this many positions per call (the max_batch the
+                               // context was created with) and walk them in chunks of maxBatch
     hipStream_t stream = nullptr;
     // weights
     int16_t* dPsqW = nullptr;
@@ -367,7 +369,7 @@ struct CtxDeleter {  // a context that fails half-way through its creation relea
 }  // namespace
 
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out) {
-    if (!net || !out || max_batch == 0 || max_batch > (1ull << 30) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS))) {
+    if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS))) {
         setError("spx_ctx_create: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -380,7 +382,14 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipSetDevice(device));
     std::unique_ptr<spx_ctx, CtxDeleter> ctx(new spx_ctx());
     ctx->device = device;
-    ctx->maxBatch = max_batch;
+    // Intermediates (1 KiB of activations + sort scratch per position) are kept for at most SPX_SCRATCH_CAP positions
+    // (default 4 Mi): a context created for an HBM-filling batch (BASELINE config 5: 36 bytes per resident position -
+    // record in, score out) walks it in chunks of that size instead of reserving ~1.1 KB of scratch per position
+    size_t scratchCap = size_t(1) << 22;
+    if (const char* env = std::getenv("SPX_SCRATCH_CAP")) scratchCap = std::max<size_t>(1024, size_t(std::atoll(env)));
+    ctx->callLimit = max_batch;
+    ctx->maxBatch = std::min(max_batch, scratchCap);
+    max_batch = ctx->maxBatch;
     SPX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 
     int rc;
@@ -517,12 +526,13 @@ void spx_ctx_destroy(spx_ctx* ctx) {
 
 // sort (both keys) on `d_records`, then the MLP over ctx->dFtOut[0..n) -> d_out
 static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp,
-                         const uint32_t* d_count = nullptr) {
+                         const uint32_t* d_count = nullptr, bool outOnly = false) {
     if (!mlp) {
         SortParams sp{};
         sp.positions = static_cast<const uint64_t*>(d_records);
         sp.nPositions = uint32_t(n);
         sp.nPositionsPtr = d_count;
+        sp.outOnly = outOnly;
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
         if (n <= 1024 && !d_count) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
@@ -584,11 +594,19 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         setError("spx_eval_full_device: null argument");
         return SPX_ERR_INVALID_ARG;
     }
-    if (n > ctx->maxBatch) {
-        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->maxBatch));
+    if (n > ctx->callLimit) {
+        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->callLimit));
         return SPX_ERR_CAPACITY;
     }
     if (n == 0) {
+        return SPX_OK;
+    }
+    if (n > ctx->maxBatch) {  // more positions than the scratch holds: chunk by chunk, stream-ordered
+        for (size_t lo = 0; lo < n; lo += ctx->maxBatch) {
+            const int rc = spx_eval_full_device(ctx, static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos),
+                                                std::min(ctx->maxBatch, n - lo), static_cast<int32_t*>(d_out) + lo, stream);
+            if (rc != SPX_OK) return rc;
+        }
         return SPX_OK;
     }
     SPX_HIP(hipSetDevice(ctx->device));
@@ -700,19 +718,32 @@ int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, 
         if (done_event) *done_event = ctx->fallbackDone;
         return SPX_OK;
     }
-    spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
-    spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
-    ++ctx->laneNext;
-    swapLane(ctx, lane);
-    ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
-    ctx->ftGateRecord = lane.ftDone;
-    rc = spx_eval_full_device(ctx, d_positions, n, d_out, lane.stream);
-    ctx->ftGateWait = ctx->ftGateRecord = nullptr;
-    swapLane(ctx, lane);
-    if (rc != SPX_OK) return rc;
-    if (n) lane.ftRecorded = true;
-    SPX_HIP(hipEventRecord(lane.done, lane.stream));
-    if (done_event) *done_event = lane.done;
+    if (n > ctx->callLimit) {
+        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->callLimit));
+        return SPX_ERR_CAPACITY;
+    }
+    // chunks of the scratch capacity alternate between the two lanes (one chunk for an ordinary batch)
+    spx_ctx::EvalLane* last = nullptr;
+    for (size_t lo = 0; lo < n || lo == 0; lo += ctx->maxBatch) {
+        const size_t m = std::min(ctx->maxBatch, n - lo);
+        spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
+        spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
+        ++ctx->laneNext;
+        swapLane(ctx, lane);
+        ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
+        ctx->ftGateRecord = lane.ftDone;
+        rc = spx_eval_full_device(ctx, static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos), m,
+                                  static_cast<int32_t*>(d_out) + lo, lane.stream);
+        ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+        swapLane(ctx, lane);
+        if (rc != SPX_OK) return rc;
+        if (m) lane.ftRecorded = true;
+        if (last) SPX_HIP(hipStreamWaitEvent(lane.stream, last->done, 0));  // `done` of the call covers every chunk
+        SPX_HIP(hipEventRecord(lane.done, lane.stream));
+        last = &lane;
+        if (n == 0) break;
+    }
+    if (done_event) *done_event = last->done;
     return SPX_OK;
 }
 
@@ -765,15 +796,30 @@ int spx_acc_reserve(spx_ctx* ctx, size_t n_slots) {
     SPX_HIP(hipSetDevice(ctx->device));
     if (n_slots <= ctx->nSlots) return SPX_OK;
     SPX_HIP(hipDeviceSynchronize());
+    // growing keeps every materialised slot: the old arena and records are copied into the new allocation
+    uint8_t *arena = nullptr, *records = nullptr;
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&arena), n_slots * kAccSlotBytes));
+    if (hipMalloc(reinterpret_cast<void**>(&records), n_slots * 32) != hipSuccess) {
+        (void)hipFree(arena);
+        setError("spx_acc_reserve: out of device memory");
+        return SPX_ERR_HIP;
+    }
+    hipError_t e = hipMemset(records, 0, n_slots * 32);
+    if (e == hipSuccess && ctx->nSlots) {
+        e = hipMemcpy(arena, ctx->dArena, ctx->nSlots * kAccSlotBytes, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(records, ctx->dSlotRecords, ctx->nSlots * 32, hipMemcpyDeviceToDevice);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // null-stream work vs. the non-blocking streams that use the arena next
+    if (e != hipSuccess) {
+        (void)hipFree(arena);
+        (void)hipFree(records);
+        setError(std::string("spx_acc_reserve: ") + hipGetErrorString(e));
+        return SPX_ERR_HIP;
+    }
     if (ctx->dArena) (void)hipFree(ctx->dArena);
     if (ctx->dSlotRecords) (void)hipFree(ctx->dSlotRecords);
-    ctx->dArena = nullptr;
-    ctx->dSlotRecords = nullptr;
-    ctx->nSlots = 0;
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dArena), n_slots * kAccSlotBytes));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotRecords), n_slots * 32));
-    SPX_HIP(hipMemset(ctx->dSlotRecords, 0, n_slots * 32));
-    SPX_HIP(hipDeviceSynchronize());  // null-stream memset vs. the non-blocking streams that use the arena next
+    ctx->dArena = arena;
+    ctx->dSlotRecords = records;
     ctx->nSlots = n_slots;
     return SPX_OK;
 }
@@ -916,12 +962,51 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
     if (!d_count && n <= ctx->tinyBatchMax) {
         rc = runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
     } else {
-        rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count);
+        rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, d_count, true);
         if (rc != SPX_OK) return rc;
         rc = runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true, d_count);
     }
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    return SPX_OK;
+}
+
+// Pipelined plies: consecutive calls alternate the context's two lanes (scratch sets + streams). The update kernels (and
+// their rebuild passes) run in call order, chained by events - a ply's parents are the previous ply's children - while
+// the output-bucket sort and the MLP of one ply run beside the update kernel of the next.
+int spx_acc_update_eval_device_async(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                     const void* d_child_positions, size_t n, void* d_out, void** done_event) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_eval_device_async");
+    if (rc != SPX_OK) return rc;
+    rc = ctx->lanesUnavailable ? SPX_ERR_HIP : ensureLanes(ctx);
+    if (rc != SPX_OK) {  // no room for the second scratch set: same results, stream-ordered on the context's own stream
+        if (!ctx->lanesUnavailable) {
+            (void)hipGetLastError();
+            releaseLanes(ctx);
+            ctx->lanesUnavailable = true;
+            if (!ctx->fallbackDone) SPX_HIP(hipEventCreateWithFlags(&ctx->fallbackDone, hipEventDisableTiming));
+        }
+        rc = updateEvalDevice(ctx, d_parent_slots, d_child_slots, d_child_positions, n, nullptr, d_out, ctx->stream,
+                              "spx_acc_update_eval_device_async");
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipEventRecord(ctx->fallbackDone, ctx->stream));
+        if (done_event) *done_event = ctx->fallbackDone;
+        return SPX_OK;
+    }
+    spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
+    spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
+    ++ctx->laneNext;
+    swapLane(ctx, lane);
+    ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
+    ctx->ftGateRecord = lane.ftDone;
+    rc = updateEvalDevice(ctx, d_parent_slots, d_child_slots, d_child_positions, n, nullptr, d_out, lane.stream,
+                          "spx_acc_update_eval_device_async");
+    ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+    swapLane(ctx, lane);
+    if (rc != SPX_OK) return rc;
+    if (n) lane.ftRecorded = true;
+    SPX_HIP(hipEventRecord(lane.done, lane.stream));
+    if (done_event) *done_event = lane.done;
     return SPX_OK;
 }
 
@@ -948,7 +1033,7 @@ int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, con
     }
     SPX_HIP(launchUpdateObserved(up, ftGrid(ctx, 2 * n), s));  // one wave per (record, perspective)
     if (!d_out) return SPX_OK;
-    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, nullptr, true);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
 }
@@ -996,7 +1081,7 @@ int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out
     if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
     SPX_HIP(launchSlotAct(ap, blocks, s));
     if (n <= ctx->tinyBatchMax) return runTinyMlp(ctx, ctx->dStaged, n, d_out, s);
-    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false);
+    rc = runSortAndMlp(ctx, ctx->dStaged, n, nullptr, s, false, nullptr, true);
     if (rc != SPX_OK) return rc;
     return runSortAndMlp(ctx, ctx->dStaged, n, d_out, s, true);
 }
@@ -1135,6 +1220,10 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
     }
     ctx->profUsed = 0;
     return SPX_OK;
+}
+
+size_t spx_ctx_scratch_batch(const spx_ctx* ctx) {
+    return ctx ? ctx->maxBatch : 0;
 }
 
 uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx) {

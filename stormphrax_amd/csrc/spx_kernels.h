@@ -128,6 +128,7 @@ struct SortParams {
     const uint64_t* positions;  // records as u64[4]
     uint32_t nPositions;
     const uint32_t* nPositionsPtr;  // optional device-resident count (<= nPositions), as in UpdateParams
+    bool outOnly;               // large sorts: only the output-bucket order (arena paths: nobody reads the king-bucket order)
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
     uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)

@@ -799,9 +799,6 @@ __device__ __forceinline__ uint32_t emitPawnPairDelta(uint32_t* list, uint32_t n
 
 }  // namespace
 
-#ifndef SPX_OPT_PREFETCH
-#define SPX_OPT_PREFETCH 1
-#endif
 #ifndef SPX_UPDATE_WAVES
 #define SPX_UPDATE_WAVES 5  // 96 VGPRs: no spills (6 -> 80 VGPRs spills 14-25)
 #endif
@@ -842,12 +839,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
         const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
 
-#if SPX_OPT_PREFETCH
-        // the parent accumulators are the one HBM-latency read of an update: one dword per 64 bytes pulls the whole slot
-        // (4 KiB, or this perspective's 2 KiB) towards the CU while phase 1 runs; the value itself is never used
-        const uint32_t warm = *reinterpret_cast<const uint32_t*>(p.arena + size_t(parentSlot) * kAccSlotBytes +
-                                                                 (kSplit ? size_t(cFirst) * (kL1 * 2) + 32 * lane : 64 * lane));
-#endif
         // ================= phase 1: the delta row lists of the perspective(s), into LDS =================
         uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
         bool refresh[2] = {false, false};
@@ -943,9 +934,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         }
 
         // ================= phase 2: child = parent - removed rows + added rows =================
-#if SPX_OPT_PREFETCH
-        asm volatile("" ::"v"(warm));  // keeps the warming load alive (and waited for) up to here
-#endif
 #pragma unroll 1
         for (int c = cFirst; c < cLast; ++c) {
             // (selects, not indexing: a dynamically indexed register array would live in scratch memory)
@@ -1197,7 +1185,11 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
     __syncthreads();
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
-    if (pos < nPositions) {
+    if (pos < nPositions && p.outOnly) {  // arena paths: only the MLP's output-bucket order is needed
+        const uint32_t outKey = min((uint32_t(popc64(p.positions[size_t(pos) * 4])) - 2u) / 4u, uint32_t(kOutKeys - 1));
+        p.outKeys[pos] = uint8_t(outKey);
+        atomicAdd(&sHist[kHistOut + outKey], 1u);
+    } else if (pos < nPositions) {
         const uint64_t* rec = p.positions + size_t(pos) * 4;
         uint64_t occ = rec[0];
         const uint64_t nibLo = rec[1], nibHi = rec[2];
@@ -1317,7 +1309,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
         return hipGetLastError();
     }
-    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = (2 * p.nPositions + 255) / 256;
+    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = p.outOnly ? 0u : (2 * p.nPositions + 255) / 256;
     hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2 + b1), dim3(256), 0, stream, p, b2);
     return hipGetLastError();

@@ -160,6 +160,11 @@ class NnueState:
                 "in_check": in_check.astype(bool)}
 
     @property
+    def scratch_batch(self):
+        """Positions per internal chunk (spx_ctx_scratch_batch): larger spx_eval_full* calls are walked in chunks."""
+        return int(_lib.load().spx_ctx_scratch_batch(self._h))
+
+    @property
     def compact_psq_rows(self):
         """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
         return int(_lib.load().spx_ctx_compact_psq_rows(self._h))

@@ -1,0 +1,124 @@
+"""BASELINE.json configurations at (or near) their stated sizes on one MI355X: configs[3] self-play with 4 096 concurrent
+games, configs[4] the HBM-filling batch, and the N = 2 control flow of bench.py / tools/spx_selfplay.py with both ranks
+on this box's one GPU (the driver measures real multi-GPU scaling itself)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def game_lengths(blob):
+    lengths, off = [], 0
+    while off < len(blob):
+        off += 32
+        n = 0
+        while blob[off:off + 4] != b"\x00\x00\x00\x00":
+            off += 4
+            n += 1
+        off += 4
+        lengths.append(n)
+    return lengths
+
+
+def test_config3_selfplay_with_4096_concurrent_games(sp, net_blob, tmp_path):
+    """configs[3] at its stated width: 4 096 concurrent games (double-Chess960 starts), moves generated and chosen on the
+    device, leaf evaluations through the incremental update + eval path. Checked: every recorded move is legal (the host
+    expander replays each game against its own move generator), the device replay of the file is identical, and every
+    recorded score is the white-point-of-view negamax value of a from-scratch evaluation of the position reached."""
+    st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=4096 * 64)
+    try:
+        path = str(tmp_path / "games.vf")
+        stats = st.selfplay(n_games=4096, target_games=5000, out_path=path, max_plies=200, dfrc=True, temperature_cp=20, seed=4)
+        assert stats["games"] == 5000 and sum(stats["outcomes"]) == 5000 and stats["evals"] > 5_000_000
+        blob = open(path, "rb").read()
+        positions, games = sp.viri_expand(blob)          # validates every move against the host move generator
+        assert games == 5000 and len(positions) == stats["positions"]
+        device_records, device_games, bad = st.viri_expand(blob)
+        assert (device_games, bad) == (5000, 0) and device_records.tobytes() == positions.tobytes()
+        full = st.evaluate_once(positions)
+        start = checked = 0
+        for n in game_lengths(blob):
+            idx = np.arange(start, start + n - 1)
+            want = -full[idx + 1].astype(np.int64)
+            want = np.where(positions["stm_ep"][idx] & 0x80, -want, want)      # white's point of view (search.cpp:237)
+            want = np.where(np.abs(want) <= 2, 0, np.clip(want, -32000, 32000))
+            assert np.array_equal(positions["eval"][idx].astype(np.int64), want), start
+            checked += len(idx)
+            start += n
+        assert checked > 400_000
+    finally:
+        st.close()
+
+
+def test_config4_hbm_filling_batch(sp, oracle, net_blob):
+    """configs[4]: the largest position batch that fits this GPU's HBM (36 bytes resident per position: record in, score
+    out; intermediates only for one 4 Mi chunk per lane), evaluated in ONE call. Properties that do not need a CPU pass
+    over billions of positions: the batch is a device-side tiling of 131 072 distinct positions, so every tile must repeat
+    tile 0's scores (independence of position order / chunk boundaries - the tiles straddle the internal chunks), and
+    tile 0 itself is checked against the CPU oracle on a sample."""
+    import torch
+
+    blob = net_blob("tame")
+    free, total = torch.cuda.mem_get_info(0)
+    distinct = 1 << 17
+    n = int(free * 0.90 - 12e9) // 36 // distinct * distinct   # leave room for the net, 2 x ~4.6 GB of chunk scratch, torch
+    assert n >= 64 * distinct, f"only {free / 1e9:.0f} GB free"
+    base = sp.random_positions(distinct, seed=99, min_ply=8, max_ply=120, dfrc_every=4)
+    d_base = torch.from_numpy(base.view(np.uint8).reshape(-1, 32)).cuda()
+    d_pos = d_base.repeat(n // distinct, 1)
+    d_out = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = sp.NnueState(sp.Network(blob), device=0, max_batch=n)
+    try:
+        assert st.scratch_batch < n
+        st.evaluate_once_device_async(d_pos.data_ptr(), n, d_out.data_ptr())
+        st.synchronize()
+        torch.cuda.synchronize()
+        in_use = total - torch.cuda.mem_get_info(0)[0]
+        tiles = d_out.view(n // distinct, distinct)
+        assert bool((tiles == tiles[0]).all()), "tiles of the same positions scored differently"
+        sample = np.arange(0, distinct, distinct // 4096)
+        oracle.use(blob, "tame")
+        mail, stm = sp.positions_to_mailboxes(base[sample])
+        assert np.array_equal(tiles[0].cpu().numpy()[sample], oracle.eval_mailboxes(mail, stm))
+        print(f"config 5 batch: {n} positions, {in_use / 1e9:.1f} GB of {total / 1e9:.1f} GB in use")
+        assert in_use > 0.8 * total
+    finally:
+        st.close()
+
+
+@pytest.mark.parametrize("script", ["bench", "selfplay"])
+def test_two_rank_control_flow_on_one_gpu(script, tmp_path):
+    """The N > 1 paths of bench.py (net broadcast, barrier / MAX / SUM, score gather) and tools/spx_selfplay.py under
+    torch.distributed.run with 2 ranks sharing GPU 0 (gloo for the collectives: RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, SPX_BENCH_SHARE_GPU="1", SPX_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                "127.0.0.1", "--master-port", str(free_port())]
+    if script == "bench":
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "16384",
+                          "--gather", "--no-wide"]
+    else:
+        cmd = launcher + [os.path.join(ROOT, "tools", "spx_selfplay.py"), "--games", "512", "--target", "700", "--dfrc",
+                          "--out", str(tmp_path / "sp")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    if script == "bench":
+        assert line["bit_exact_sample"] is True and line["config"]["gathered_scores_ok"] is True
+        assert line["value"] > 1e6 and "cpu_baseline" not in line
+    else:
+        assert line["games"] == 1400 and sum(line["outcomes_white_loss_draw_win"]) == 1400
+        assert os.path.getsize(tmp_path / "sp.0.vf") > 0 and os.path.getsize(tmp_path / "sp.1.vf") > 0

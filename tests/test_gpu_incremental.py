@@ -280,3 +280,73 @@ def test_big_update_batches_take_the_streaming_store_variant(sp, net_blob):
         assert np.array_equal(got, st.evaluate_once(grand))
     finally:
         st.close()
+
+
+def test_growing_the_arena_keeps_materialised_slots(sp, net_blob):
+    """spx_acc_reserve with a larger slot count copies accumulators and records into the new arena: slots materialised
+    before the call evaluate the same afterwards and still serve as parents."""
+    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=1024)
+    try:
+        pos = sp.random_positions(600, seed=77)
+        slots = np.arange(600, dtype=np.uint32)
+        st.reserve_slots(600)
+        st.reset(pos, slots)
+        before = st.evaluate(slots)
+        st.reserve_slots(5000)
+        assert np.array_equal(st.evaluate(slots), before)
+        child, moved = sp.random_successors(pos, seed=3)
+        idx = np.nonzero(moved)[0]
+        got = st.update_evaluate(slots[idx], slots[idx] + 4000, child[idx])
+        assert np.array_equal(got, st.evaluate_once(child[idx]))
+    finally:
+        st.close()
+
+
+def test_pipelined_plies_equal_full_refreshes(sp, net_blob):
+    """spx_acc_update_eval_device_async: a chain of plies issued without waiting (each ply's parents are the previous
+    ply's children; sort + MLP of one ply run beside the next ply's update kernel on the context's second lane) gives, for
+    every ply, exactly the evaluations of a full refresh. 12 000 games: the second-generation update kernel with its
+    deferred rebuild pass, both lanes' refresh lists and counters in use. Buffers in page-locked host memory."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    games, plies = 12000, 9
+    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=games)
+    ptrs = []
+
+    def pinned(array):
+        raw = np.ascontiguousarray(array).view(np.uint8).reshape(-1)
+        p = lib.spx_host_alloc(raw.size)
+        assert p
+        ptrs.append(p)
+        np.ctypeslib.as_array((ctypes.c_uint8 * raw.size).from_address(p))[:] = raw
+        return p
+
+    try:
+        chain = [sp.random_positions(games, seed=31, min_ply=0, max_ply=100, dfrc_every=3)]
+        for ply in range(plies):
+            chain.append(sp.random_successors(chain[-1], seed=700 + ply)[0])
+        st.reserve_slots(2 * games)
+        slot_sets = [np.arange(games, dtype=np.uint32), np.arange(games, 2 * games, dtype=np.uint32)]
+        st.reset(chain[0], slot_sets[0])
+        d_slots = [pinned(s) for s in slot_sets]
+        d_boards = [pinned(c) for c in chain[1:]]
+        outs = []
+        for ply in range(plies):
+            p = lib.spx_host_alloc(games * 4)
+            assert p
+            ptrs.append(p)
+            outs.append(np.ctypeslib.as_array((ctypes.c_int32 * games).from_address(p)))
+            outs[-1][:] = -1
+        for ply in range(plies):
+            _lib.check(lib.spx_acc_update_eval_device_async(st._h, d_slots[ply & 1], d_slots[(ply + 1) & 1], d_boards[ply],
+                                                            games, outs[ply].ctypes.data, None))
+        st.synchronize()
+        for ply in range(plies):
+            assert np.array_equal(outs[ply], st.evaluate_once(chain[ply + 1])), f"ply {ply}"
+    finally:
+        for p in ptrs:
+            lib.spx_host_free(p)
+        st.close()

@@ -5,8 +5,10 @@ evaluated in one incremental update+eval batch per ply (depth-1 policy), virifor
     python tools/spx_selfplay.py --games 4096 --target 8192 --out /tmp/games            # 1 GPU
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/spx_selfplay.py --games 4096 ...
 
-Games are independent: each rank plays its own games on its own GPU (seed + rank) and writes <out>.<rank>.vf; the only
-communication is the final SUM of the counters (gloo). Prints one JSON line on rank 0."""
+Games are independent (config 4: "games sharded 2/4/8 MI355X via RCCL/xGMI"): each rank plays its own games on its own
+GPU (seed + rank) and writes <out>.<rank>.vf; the communication - over RCCL (torch.distributed backend "nccl") - is the
+broadcast of rank 0's net image at start-up and the final SUM / MAX of the counters. Prints one JSON line on rank 0.
+SPX_BENCH_BACKEND=gloo + SPX_BENCH_SHARE_GPU=1 run the same control flow with every rank on GPU 0 (single-GPU boxes)."""
 import argparse
 import json
 import os
@@ -31,10 +33,21 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
-    group = Group(backend="gloo")
-    net = sp.Network(open(args.net, "rb").read()) if args.net else sp.Network.synthetic(args.preset)
+    import numpy as np
+    import torch
+
+    from stormphrax_amd.distributed import env_rank
+
     # SPX_BENCH_SHARE_GPU=1 (debug, as in bench.py): every rank on GPU 0, to exercise the N > 1 control flow on one GPU
-    device = 0 if os.environ.get("SPX_BENCH_SHARE_GPU") == "1" else group.local_rank
+    device = 0 if os.environ.get("SPX_BENCH_SHARE_GPU") == "1" else env_rank()[1]
+    backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
+    if backend == "nccl":
+        torch.cuda.set_device(device)
+    group = Group(backend=backend, device=torch.device("cuda", device) if backend == "nccl" else None)
+    blob = None
+    if group.rank == 0:
+        blob = np.fromfile(args.net, dtype=np.uint8) if args.net else sp.synthetic_net_bytes(args.preset)
+    net = sp.Network(group.broadcast_bytes(blob))
     state = sp.NnueState(net, device=device, max_batch=args.games * 64)
     out = f"{args.out}.{group.rank}.vf" if args.out else None
     stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
@@ -47,7 +60,7 @@ def main():
     if group.rank == 0:
         print(json.dumps({
             "metric": "selfplay_leaf_evals_per_sec", "value": total["evals"] / slowest, "unit": "evals/s",
-            "n_gpus": group.world, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
+            "n_gpus": group.world, "collectives": backend, "net_digest": "%016x" % net.digest, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
             "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
             "outcomes_white_loss_draw_win": outcomes, "host_threads": args.threads or "auto",
