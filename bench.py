@@ -316,7 +316,9 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
 def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
     """Settle, W warm-up steps, then exactly K timed steps of the full-refresh path on `state`.
     -> (elapsed max over ranks, per-kernel ms (sort, ft, mlp, calls), settle steps, the output tensor of the last step)."""
-    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(n_outs if pipelined else 1)]
+    # (a batch above the scratch capacity is pipelined chunk by chunk inside ONE call: a second output buffer buys nothing)
+    many = n_outs if pipelined and args.batch <= state.scratch_batch else 1
+    d_outs = [torch.empty(args.batch, dtype=torch.int32, device="cuda") for _ in range(many)]
     stream = torch.cuda.current_stream().cuda_stream
     counter = [0]
 
@@ -430,7 +432,9 @@ def main():
     pipelined = not args.no_pipeline
 
     elapsed, (sort_ms, ft_ms, mlp_ms, calls), settle_steps, d_last = timed_full_run(args, torch, group, state, d_pos, pipelined)
-    checksum = group.sum_int(int(d_last.to(torch.int64).sum().item()))  # checksum of checksums over all shards
+    # checksum of checksums over all shards (summed in slabs: no 8-byte copy of an HBM-filling score array)
+    checksum = group.sum_int(sum(int(d_last[lo:lo + (1 << 26)].sum(dtype=torch.int64).item())
+                                 for lo in range(0, args.batch, 1 << 26)))
 
     # ---- parity inside the bench (outside the timed region): oracle on a sample of every rank's shard ----
     n_sample = min(4096, n_distinct)
@@ -443,7 +447,7 @@ def main():
         full = group.gather_scores(d_last.cpu().numpy(), args.batch * world)
         lo = rank * args.batch
         mine_ok = np.array_equal(full[lo:lo + args.batch], d_last.cpu().numpy())
-        gathered_ok = group.sum_int(int(mine_ok and int(full.astype(np.int64).sum()) == checksum)) == world
+        gathered_ok = group.sum_int(int(mine_ok and int(full.sum(dtype=np.int64)) == checksum)) == world
 
     # ---- second headline: the same run without compact piece-square rows ----
     wide = None

@@ -150,6 +150,17 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream);
 
+/* A recorded make/unmake TREE (BASELINE config 3: the PUSH / POP / EVAL stream of a search, src/thread.cpp:46-67,
+ * src/thread.h:116-122) replayed natively: node 0 is the root (NnueState::reset), node k > 0 was reached from node
+ * parents[k] < k by one move and positions[k] is its record. Every node gets arena slot k (the arena is grown to n_nodes
+ * slots); the tree is processed LEVEL BY LEVEL - all updates of one depth are one batch of independent records - on
+ * buffers uploaded once, with no host synchronisation between the levels; then the n_evals nodes of eval_nodes are
+ * evaluated (NnueState::evaluate at those nodes) into out[]. *gpu_ms (optional) = device time from the root refresh to the
+ * last evaluation. The reference walks the same tree depth-first with one lazily updated accumulator stack
+ * (nnue_state.cpp:636-697); the values are identical. */
+int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uint32_t* parents, size_t n_nodes,
+                        const uint32_t* eval_nodes, size_t n_evals, int32_t* out, double* gpu_ms);
+
 /* Pipelined variant for chains of plies (self-play style loops, trace replays level by level): returns at once; the
  * update kernels of consecutive calls run in call order (a ply's parents may be the previous call's children), while the
  * sort and the MLP of one call overlap the update kernel of the next on the context's second internal stream. Inputs and

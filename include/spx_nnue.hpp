@@ -146,6 +146,19 @@ public:
         check(spx_adjust(ctx_, &pos, 1, &params, nullptr, &v));
         return v;
     }
+    // A whole recorded search tree at once (BASELINE config 3): node k > 0 was reached from node parents[k] < k, node 0 is
+    // the root; returns NnueState::evaluate at evalNodes. Levels are batched on the device (spx_acc_replay_tree); the
+    // stack of this object is left at the root.
+    std::vector<int32_t> replayTree(const std::vector<spx_packed_pos>& positions, const std::vector<uint32_t>& parents,
+                                    const std::vector<uint32_t>& evalNodes, double* gpuMs = nullptr) {
+        if (positions.empty() || positions.size() != parents.size()) throw Error(SPX_ERR_INVALID_ARG, "replayTree: sizes");
+        std::vector<int32_t> out(evalNodes.size());
+        check(spx_acc_replay_tree(ctx_, positions.data(), parents.data(), positions.size(), evalNodes.data(), evalNodes.size(),
+                                  out.data(), gpuMs));
+        stack_.assign(1, positions[0]);
+        clean_ = 0;
+        return out;
+    }
     size_t depth() const {
         return stack_.empty() ? 0 : stack_.size() - 1;
     }

@@ -228,8 +228,14 @@ const ZstdApi* zstdApi() {
 void relayoutThreatRow(const int8_t* src, uint8_t* dst) {
     for (uint32_t l = 0; l < 64; ++l) {
         for (uint32_t j = 0; j < 8; ++j) {
-            dst[16 * l + j] = uint8_t(src[8 * l + j]) ^ 0x80u;
-            dst[16 * l + 8 + j] = uint8_t(src[512 + 8 * l + j]) ^ 0x80u;
+#if SPX_OPT_ANDPERM
+            // within a dword: columns (c, c + 2, c + 1, c + 3) - bytes 0, 2 are one accumulator word, bytes 1, 3 the next
+            const uint32_t k = (j & 4) | ((j & 1) << 1) | ((j & 2) >> 1);
+#else
+            const uint32_t k = j;
+#endif
+            dst[16 * l + k] = uint8_t(src[8 * l + j]) ^ 0x80u;
+            dst[16 * l + 8 + k] = uint8_t(src[512 + 8 * l + j]) ^ 0x80u;
         }
     }
 }
@@ -968,6 +974,106 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
     }
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    return SPX_OK;
+}
+
+// ---- BASELINE config 3 natively: a recorded make/unmake tree replayed level by level on device-resident buffers ----
+int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uint32_t* parents, size_t n_nodes,
+                        const uint32_t* eval_nodes, size_t n_evals, int32_t* out, double* gpu_ms) {
+    if (!ctx || !positions || !parents || n_nodes == 0 || (n_evals && (!eval_nodes || !out)) || n_nodes > (1ull << 31)) {
+        setError("spx_acc_replay_tree: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    // levels: nodes are numbered in visiting order (a parent before its children), so depths come in one pass; a
+    // counting sort by depth gives the level-ordered (parent slot, child slot, child record) batches
+    std::vector<uint32_t> depth(n_nodes, 0), levelStart;
+    uint32_t maxDepth = 0;
+    for (size_t k = 1; k < n_nodes; ++k) {
+        if (parents[k] >= k) {
+            setError("spx_acc_replay_tree: node " + std::to_string(k) + " does not come after its parent");
+            return SPX_ERR_INVALID_ARG;
+        }
+        depth[k] = depth[parents[k]] + 1;
+        maxDepth = std::max(maxDepth, depth[k]);
+    }
+    for (size_t k = 0; k < n_evals; ++k) {
+        if (eval_nodes[k] >= n_nodes) {
+            setError("spx_acc_replay_tree: eval node out of range");
+            return SPX_ERR_INVALID_ARG;
+        }
+    }
+    levelStart.assign(maxDepth + 2, 0);
+    for (size_t k = 1; k < n_nodes; ++k) ++levelStart[depth[k] + 1];
+    for (uint32_t d = 1; d <= maxDepth + 1; ++d) levelStart[d] += levelStart[d - 1];  // levelStart[d] = first index of depth d
+    const size_t nUpdates = n_nodes - 1;
+    std::vector<uint32_t> hParents(nUpdates), hChildren(nUpdates), cursor(levelStart.begin(), levelStart.end() - 1);
+    std::vector<spx_packed_pos> hRecords(nUpdates);
+    for (size_t k = 1; k < n_nodes; ++k) {
+        const uint32_t at = cursor[depth[k]]++;  // levelStart[1] == 0: depth-1 nodes come first
+        hParents[at] = parents[k];
+        hChildren[at] = uint32_t(k);
+        hRecords[at] = positions[k];
+    }
+    int rc = spx_acc_reserve(ctx, n_nodes);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ctx->device));
+    struct Temp {
+        std::vector<void*> ptrs;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Temp() {
+            for (void* p : ptrs) (void)hipFree(p);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } temp;
+    auto alloc = [&](size_t bytes, void** out) -> hipError_t {
+        const hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) temp.ptrs.push_back(*out);
+        return e;
+    };
+    void *dRecords = nullptr, *dParents = nullptr, *dChildren = nullptr, *dEvalNodes = nullptr, *dOut = nullptr, *dRoot = nullptr;
+    SPX_HIP(alloc(nUpdates * sizeof(spx_packed_pos), &dRecords));
+    SPX_HIP(alloc(nUpdates * 4, &dParents));
+    SPX_HIP(alloc(nUpdates * 4, &dChildren));
+    SPX_HIP(alloc(n_evals * 4, &dEvalNodes));
+    SPX_HIP(alloc(n_evals * 4, &dOut));
+    SPX_HIP(alloc(sizeof(spx_packed_pos) + 4, &dRoot));
+    hipStream_t s = ctx->stream;
+    const uint32_t rootSlot = 0;
+    SPX_HIP(hipMemcpyAsync(dRoot, &positions[0], sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
+    SPX_HIP(hipMemcpyAsync(static_cast<char*>(dRoot) + sizeof(spx_packed_pos), &rootSlot, 4, hipMemcpyHostToDevice, s));
+    if (nUpdates) {
+        SPX_HIP(hipMemcpyAsync(dRecords, hRecords.data(), nUpdates * sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
+        SPX_HIP(hipMemcpyAsync(dParents, hParents.data(), nUpdates * 4, hipMemcpyHostToDevice, s));
+        SPX_HIP(hipMemcpyAsync(dChildren, hChildren.data(), nUpdates * 4, hipMemcpyHostToDevice, s));
+    }
+    if (n_evals) SPX_HIP(hipMemcpyAsync(dEvalNodes, eval_nodes, n_evals * 4, hipMemcpyHostToDevice, s));
+    SPX_HIP(hipEventCreate(&temp.e0));
+    SPX_HIP(hipEventCreate(&temp.e1));
+    SPX_HIP(hipEventRecord(temp.e0, s));
+    rc = spx_acc_refresh_device(ctx, dRoot, static_cast<char*>(dRoot) + sizeof(spx_packed_pos), 1, s);
+    if (rc != SPX_OK) return rc;
+    for (uint32_t d = 1; d <= maxDepth; ++d) {  // one update batch per level (chunked by the context's capacity); no host sync
+        for (size_t lo = levelStart[d]; lo < levelStart[d + 1]; lo += ctx->maxBatch) {
+            const size_t m = std::min<size_t>(ctx->maxBatch, levelStart[d + 1] - lo);
+            rc = spx_acc_update_device(ctx, static_cast<char*>(dParents) + lo * 4, static_cast<char*>(dChildren) + lo * 4,
+                                       static_cast<char*>(dRecords) + lo * sizeof(spx_packed_pos), m, s);
+            if (rc != SPX_OK) return rc;
+        }
+    }
+    for (size_t lo = 0; lo < n_evals; lo += ctx->maxBatch) {
+        const size_t m = std::min<size_t>(ctx->maxBatch, n_evals - lo);
+        rc = spx_acc_eval_device(ctx, static_cast<char*>(dEvalNodes) + lo * 4, m, static_cast<char*>(dOut) + lo * 4, s);
+        if (rc != SPX_OK) return rc;
+    }
+    SPX_HIP(hipEventRecord(temp.e1, s));
+    if (n_evals) SPX_HIP(hipMemcpyAsync(out, dOut, n_evals * 4, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    if (gpu_ms) {
+        float ms = 0.f;
+        SPX_HIP(hipEventElapsedTime(&ms, temp.e0, temp.e1));
+        *gpu_ms = ms;
+    }
     return SPX_OK;
 }
 

@@ -6,6 +6,12 @@
 #include <cstddef>
 #include <cstdint>
 
+// u8 row table byte order within a dword (host relayout in spx_api.cpp and the kernels' widening must agree):
+// 1 = columns (c, c + 2, c + 1, c + 3): even bytes widen with v_and_b32, odd bytes with v_perm_b32; 0 = natural order
+#ifndef SPX_OPT_ANDPERM
+#define SPX_OPT_ANDPERM 1
+#endif
+
 namespace spx {
 
 constexpr size_t kAccSlotBytes = 2 * 1024 * 2;  // one arena slot: 2 perspectives x i16[1024] (psq + threat combined)

@@ -30,6 +30,12 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+#ifndef SPX_OPT_SADDR
+#define SPX_OPT_SADDR 1
+#endif
+#ifndef SPX_OPT_PSEUDOTAB
+#define SPX_OPT_PSEUDOTAB 1
+#endif
 #ifndef SPX_FT_WAVES_PER_SIMD
 #define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
@@ -64,12 +70,57 @@ __device__ __forceinline__ uint32_t pkSub16(uint32_t a, uint32_t b) {
     const u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
     return __builtin_bit_cast(uint32_t, r);
 }
-// zero-extend bytes (0,1) / (2,3) of x into two 16-bit fields: one v_perm_b32 each (selector 0x0c = constant 0)
+// Row fetch: every row load of the gather is `table + wave-uniform row offset + this lane's 16 * lane`. As a BUFFER load the
+// three terms map onto the instruction itself - resource descriptor (table base, SGPRs, built once), soffset (the row
+// offset straight from v_readfirstlane), voffset (the lane's constant) - so a row costs no address arithmetic at all;
+// the flat-global form pays a 64-bit v_lshl_add_u64 (or s_add_u32 + s_addc_u32) per load. Out-of-range offsets (malformed
+// lists cannot produce them; belt and braces) read zeros instead of faulting. Used by the UPDATE kernel (+5 % there);
+// the full-refresh gather keeps global loads (see gatherFull). SPX_OPT_SADDR=0: global loads here too.
+struct RowTable {
+#if SPX_OPT_SADDR
+    __amdgpu_buffer_rsrc_t rsrc;
+#else
+    const uint8_t* base;
+#endif
+};
+__device__ __forceinline__ RowTable makeRowTable(const void* base, uint32_t bytes) {
+    RowTable t;
+#if SPX_OPT_SADDR
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);  // raw buffer, gfx9 DATA_FORMAT_32
+#else
+    t.base = static_cast<const uint8_t*>(base);
+    (void)bytes;
+#endif
+    return t;
+}
+__device__ __forceinline__ u32x4 loadRow16(const RowTable& t, uint32_t rowOffset, uint32_t laneOffset) {
+#if SPX_OPT_SADDR
+    return __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, int(laneOffset), int(rowOffset), 0);
+#else
+    return *reinterpret_cast<const u32x4*>(t.base + rowOffset + laneOffset);
+#endif
+}
+constexpr uint32_t kU8TableBytes = (kThreatRows + kPsqRows) * kL1;  // threat rows + the compact piece-square slots
+
+// The 16 bytes a lane holds of a u8 row are widened into two accumulator words per dword. Storage order of the table
+// (relayoutThreatRow, spx_api.cpp): within a dword the bytes are columns (c, c + 2, c + 1, c + 3) - i.e. the EVEN bytes
+// 0, 2 are one packed-i16 accumulator word (columns c, c + 1) and the ODD bytes 1, 3 the next one (c + 2, c + 3). So:
+//   unpackEven: bytes 0, 2 -> 16-bit fields = x & 0x00FF00FF      (v_and_b32: 2 SIMD cycles, tools/probes/valu_rate_probe)
+//   unpackOdd:  bytes 1, 3 -> 16-bit fields = v_perm_b32          (4 cycles; a shift + and would be 6)
+// Round 1 stored (c, c + 1, c + 2, c + 3) and paid two v_perm_b32 per dword.
 __device__ __forceinline__ uint32_t unpackLo(uint32_t x) {
+#if SPX_OPT_ANDPERM
+    return x & 0x00FF00FFu;
+#else
     return __builtin_amdgcn_perm(0u, x, 0x0C010C00u);
+#endif
 }
 __device__ __forceinline__ uint32_t unpackHi(uint32_t x) {
+#if SPX_OPT_ANDPERM
+    return __builtin_amdgcn_perm(0u, x, 0x0C030C01u);
+#else
     return __builtin_amdgcn_perm(0u, x, 0x0C030C02u);
+#endif
 }
 
 // pairwise clipped ReLU of one column pair (multilayer.h:108-145): a = column j, b = column j+512 (i16, wrapped)
@@ -132,12 +183,16 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
 // attacker = this lane's `piece` on square `lane`, victim piece fetched from the lane that owns the target square.
 // Rows the reference excludes (threatFeatureIndex < 0) are dropped. Returns the new list length (capacity kThreatCap).
 __device__ __forceinline__ uint32_t emitThreatRows(uint32_t* list, uint32_t n, uint64_t targets, int piece,
-                                                   uint32_t lane, int x, int flipColour, const uint32_t* lut) {
+                                                   uint32_t lane, int x, int flipColour, const uint32_t* lut,
+                                                   const uint64_t* pseudoTab = nullptr) {
     const int pieceRel = piece ^ flipColour;
     const int sqRel = int(lane) ^ x;
     uint64_t pseudoRel = 0;
-    if (targets) {
-        pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
+    if (targets) {  // (only non-king pieces have targets)
+        // pseudo-attack set of the attacker in the perspective's frame: one LDS read where the table is staged
+        // (pseudo[k][sq], spx_device_math.h), else the per-lane arithmetic (~40 instructions for the union of piece types)
+        pseudoRel = pseudoTab ? pseudoTab[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel]
+                              : piecePseudoAttacks(pieceRel, sqRel);
     }
     while (__ballot(targets != 0)) {
         const bool active = targets != 0;
@@ -209,7 +264,8 @@ __device__ __forceinline__ uint32_t emitPsqDeltaRows(bool active, uint32_t row, 
 // into the i16 piece-square table, thrList (capacity kU8Cap) = byte offsets into the u8 row table; nThr counts both the
 // compact piece-square rows and the threat / pawn-pair rows in it.
 __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
-                                               uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr) {
+                                               uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
+                                               const uint64_t* pseudoTab = nullptr) {
     const int piece = b.piece;
     const bool occupied = piece != kNoPiece;
     const int type = piece >> 1;
@@ -249,7 +305,7 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     if (occupied && type != 5) {
         targets = pieceAttacks(piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
     }
-    nThr = emitThreatRows(threatList, 0, targets, piece, lane, x, flipColour, lut);
+    nThr = emitThreatRows(threatList, 0, targets, piece, lane, x, flipColour, lut, pseudoTab);
 
     // pawn-pair rows (nnue_state.cpp:330-351)
     const bool isPawn = type == 0;
@@ -272,16 +328,22 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             acc[4 + r] = b1[r];
         }
     }
+    // Full-refresh rows come in through plain global loads from per-lane base pointers (one v_lshl_add_u64 per row). The
+    // buffer-load form the update kernel uses (RowTable: no address arithmetic at all) was A/B-measured here too and LOSES
+    // 10 % (FT kernel 0.469 -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is
+    // bound by the vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
+    // latency-bound) they win 5 %.
     const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
+    const uint8_t* thrBase = t.thrW + 16 * lane;
     {
         uint32_t i = 0;
         for (; i + 4 <= nPsq; i += 4) {  // 8 x 1 KiB wave loads in flight
             u32x4 lo[4], hi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqList[i + u]);
-                lo[u] = *reinterpret_cast<const u32x4*>(row);
-                hi[u] = *reinterpret_cast<const u32x4*>(row + 1024);
+                const uint32_t row = uint32_t(__builtin_amdgcn_readfirstlane(psqList[i + u]));
+                lo[u] = *reinterpret_cast<const u32x4*>(psqBase + row);
+                hi[u] = *reinterpret_cast<const u32x4*>(psqBase + row + 1024);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -293,9 +355,9 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         for (; i < nPsq; ++i) {
-            const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqList[i]);
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
+            const uint32_t row = uint32_t(__builtin_amdgcn_readfirstlane(psqList[i]));
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(psqBase + row);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(psqBase + row + 1024);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[r] = pkAdd16(acc[r], lo[r]);
@@ -307,7 +369,6 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
     // x 255 never overflows a 16-bit field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry
     // crosses fields. Folded into acc (mod 2^16) per segment of 256 rows; a second segment exists only when compact
     // piece-square rows push the list beyond 256 entries.
-    const uint8_t* thrBase = t.thrW + 16 * lane;
     for (uint32_t segBegin = 0; segBegin < nThr; segBegin += uint32_t(kThreatCap)) {
         const uint32_t segEnd = min(nThr, segBegin + uint32_t(kThreatCap));
         uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -316,7 +377,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             u32x4 w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                w[u] = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i + u]));
+                w[u] = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i + u])));
             }
 #pragma unroll
             for (int u = 0; u < 8; u += 2) {
@@ -328,9 +389,8 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         for (; i + 2 <= segEnd; i += 2) {
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
-            const u32x4 w1 =
-                *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i + 1]));
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i])));
+            const u32x4 w1 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i + 1])));
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
@@ -338,7 +398,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         if (i < segEnd) {
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrList[i]));
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i])));
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 tacc[2 * d] += unpackLo(w0[d]);
@@ -512,12 +572,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
+#if SPX_OPT_PSEUDOTAB
+    __shared__ uint64_t sPseudo[kDeltaPseudoWords];        // pseudo-attack sets per (piece kind, square), 3 KiB
+#endif
 
     if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
     if (p.nPerspPtr && *p.nPerspPtr == 0) return;  // nothing was deferred: the refresh pass costs one empty launch
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
         sLut[i] = p.t.lut[i];
     }
+#if SPX_OPT_PSEUDOTAB
+    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
+        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    }
+    const uint64_t* pseudoTab = sPseudo;
+#else
+    const uint64_t* pseudoTab = nullptr;
+#endif
     __syncthreads();
 
     const uint32_t lane = laneId();
@@ -540,7 +611,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
+        buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, pseudoTab);
         uint32_t acc[8];
         gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
 
@@ -701,13 +772,12 @@ namespace {
 // 128 * nAdd + 127 * nSub per column (mod 2^16). nAdd + nSub <= 256 (16-bit fields: 256 * 255 < 2^16).
 // Rows are fetched kN at a time - the round-1 kernel waited for every row before asking for the next.
 template <int kN>
-__device__ __forceinline__ void loadAddRows(const uint8_t* thrW, uint32_t laneOff, const uint32_t* list, uint32_t flip,
+__device__ __forceinline__ void loadAddRows(const RowTable& table, uint32_t laneOff, const uint32_t* list, uint32_t flip,
                                             uint32_t (&tacc)[8]) {
     u32x4 w[kN];
 #pragma unroll
-    for (int u = 0; u < kN; ++u) {  // uniform row base + 32-bit lane offset: the saddr form of global_load, no 64-bit VALU add
-        const uint8_t* row = thrW + __builtin_amdgcn_readfirstlane(list[u]);
-        w[u] = *reinterpret_cast<const u32x4*>(row + laneOff);
+    for (int u = 0; u < kN; ++u) {
+        w[u] = loadRow16(table, uint32_t(__builtin_amdgcn_readfirstlane(list[u])), laneOff);
     }
 #pragma unroll
     for (int u = 0; u < kN; ++u) {
@@ -721,26 +791,27 @@ __device__ __forceinline__ void loadAddRows(const uint8_t* thrW, uint32_t laneOf
     }
 }
 
-__device__ __forceinline__ void accumulateRows(const uint8_t* thrW, uint32_t laneOff, const uint32_t* list, uint32_t n,
+__device__ __forceinline__ void accumulateRows(const RowTable& table, uint32_t laneOff, const uint32_t* list, uint32_t n,
                                                uint32_t flip, uint32_t (&tacc)[8]) {
     uint32_t i = 0;
 #pragma unroll 1
-    for (; i + 4 <= n; i += 4) loadAddRows<4>(thrW, laneOff, list + i, flip, tacc);
+    for (; i + 4 <= n; i += 4) loadAddRows<4>(table, laneOff, list + i, flip, tacc);
     const uint32_t rest = n - i;  // wave-uniform
     if (rest == 3) {
-        loadAddRows<3>(thrW, laneOff, list + i, flip, tacc);
+        loadAddRows<3>(table, laneOff, list + i, flip, tacc);
     } else if (rest == 2) {
-        loadAddRows<2>(thrW, laneOff, list + i, flip, tacc);
+        loadAddRows<2>(table, laneOff, list + i, flip, tacc);
     } else if (rest == 1) {
-        loadAddRows<1>(thrW, laneOff, list + i, flip, tacc);
+        loadAddRows<1>(table, laneOff, list + i, flip, tacc);
     }
 }
 
 __device__ __forceinline__ void applyU8Delta(const FtTables& t, uint32_t lane, const uint32_t* addList, uint32_t nAdd,
                                              const uint32_t* subList, uint32_t nSub, uint32_t (&acc)[8]) {
+    const RowTable table = makeRowTable(t.thrW, kU8TableBytes);
     uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    accumulateRows(t.thrW, 16 * lane, addList, nAdd, 0u, tacc);
-    accumulateRows(t.thrW, 16 * lane, subList, nSub, 0xFFFFFFFFu, tacc);
+    accumulateRows(table, 16 * lane, addList, nAdd, 0u, tacc);
+    accumulateRows(table, 16 * lane, subList, nSub, 0xFFFFFFFFu, tacc);
     const uint32_t corr = (nAdd * 128u + nSub * 127u) & 0xFFFFu;
     const uint32_t corr2 = corr | (corr << 16);
 #pragma unroll

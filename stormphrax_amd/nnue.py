@@ -236,6 +236,17 @@ class NnueState:
                                                   out.ctypes.data if evaluate else None))
         return out
 
+    def replay_tree(self, positions, parents, eval_nodes):
+        """spx_acc_replay_tree: the whole recorded tree level by level on the device -> (values at eval_nodes, gpu ms)."""
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        par = np.ascontiguousarray(parents, dtype=np.uint32)
+        nodes = np.ascontiguousarray(eval_nodes, dtype=np.uint32)
+        out = np.empty(nodes.shape[0], dtype=np.int32)
+        ms = ctypes.c_double()
+        check(_lib.load().spx_acc_replay_tree(self._h, pos.ctypes.data, par.ctypes.data, pos.shape[0], nodes.ctypes.data,
+                                              nodes.shape[0], out.ctypes.data, ctypes.byref(ms)))
+        return out, ms.value
+
     def evaluate(self, slots):
         """NnueState::evaluate on materialised slots -> int32 raw evals (side to move of each slot's position)."""
         slots = np.ascontiguousarray(slots, dtype=np.uint32)

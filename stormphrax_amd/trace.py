@@ -75,3 +75,14 @@ def replay(state, trace, positions=None):
     nodes = np.array([e[0] for e in trace.evals], dtype=np.uint32)
     got = np.concatenate([state.evaluate(nodes[lo:lo + state.max_batch]) for lo in range(0, len(nodes), state.max_batch)])
     return got, np.array([e[1] for e in trace.evals], dtype=np.int32), np.array([e[2] for e in trace.evals], dtype=np.int32)
+
+
+def replay_native(state, trace, positions=None):
+    """The same replay through spx_acc_replay_tree: one native call, levels on device-resident buffers, no host round trip
+    per level. Returns (gpu values, reference incremental values, device milliseconds)."""
+    pos = trace.positions() if positions is None else positions
+    parents = np.asarray(trace.parent, dtype=np.int64)
+    parents[0] = 0
+    nodes = np.array([e[0] for e in trace.evals], dtype=np.uint32)
+    got, ms = state.replay_tree(pos, parents.astype(np.uint32), nodes)
+    return got, np.array([e[1] for e in trace.evals], dtype=np.int32), ms

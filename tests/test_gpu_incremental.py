@@ -350,3 +350,25 @@ def test_pipelined_plies_equal_full_refreshes(sp, net_blob):
         for p in ptrs:
             lib.spx_host_free(p)
         st.close()
+
+
+def test_native_tree_replay_of_the_config3_trace(sp, net_blob):
+    """BASELINE config 3 through ONE native call: the 65 536-EVAL reference trace (a depth-12 make/unmake walk from the
+    start position) replayed level by level on device-resident buffers by spx_acc_replay_tree - every EVAL equals what the
+    reference's lazily updated NnueState::evaluate returned, and the device time is that of a few dozen kernel launches
+    (the Python harness replay of the same trace: ~12 ms)."""
+    from stormphrax_amd.trace import Trace, replay_native
+
+    path = os.path.join(GOLDEN, "trace_startpos_tame_64k.txt.gz")
+    trace = Trace(path)
+    st = sp.NnueState(sp.Network(net_blob(preset_of(path))), device=0, max_batch=65536)
+    try:
+        pos = trace.positions()
+        got, want, ms = replay_native(st, trace, pos)
+        assert len(want) == 65536 and np.array_equal(got, want)
+        got2, _, ms2 = replay_native(st, trace, pos)  # warm: arena already reserved
+        assert np.array_equal(got2, want)
+        print(f"config-3 trace: {trace.n_nodes - 1} updates + {len(want)} evals in {min(ms, ms2):.2f} ms on the device")
+        assert min(ms, ms2) < 8.0
+    finally:
+        st.close()

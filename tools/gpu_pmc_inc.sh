@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_inc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --mode incremental --steps 40 --warmup 5 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --mode incremental --steps 50 --warmup 10 --no-cpu-baseline --no-settle $*"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o t -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
@@ -34,3 +34,4 @@ for f in sorted(glob.glob(out + "/pmc_*/*.db")):
         print("   %-40s %-30s mean/dispatch %18.1f  dispatches %d" % (r[0][:40], r[1], r[2], r[3]))
 PY
 cat $OUT/summary.txt
+python3 $REPO/tools/pmc_to_json.py $OUT $OUT/pmc.json --command "$BENCH"

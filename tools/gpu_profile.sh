@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-settle --no-wide $*"
 # 1) kernel trace + stats (no counters)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o t -- $BENCH > $OUT/stats.log 2>&1
 # 2) counters, one group per pass (TCC: FETCH_SIZE costs 3 of 4 slots, WRITE_SIZE 2), kernel-trace only
@@ -38,3 +38,4 @@ for f in sorted(glob.glob(out + "/pmc_*/*.db")):
         print("   %-34s %-30s mean/dispatch %18.1f  dispatches %d" % (r[0][:34], r[1], r[2], r[3]))
 PY
 cat $OUT/summary.txt
+python3 $REPO/tools/pmc_to_json.py $OUT $OUT/pmc.json --command "$BENCH"
