@@ -374,6 +374,9 @@ def main():
                     help="issue the steps with the strictly stream-ordered spx_eval_full_device instead of the pipelined "
                          "spx_eval_full_device_async (consecutive batches overlap: sorts / MLP of one beside the "
                          "feature-transformer kernel of the next)")
+    ap.add_argument("--device-positions", action="store_true",
+                    help="generate the batch with spx_random_positions_gpu (random playouts on the device: move generation + "
+                         "uniform move choice kernels) instead of the host chess core - for nodes whose ranks share few CPUs")
     ap.add_argument("--no-settle", action="store_true", help="skip the time-based clock warm-up before the W warm-up steps")
     ap.add_argument("--no-wide", action="store_true", help="skip the second timed run with SPX_CTX_WIDE_PSQ_ROWS")
     ap.add_argument("--gather", action="store_true",
@@ -421,8 +424,13 @@ def main():
 
     # ---- workload: this rank's shard of seeded random legal positions, resident in HBM ----
     n_distinct = min(args.distinct or args.batch, args.batch)
-    distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
-    d_distinct = torch.from_numpy(distinct.view(np.uint8).reshape(-1, 32)).cuda()
+    if args.device_positions:
+        d_distinct = torch.empty((n_distinct, 32), dtype=torch.uint8, device="cuda")
+        state.random_positions_device(d_distinct.data_ptr(), n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
+        distinct = d_distinct.cpu().numpy().reshape(-1).view(sp.PACKED_DTYPE)  # for the oracle / row-count legs
+    else:
+        distinct = sp.random_positions(n_distinct, seed=20260927 + rank, min_ply=8, max_ply=120, dfrc_every=4)
+        d_distinct = torch.from_numpy(distinct.view(np.uint8).reshape(-1, 32)).cuda()
     if n_distinct < args.batch:  # tiled ON THE DEVICE: an HBM-filling batch (config 5) never exists in host memory
         reps = -(-args.batch // n_distinct)
         d_pos = d_distinct.repeat(reps, 1)[: args.batch].contiguous()
@@ -522,7 +530,8 @@ def main():
             "bit_exact_sample": bool(exact),
             "config": {
                 "workload": (f"BASELINE configs[1]: full-refresh NNUE forward on {args.batch} seeded random legal positions "
-                             "per GPU (random playouts 8-120 plies, every 4th game DFRC), bit-exact vs CPU"
+                             "per GPU (random playouts 8-120 plies, every 4th game DFRC"
+                             + (", generated on the device" if args.device_positions else "") + "), bit-exact vs CPU"
                              + (f"; batch tiled from {n_distinct} distinct positions" if n_distinct < args.batch else "")),
                 "batch_per_gpu": args.batch,
                 "resident_bytes": int(torch.cuda.max_memory_allocated()) if hasattr(torch.cuda, "max_memory_allocated") else None,

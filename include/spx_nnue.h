@@ -280,6 +280,11 @@ int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, con
                                    const void* d_child_positions, const void* d_deltas, size_t n, void* d_out,
                                    void* stream);
 int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
+/* The same kind of batch generated ON THE DEVICE (move generation + uniform move choice kernels, no evaluations) straight
+ * into d_out (count records of device memory): game i plays min_ply + (draw mod range) random plies from the standard start
+ * or, every dfrc_every-th game, a double-Chess960 start; a game that runs out of moves keeps its final position. Seeded and
+ * reproducible, but a different stream of positions than spx_random_positions. The host only places the start pieces. */
+int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, void* d_out);
 /* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
  * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */
 int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);

@@ -127,6 +127,7 @@ SYMBOLS = {
     "spx_acc_update_observed": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_observed_device": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "spx_random_positions_gpu": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_random_successors": (ctypes.c_int, [ctypes.c_uint64, _P, ctypes.c_size_t, _P, _P]),
     "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),

@@ -125,6 +125,10 @@ int ctxDevice(const spx_ctx* ctx) {
     return ctx->device;
 }
 
+void* ctxStream(const spx_ctx* ctx) {
+    return ctx->stream;
+}
+
 size_t ctxMaxBatch(const spx_ctx* ctx) {
     return ctx->maxBatch;
 }

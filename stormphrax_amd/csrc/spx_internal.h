@@ -21,6 +21,7 @@ struct spx_ctx;
 namespace spx {
 size_t ctxMaxBatch(const spx_ctx* ctx);
 int ctxDevice(const spx_ctx* ctx);
+void* ctxStream(const spx_ctx* ctx);  // the context's own hipStream_t (what a NULL stream argument means)
 // lanes: see spx_api.cpp (two scratch sets + streams; big kernels chained by events)
 int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream);
 void ctxLaneEnd(spx_ctx* ctx, int laneIndex);

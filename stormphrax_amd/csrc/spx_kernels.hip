@@ -46,7 +46,10 @@ constexpr int kWavesPerBlock = 4;
 #define SPX_UPDATE_SPLIT_WAVES 4
 #endif
 #ifndef SPX_MLP_WAVES_PER_SIMD
-#define SPX_MLP_WAVES_PER_SIMD 3
+#define SPX_MLP_WAVES_PER_SIMD 4  // A/B on MI355X with the batched tail: 3 -> 39.0 us, 4 -> 35.5 us per 65 536 positions (round-1 tail: 38.3)
+#endif
+#ifndef SPX_OPT_MLP_BATCHED
+#define SPX_OPT_MLP_BATCHED 1
 #endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
@@ -1406,7 +1409,11 @@ template <bool kSmallL2W, int kTiling>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
     constexpr bool kShareTile = kTiling == kMlpTileShared;
     __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
+#if SPX_OPT_MLP_BATCHED
+    __shared__ __align__(16) int32_t sIn[4][16][kL2Full];  // L2 inputs of the tile's positions (broadcast reads); then L3 terms
+#else
     __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
+#endif
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
@@ -1489,6 +1496,80 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     }
     __builtin_amdgcn_wave_barrier();
 
+#if SPX_OPT_MLP_BATCHED
+    // The tile's positions move through the tail TOGETHER, layer by layer (round 1 took them one at a time: per position a
+    // store -> barrier -> 16 broadcast reads -> 64-long multiply-add -> 6-step wave reduction, all latency, 16 times):
+    //   A  lane = L1 output o: dual activation of every position's sum; L2 inputs to LDS
+    //   B  lane = L2 output o: kRows independent accumulators over the 64 inputs (weights in registers, inputs broadcast)
+    //   C  lane = L3 input o:  (clamp(l2) + l1o) * W3 per position to LDS; four lanes per position add 16 terms each
+    constexpr int kRows = kShareTile ? 4 : (kTiling == kMlpTilePerPosition ? 1 : 16);  // positions this wave finishes
+    const uint32_t rowBegin = kShareTile ? wave : 0u, rowStep = kShareTile ? 4u : 1u;
+    int32_t mine[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t r = rowBegin + uint32_t(k) * rowStep;
+        mine[k] = 0;
+        if (r < count) {
+            const int32_t s = sSum[wave][r][o1];
+            const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
+            const int32_t ts = int32_t(t);
+            const int32_t c0 = min(max(ts, 0), 4096) << kQBits;  // CReLU side, pre-shifted for the skip connection
+            const int32_t sq = int32_t(t * t);                    // mullo wraps BEFORE the signed min
+            const int32_t c1 = min(sq, 1 << 24) >> kQBits;        // SCReLU side
+            mine[k] = lane < kL2 ? c0 : c1;                       // l1o[lane] = [CReLU(32) | SCReLU(32)]
+            sIn[wave][k][lane] = mine[k] >> kQBits;               // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // L2: l2[o] = bias + sum_i in[i] * W2[b][i][o], wrapping i32
+    uint32_t acc2[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) acc2[k] = uint32_t(l2Bias);
+#pragma unroll
+    for (int i = 0; i < int(kL2Full); i += 4) {
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            if (rowBegin + uint32_t(k) * rowStep < count) {  // wave-uniform
+                const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sIn[wave][k][i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (kSmallL2W) {
+                        acc2[k] += uint32_t(__mul24(in4[j], w2[i + j]));
+                    } else {
+                        acc2[k] += uint32_t(in4[j]) * uint32_t(w2[i + j]);
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading the inputs: the buffer now takes the L3 terms
+    // L3 with skip connection: (clamp(l2, 0, Q^3) + l1o) * W3, wrapping
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int32_t l2v = min(max(int32_t(acc2[k]), 0), 262144);
+        sIn[wave][k][lane] = int32_t((uint32_t(l2v) + uint32_t(mine[k])) * uint32_t(l3Weight));
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t k = lane >> 2, q = lane & 3;  // four lanes per position, 16 terms each
+        uint32_t sum = 0;
+        if (k < uint32_t(kRows)) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const i32x4 t4 = *reinterpret_cast<const i32x4*>(&sIn[wave][k][q * 16 + j]);
+                sum += uint32_t(t4[0]) + uint32_t(t4[1]) + uint32_t(t4[2]) + uint32_t(t4[3]);
+            }
+        }
+        sum += uint32_t(__shfl_xor(int32_t(sum), 1, 64));
+        sum += uint32_t(__shfl_xor(int32_t(sum), 2, 64));
+        const uint32_t r = rowBegin + k * rowStep;
+        if (q == 0 && k < uint32_t(kRows) && r < count) {
+            const int32_t l3 = int32_t(sum + uint32_t(l3Bias));
+            const int64_t scaled = int64_t(l3) * kScale / (int64_t(1) << (4 * kQBits));  // truncating division
+            p.out[kTiling == kMlpTilePerPosition ? sortedBase : p.posOrder[sortedBase + r]] = int32_t(scaled);
+        }
+    }
+#else
     for (uint32_t r = kShareTile ? wave : 0u; r < count; r += kShareTile ? 4u : 1u) {
         const int32_t s = sSum[wave][r][o1];
         const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
@@ -1529,6 +1610,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
         }
         __builtin_amdgcn_wave_barrier();
     }
+#endif
 }
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {

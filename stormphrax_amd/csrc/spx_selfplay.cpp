@@ -709,6 +709,98 @@ private:
     size_t next_ = 0;
 };
 
+}  // namespace
+
+// Seeded random playouts ON THE DEVICE (the bulk form of spx_random_positions: datagen-style random plies from the start
+// position or a double-Chess960 start): spx_movegen_kernel + spx_pick_kernel without evaluations, position i playing
+// min_ply + (draw mod range) plies; a position that runs out of moves keeps its last (mated / stalemated) position. The
+// host only places the start pieces - a rank that shares its node's CPUs with seven others generates its batch here.
+extern "C" int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every,
+                                        void* d_out) {
+    if (!ctx || (count && !d_out) || min_ply < 0 || max_ply < min_ply || max_ply > 1000) {
+        setError("spx_random_positions_gpu: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if (count == 0) return SPX_OK;
+    constexpr size_t kRound = 16384, kPerSeat = 96;
+    if (hipSetDevice(ctxDevice(ctx)) != hipSuccess) {
+        setError("spx_random_positions_gpu: hipSetDevice failed");
+        return SPX_ERR_HIP;
+    }
+    const size_t round = std::min(kRound, ctxMaxBatch(ctx));
+    DeviceBuffers dev;
+    uint64_t* dRng = dev.get<uint64_t>(round);
+    uint8_t* dEnable = dev.get<uint8_t>(round);
+    uint64_t* dChildren = dev.get<uint64_t>(round * kPerSeat * 4);
+    uint16_t* dMoves = dev.get<uint16_t>(round * kPerSeat);
+    uint32_t* dParents = dev.get<uint32_t>(round * kPerSeat);
+    uint32_t* dFirst = dev.get<uint32_t>(round);
+    uint32_t* dCount = dev.get<uint32_t>(round);
+    uint8_t* dInCheck = dev.get<uint8_t>(round);
+    uint32_t* dTotal = dev.get<uint32_t>(1);
+    if (!dRng || !dEnable || !dChildren || !dMoves || !dParents || !dFirst || !dCount || !dInCheck || !dTotal) {
+        setError("spx_random_positions_gpu: out of device memory");
+        return SPX_ERR_HIP;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(ctxStream(ctx));  // the context's own stream (what NULL means to spx_movegen_device)
+    Rng rng{seed ^ 0x5DEECE66Dull};
+    spx_packed_pos standard;
+    packBoard(startpos(), standard);
+    std::vector<spx_packed_pos> start(round);
+    std::vector<uint64_t> seeds(round);
+    std::vector<uint32_t> plies(round);
+    std::vector<uint8_t> enable(round);
+    for (size_t lo = 0; lo < count; lo += round) {
+        const size_t b = std::min(round, count - lo);
+        uint64_t* dPositions = static_cast<uint64_t*>(d_out) + lo * 4;
+        uint32_t longest = 0;
+        for (size_t i = 0; i < b; ++i) {
+            const size_t game = lo + i;
+            if (dfrc_every > 0 && game % size_t(dfrc_every) == size_t(dfrc_every) - 1) {
+                const uint32_t w = rng.below(960), k = rng.below(960);
+                packBoard(dfrcStart(w, k), start[i]);
+            } else {
+                start[i] = standard;
+            }
+            plies[i] = uint32_t(min_ply) + rng.below(uint32_t(max_ply - min_ply + 1));
+            longest = std::max(longest, plies[i]);
+            seeds[i] = rng.next();
+        }
+        SPX_SP_HIP(hipMemcpyAsync(dPositions, start.data(), b * 32, hipMemcpyHostToDevice, stream));
+        SPX_SP_HIP(hipMemcpyAsync(dRng, seeds.data(), b * 8, hipMemcpyHostToDevice, stream));
+        for (uint32_t ply = 0; ply < longest; ++ply) {
+            for (size_t i = 0; i < b; ++i) enable[i] = ply < plies[i];
+            SPX_SP_HIP(hipMemcpyAsync(dEnable, enable.data(), b, hipMemcpyHostToDevice, stream));
+            const int rc = spx_movegen_device(ctx, dPositions, b, nullptr, dChildren, dMoves, dParents, dFirst, dCount, dInCheck,
+                                              round * kPerSeat, dTotal, nullptr);
+            if (rc != SPX_OK) return rc;
+            PickParams pk{};
+            pk.nGames = uint32_t(b);
+            pk.first = dFirst;
+            pk.count = dCount;
+            pk.inCheck = dInCheck;
+            pk.enable = dEnable;
+            pk.moves = dMoves;
+            pk.children = dChildren;
+            pk.positions = dPositions;
+            pk.rng = dRng;
+            pk.temperature = 0x3FFFFFFF;  // no evaluations: every legal move is within the margin
+            SPX_SP_HIP(launchPick(pk, stream));
+            SPX_SP_HIP(hipStreamSynchronize(stream));  // the host rewrites `enable` for the next ply
+        }
+        uint32_t total = 0;
+        SPX_SP_HIP(hipMemcpyAsync(&total, dTotal, 4, hipMemcpyDeviceToHost, stream));
+        SPX_SP_HIP(hipStreamSynchronize(stream));
+        if (total > round * kPerSeat) {
+            setError("spx_random_positions_gpu: a generation overflowed its child buffer");
+            return SPX_ERR_CAPACITY;
+        }
+    }
+    return SPX_OK;
+}
+
+namespace {
+
 // One half of the seats: its own child buffers and scratch-slot regions. The halves alternate so that the host's
 // bookkeeping for one half runs while the GPU evaluates the children of the other.
 struct DeviceHalf {

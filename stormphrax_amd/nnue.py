@@ -178,6 +178,10 @@ class NnueState:
                                              ctypes.byref(c)))
         return a.value, b.value, c.value
 
+    def random_positions_device(self, d_out_ptr, count, seed=1, min_ply=8, max_ply=120, dfrc_every=4):
+        """spx_random_positions_gpu: `count` seeded random-playout records written to device memory at d_out_ptr."""
+        check(_lib.load().spx_random_positions_gpu(self._h, seed, count, min_ply, max_ply, dfrc_every, d_out_ptr))
+
     def evaluate_once_device_async(self, d_positions_ptr, n, d_out_ptr):
         """Pipelined variant (spx_eval_full_device_async): returns the hipEvent_t handle that marks the batch done."""
         ev = ctypes.c_void_p()

@@ -181,3 +181,38 @@ def test_viriformat_expansion_on_the_device_matches_the_host_replay(sp, st):
     broken[33] &= 0xF0
     _, _, bad = st.viri_expand(bytes(broken))
     assert bad == 1
+
+
+def test_random_playouts_on_the_device_are_legal_positions(sp, oracle, net_blob):
+    """spx_random_positions_gpu: seeded, reproducible batches of random-playout positions written straight to device
+    memory (page-locked host memory here, which the device addresses). Every record must be a position the host chess
+    core accepts and reproduces (FEN round trip), evaluate like the CPU oracle, and contain Chess960 starts."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192)
+    n = 6000
+    bufs = [lib.spx_host_alloc(n * 32) for _ in range(3)]
+    try:
+        assert all(bufs)
+        views = [np.ctypeslib.as_array((ctypes.c_uint8 * (n * 32)).from_address(b)) for b in bufs]
+        st.random_positions_device(bufs[0], n, seed=5, min_ply=6, max_ply=90, dfrc_every=3)
+        st.random_positions_device(bufs[1], n, seed=5, min_ply=6, max_ply=90, dfrc_every=3)
+        st.random_positions_device(bufs[2], n, seed=6, min_ply=6, max_ply=90, dfrc_every=3)
+        assert np.array_equal(views[0], views[1]) and not np.array_equal(views[0], views[2])
+        pos = views[0].copy().view(sp.PACKED_DTYPE)
+        fens = [sp.position_to_fen(p) for p in pos]
+        again = sp.positions_from_fens(fens)
+        assert again.tobytes() == pos.tobytes(), "a generated record is not what the host core packs for its own FEN"
+        assert len(set(fens)) > 0.95 * n
+        mail, stm = sp.positions_to_mailboxes(pos[:2048])
+        oracle.use(net_blob("tame"), "tame")
+        assert np.array_equal(st.evaluate_once(pos[:2048]), oracle.eval_mailboxes(mail, stm))
+        plies = np.array([2 * (int(f.split()[-1]) - 1) + (f.split()[1] == "b") for f in fens])
+        assert plies.min() >= 6 and plies.max() <= 90 and plies.std() > 15
+    finally:
+        for b in bufs:
+            lib.spx_host_free(b)
+        st.close()
