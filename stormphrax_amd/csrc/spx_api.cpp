@@ -108,7 +108,9 @@ struct spx_ctx {
     bool updateLegacy = false;     // the round-1 update kernel (two full attack generations, rebuilds inline: ONE launch) serves
     bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
-    size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = records / 4)
+    size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = automatic)
+    bool refreshCoop = false;      // SPX_REFRESH_COOP=1: one WORKGROUP per rebuilt perspective (four waves share the gather) -
+                                   // measured slower than one wave each (update + rebuild 327 vs 299 us per 65 536-record ply)
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
@@ -485,6 +487,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     ctx->updateSplitMaxV2 = 16384;
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_REFRESH_COOP")) ctx->refreshCoop = env[0] != '0';
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -917,7 +920,10 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     fp.slots = up.childSlots;
     fp.slotRecords = up.slotRecords;
     ctx->refreshCur ^= 1;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, ctx->refreshWaves ? ctx->refreshWaves : std::max<size_t>(256, n / 4)), s));
+    // one workgroup per deferred perspective (cooperative gather): ~n / 15 of them in play, grid-stride beyond
+    const bool coop = ctx->refreshCoop;
+    const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : (coop ? std::max<size_t>(1024, n) : std::max<size_t>(256, n / 4));
+    SPX_HIP(launchFt(fp, ftGrid(ctx, waves), s, coop));
     return SPX_OK;
 }
 

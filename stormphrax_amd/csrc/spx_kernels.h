@@ -160,7 +160,8 @@ struct MlpParams {
     int32_t* out;               // [nPositions]
 };
 
-hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
+// cooperative: one workgroup (four waves) per perspective instead of one wave - the latency-bound rebuild pass
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, bool cooperative = false);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,

@@ -321,10 +321,14 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
 // acc = ftBias + sum(piece-square rows) + sum(threat rows), all mod 2^16 per column.
 // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
 __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
-                                           const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8]) {
-    {
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(t.ftBias + 8 * lane);
-        const u32x4 b1 = *reinterpret_cast<const u32x4*>(t.ftBias + 512 + 8 * lane);
+                                           const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8],
+                                           bool withBias = true) {
+    {   // (withBias = false: a partial sum over a slice of the lists - the cooperative rebuild pass adds the slices up)
+        u32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        if (withBias) {
+            b0 = *reinterpret_cast<const u32x4*>(t.ftBias + 8 * lane);
+            b1 = *reinterpret_cast<const u32x4*>(t.ftBias + 512 + 8 * lane);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             acc[r] = b0[r];
@@ -571,13 +575,20 @@ __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* are
 //   ftOut   != nullptr: pairwise-activated u8[512] halves (stm first) for the MLP kernel     == evaluateOnce
 //   accOut  != nullptr: raw i16 accumulators into arena slot slots[position] + the record     == NnueState::reset
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
+// kCoop = false: one wavefront per perspective (throughput: the full-refresh batches).
+// kCoop = true:  one WORKGROUP per perspective - the rebuild pass behind the update kernel, a few thousand perspectives on
+//                an otherwise idle chip, where the time is the latency of one cold 65-row gather (8 rows per round trip):
+//                all four waves build the lists, each gathers a quarter of them (2-3 round trips instead of 9) and
+//                wave 0 adds the four partial accumulators up through LDS.
+template <bool kCoop>
+__global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
 #if SPX_OPT_PSEUDOTAB
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];        // pseudo-attack sets per (piece kind, square), 3 KiB
 #endif
+    __shared__ uint32_t sPart[kCoop ? kWavesPerBlock : 1][8][64];  // kCoop: the waves' partial accumulators
 
     if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
     if (p.nPerspPtr && *p.nPerspPtr == 0) return;  // nothing was deferred: the refresh pass costs one empty launch
@@ -604,9 +615,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
     const uint32_t sliceBegin = uint32_t(uint64_t(nPersp) * xcd / 8);
     const uint32_t sliceEnd = uint32_t(uint64_t(nPersp) * (xcd + 1) / 8);
-    const uint32_t stride = blocksPerXcd * kWavesPerBlock;
+    const uint32_t stride = kCoop ? blocksPerXcd : blocksPerXcd * kWavesPerBlock;
 
-    for (uint32_t it = sliceBegin + blockInXcd * kWavesPerBlock + wave; it < sliceEnd; it += stride) {
+    for (uint32_t it = sliceBegin + (kCoop ? blockInXcd : blockInXcd * kWavesPerBlock + wave); it < sliceEnd; it += stride) {
         const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
         const uint32_t posIdx = q >> 1;
         const int c = int(q & 1);
@@ -616,7 +627,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         uint32_t nPsq, nThr;
         buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, pseudoTab);
         uint32_t acc[8];
-        gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+        if constexpr (kCoop) {
+            // this wave's quarter of both lists (every wave built the same lists)
+            const uint32_t p0 = nPsq * wave / kWavesPerBlock, p1 = nPsq * (wave + 1) / kWavesPerBlock;
+            const uint32_t t0 = nThr * wave / kWavesPerBlock, t1 = nThr * (wave + 1) / kWavesPerBlock;
+            gatherFull(p.t, lane, sPsq[wave] + p0, p1 - p0, sThr[wave] + t0, t1 - t0, acc, wave == 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sPart[wave][r][lane] = acc[r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r] = pkAdd16(acc[r], sPart[w][r][lane]);
+                }
+            }
+            __syncthreads();  // the partials are consumed before the next item overwrites them
+            if (wave != 0) continue;
+        } else {
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+        }
 
         if (p.accOut) {
             const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
@@ -1613,8 +1643,12 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 #endif
 }
 
-hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_ft_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, bool cooperative) {
+    if (cooperative) {
+        hipLaunchKernelGGL(spx_ft_kernel<true>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(spx_ft_kernel<false>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
