@@ -66,7 +66,7 @@ struct spx_ctx {
     uint8_t* dFtOut = nullptr;
     uint8_t* dKingKeys = nullptr;  // counting-sort scratch
     uint8_t* dOutKeys = nullptr;
-    uint32_t* dHist = nullptr;     // 64 words: counts + cursors
+    uint32_t* dHist = nullptr;     // 3 sort-histogram buffers of kHistWords + 64 words of counters
     uint32_t* dPerspOrder = nullptr;  // perspective ids grouped by king bucket
     uint32_t* dPosOrder = nullptr;    // position ids grouped by output bucket
     // accumulator arena (incremental path): nSlots x (4 KiB accumulators + 32 B record)
@@ -76,9 +76,9 @@ struct spx_ctx {
     uint32_t *dSlotsA = nullptr, *dSlotsB = nullptr;  // staging for the host-buffer entry points [max_batch]
     uint8_t* dStaged = nullptr;                        // [max_batch][32] records of the slots being evaluated
     uint8_t* dDeltas = nullptr;                        // [max_batch] spx_move_delta staging (allocated on first use)
-    int histCur = 0;               // dHist holds 4 x 64 words: [0],[1] alternate between large sorts (each sort clears
-                                   // the other one for its successor), [2] belongs to the single-launch small sort,
-                                   // [3] words 0,1: alternating counters of the update kernel's deferred-refresh list
+    int histCur = 0;               // dHist: buffers [0],[1] alternate between large sorts (each sort clears the other one
+                                   // for its successor), [2] belongs to the single-launch small sort; behind them words
+                                   // 0,1: alternating counters of the update kernel's deferred-refresh list
     int refreshCur = 0;            // which of the two counters the next update uses (its refresh pass clears the other)
     uint32_t* histUsed = nullptr;  // the buffer the latest sort wrote (what the MLP kernel reads)
     // spx_eval_full_device_async: two scratch sets ("lanes") with their own streams alternate, so that the sorts and
@@ -114,6 +114,8 @@ struct spx_ctx {
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
+    bool ftPosMajor = false;       // SPX_FT_POS_MAJOR=1: full refresh with one wave per POSITION (extraction shared by the two
+                                   // perspectives, positions sorted by the pair of king buckets)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
@@ -460,14 +462,15 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dFtOut), max_batch * size_t(kL1)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dKingKeys), max_batch * 2));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dOutKeys), max_batch));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), 4 * 64 * sizeof(uint32_t)));
-    SPX_HIP(hipMemset(ctx->dHist, 0, 4 * 64 * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dHist), (3 * kHistWords + 64) * sizeof(uint32_t)));
+    SPX_HIP(hipMemset(ctx->dHist, 0, (3 * kHistWords + 64) * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
+    if (const char* env = std::getenv("SPX_FT_POS_MAJOR")) ctx->ftPosMajor = env[0] == '1';
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
@@ -539,21 +542,22 @@ void spx_ctx_destroy(spx_ctx* ctx) {
 
 // sort (both keys) on `d_records`, then the MLP over ctx->dFtOut[0..n) -> d_out
 static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp,
-                         const uint32_t* d_count = nullptr, bool outOnly = false) {
+                         const uint32_t* d_count = nullptr, bool outOnly = false, bool pairMode = false) {
     if (!mlp) {
         SortParams sp{};
         sp.positions = static_cast<const uint64_t*>(d_records);
         sp.nPositions = uint32_t(n);
         sp.nPositionsPtr = d_count;
         sp.outOnly = outOnly;
+        sp.pairMode = pairMode;
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
         if (n <= 1024 && !d_count) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
-            sp.hist = ctx->dHist + 128;
+            sp.hist = ctx->dHist + 2 * kHistWords;
             sp.histNext = sp.hist;
         } else {
-            sp.hist = ctx->dHist + 64 * ctx->histCur;
-            sp.histNext = ctx->dHist + 64 * (ctx->histCur ^ 1);
+            sp.hist = ctx->dHist + kHistWords * ctx->histCur;
+            sp.histNext = ctx->dHist + kHistWords * (ctx->histCur ^ 1);
             ctx->histCur ^= 1;
         }
         ctx->histUsed = sp.hist;
@@ -631,7 +635,8 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         SPX_HIP(hipEventRecord(ev[0], s));
     }
     const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
-    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
+    const bool posMajor = ctx->ftPosMajor && ctx->kingSortEnabled && n > 1024 && !tiny;  // (the small single-launch sort has no pair mode)
+    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, false, posMajor);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
@@ -640,9 +645,10 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
     fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
+    fp.posMajor = posMajor;
     fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
+    SPX_HIP(launchFt(fp, ftGrid(ctx, posMajor ? n : 2 * n), s));
     if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
@@ -677,8 +683,8 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dKingKeys), ctx->maxBatch * 2));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dOutKeys), ctx->maxBatch));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dStaged), ctx->maxBatch * 32));
-        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), 4 * 64 * sizeof(uint32_t)));
-        SPX_HIP(hipMemset(lane.dHist, 0, 4 * 64 * sizeof(uint32_t)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dHist), (3 * kHistWords + 64) * sizeof(uint32_t)));
+        SPX_HIP(hipMemset(lane.dHist, 0, (3 * kHistWords + 64) * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
         SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking,
@@ -903,7 +909,7 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
 static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipStream_t s) {
     const bool legacy = ctx->updateLegacyForced ? ctx->updateLegacy : (n <= ctx->tinyBatchMax && !up.nRecordsPtr);
     const bool split = n <= (legacy ? ctx->updateSplitMax : ctx->updateSplitMaxV2);  // one wave per (record, perspective)
-    uint32_t* counters = ctx->dHist + 192;
+    uint32_t* counters = ctx->dHist + 3 * kHistWords;
     up.refreshList = ctx->dPerspOrder;
     up.refreshCount = counters + ctx->refreshCur;
     SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));

@@ -14,6 +14,8 @@
 
 namespace spx {
 
+constexpr int kHistWords = 1024;  // one sort-histogram buffer (counts + cursors for up to 256 first keys and 8 output keys)
+
 constexpr size_t kAccSlotBytes = 2 * 1024 * 2;  // one arena slot: 2 perspectives x i16[1024] (psq + threat combined)
 
 // device-resident network tables shared by the feature-transformer and update kernels
@@ -29,6 +31,7 @@ struct FtParams {
     const void* positions;   // spx_packed_pos[nPositions] (32 B records)
     uint32_t nPositions;
     const uint32_t* order;   // optional permutation of perspective ids (2*pos + colour), or nullptr
+    bool posMajor;           // `order` holds POSITION ids (pair-sorted): one wave extracts once and gathers both perspectives
     FtTables t;
     uint8_t* ftOut;          // mode A: [nPositions][1024] u8 activations (stm half, then nstm half)
     uint8_t* accOut;         // mode B (ftOut == nullptr): accumulator arena ...
@@ -135,10 +138,12 @@ struct SortParams {
     uint32_t nPositions;
     const uint32_t* nPositionsPtr;  // optional device-resident count (<= nPositions), as in UpdateParams
     bool outOnly;               // large sorts: only the output-bucket order (arena paths: nobody reads the king-bucket order)
+    bool pairMode;              // large sorts: perspOrder receives POSITION ids grouped by the pair of king buckets
+                                // (256 keys) instead of perspective ids grouped by king bucket - the position-major FT kernel
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
-    uint32_t* hist;             // [64] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)
-    uint32_t* histNext;         // [64] cleared by this sort for the next large sort
+    uint32_t* hist;             // [kHistWords] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)
+    uint32_t* histNext;         // [kHistWords] cleared by this sort for the next large sort
     uint32_t* perspOrder;       // out: [2 * nPositions] perspective ids grouped by king bucket
     uint32_t* posOrder;         // out: [nPositions] position ids grouped by output bucket
 };

@@ -266,9 +266,20 @@ __device__ __forceinline__ uint32_t emitPsqDeltaRows(bool active, uint32_t row, 
 // Row lists of one perspective of one board (the full-refresh feature set): psqList (capacity kPsqCap) = byte offsets
 // into the i16 piece-square table, thrList (capacity kU8Cap) = byte offsets into the u8 row table; nThr counts both the
 // compact piece-square rows and the threat / pawn-pair rows in it.
+// this lane's threat targets (perspective independent): the occupied non-king squares its piece attacks
+__device__ __forceinline__ uint64_t laneTargets(const LaneBoard& b, uint32_t lane) {
+    const int type = b.piece >> 1;
+    uint64_t targets = 0;
+    if (b.piece != kNoPiece && type != 5) {
+        targets = pieceAttacks(b.piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
+    }
+    return targets;
+}
+
 __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
                                                uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
-                                               const uint64_t* pseudoTab = nullptr) {
+                                               const uint64_t* pseudoTab = nullptr, bool haveTargets = false,
+                                               uint64_t sharedTargets = 0) {
     const int piece = b.piece;
     const bool occupied = piece != kNoPiece;
     const int type = piece >> 1;
@@ -303,11 +314,8 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     }
     uint32_t* threatList = thrList + nCompact;  // the reference's <= 256-entry threat list proper
 
-    // threat rows (addThreatFeatures, nnue_state.cpp:309-328)
-    uint64_t targets = 0;
-    if (occupied && type != 5) {
-        targets = pieceAttacks(piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
-    }
+    // threat rows (addThreatFeatures, nnue_state.cpp:309-328); the position-major kernel computes the targets once
+    const uint64_t targets = haveTargets ? sharedTargets : laneTargets(b, lane);
     nThr = emitThreatRows(threatList, 0, targets, piece, lane, x, flipColour, lut, pseudoTab);
 
     // pawn-pair rows (nnue_state.cpp:330-351)
@@ -1277,22 +1285,25 @@ __global__ __launch_bounds__(256) void spx_adjust_kernel(AdjustParams p) {
 //     same 1.4 MiB slab of the piece-square table (L2-resident per XCD);
 //   positions by OUTPUT BUCKET (8 keys, output.h:51-54): every 16-position MFMA tile of the MLP kernel shares one
 //     set of L1/L2/L3 weights.
-// hist layout (u32 words): [0,16) king counts  [16,24) output counts  [32,48) king cursors  [48,56) output cursors
+// hist layout: see the constants below
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kKingKeys = 16;
+constexpr int kPairKeys = 256;  // position-major full refresh: positions by the PAIR of king buckets (white * 16 + black)
 constexpr int kOutKeys = 8;
-constexpr int kHistOut = 16, kCursorKing = 32, kCursorOut = 48;
+// hist layout (kHistWords u32 words per buffer): [0, 256) first-key counts (16 king keys or 256 pair keys),
+// [256, 264) output-bucket counts, [512, 768) first-key cursors, [768, 776) output-bucket cursors
+constexpr int kHistOut = 256, kCursorKing = 512, kCursorOut = 768;
 
 __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
-    __shared__ uint32_t sHist[kKingKeys + kOutKeys];
-    if (threadIdx.x < kKingKeys + kOutKeys) sHist[threadIdx.x] = 0;
+    __shared__ uint32_t sHist[kPairKeys + kOutKeys];
+    for (uint32_t i = threadIdx.x; i < kPairKeys + kOutKeys; i += blockDim.x) sHist[i] = 0;
     __syncthreads();
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
     if (pos < nPositions && p.outOnly) {  // arena paths: only the MLP's output-bucket order is needed
         const uint32_t outKey = min((uint32_t(popc64(p.positions[size_t(pos) * 4])) - 2u) / 4u, uint32_t(kOutKeys - 1));
         p.outKeys[pos] = uint8_t(outKey);
-        atomicAdd(&sHist[kHistOut + outKey], 1u);
+        atomicAdd(&sHist[kPairKeys + outKey], 1u);
     } else if (pos < nPositions) {
         const uint64_t* rec = p.positions + size_t(pos) * 4;
         uint64_t occ = rec[0];
@@ -1307,46 +1318,56 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
             ++idx;
             if ((nib & 7) == 5) kingSq[(nib & 8) ? 0 : 1] = sq;
         }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const uint32_t key = uint32_t(kingBucket(c == 0 ? (kingSq[c] ^ 56) : kingSq[c]));
-            p.kingKeys[2 * pos + c] = uint8_t(key);
-            atomicAdd(&sHist[key], 1u);
+        const uint32_t keyB = uint32_t(kingBucket(kingSq[0] ^ 56)), keyW = uint32_t(kingBucket(kingSq[1]));
+        if (p.pairMode) {  // one key per POSITION: both perspectives are gathered by the same wave
+            p.kingKeys[pos] = uint8_t(keyW * 16 + keyB);
+            atomicAdd(&sHist[keyW * 16 + keyB], 1u);
+        } else {
+            p.kingKeys[2 * pos] = uint8_t(keyB);
+            p.kingKeys[2 * pos + 1] = uint8_t(keyW);
+            atomicAdd(&sHist[keyB], 1u);
+            atomicAdd(&sHist[keyW], 1u);
         }
         p.outKeys[pos] = uint8_t(outKey);
-        atomicAdd(&sHist[kHistOut + outKey], 1u);
+        atomicAdd(&sHist[kPairKeys + outKey], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kKingKeys + kOutKeys && sHist[threadIdx.x]) atomicAdd(&p.hist[threadIdx.x], sHist[threadIdx.x]);
+    for (uint32_t i = threadIdx.x; i < kPairKeys + kOutKeys; i += blockDim.x) {
+        if (sHist[i]) atomicAdd(&p.hist[i], sHist[i]);  // (i >= 256: the output-bucket counts sit at kHistOut = 256)
+    }
 }
 
-// blocks [0, nb) scatter perspectives by king key; blocks [nb, nb + nb2) scatter positions by output key
-__global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uint32_t perspBlocks) {
-    __shared__ uint32_t sCount[kKingKeys];
-    __shared__ uint32_t sBase[kKingKeys];
-    if (threadIdx.x < kKingKeys) sCount[threadIdx.x] = 0;
-    __syncthreads();
-    const bool persp = blockIdx.x < perspBlocks;
-    const uint32_t id = (persp ? blockIdx.x : blockIdx.x - perspBlocks) * blockDim.x + threadIdx.x;
+// blocks [0, nb) scatter the first key (perspectives by king key, or positions by pair key); blocks [nb, nb + nb2) scatter
+// positions by output key
+__global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uint32_t firstBlocks) {
+    __shared__ uint32_t sCount[kPairKeys];
+    __shared__ uint32_t sBase[kPairKeys];
+    sCount[threadIdx.x] = 0;  // blockDim.x == kPairKeys
+    const bool first = blockIdx.x < firstBlocks;
+    const uint32_t id = (first ? blockIdx.x : blockIdx.x - firstBlocks) * blockDim.x + threadIdx.x;
     const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
-    const uint32_t count = persp ? nPositions * 2 : nPositions;
-    const uint32_t nKeys = persp ? kKingKeys : kOutKeys;
-    const uint32_t histOff = persp ? 0 : kHistOut, cursorOff = persp ? kCursorKing : kCursorOut;
+    const uint32_t count = (first && !p.pairMode) ? nPositions * 2 : nPositions;
+    const uint32_t nKeys = first ? (p.pairMode ? kPairKeys : kKingKeys) : kOutKeys;
+    const uint32_t histOff = first ? 0 : kHistOut, cursorOff = first ? kCursorKing : kCursorOut;
+    sBase[threadIdx.x] = threadIdx.x < nKeys ? p.hist[histOff + threadIdx.x] : 0u;  // counts, turned into bases below
+    __syncthreads();
     uint32_t key = 0, rank = 0;
     if (id < count) {
-        key = persp ? p.kingKeys[id] : p.outKeys[id];
+        key = first ? p.kingKeys[id] : p.outKeys[id];
         rank = atomicAdd(&sCount[key], 1u);
     }
+    uint32_t prefix = 0;
+    for (uint32_t k = 0; k < threadIdx.x && k < nKeys; ++k) prefix += sBase[k];
     __syncthreads();
     if (threadIdx.x < nKeys) {
-        uint32_t prefix = 0;
-        for (uint32_t k = 0; k < threadIdx.x; ++k) prefix += p.hist[histOff + k];
         const uint32_t mine = sCount[threadIdx.x];
         sBase[threadIdx.x] = prefix + (mine ? atomicAdd(&p.hist[cursorOff + threadIdx.x], mine) : 0u);
     }
     __syncthreads();
-    if (id < count) (persp ? p.perspOrder : p.posOrder)[sBase[key] + rank] = id;
-    if (blockIdx.x == 0 && threadIdx.x < 64) p.histNext[threadIdx.x] = 0;
+    if (id < count) (first ? p.perspOrder : p.posOrder)[sBase[key] + rank] = id;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < uint32_t(kHistWords); i += blockDim.x) p.histNext[i] = 0;
+    }
 }
 
 // Small batches (<= kSmallSortMax positions, e.g. the one-position drop-in call): the whole two-key counting sort in
@@ -1385,15 +1406,16 @@ __global__ __launch_bounds__(1024) void spx_sort_small_kernel(SortParams p) {
             atomicAdd(&sHist[key], 1u);
         }
         sOut[pos] = uint8_t(outKey);
-        atomicAdd(&sHist[kHistOut + outKey], 1u);
+        atomicAdd(&sHist[kKingKeys + outKey], 1u);
     }
     __syncthreads();
     if (threadIdx.x < kKingKeys + kOutKeys) {
-        const uint32_t first = threadIdx.x < kKingKeys ? 0 : kHistOut;
+        const uint32_t first = threadIdx.x < kKingKeys ? 0 : kKingKeys;
         uint32_t prefix = 0;
         for (uint32_t k = first; k < threadIdx.x; ++k) prefix += sHist[k];
         sBase[threadIdx.x] = prefix;
-        p.hist[threadIdx.x] = sHist[threadIdx.x];  // the MLP kernel maps tiles from the output-bucket counts
+        // the MLP kernel maps tiles from the output-bucket counts (at kHistOut in the global layout)
+        p.hist[threadIdx.x < kKingKeys ? threadIdx.x : kHistOut + (threadIdx.x - kKingKeys)] = sHist[threadIdx.x];
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < 2 * p.nPositions; q += blockDim.x) {
@@ -1401,7 +1423,7 @@ __global__ __launch_bounds__(1024) void spx_sort_small_kernel(SortParams p) {
         p.perspOrder[sBase[key] + atomicAdd(&sCursor[key], 1u)] = q;
     }
     for (uint32_t pos = threadIdx.x; pos < p.nPositions; pos += blockDim.x) {
-        const uint32_t key = kHistOut + sOut[pos];
+        const uint32_t key = kKingKeys + sOut[pos];
         p.posOrder[sBase[key] + atomicAdd(&sCursor[key], 1u)] = pos;
     }
 }
@@ -1413,7 +1435,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
         return hipGetLastError();
     }
-    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = p.outOnly ? 0u : (2 * p.nPositions + 255) / 256;
+    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = p.outOnly ? 0u : (p.pairMode ? b1 : (2 * p.nPositions + 255) / 256);
     hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2 + b1), dim3(256), 0, stream, p, b2);
     return hipGetLastError();
@@ -1643,8 +1665,52 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Position-major full refresh ("one extraction per position, not per perspective"): one wavefront per
+// POSITION. The record is decoded and the attack sets are generated once; the two perspectives then build their lists and
+// gather one after the other. `order` holds position ids grouped by the PAIR of king buckets (256 keys), each XCD walking
+// one contiguous eighth, so an XCD's L2 holds one white slab and a slowly changing black slab. Evaluation mode (ftOut) only.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_pos_kernel(FtParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint64_t sPseudo[kDeltaPseudoWords];
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
+        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    }
+    __syncthreads();
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
+    const uint32_t sliceBegin = uint32_t(uint64_t(p.nPositions) * xcd / 8);
+    const uint32_t sliceEnd = uint32_t(uint64_t(p.nPositions) * (xcd + 1) / 8);
+    const uint32_t stride = blocksPerXcd * kWavesPerBlock;
+    for (uint32_t it = sliceBegin + blockInXcd * kWavesPerBlock + wave; it < sliceEnd; it += stride) {
+        const uint32_t posIdx = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
+        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
+        const LaneBoard board = decodeBoard(rec, lane);
+        const uint64_t targets = laneTargets(board, lane);
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            uint32_t nPsq, nThr;
+            buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo, true, targets);
+            uint32_t acc[8];
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+            const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
+            *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            __builtin_amdgcn_wave_barrier();  // the lists are rebuilt for the other perspective
+        }
+    }
+}
+
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, bool cooperative) {
-    if (cooperative) {
+    if (p.posMajor) {
+        hipLaunchKernelGGL(spx_ft_pos_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    } else if (cooperative) {
         hipLaunchKernelGGL(spx_ft_kernel<true>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     } else {
         hipLaunchKernelGGL(spx_ft_kernel<false>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
