@@ -502,7 +502,8 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipGetDeviceProperties(&prop, device));
     // persistent-ish grid: workgroups (4 waves) per CU, grid-stride over perspectives. A/B on MI355X: 2 -> 0.72 ms,
     // 4 -> 0.575, 8 -> 0.565, 16 -> 0.557, 64 -> 0.554 (finer-grained tail balancing)
-    uint32_t blocksPerCu = 32;
+    // round 2, with the round-robin chunk traversal (tools/gpu_r02_p.sh): 16 -> 0.4427, 32 -> 0.4204, 48 -> 0.4160, 64 -> 0.4203, 96 -> 0.4284
+    uint32_t blocksPerCu = 48;
     if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
     SPX_HIP(hipDeviceSynchronize());  // the hist memset ran on the null stream, the context's stream does not wait for it

@@ -36,6 +36,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_OPT_PSEUDOTAB
 #define SPX_OPT_PSEUDOTAB 1
 #endif
+#ifndef SPX_FT_CHUNK
+#define SPX_FT_CHUNK 128  // perspectives per round-robin chunk of the XCD traversal, a power of two (0 = one contiguous eighth per XCD)
+#endif
 #ifndef SPX_FT_WAVES_PER_SIMD
 #define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
 #endif
@@ -617,15 +620,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
     const uint32_t wave = threadIdx.x >> 6;
     // nPerspPtr: the list in `order` was produced on the device (deferred refreshes of the update kernel) and so was its length
     const uint32_t nPersp = p.nPerspPtr ? min(*p.nPerspPtr, p.nPositions * 2) : p.nPositions * 2;
-    // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch order; affects speed only). Each XCD walks
-    // one contiguous eighth of the (king-bucket sorted) perspective order, so its private 4 MiB L2 only ever holds
-    // the 1.4 MiB piece-square slab of the bucket(s) in its slice plus the hot threat rows.
+    // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch order; affects speed only). The (king-bucket
+    // sorted) perspective order is dealt to the XCDs in chunks of SPX_FT_CHUNK perspectives, round robin: all eight walk
+    // the order side by side, so at any moment each private 4 MiB L2 holds the 0.7-1.4 MiB piece-square slab of the SAME
+    // current bucket plus the hot threat rows - and every XCD gets the same mix of light and heavy buckets. Round 1 gave
+    // each XCD one contiguous eighth: the slices differ in WORK (castled-king buckets average 76 rows per perspective,
+    // advanced-king endgame buckets 40-50: the heaviest eighth of the bench batch carries 17 % more rows than the mean)
+    // and the kernel waited for the slowest XCD: FT kernel 0.4407 -> 0.4210 ms. SPX_FT_CHUNK=0: contiguous slices.
     const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
+    const uint32_t stride = kCoop ? blocksPerXcd : blocksPerXcd * kWavesPerBlock;
+#if SPX_FT_CHUNK > 0
+    // (batches too small to give every XCD several chunks are dealt perspective by perspective: chunk = 1)
+    const uint32_t chunkShift = nPersp >= 64u * SPX_FT_CHUNK ? uint32_t(__builtin_ctz(SPX_FT_CHUNK)) : 0u;
+    const uint32_t nChunks = (nPersp + (1u << chunkShift) - 1) >> chunkShift;
+    const uint32_t myItems = ((nChunks + 7 - xcd) / 8) << chunkShift;  // chunks xcd, xcd + 8, ...
+    for (uint32_t t = kCoop ? blockInXcd : blockInXcd * kWavesPerBlock + wave; t < myItems; t += stride) {
+        const uint32_t it = ((((t >> chunkShift) * 8 + xcd)) << chunkShift) + (t & ((1u << chunkShift) - 1));
+        if (it >= nPersp) continue;  // the last chunk may be partial (`it` is block-uniform in kCoop mode: no barrier is split)
+#else
     const uint32_t sliceBegin = uint32_t(uint64_t(nPersp) * xcd / 8);
     const uint32_t sliceEnd = uint32_t(uint64_t(nPersp) * (xcd + 1) / 8);
-    const uint32_t stride = kCoop ? blocksPerXcd : blocksPerXcd * kWavesPerBlock;
-
     for (uint32_t it = sliceBegin + (kCoop ? blockInXcd : blockInXcd * kWavesPerBlock + wave); it < sliceEnd; it += stride) {
+#endif
         const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
         const uint32_t posIdx = q >> 1;
         const int c = int(q & 1);

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02n; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_incremental.py tests/test_gpu_native_host.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -3
+echo "== pipelined"; timeout 1200 bash tools/gpu_ab.sh 2 --no-wide 2>&1 | grep -v amdgpu.ids | tee $O/ab_chunk.txt
+echo "== stream-ordered"; timeout 1200 bash tools/gpu_ab.sh 2 --no-wide --no-pipeline 2>&1 | grep -v amdgpu.ids | tee $O/ab_chunk_strict.txt
+python tools/gpu_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/latency.txt
