@@ -118,6 +118,7 @@ struct spx_ctx {
                                    // perspectives, positions sorted by the pair of king buckets)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
+    uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
     std::vector<hipEvent_t> profEvents;  // kProfEventsPerCall per recorded call: [0] start, [1] after the sorts, [4] before
                                          // the FT kernel (after a pipelined call's wait), [2] after it, [3] after the MLP
@@ -506,6 +507,11 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     uint32_t blocksPerCu = 48;
     if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
+    // the update kernel measured on the same sweep (tools/gpu_r02_r.sh, us per ply at 65 536 records):
+    // 16 -> 318.5, 32 -> 318.2, 48 -> 325.2, 64 -> 336.0
+    uint32_t updateBlocksPerCu = 32;
+    if (const char* env = std::getenv("SPX_UPDATE_BLOCKS_PER_CU")) updateBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
+    ctx->updateGridCap = uint32_t(prop.multiProcessorCount) * updateBlocksPerCu;
     SPX_HIP(hipDeviceSynchronize());  // the hist memset ran on the null stream, the context's stream does not wait for it
     *out = ctx.release();
     return SPX_OK;
@@ -583,12 +589,14 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
     return SPX_OK;
 }
 
-static uint32_t ftGrid(const spx_ctx* ctx, size_t waves) {
+static uint32_t cappedGrid(size_t waves, uint32_t cap) {
     const uint32_t wavesPerBlock = ftWavesPerBlock();
     uint32_t blocks = uint32_t((waves + wavesPerBlock - 1) / wavesPerBlock);
-    if (blocks > ctx->ftGridCap) blocks = ctx->ftGridCap;
+    if (blocks > cap) blocks = cap;
     return (blocks + 7u) & ~7u;  // whole multiples of the 8 XCDs
 }
+static uint32_t ftGrid(const spx_ctx* ctx, size_t waves) { return cappedGrid(waves, ctx->ftGridCap); }
+static uint32_t updateGrid(const spx_ctx* ctx, size_t waves) { return cappedGrid(waves, ctx->updateGridCap); }
 
 // MLP of a handful of positions without any sort: every position is its own tile and finds its bucket from its record
 static int runTinyMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s) {
@@ -913,7 +921,7 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     uint32_t* counters = ctx->dHist + 3 * kHistWords;
     up.refreshList = ctx->dPerspOrder;
     up.refreshCount = counters + ctx->refreshCur;
-    SPX_HIP(launchUpdate(up, ftGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));
+    SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));
     if (legacy) return SPX_OK;
     FtParams fp{};
     fp.positions = up.childPositions;

@@ -329,6 +329,38 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
 }
 
+// One lane's 16 bytes of a table row for the full-refresh gather. The row's byte offset stays in a VGPR (every lane reads
+// the list entry from LDS itself) and goes into the 32-bit offset operand of `global_load_dwordx4 v, voff, s[base]` next to
+// the table's SGPR base: ONE v_add_u32 per row (2.6 SIMD cycles) where round 1 / early round 2 paid v_readfirstlane + a
+// 64-bit per-lane pointer add (v_lshl_add_u64), 4.1-4.2 cycles each (tools/probes/valu_rate_probe). +5.3 % on the whole
+// bench in the same-run A/B (profiles/r02_ab_variants.txt). SPX_OPT_VOFF=0 restores the old form.
+#ifndef SPX_OPT_VOFF
+#define SPX_OPT_VOFF 1
+#endif
+__device__ __forceinline__ u32x4 loadGatherRow(const uint8_t* table, const uint8_t* laneBase, uint32_t rowOffset,
+                                               uint32_t laneOff) {
+#if SPX_OPT_VOFF
+    return *reinterpret_cast<const u32x4*>(table + size_t(rowOffset + laneOff));
+#else
+    return *reinterpret_cast<const u32x4*>(laneBase + uint32_t(__builtin_amdgcn_readfirstlane(rowOffset)));
+#endif
+}
+
+#ifndef SPX_OPT_MFMAW
+#define SPX_OPT_MFMAW 0
+#endif
+#ifndef SPX_MFMAW_SWAP
+#define SPX_MFMAW_SWAP 0
+#endif
+__device__ __forceinline__ i32x4 widenAdd(int ident, uint32_t biased, i32x4 sum) {
+    const int x = int(biased ^ 0x80808080u);
+#if SPX_MFMAW_SWAP
+    return __builtin_amdgcn_mfma_i32_4x4x4i8(x, ident, sum, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_i32_4x4x4i8(ident, x, sum, 0, 0, 0);
+#endif
+}
+
 // acc = ftBias + sum(piece-square rows) + sum(threat rows), all mod 2^16 per column.
 // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
 __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
@@ -346,22 +378,23 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             acc[4 + r] = b1[r];
         }
     }
-    // Full-refresh rows come in through plain global loads from per-lane base pointers (one v_lshl_add_u64 per row). The
-    // buffer-load form the update kernel uses (RowTable: no address arithmetic at all) was A/B-measured here too and LOSES
-    // 10 % (FT kernel 0.469 -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is
-    // bound by the vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
+    // Full-refresh rows come in through plain global loads (loadGatherRow). The buffer-load form the update kernel uses
+    // (RowTable: SGPR row offset, no address arithmetic at all) was A/B-measured here too and LOSES 10 % (FT kernel 0.469
+    // -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is bound by the
+    // vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
     // latency-bound) they win 5 %.
     const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
     const uint8_t* thrBase = t.thrW + 16 * lane;
+    const uint8_t* psqTable = reinterpret_cast<const uint8_t*>(t.psqW);
+    const uint32_t laneOff = 16 * lane;
     {
         uint32_t i = 0;
         for (; i + 4 <= nPsq; i += 4) {  // 8 x 1 KiB wave loads in flight
             u32x4 lo[4], hi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t row = uint32_t(__builtin_amdgcn_readfirstlane(psqList[i + u]));
-                lo[u] = *reinterpret_cast<const u32x4*>(psqBase + row);
-                hi[u] = *reinterpret_cast<const u32x4*>(psqBase + row + 1024);
+                lo[u] = loadGatherRow(psqTable, psqBase, psqList[i + u], laneOff);
+                hi[u] = loadGatherRow(psqTable, psqBase, psqList[i + u], laneOff + 1024);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -373,9 +406,8 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         for (; i < nPsq; ++i) {
-            const uint32_t row = uint32_t(__builtin_amdgcn_readfirstlane(psqList[i]));
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(psqBase + row);
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(psqBase + row + 1024);
+            const u32x4 lo = loadGatherRow(psqTable, psqBase, psqList[i], laneOff);
+            const u32x4 hi = loadGatherRow(psqTable, psqBase, psqList[i], laneOff + 1024);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[r] = pkAdd16(acc[r], lo[r]);
@@ -383,6 +415,45 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
     }
+#if SPX_OPT_MFMAW
+    // u8 rows widened and summed on the matrix pipe: v_mfma_i32_4x4x4_16B_i8 with a per-block identity A turns a lane's
+    // dword of four i8 into its four i32 accumulators (D[i][j] = sum_k A[i][k] B[k][j] = byte i of lane j's dword) - ONE
+    // instruction per dword and row where the VALU form pays and + perm + add; the stored bytes are +128-biased u8, one
+    // v_xor_b32 makes them two's complement.
+    {
+        i32x4 dacc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        const int ident = 1 << (8 * (lane & 3));
+        uint32_t i = 0;
+        for (; i + 8 <= nThr; i += 8) {  // 8 x 1 KiB wave loads in flight
+            u32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    dacc[d] = widenAdd(ident, w[u][d], dacc[d]);
+                }
+            }
+        }
+        for (; i < nThr; ++i) {
+            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dacc[d] = widenAdd(ident, w0[d], dacc[d]);
+            }
+        }
+        // bytes of a dword are columns (c, c + 2, c + 1, c + 3): accumulators 0, 2 -> word (c, c + 1); 1, 3 -> (c + 2, c + 3)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            acc[2 * d] = pkAdd16(acc[2 * d], __builtin_amdgcn_perm(uint32_t(dacc[d][2]), uint32_t(dacc[d][0]), 0x05040100u));
+            acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], __builtin_amdgcn_perm(uint32_t(dacc[d][3]), uint32_t(dacc[d][1]), 0x05040100u));
+        }
+    }
+    return;
+#endif
     // u8 rows (threat, pawn-pair and compact piece-square rows, stored +128) go to their own accumulator: <= 256 rows
     // x 255 never overflows a 16-bit field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry
     // crosses fields. Folded into acc (mod 2^16) per segment of 256 rows; a second segment exists only when compact
@@ -395,7 +466,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             u32x4 w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                w[u] = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i + u])));
+                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
             }
 #pragma unroll
             for (int u = 0; u < 8; u += 2) {
@@ -407,8 +478,8 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         for (; i + 2 <= segEnd; i += 2) {
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i])));
-            const u32x4 w1 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i + 1])));
+            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
+            const u32x4 w1 = loadGatherRow(t.thrW, thrBase, thrList[i + 1], laneOff);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
@@ -416,7 +487,7 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
         if (i < segEnd) {
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(thrBase + uint32_t(__builtin_amdgcn_readfirstlane(thrList[i])));
+            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 tacc[2 * d] += unpackLo(w0[d]);

@@ -78,6 +78,43 @@ KERNEL(k_max, I_MAX)
 KERNEL(k_med3, I_MED3)
 KERNEL(k_dot4, I_DOT4)
 
+// 64-bit forms (register pairs): the 64-bit multiply-add the u8 gather accumulates whole dwords with, the 64-bit pointer
+// add of a per-lane global address, and v_readfirstlane (VALU slot, scalar destination)
+#define KERNEL64(NAME, ASM)                                                            \
+    __global__ __launch_bounds__(64) void NAME(uint32_t* out, uint32_t k) {             \
+        uint64_t r[8];                                                                  \
+        for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 2654435761u + i;               \
+        for (int it = 0; it < kIters; ++it) {                                           \
+            _Pragma("unroll") for (int rep = 0; rep < 8; ++rep) {                       \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) {                         \
+                    asm volatile(ASM : "+v"(r[i]) : "v"(k) : "vcc");                    \
+                }                                                                       \
+            }                                                                           \
+        }                                                                               \
+        uint64_t s = 0;                                                                 \
+        for (int i = 0; i < 8; ++i) s ^= r[i];                                          \
+        if (s == 0x12345678u) out[threadIdx.x] = uint32_t(s);                           \
+    }
+KERNEL64(k_mad64, "v_mad_u64_u32 %0, vcc, %1, 1, %0")
+KERNEL64(k_lshladd64, "v_lshl_add_u64 %0, %0, 0, s[2:3]")
+__global__ __launch_bounds__(64) void k_rfl(uint32_t* out, uint32_t k) {
+    uint32_t r[8];
+    for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 2654435761u + i;
+    uint32_t acc = 0;
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) {
+            asm volatile("v_readfirstlane_b32 s20, %0\nv_readfirstlane_b32 s21, %1\nv_readfirstlane_b32 s22, %2\n"
+                         "v_readfirstlane_b32 s23, %3\nv_readfirstlane_b32 s24, %4\nv_readfirstlane_b32 s25, %5\n"
+                         "v_readfirstlane_b32 s26, %6\nv_readfirstlane_b32 s27, %7\n"
+                         :
+                         : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7])
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        }
+    }
+    if (acc == 0x12345678u + k) out[threadIdx.x] = acc;
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 
 int main() {
@@ -99,7 +136,8 @@ int main() {
                    {"v_bfrev_b32", k_bfrev},   {"v_mul_lo_u32", k_mullo},    {"v_mad_i32_i24", k_mad24},
                    {"v_fma_f32", k_fma},       {"v_bcnt_u32_b32", k_bcnt},   {"v_cndmask_b32", k_cndmask},
                    {"v_mbcnt_lo", k_mbcnt},    {"v_cmp_lt_u32", k_cmp},      {"v_max_i32", k_max},
-                   {"v_med3_i32", k_med3},     {"v_dot4_i32_i8", k_dot4}};
+                   {"v_med3_i32", k_med3},     {"v_dot4_i32_i8", k_dot4},
+                   {"v_mad_u64_u32", k_mad64}, {"v_lshl_add_u64", k_lshladd64}, {"v_readfirstlane", k_rfl}};
     printf("%-16s", "instruction");
     const int wavesList[] = {1, 2, 4, 8};
     for (int w : wavesList) printf("  W=%d cyc/instr/SIMD", w);
