@@ -96,6 +96,25 @@ size_t spx_ctx_scratch_batch(const spx_ctx* ctx);
 void spx_ctx_destroy(spx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Multi-device group: one context per GPU inside ONE process, for a native host that embeds the library (the
+ * reference builds one NnueState per search thread, src/search.cpp:206,381 - here one context per device). The weights
+ * are uploaded once per member; batches are cut into contiguous shards (sizes differ by at most one, spx_group_shard) and
+ * every member evaluates its shard on its own host thread - no collective on the data path, results identical to one
+ * context evaluating the whole batch. `devices` = HIP device ordinals (NULL / 0 = every visible device; an ordinal may
+ * repeat: two members on one GPU). spx_group_member exposes a member for every per-context entry point above / below.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct spx_group spx_group;
+int spx_device_count(int* count); /* visible HIP devices; SPX_ERR_NO_DEVICE (and *count = 0) when there is none */
+int spx_group_create(const spx_net* net, const int* devices, size_t n_devices, size_t max_batch_per_device,
+                     uint32_t flags, spx_group** out);
+void spx_group_destroy(spx_group* group);
+size_t spx_group_size(const spx_group* group);
+spx_ctx* spx_group_member(spx_group* group, size_t index);
+int spx_group_shard(const spx_group* group, size_t n, size_t index, size_t* lo, size_t* hi);
+/* == spx_eval_full / spx_adjust over the whole group; n may be up to spx_group_size x max_batch_per_device */
+int spx_group_eval_full(spx_group* group, const spx_packed_pos* positions, size_t n, int32_t* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Full-refresh evaluation == n x NnueState::evaluateOnce(pos, pos.stm()) (src/eval/nnue_state.cpp:612-634): raw
  * network output in centipawn-like units from the side to move's point of view, BEFORE eval::adjustStatic's
  * contempt/clamp (src/eval/eval.cpp:25-28).
@@ -207,6 +226,8 @@ int spx_adjust(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, const sp
                const int32_t* corrections, int32_t* evals);
 int spx_adjust_device(spx_ctx* ctx, const void* d_positions, size_t n, const spx_adjust_params* params,
                       const void* d_corrections, void* d_evals, void* stream);
+int spx_group_adjust(spx_group* group, const spx_packed_pos* positions, size_t n, const spx_adjust_params* params,
+                     const int32_t* corrections, int32_t* evals);
 
 /* As spx_acc_update_eval_device, but the number of records is read on the DEVICE from *d_count (u32, at most `capacity`;
  * `capacity` sizes the launches and must fit the context): a producer kernel - spx_movegen_device's d_total - feeds the

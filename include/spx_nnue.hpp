@@ -175,6 +175,36 @@ private:
     uint32_t clean_ = 0;                 // deepest stack entry whose slot holds up-to-date accumulators
 };
 
+// One context per GPU inside this process (spx_group): evaluateBatch cuts a batch into contiguous shards, one
+// per device, each evaluated on its own host thread - same results as one NnueState evaluating the whole batch.
+class DeviceGroup {
+public:
+    // devices: HIP ordinals; empty = every visible device
+    DeviceGroup(const Network& net, const std::vector<int>& devices, size_t maxBatchPerDevice) {
+        check(spx_group_create(net.handle(), devices.empty() ? nullptr : devices.data(), devices.size(), maxBatchPerDevice, 0,
+                               &group_));
+    }
+    DeviceGroup(const DeviceGroup&) = delete;
+    DeviceGroup& operator=(const DeviceGroup&) = delete;
+    ~DeviceGroup() {
+        spx_group_destroy(group_);
+    }
+    size_t size() const {
+        return spx_group_size(group_);
+    }
+    std::vector<int32_t> evaluateBatch(const spx_packed_pos* positions, size_t n) {
+        std::vector<int32_t> out(n);
+        check(spx_group_eval_full(group_, positions, n, out.data()));
+        return out;
+    }
+    spx_group* handle() {
+        return group_;
+    }
+
+private:
+    spx_group* group_ = nullptr;
+};
+
 }  // namespace spx_nnue
 
 #endif  // SPX_NNUE_HPP

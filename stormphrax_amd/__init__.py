@@ -9,6 +9,7 @@ from .nnue import (  # noqa: F401
     ADJUST_WDL,
     ADJUST_WHITE_POV,
     PACKED_DTYPE,
+    DeviceGroup,
     Network,
     NnueState,
     adjust_params,
@@ -16,6 +17,7 @@ from .nnue import (  # noqa: F401
     count_rows,
     debug_delta,
     debug_features,
+    device_count,
     legal_moves,
     perft,
     position_to_fen,

@@ -85,6 +85,14 @@ SYMBOLS = {
     "spx_ctx_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_P)]),
     "spx_ctx_create_ex": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
     "spx_ctx_scratch_batch": (ctypes.c_size_t, [_P]),
+    "spx_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "spx_group_create": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    "spx_group_destroy": (None, [_P]),
+    "spx_group_size": (ctypes.c_size_t, [_P]),
+    "spx_group_member": (_P, [_P, ctypes.c_size_t]),
+    "spx_group_shard": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_group_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
+    "spx_group_adjust": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, _P]),
     "spx_ctx_destroy": (None, [_P]),
     "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),

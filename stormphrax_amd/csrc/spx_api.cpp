@@ -118,6 +118,7 @@ struct spx_ctx {
                                    // perspectives, positions sorted by the pair of king buckets)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
+    uint32_t sortPhaseKeys = 1;    // SPX_SORT_PHASE=1: perspectives ordered by (king bucket, output bucket), 128 keys
     uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
     std::vector<hipEvent_t> profEvents;  // kProfEventsPerCall per recorded call: [0] start, [1] after the sorts, [4] before
@@ -373,6 +374,22 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes) {
 constexpr size_t kTinyIoRecords = 8192;
 constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
 
+int spx_device_count(int* count) {
+    if (!count) {
+        setError("spx_device_count: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        *count = 0;
+        setError("no HIP device visible (libspx_nnue has no CPU fallback)");
+        return SPX_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return SPX_OK;
+}
+
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
     return spx_ctx_create_ex(net, device, max_batch, 0u, out);
 }
@@ -472,6 +489,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
     if (const char* env = std::getenv("SPX_FT_POS_MAJOR")) ctx->ftPosMajor = env[0] == '1';
+    if (const char* env = std::getenv("SPX_SORT_PHASE")) ctx->sortPhaseKeys = env[0] == '1' ? 8u : 1u;
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
@@ -557,6 +575,7 @@ static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_
         sp.nPositionsPtr = d_count;
         sp.outOnly = outOnly;
         sp.pairMode = pairMode;
+        sp.phaseKeys = ctx->sortPhaseKeys;
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
         if (n <= 1024 && !d_count) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing

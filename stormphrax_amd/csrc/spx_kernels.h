@@ -140,6 +140,7 @@ struct SortParams {
     bool outOnly;               // large sorts: only the output-bucket order (arena paths: nobody reads the king-bucket order)
     bool pairMode;              // large sorts: perspOrder receives POSITION ids grouped by the pair of king buckets
                                 // (256 keys) instead of perspective ids grouped by king bucket - the position-major FT kernel
+    uint32_t phaseKeys;         // perspective-major large sorts: sub-keys per king bucket (1 = king bucket alone; 8 = x output bucket)
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
     uint32_t* hist;             // [kHistWords] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)

@@ -36,6 +36,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_OPT_PSEUDOTAB
 #define SPX_OPT_PSEUDOTAB 1
 #endif
+#ifndef SPX_OPT_RAYTAB
+#define SPX_OPT_RAYTAB 0  // threat targets from LDS ray tables (needs SPX_OPT_PSEUDOTAB): -80 VALU, -14 VGPRs, no gain (see laneTargetsFromTables)
+#endif
 #ifndef SPX_FT_CHUNK
 #define SPX_FT_CHUNK 128  // perspectives per round-robin chunk of the XCD traversal, a power of two (0 = one contiguous eighth per XCD)
 #endif
@@ -188,6 +191,7 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
 // Appends one threat row per set bit of this lane's `targets` (victims popped one per wave iteration):
 // attacker = this lane's `piece` on square `lane`, victim piece fetched from the lane that owns the target square.
 // Rows the reference excludes (threatFeatureIndex < 0) are dropped. Returns the new list length (capacity kThreatCap).
+template <bool kHaveTable = false>  // true: `pseudoTab` is staged for sure (a null test of an LDS address keeps both forms alive)
 __device__ __forceinline__ uint32_t emitThreatRows(uint32_t* list, uint32_t n, uint64_t targets, int piece,
                                                    uint32_t lane, int x, int flipColour, const uint32_t* lut,
                                                    const uint64_t* pseudoTab = nullptr) {
@@ -197,8 +201,11 @@ __device__ __forceinline__ uint32_t emitThreatRows(uint32_t* list, uint32_t n, u
     if (targets) {  // (only non-king pieces have targets)
         // pseudo-attack set of the attacker in the perspective's frame: one LDS read where the table is staged
         // (pseudo[k][sq], spx_device_math.h), else the per-lane arithmetic (~40 instructions for the union of piece types)
-        pseudoRel = pseudoTab ? pseudoTab[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel]
-                              : piecePseudoAttacks(pieceRel, sqRel);
+        if (kHaveTable || pseudoTab) {
+            pseudoRel = pseudoTab[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
+        } else {
+            pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
+        }
     }
     while (__ballot(targets != 0)) {
         const bool active = targets != 0;
@@ -279,10 +286,39 @@ __device__ __forceinline__ uint64_t laneTargets(const LaneBoard& b, uint32_t lan
     return targets;
 }
 
+// The same set from LDS tables, straight-line for every lane (SPX_OPT_RAYTAB). A slider's targets are exactly the NEAREST
+// occupied square on each of its rays: blockers = ray & occ, nearest = lowest set bit (b & -b) for the four rays that run
+// towards higher squares; the other four are stored bit-reversed (`rays`, staged by the kernel) and met with the reversed
+// occupancy (one s_brev_b64 per board), so they isolate the lowest bit too and ONE 64-bit reversal brings all four back.
+// Pawns and knights read their pseudo-attack set. ~80 VALU instead of ~165 (four hyperbola-quintessence lines, three bit
+// reversals each, plus shifted leaper masks) - and none of the per-lane line masks the arithmetic form keeps hoisted in
+// ~16 VGPRs for the whole kernel (96 -> 82). Bit-exact, and measured: FT kernel 0.4253 ms vs 0.4224 with the arithmetic
+// form in the same run, 0.434 at the 6 waves/SIMD the freed registers allow (profiles/r02_ab_variants.txt) - the kernel is
+// bound by the vector-memory return path, extraction instructions overlap with it for free. Opt-in, off by default.
+__device__ __forceinline__ uint64_t laneTargetsFromTables(const LaneBoard& b, uint32_t lane, const uint64_t* rays,
+                                                          const uint64_t* pseudoTab) {
+    const uint32_t type = uint32_t(b.piece) >> 1;  // 6 = empty
+    const bool diag = type == 2 || type == 4, orth = type == 3 || type == 4;
+    const uint64_t occRev = __builtin_bitreverse64(b.occ);
+    const uint64_t occD = diag ? b.occ : 0, occO = orth ? b.occ : 0;
+    const uint64_t occDr = diag ? occRev : 0, occOr = orth ? occRev : 0;
+    uint64_t up = 0, down = 0;
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) {  // N, NE, E, NW | S, SW, W, SE: odd = diagonal
+        const uint64_t bu = rays[dir * 64 + lane] & ((dir & 1) ? occD : occO);
+        up |= bu & (0 - bu);
+        const uint64_t bd = rays[(4 + dir) * 64 + lane] & ((dir & 1) ? occDr : occOr);
+        down |= bd & (0 - bd);
+    }
+    const uint64_t leaper = type <= 1 ? pseudoTab[(type ? 2 : b.piece) * 64 + lane] & b.occ : 0;  // pawns by colour, knight
+    return (up | __builtin_bitreverse64(down) | leaper) & ~b.kingsBb;
+}
+
+template <bool kRayTab = false>
 __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
                                                uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
                                                const uint64_t* pseudoTab = nullptr, bool haveTargets = false,
-                                               uint64_t sharedTargets = 0) {
+                                               uint64_t sharedTargets = 0, const uint64_t* rayTab = nullptr) {
     const int piece = b.piece;
     const bool occupied = piece != kNoPiece;
     const int type = piece >> 1;
@@ -318,8 +354,15 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     uint32_t* threatList = thrList + nCompact;  // the reference's <= 256-entry threat list proper
 
     // threat rows (addThreatFeatures, nnue_state.cpp:309-328); the position-major kernel computes the targets once
-    const uint64_t targets = haveTargets ? sharedTargets : laneTargets(b, lane);
-    nThr = emitThreatRows(threatList, 0, targets, piece, lane, x, flipColour, lut, pseudoTab);
+    uint64_t targets = sharedTargets;
+    if (!haveTargets) {
+        if constexpr (kRayTab) {
+            targets = laneTargetsFromTables(b, lane, rayTab, pseudoTab);
+        } else {
+            targets = laneTargets(b, lane);
+        }
+    }
+    nThr = emitThreatRows<kRayTab>(threatList, 0, targets, piece, lane, x, flipColour, lut, pseudoTab);
 
     // pawn-pair rows (nnue_state.cpp:330-351)
     const bool isPawn = type == 0;
@@ -346,26 +389,63 @@ __device__ __forceinline__ u32x4 loadGatherRow(const uint8_t* table, const uint8
 #endif
 }
 
-#ifndef SPX_OPT_MFMAW
-#define SPX_OPT_MFMAW 0
-#endif
-#ifndef SPX_MFMAW_SWAP
-#define SPX_MFMAW_SWAP 0
-#endif
-__device__ __forceinline__ i32x4 widenAdd(int ident, uint32_t biased, i32x4 sum) {
-    const int x = int(biased ^ 0x80808080u);
-#if SPX_MFMAW_SWAP
-    return __builtin_amdgcn_mfma_i32_4x4x4i8(x, ident, sum, 0, 0, 0);
-#else
-    return __builtin_amdgcn_mfma_i32_4x4x4i8(ident, x, sum, 0, 0, 0);
-#endif
-}
-
 // acc = ftBias + sum(piece-square rows) + sum(threat rows), all mod 2^16 per column.
 // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
 __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
                                            const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8],
                                            bool withBias = true) {
+    // Full-refresh rows come in through plain global loads (loadGatherRow). The buffer-load form the update kernel uses
+    // (RowTable: SGPR row offset, no address arithmetic at all) was A/B-measured here too and LOSES 10 % (FT kernel 0.469
+    // -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is bound by the
+    // vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
+    // latency-bound) they win 5 %.
+    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
+    const uint8_t* thrBase = t.thrW + 16 * lane;
+    const uint8_t* psqTable = reinterpret_cast<const uint8_t*>(t.psqW);
+    const uint32_t laneOff = 16 * lane;
+
+    // (1) u8 rows (threat, pawn-pair and compact piece-square rows, stored +128) FIRST, into their own accumulator while
+    // the packed-i16 one is not live yet (8 VGPRs less in the hot loop): <= 256 rows x 255 never overflow a 16-bit
+    // field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry crosses fields.
+    const uint32_t nFirst = min(nThr, uint32_t(kThreatCap));
+    uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        uint32_t i = 0;
+        for (; i + 8 <= nFirst; i += 8) {  // 8 x 1 KiB wave loads in flight
+            u32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
+                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
+                }
+            }
+        }
+        for (; i + 2 <= nFirst; i += 2) {
+            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
+            const u32x4 w1 = loadGatherRow(t.thrW, thrBase, thrList[i + 1], laneOff);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
+                tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
+            }
+        }
+        if (i < nFirst) {
+            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                tacc[2 * d] += unpackLo(w0[d]);
+                tacc[2 * d + 1] += unpackHi(w0[d]);
+            }
+        }
+    }
+
+    // (2) bias + wide (i16) piece-square rows
     {   // (withBias = false: a partial sum over a slice of the lists - the cooperative rebuild pass adds the slices up)
         u32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
         if (withBias) {
@@ -378,15 +458,6 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             acc[4 + r] = b1[r];
         }
     }
-    // Full-refresh rows come in through plain global loads (loadGatherRow). The buffer-load form the update kernel uses
-    // (RowTable: SGPR row offset, no address arithmetic at all) was A/B-measured here too and LOSES 10 % (FT kernel 0.469
-    // -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is bound by the
-    // vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
-    // latency-bound) they win 5 %.
-    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
-    const uint8_t* thrBase = t.thrW + 16 * lane;
-    const uint8_t* psqTable = reinterpret_cast<const uint8_t*>(t.psqW);
-    const uint32_t laneOff = 16 * lane;
     {
         uint32_t i = 0;
         for (; i + 4 <= nPsq; i += 4) {  // 8 x 1 KiB wave loads in flight
@@ -415,91 +486,24 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
             }
         }
     }
-#if SPX_OPT_MFMAW
-    // u8 rows widened and summed on the matrix pipe: v_mfma_i32_4x4x4_16B_i8 with a per-block identity A turns a lane's
-    // dword of four i8 into its four i32 accumulators (D[i][j] = sum_k A[i][k] B[k][j] = byte i of lane j's dword) - ONE
-    // instruction per dword and row where the VALU form pays and + perm + add; the stored bytes are +128-biased u8, one
-    // v_xor_b32 makes them two's complement.
+
+    // (3) fold the u8 sums in (mod 2^16), removing the +128 storage bias: every u8 row contributed 128 to every column
     {
-        i32x4 dacc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        const int ident = 1 << (8 * (lane & 3));
-        uint32_t i = 0;
-        for (; i + 8 <= nThr; i += 8) {  // 8 x 1 KiB wave loads in flight
-            u32x4 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    dacc[d] = widenAdd(ident, w[u][d], dacc[d]);
-                }
-            }
-        }
-        for (; i < nThr; ++i) {
-            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                dacc[d] = widenAdd(ident, w0[d], dacc[d]);
-            }
-        }
-        // bytes of a dword are columns (c, c + 2, c + 1, c + 3): accumulators 0, 2 -> word (c, c + 1); 1, 3 -> (c + 2, c + 3)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            acc[2 * d] = pkAdd16(acc[2 * d], __builtin_amdgcn_perm(uint32_t(dacc[d][2]), uint32_t(dacc[d][0]), 0x05040100u));
-            acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], __builtin_amdgcn_perm(uint32_t(dacc[d][3]), uint32_t(dacc[d][1]), 0x05040100u));
-        }
-    }
-    return;
-#endif
-    // u8 rows (threat, pawn-pair and compact piece-square rows, stored +128) go to their own accumulator: <= 256 rows
-    // x 255 never overflows a 16-bit field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry
-    // crosses fields. Folded into acc (mod 2^16) per segment of 256 rows; a second segment exists only when compact
-    // piece-square rows push the list beyond 256 entries.
-    for (uint32_t segBegin = 0; segBegin < nThr; segBegin += uint32_t(kThreatCap)) {
-        const uint32_t segEnd = min(nThr, segBegin + uint32_t(kThreatCap));
-        uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t i = segBegin;
-        for (; i + 8 <= segEnd; i += 8) {  // 8 x 1 KiB wave loads in flight
-            u32x4 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
-                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
-                }
-            }
-        }
-        for (; i + 2 <= segEnd; i += 2) {
-            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-            const u32x4 w1 = loadGatherRow(t.thrW, thrBase, thrList[i + 1], laneOff);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
-                tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
-            }
-        }
-        if (i < segEnd) {
-            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                tacc[2 * d] += unpackLo(w0[d]);
-                tacc[2 * d + 1] += unpackHi(w0[d]);
-            }
-        }
-        // fold in, removing the +128 storage bias: every u8 row contributed 128 to every column
-        const uint32_t corr = ((segEnd - segBegin) * 128u) & 0xFFFFu;
+        const uint32_t corr = (nThr * 128u) & 0xFFFFu;
         const uint32_t corr2 = corr | (corr << 16);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
+        }
+    }
+    // (4) rows beyond 256 exist only when compact piece-square rows sit in front of a near-full threat list: one at a
+    // time, straight into the wrapping accumulator
+    for (uint32_t i = nFirst; i < nThr; ++i) {
+        const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            acc[2 * d] = pkAdd16(acc[2 * d], unpackLo(w0[d]));
+            acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], unpackHi(w0[d]));
         }
     }
 }
@@ -670,6 +674,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
 #if SPX_OPT_PSEUDOTAB
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];        // pseudo-attack sets per (piece kind, square), 3 KiB
 #endif
+#if SPX_OPT_RAYTAB
+    __shared__ uint64_t sRays[8 * 64];                     // ray masks per (direction, square), 4 KiB; S, SW, W, SE reversed
+#endif
     __shared__ uint32_t sPart[kCoop ? kWavesPerBlock : 1][8][64];  // kCoop: the waves' partial accumulators
 
     if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
@@ -684,6 +691,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
     const uint64_t* pseudoTab = sPseudo;
 #else
     const uint64_t* pseudoTab = nullptr;
+#endif
+#if SPX_OPT_RAYTAB
+    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) {
+        const uint64_t ray = p.t.deltaTab[i];
+        sRays[i] = i >= 4 * 64 ? __builtin_bitreverse64(ray) : ray;
+    }
+    const uint64_t* rayTab = sRays;
+#else
+    const uint64_t* rayTab = nullptr;
 #endif
     __syncthreads();
 
@@ -720,7 +736,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, pseudoTab);
+        buildFullLists<SPX_OPT_RAYTAB != 0>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, pseudoTab, false, 0, rayTab);
         uint32_t acc[8];
         if constexpr (kCoop) {
             // this wave's quarter of both lists (every wave built the same lists)
@@ -1410,10 +1426,11 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
             p.kingKeys[pos] = uint8_t(keyW * 16 + keyB);
             atomicAdd(&sHist[keyW * 16 + keyB], 1u);
         } else {
-            p.kingKeys[2 * pos] = uint8_t(keyB);
-            p.kingKeys[2 * pos + 1] = uint8_t(keyW);
-            atomicAdd(&sHist[keyB], 1u);
-            atomicAdd(&sHist[keyW], 1u);
+            const uint32_t sub = p.phaseKeys > 1 ? outKey : 0u, kB = keyB * p.phaseKeys + sub, kW = keyW * p.phaseKeys + sub;
+            p.kingKeys[2 * pos] = uint8_t(kB);
+            p.kingKeys[2 * pos + 1] = uint8_t(kW);
+            atomicAdd(&sHist[kB], 1u);
+            atomicAdd(&sHist[kW], 1u);
         }
         p.outKeys[pos] = uint8_t(outKey);
         atomicAdd(&sHist[kPairKeys + outKey], 1u);
@@ -1434,7 +1451,7 @@ __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uin
     const uint32_t id = (first ? blockIdx.x : blockIdx.x - firstBlocks) * blockDim.x + threadIdx.x;
     const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
     const uint32_t count = (first && !p.pairMode) ? nPositions * 2 : nPositions;
-    const uint32_t nKeys = first ? (p.pairMode ? kPairKeys : kKingKeys) : kOutKeys;
+    const uint32_t nKeys = first ? (p.pairMode ? kPairKeys : kKingKeys * p.phaseKeys) : kOutKeys;
     const uint32_t histOff = first ? 0 : kHistOut, cursorOff = first ? kCursorKing : kCursorOut;
     sBase[threadIdx.x] = threadIdx.x < nKeys ? p.hist[histOff + threadIdx.x] : 0u;  // counts, turned into bases below
     __syncthreads();

@@ -293,6 +293,71 @@ class NnueState:
         self.close()
 
 
+class DeviceGroup:
+    """spx_group: one context per GPU inside this process; a batch is cut into contiguous shards, one per member, each
+    evaluated on its own host thread (SURVEY 8e for a native host; the harnesses' multi-GPU runs use one process per GPU,
+    stormphrax_amd/distributed.py). `devices` = HIP ordinals, None = every visible device; an ordinal may repeat."""
+
+    def __init__(self, network, devices=None, max_batch_per_device=65536, wide_psq_rows=False):
+        lib = _lib.load()
+        handle = ctypes.c_void_p()
+        ids = [] if devices is None else [int(d) for d in devices]
+        arr = (ctypes.c_int * len(ids))(*ids) if ids else None
+        flags = CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0
+        check(lib.spx_group_create(network._h, arr, len(ids), max_batch_per_device, flags, ctypes.byref(handle)))
+        self._h = handle
+        self._net = network
+
+    def __len__(self):
+        return int(_lib.load().spx_group_size(self._h))
+
+    def shard(self, n, index):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        check(_lib.load().spx_group_shard(self._h, n, index, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def evaluate_once(self, positions):
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        out = np.empty(pos.shape[0], dtype=np.int32)
+        check(_lib.load().spx_group_eval_full(self._h, pos.ctypes.data, pos.shape[0], out.ctypes.data))
+        return out
+
+    def adjust(self, positions, evals, contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL,
+               corrections=None):
+        pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)
+        out = np.array(evals, dtype=np.int32, copy=True)
+        assert pos.shape[0] == out.shape[0]
+        params = adjust_params(contempt, optimism, stages)
+        corr = None if corrections is None else np.ascontiguousarray(corrections, dtype=np.int32)
+        check(_lib.load().spx_group_adjust(self._h, pos.ctypes.data, pos.shape[0], ctypes.byref(params),
+                                           None if corr is None else corr.ctypes.data, out.ctypes.data))
+        return out
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.load().spx_group_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def device_count():
+    """Visible HIP devices (0 when there is none - every evaluation entry point then fails with SPX_ERR_NO_DEVICE)."""
+    n = ctypes.c_int(0)
+    _lib.load().spx_device_count(ctypes.byref(n))
+    return n.value
+
+
 # ---- position plumbing ----
 def positions_from_fens(fens):
     lib = _lib.load()

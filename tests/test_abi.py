@@ -38,6 +38,12 @@ def test_no_cpu_fallback_without_device(sp, net_blob):
     with pytest.raises(_lib.SpxError) as err:
         sp.NnueState(net, device=0, max_batch=16)
     assert err.value.code == 4 and "no CPU fallback" in str(err.value)
+    # the multi-device group refuses the same way, with every visible device (none) as well as a named one
+    assert sp.device_count() == 0
+    for devices in (None, [0], [0, 1]):
+        with pytest.raises(_lib.SpxError) as err:
+            sp.DeviceGroup(net, devices=devices, max_batch_per_device=16)
+        assert err.value.code == 4
 
 
 def test_product_never_references_the_oracle():

@@ -100,3 +100,30 @@ def test_two_rank_control_flow_on_one_gpu(script, tmp_path):
     else:
         assert line["games"] == 1400 and sum(line["outcomes_white_loss_draw_win"]) == 1400
         assert os.path.getsize(tmp_path / "sp.0.vf") > 0 and os.path.getsize(tmp_path / "sp.1.vf") > 0
+
+
+def test_device_group_shards_a_batch_over_its_members(sp, net_blob, oracle):
+    """spx_group (the C ABI's multi-device entry): two members on this box's one GPU evaluate contiguous shards on their own
+    host threads - scores identical to one context over the whole batch and to the CPU oracle, for ragged and tiny
+    batches; the default group has one member per visible device."""
+    net = sp.Network(net_blob("tame"))
+    pos = sp.random_positions(20001, seed=77)
+    with sp.NnueState(net, max_batch=32768) as st:
+        want = st.evaluate_once(pos)
+        want_adj = st.adjust(pos, want, contempt=(3, -5))
+    oracle.use(net_blob("tame"), "tame")
+    mail, stm = sp.positions_to_mailboxes(pos[:2000])
+    assert np.array_equal(want[:2000], oracle.eval_mailboxes(mail, stm))
+    with sp.DeviceGroup(net, devices=[0, 0], max_batch_per_device=16384) as grp:
+        assert len(grp) == 2 and grp.shard(20001, 0) == (0, 10001) and grp.shard(20001, 1) == (10001, 20001)
+        got = grp.evaluate_once(pos)
+        assert np.array_equal(got, want)
+        assert np.array_equal(grp.adjust(pos, got, contempt=(3, -5)), want_adj)
+        for n in (1, 2, 3, 4097):  # one member idle / odd splits
+            assert np.array_equal(grp.evaluate_once(pos[:n]), want[:n])
+        # more than both members hold at once in one call: each member walks its shard in chunks
+        big = np.concatenate([pos, pos])
+        assert np.array_equal(grp.evaluate_once(big), np.concatenate([want, want]))
+    with sp.DeviceGroup(net, max_batch_per_device=4096) as grp:
+        assert len(grp) == sp.device_count() >= 1
+        assert np.array_equal(grp.evaluate_once(pos[:5000]), want[:5000])

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02v; mkdir -p $O
+echo "== parity of the reordered gather (default build) and the rolling variant"; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_incremental.py -x -q -m gpu 2>&1 | tail -3 | tee $O/parity_default.txt
+SPX_LIB=$PWD/variants/libspx_rollc4.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3 | tee $O/parity_rollc4.txt
+echo "== full-refresh A/B"; timeout 1800 bash tools/gpu_ab.sh 3 2>&1 | grep -v amdgpu.ids | tee $O/ab_ft.txt
