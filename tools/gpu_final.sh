@@ -5,6 +5,17 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $REPO
+# counters FIRST: bench.py quotes the VALU / L2 counter blocks from profiles/<tag>_pmc_*.json, so the files of THIS build
+# are put in place (on the box) before the bench lines are taken
+bash tools/gpu_profile.sh $TAG > /dev/null 2>&1
+cp $REPO/gpurun_out/prof_$TAG/summary.txt $OUT/rocprofv3_summary_full_refresh.txt
+cp $REPO/gpurun_out/prof_$TAG/pmc.json $OUT/pmc_full_refresh.json
+bash tools/gpu_pmc_inc.sh $TAG > /dev/null 2>&1
+cp $REPO/gpurun_out/pmc_inc_$TAG/summary.txt $OUT/rocprofv3_summary_incremental.txt
+cp $REPO/gpurun_out/pmc_inc_$TAG/pmc.json $OUT/pmc_incremental.json
+rm -rf $REPO/gpurun_out/prof_$TAG $REPO/gpurun_out/pmc_inc_$TAG
+[ -s $OUT/pmc_full_refresh.json ] && cp $OUT/pmc_full_refresh.json $REPO/profiles/${TAG}_pmc_full_refresh.json
+[ -s $OUT/pmc_incremental.json ] && cp $OUT/pmc_incremental.json $REPO/profiles/${TAG}_pmc_incremental.json
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1_driver_args.json 2> $OUT/bench_driver.err
 python bench.py --no-pipeline --no-cpu-baseline > $OUT/bench_n1_strict_stream_order.json 2> $OUT/bench_strict.err
@@ -21,13 +32,6 @@ python tools/spx_selfplay.py --games 1024 --target 2048 > $OUT/selfplay_1024.jso
 python tools/gpu_movegen_rate.py > $OUT/movegen_rate.json 2>> $OUT/selfplay.err
 python tools/gpu_latency.py > $OUT/latency.txt 2>&1
 python tools/gpu_replay_rate.py > $OUT/config3_replay.json 2> $OUT/replay.err
-bash tools/gpu_profile.sh $TAG > /dev/null 2>&1
-cp $REPO/gpurun_out/prof_$TAG/summary.txt $OUT/rocprofv3_summary_full_refresh.txt
-cp $REPO/gpurun_out/prof_$TAG/pmc.json $OUT/pmc_full_refresh.json
-bash tools/gpu_pmc_inc.sh $TAG > /dev/null 2>&1
-cp $REPO/gpurun_out/pmc_inc_$TAG/summary.txt $OUT/rocprofv3_summary_incremental.txt
-cp $REPO/gpurun_out/pmc_inc_$TAG/pmc.json $OUT/pmc_incremental.json
-rm -rf $REPO/gpurun_out/prof_$TAG $REPO/gpurun_out/pmc_inc_$TAG
 # (the TA/TD/TCP counter groups are NOT collected here: on 2026-09-28 rocprofv3 aborted inside hipMemcpy with them and
 #  then hung in its signal handler until the timeout - every rocprofv3 call in tools/ runs under `timeout 300`)
 bash tools/gpu_stats.sh default_$TAG --no-wide > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
