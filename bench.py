@@ -37,6 +37,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks (before the HIP runtime starts)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
@@ -295,6 +296,10 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
         }
         if kp and "FETCH_SIZE" in kp["counters"] and "WRITE_SIZE" in kp["counters"]:
             roofline["traffic"] = (2 * kp["counters"]["FETCH_SIZE"] + kp["counters"]["WRITE_SIZE"]) * 1024
+            # what actually crosses the fabric (arena + the delta rows that miss the L2s; Infinity-Cache hits included, so an
+            # upper bound on HBM bytes) against the same HBM peak: the figure that says how close the kernel is to a memory roof
+            roofline["traffic_gbs"] = roofline["traffic"] / update_s / 1e9
+            roofline["traffic_over_hbm_peak"] = roofline["traffic_gbs"] / HBM_PEAK_GBS
         if pmc:
             roofline["valu"] = valu_block(kp, pmc.get("valu_cycles_per_wave_instr", 4))
         print(json.dumps({

@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 
+# The host driver of these boxes only supports dmabuf IPC: without this RCCL (and any sharing of device memory between the
+# ranks of one node) fails with "hipIpcGetMemHandle: invalid argument". It must be in the environment before the HIP runtime
+# starts, so the entry scripts import this module before torch.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))

@@ -15,6 +15,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks (before the HIP runtime starts)
 import stormphrax_amd as sp  # noqa: E402
 from stormphrax_amd.distributed import Group  # noqa: E402
 
