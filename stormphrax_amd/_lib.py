@@ -111,6 +111,7 @@ SYMBOLS = {
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_net_digest": (ctypes.c_uint64, [_P]),
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
+    "spx_ctx_near_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_eval_full_device_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_ctx_synchronize": (ctypes.c_int, [_P]),

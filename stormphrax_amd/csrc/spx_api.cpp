@@ -60,6 +60,9 @@ struct spx_ctx {
     int32_t *dL1B = nullptr, *dL2W = nullptr, *dL2B = nullptr, *dL3W = nullptr, *dL3B = nullptr;
     uint32_t* dLut = nullptr;
     uint64_t* dDeltaTab = nullptr;  // ray / knight masks + pseudo-attack sets of the threat-delta derivation
+    uint32_t* dOutlierTab = nullptr;  // remainders of the near-compact piece-square rows (nullptr: the net has none)
+    uint32_t nearPsqRows = 0;
+    uint32_t nearBits[kLutCompactWords] = {};  // host copy of the near-compact bitmap (spx_ctx_count_rows)
     // scratch
     void* dPositions = nullptr;  // staging for the host-buffer entry point
     int32_t* dOut = nullptr;
@@ -273,6 +276,7 @@ FtTables tablesOf(const spx_ctx* ctx) {
     t.ftBias = ctx->dFtBias;
     t.lut = ctx->dLut;
     t.deltaTab = ctx->dDeltaTab;
+    t.outlierTab = ctx->dOutlierTab;
     return t;
 }
 
@@ -426,7 +430,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
 
     int rc;
     const unsigned char* b = net->blob.data();
-    uint32_t compactBits[kLutCompactWords] = {};
+    uint32_t compactBits[kLutCompactWords] = {}, nearBits[kLutCompactWords] = {};
     if ((rc = uploadArray(ctx->dPsqW, b + kOffPsqW, kPsqWBytes, ctx->stream)) != SPX_OK) return rc;
     {
         // u8 row table: the threat rows, then one slot per piece-square row holding its i8 copy when every weight of
@@ -438,16 +442,38 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
         bool useCompact = !(flags & SPX_CTX_WIDE_PSQ_ROWS);
         if (const char* env = std::getenv("SPX_NO_COMPACT")) useCompact = useCompact && env[0] == '0';
         const int16_t* psq = reinterpret_cast<const int16_t*>(b + kOffPsqW);
+        // near-compact rows: all but <= kOutlierCap weights fit i8 -> the u8 copy holds them clamped, the remainders go to
+        // a side table the full-refresh kernel adds in (SPX_NO_NEAR=1: such rows stay wide)
+        bool useNear = useCompact;
+        if (const char* env = std::getenv("SPX_NO_NEAR")) useNear = useNear && env[0] == '0';
+        std::vector<uint32_t> outliers;
         for (uint32_t r = 0; r < kPsqRows && useCompact; ++r) {
             const int16_t* row = psq + size_t(r) * kL1;
-            bool fits = true;
-            for (uint32_t j = 0; j < kL1 && fits; ++j) fits = row[j] >= -128 && row[j] <= 127;
-            if (!fits) continue;
+            uint32_t wide = 0;
+            for (uint32_t j = 0; j < kL1; ++j) wide += row[j] < -128 || row[j] > 127;
+            if (wide > (useNear ? uint32_t(kOutlierCap) : 0u)) continue;
             int8_t narrow[kL1];
-            for (uint32_t j = 0; j < kL1; ++j) narrow[j] = int8_t(row[j]);
+            uint32_t k = 0;
+            for (uint32_t j = 0; j < kL1; ++j) {
+                const int clamped = std::max(-128, std::min(127, int(row[j])));
+                narrow[j] = int8_t(clamped);
+                if (clamped != row[j]) {
+                    if (outliers.empty()) outliers.assign(size_t(kPsqRows) * kOutlierCap, 0xFFFFFFFFu);
+                    outliers[size_t(r) * kOutlierCap + k++] = j | (uint32_t(uint16_t(int(row[j]) - clamped)) << 16);
+                }
+            }
             relayoutThreatRow(narrow, thr.data() + (size_t(kThreatRows) + r) * kL1);
-            compactBits[r >> 5] |= 1u << (r & 31);
-            ++ctx->compactPsqRows;
+            if (wide) {
+                nearBits[r >> 5] |= 1u << (r & 31);
+                ++ctx->nearPsqRows;
+            } else {
+                compactBits[r >> 5] |= 1u << (r & 31);
+                ++ctx->compactPsqRows;
+            }
+        }
+        if (!outliers.empty() &&
+            (rc = uploadArray(ctx->dOutlierTab, outliers.data(), outliers.size() * sizeof(uint32_t), ctx->stream)) != SPX_OK) {
+            return rc;
         }
         if ((rc = uploadArray(ctx->dThrW, thr.data(), thr.size(), ctx->stream)) != SPX_OK) return rc;
     }
@@ -469,7 +495,9 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
             return SPX_ERR_BAD_NET;
         }
         std::memcpy(lut + kLutCompactBase, compactBits, sizeof(compactBits));
+        std::memcpy(lut + kLutNearBase, nearBits, sizeof(nearBits));
         std::memcpy(ctx->compactBits, compactBits, sizeof(compactBits));
+        std::memcpy(ctx->nearBits, nearBits, sizeof(nearBits));
         if ((rc = uploadArray(ctx->dLut, lut, sizeof(lut), ctx->stream)) != SPX_OK) return rc;
         std::vector<uint64_t> tab(kDeltaTabWords);
         buildDeltaTables(tab.data());
@@ -539,7 +567,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
-                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
+                    ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dOutlierTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
                     ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
@@ -1380,6 +1408,10 @@ uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx) {
     return ctx ? ctx->compactPsqRows : 0;
 }
 
+uint32_t spx_ctx_near_psq_rows(const spx_ctx* ctx) {
+    return ctx ? ctx->nearPsqRows : 0;
+}
+
 int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms, size_t* calls) {
     if (!ctx || !sort_ms || !ft_ms || !mlp_ms || !calls) {
         setError("spx_profile_end: null argument");
@@ -1437,7 +1469,7 @@ int spx_ctx_count_rows(const spx_ctx* ctx, const spx_packed_pos* positions, size
             const int rc = spx_debug_features(&positions[i], c, psq, &a, thr, &b);
             if (rc != SPX_OK) return rc;
             for (int k = 0; k < a; ++k) {
-                const bool compact = (ctx->compactBits[psq[k] >> 5] >> (psq[k] & 31)) & 1u;
+                const bool compact = ((ctx->compactBits[psq[k] >> 5] | ctx->nearBits[psq[k] >> 5]) >> (psq[k] & 31)) & 1u;
                 (compact ? nc : nw) += 1;
             }
             nt += uint64_t(b);

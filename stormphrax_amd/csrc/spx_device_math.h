@@ -186,7 +186,13 @@ constexpr int kLutOffsetsWords = 12 * 64;
 constexpr int kLutAttackWords = 12 * 12 * 2;
 constexpr int kLutCompactBase = kLutOffsetsWords + kLutAttackWords;
 constexpr int kLutCompactWords = int(kPsqRows) / 32;
-constexpr int kLutWords = kLutCompactBase + kLutCompactWords;
+// [kLutNearBase, +kLutCompactWords): bitmap of the NEAR-compact piece-square rows: all but at most kOutlierCap of the 1 024
+//                 weights fit i8. The u8 table holds the row with those weights clamped, FtTables::outlierTab the exact
+//                 remainders (column | (weight - clamped) << 16, unused entries 0xFFFFFFFF); only the full-refresh kernel
+//                 uses them (the update kernels see such a row as a wide row - the i16 table always holds every row)
+constexpr int kLutNearBase = kLutCompactBase + kLutCompactWords;
+constexpr int kLutWords = kLutNearBase + kLutCompactWords;
+constexpr int kOutlierCap = 16;
 
 // threats::threatFeatureIndex. pseudoRel = piecePseudoAttacks(attacker', asq') precomputed by the caller in the
 // transformed frame (it replaces the 48 KB kPieceIndices table: popcount of pseudo-attacked squares below vsq').

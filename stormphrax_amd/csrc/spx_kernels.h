@@ -25,6 +25,7 @@ struct FtTables {
     const int16_t* ftBias;   // [1024]
     const uint32_t* lut;     // kLutWords threat LUT
     const uint64_t* deltaTab;  // kDeltaTabWords ray / knight masks + pseudo-attack sets (threat-delta derivation)
+    const uint32_t* outlierTab;  // [kPsqRows][kOutlierCap] remainders of the near-compact rows, or nullptr (net has none)
 };
 
 struct FtParams {

@@ -314,11 +314,15 @@ __device__ __forceinline__ uint64_t laneTargetsFromTables(const LaneBoard& b, ui
     return (up | __builtin_bitreverse64(down) | leaper) & ~b.kingsBb;
 }
 
-template <bool kRayTab = false>
-__device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
+// kNear (full-refresh kernel of a net that has near-compact rows): such rows take the 1 KiB path too; the remainders of
+// their <= kOutlierCap wide weights (FtTables::outlierTab) are summed per column into `nearAcc` (this wave's 1 024 i32 in
+// LDS; lane = the row's square, one LDS atomic per remainder) and folded in after the gather. Returns whether any was.
+template <bool kRayTab = false, bool kNear = false>
+__device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
                                                uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
                                                const uint64_t* pseudoTab = nullptr, bool haveTargets = false,
-                                               uint64_t sharedTargets = 0, const uint64_t* rayTab = nullptr) {
+                                               uint64_t sharedTargets = 0, const uint64_t* rayTab = nullptr,
+                                               const uint32_t* outlierTab = nullptr, int32_t* nearAcc = nullptr) {
     const int piece = b.piece;
     const bool occupied = piece != kNoPiece;
     const int type = piece >> 1;
@@ -328,16 +332,42 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
     const int x = perspXor(c, kingSq);
     const int flipColour = (c == 0) ? 1 : 0;
+    bool hasNear = false;
 
     // piece-square rows: one per occupied square (resetPsqAccumulator, nnue_state.cpp:440-449). Rows whose weights all
     // fit i8 have a 1 KiB copy in the u8 table: those go to the head of the u8 list, the rest to the i16 list.
     uint32_t nCompact;
     {
         uint32_t row = 0;
-        bool compact = false;
+        bool compact = false, near = false;
         if (occupied) {
             row = psqRow(c, piece, int(lane), kingSq);
             compact = (lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u;
+            if constexpr (kNear) {
+                near = (lut[kLutNearBase + (row >> 5)] >> (row & 31)) & 1u;
+                compact = compact || near;
+            }
+        }
+        if constexpr (kNear) {
+            hasNear = __ballot(near) != 0;
+            if (hasNear) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // 1 024 sums back to zero: 4 x 16 bytes per lane
+                    *reinterpret_cast<u32x4*>(nearAcc + 256 * k + 4 * lane) = u32x4{0, 0, 0, 0};
+                }
+                __builtin_amdgcn_wave_barrier();
+                u32x4 e[kOutlierCap / 4];
+#pragma unroll
+                for (int k = 0; k < kOutlierCap / 4; ++k) {
+                    e[k] = near ? *reinterpret_cast<const u32x4*>(outlierTab + size_t(row) * kOutlierCap + 4 * k)
+                                : u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                }
+#pragma unroll
+                for (int k = 0; k < kOutlierCap; ++k) {
+                    const uint32_t entry = e[k / 4][k % 4];
+                    if (entry != 0xFFFFFFFFu) atomicAdd(nearAcc + (entry & 0xFFFFu), int32_t(int16_t(entry >> 16)));
+                }
+            }
         }
         const uint64_t compactMask = __ballot(occupied && compact), wideMask = b.occ & ~compactMask;
         const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
@@ -370,6 +400,7 @@ __device__ __forceinline__ void buildFullLists(const LaneBoard& b, int c, uint32
     nThr = nCompact + emitPawnPairRows(threatList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
                                        ppId(int(lane) ^ x, !own), ownPawns, x);
     __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
+    return hasNear;
 }
 
 // One lane's 16 bytes of a table row for the full-refresh gather. The row's byte offset stays in a VGPR (every lane reads
@@ -393,7 +424,7 @@ __device__ __forceinline__ u32x4 loadGatherRow(const uint8_t* table, const uint8
 // acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
 __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
                                            const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8],
-                                           bool withBias = true) {
+                                           bool withBias = true, const int32_t* nearAcc = nullptr) {
     // Full-refresh rows come in through plain global loads (loadGatherRow). The buffer-load form the update kernel uses
     // (RowTable: SGPR row offset, no address arithmetic at all) was A/B-measured here too and LOSES 10 % (FT kernel 0.469
     // -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is bound by the
@@ -494,6 +525,18 @@ __device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, con
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
+        }
+    }
+    // (3b) remainders of the near-compact rows' wide weights (buildFullLists<.., kNear>): this lane's 16 column sums, mod 2^16
+    if (nearAcc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(nearAcc + 512 * h + 8 * lane);
+            const i32x4 hi = *reinterpret_cast<const i32x4*>(nearAcc + 512 * h + 8 * lane + 4);
+            acc[4 * h + 0] = pkAdd16(acc[4 * h + 0], __builtin_amdgcn_perm(uint32_t(lo[1]), uint32_t(lo[0]), 0x05040100u));
+            acc[4 * h + 1] = pkAdd16(acc[4 * h + 1], __builtin_amdgcn_perm(uint32_t(lo[3]), uint32_t(lo[2]), 0x05040100u));
+            acc[4 * h + 2] = pkAdd16(acc[4 * h + 2], __builtin_amdgcn_perm(uint32_t(hi[1]), uint32_t(hi[0]), 0x05040100u));
+            acc[4 * h + 3] = pkAdd16(acc[4 * h + 3], __builtin_amdgcn_perm(uint32_t(hi[3]), uint32_t(hi[2]), 0x05040100u));
         }
     }
     // (4) rows beyond 256 exist only when compact piece-square rows sit in front of a near-full threat list: one at a
@@ -666,9 +709,14 @@ __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* are
 //                an otherwise idle chip, where the time is the latency of one cold 65-row gather (8 rows per round trip):
 //                all four waves build the lists, each gathers a quarter of them (2-3 round trips instead of 9) and
 //                wave 0 adds the four partial accumulators up through LDS.
-template <bool kCoop>
+// kNear: the net has near-compact piece-square rows (FtTables::outlierTab): they take the 1 KiB path, their wide weights'
+//        remainders are summed through 4 KiB of LDS per wave (buildFullLists). Nets without such rows run the kNear = false
+//        instantiation - the same code as before the feature existed.
+template <bool kCoop, bool kNear = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
+    static_assert(!(kCoop && kNear), "the cooperative rebuild pass treats near-compact rows as wide rows");
     __shared__ uint32_t sLut[kLutWords];
+    __shared__ __align__(16) int32_t sNear[kNear ? kWavesPerBlock : 1][kNear ? int(kL1) : 4];  // per-column remainder sums
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
 #if SPX_OPT_PSEUDOTAB
@@ -736,7 +784,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        buildFullLists<SPX_OPT_RAYTAB != 0>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, pseudoTab, false, 0, rayTab);
+        const bool hasNear = buildFullLists<SPX_OPT_RAYTAB != 0, kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr,
+                                                                        pseudoTab, false, 0, rayTab, p.t.outlierTab, sNear[kNear ? wave : 0]);
         uint32_t acc[8];
         if constexpr (kCoop) {
             // this wave's quarter of both lists (every wave built the same lists)
@@ -756,7 +805,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
             __syncthreads();  // the partials are consumed before the next item overwrites them
             if (wave != 0) continue;
         } else {
-            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, true, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
         }
 
         if (p.accOut) {
@@ -1815,9 +1864,13 @@ hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, 
     if (p.posMajor) {
         hipLaunchKernelGGL(spx_ft_pos_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     } else if (cooperative) {
-        hipLaunchKernelGGL(spx_ft_kernel<true>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+        FtParams q = p;
+        q.t.outlierTab = nullptr;  // (near-compact rows: wide rows for this variant)
+        hipLaunchKernelGGL((spx_ft_kernel<true, false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, q);
+    } else if (p.t.outlierTab) {
+        hipLaunchKernelGGL((spx_ft_kernel<false, true>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     } else {
-        hipLaunchKernelGGL(spx_ft_kernel<false>, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((spx_ft_kernel<false, false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     }
     return hipGetLastError();
 }

@@ -169,6 +169,11 @@ class NnueState:
         """Piece-square rows (of 11264) this context serves from their 1 KiB u8 copy (all weights fit i8)."""
         return int(_lib.load().spx_ctx_compact_psq_rows(self._h))
 
+    @property
+    def near_psq_rows(self):
+        """Piece-square rows with at most 16 weights outside i8: 1 KiB copy + exact remainders in the full-refresh kernel."""
+        return int(_lib.load().spx_ctx_near_psq_rows(self._h))
+
     def count_rows(self, positions):
         """(psq rows fetched wide (2 KiB), psq rows fetched compact (1 KiB), threat / pawn-pair rows (1 KiB)) a full
         refresh of the batch gathers through THIS context, both perspectives summed. Host-side count."""

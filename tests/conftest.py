@@ -117,11 +117,38 @@ def _mixed_rows_net(sp):
     return blob
 
 
+NEAR_ROW_KIND = np.arange(11264) % 4  # 0: compact, 1: 1-15 wide weights, 2: 17-40 (stays wide), 3: exactly 16
+
+
+def _near_rows_net(sp):
+    """The wild synthetic net with wide weights sprinkled into three quarters of the piece-square rows: 1-15 and exactly 16
+    per row (near-compact: 1 KiB copy + remainders in the full-refresh kernel) and 17-40 (wide rows). Values cover both
+    signs, the first values outside i8 and the i16 extremes; several land in the same 16-column lane group."""
+    blob = np.array(sp.synthetic_net_bytes("wild"), copy=True)
+    psq = blob[64 : 64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
+    rng = np.random.default_rng(16)
+    pool = np.array([128, -129, 255, -256, 1000, -1000, 3000, -3000, 32767, -32768, 200, -200], dtype=np.int16)
+    for r in range(11264):
+        kind = NEAR_ROW_KIND[r]
+        if kind == 0:
+            continue
+        n = int(rng.integers(1, 16)) if kind == 1 else (int(rng.integers(17, 41)) if kind == 2 else 16)
+        cols = rng.choice(1024, size=n, replace=False)
+        if n >= 4:  # neighbours: one lane owns several remainders, columns on both sides of 512
+            cols[:4] = [(cols[0] // 8) * 8 + k for k in (0, 1, 6, 7)] if cols[0] % 1024 < 1016 else cols[:4]
+            cols = np.unique(cols)
+            while cols.size < n:
+                cols = np.unique(np.append(cols, rng.integers(0, 1024)))
+        psq[r, cols] = rng.choice(pool, size=cols.size)
+    return blob
+
+
 @pytest.fixture(scope="session")
 def net_blob(sp):
     def get(preset):
         if preset not in _NETS:
-            _NETS[preset] = _mixed_rows_net(sp) if preset == "mixed" else sp.synthetic_net_bytes(preset)
+            _NETS[preset] = (_mixed_rows_net(sp) if preset == "mixed" else _near_rows_net(sp) if preset == "near"
+                             else sp.synthetic_net_bytes(preset))
         return _NETS[preset]
 
     return get

@@ -151,6 +151,37 @@ def test_mixed_compact_and_wide_piece_square_rows(sp, oracle, net_blob, states):
     assert np.array_equal(st.evaluate(np.arange(4096, dtype=np.uint32)), want)
 
 
+def test_near_compact_piece_square_rows(sp, oracle, net_blob, states):
+    """Rows with at most 16 weights outside i8 take the 1 KiB path of the full-refresh kernel too: the u8 copy holds those
+    weights clamped, the exact remainders are added from a side table (per-column sums through LDS). A net with 1-15, exactly
+    16 and 17-40 such weights per row (conftest._near_rows_net; values up to the i16 extremes, several in one lane's columns)
+    must equal the oracle bit for bit through the full refresh, the arena refresh and the incremental kernels (which read
+    such rows from the i16 table)."""
+    from conftest import NEAR_ROW_KIND
+
+    st = states("near")
+    assert st.compact_psq_rows == int((NEAR_ROW_KIND == 0).sum())
+    assert st.near_psq_rows == int(((NEAR_ROW_KIND == 1) | (NEAR_ROW_KIND == 3)).sum())
+    assert states("tame").near_psq_rows == 0
+    pos = sp.random_positions(8192, seed=78, min_ply=0, max_ply=160, dfrc_every=4)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    oracle.use(net_blob("near"), "near")
+    want = oracle.eval_mailboxes(mail, stm)
+    assert len(set(want.tolist())) > 2000
+    assert np.array_equal(st.evaluate_once(pos), want)
+    assert np.array_equal(st.evaluate_once(pos[:3]), want[:3])  # the tiny-batch route
+    st.reserve_slots(3 * 8192)
+    slots = np.arange(8192, dtype=np.uint32)
+    st.reset(pos, slots)
+    assert np.array_equal(st.evaluate(slots), want)
+    # one ply of incremental updates on top (rebuilds of king-bucket changes go through the same full-refresh kernel)
+    nxt, moved = sp.random_successors(pos, seed=5)
+    idx = np.nonzero(moved)[0]
+    got = st.update_evaluate(slots[idx], slots[idx] + 8192, nxt[idx])
+    m2, s2 = sp.positions_to_mailboxes(nxt[idx])
+    assert np.array_equal(got, oracle.eval_mailboxes(m2, s2))
+
+
 @pytest.mark.parametrize("preset", ["tame", "wild"])
 def test_adjust_on_device_matches_reference_and_oracle(sp, oracle, net_blob, states, preset):
     """spx_adjust (device post-processing, rows a18 / f-4): golden staticEvalOnce / adjustEval<false> values of the
