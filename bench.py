@@ -544,7 +544,7 @@ def main():
                 "net": (f"file {os.path.basename(args.net)} '{net.name}'" if args.net else
                         f"synthetic CBNF '{net.name}' (Stormphrax 8.0.2 shape: (704x16+64368)->1024)x2->(32x2->64->1)x8"),
                 "compact_psq_rows": f"{state.compact_psq_rows} of 11264 piece-square rows fit i8 and are served as 1 KiB copies"
-                                    + (f"; {state.near_psq_rows} more have <= 16 weights outside i8: 1 KiB copy + exact remainders"
+                                    + (f"; {state.near_psq_rows} more have <= 32 weights outside i8: 1 KiB copy + exact remainders"
                                        if state.near_psq_rows else ""),
                 "parallelism": f"positions sharded over {world} GPU(s), no collective on the data path; "
                                + ("steps issued through the pipelined spx_eval_full_device_async (two internal streams: "

@@ -256,7 +256,7 @@ int spx_ctx_count_rows(const spx_ctx* ctx, const spx_packed_pos* positions, size
  * full-refresh kernel fetches it instead of the 2 KiB i16 row (identical sums, fewer bytes). Net dependent; 0 when
  * the environment sets SPX_NO_COMPACT=1. Reported by bench.py next to the algorithmic byte count. */
 uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx);
-/* Number of NEAR-compact piece-square rows: all but at most 16 of the 1 024 weights fit i8. The full-refresh kernel fetches
+/* Number of NEAR-compact piece-square rows: all but at most 32 of the 1 024 weights fit i8. The full-refresh kernel fetches
  * their 1 KiB copy too (those weights clamped) and adds the exact remainders from a side table - identical sums again;
  * the incremental kernels read such a row from the i16 table. 0 with SPX_NO_COMPACT=1 or SPX_NO_NEAR=1. */
 uint32_t spx_ctx_near_psq_rows(const spx_ctx* ctx);

@@ -192,7 +192,7 @@ constexpr int kLutCompactWords = int(kPsqRows) / 32;
 //                 uses them (the update kernels see such a row as a wide row - the i16 table always holds every row)
 constexpr int kLutNearBase = kLutCompactBase + kLutCompactWords;
 constexpr int kLutWords = kLutNearBase + kLutCompactWords;
-constexpr int kOutlierCap = 16;
+constexpr int kOutlierCap = 32;
 
 // threats::threatFeatureIndex. pseudoRel = piecePseudoAttacks(attacker', asq') precomputed by the caller in the
 // transformed frame (it replaces the 48 KB kPieceIndices table: popcount of pseudo-attacked squares below vsq').

@@ -356,16 +356,17 @@ __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32
                     *reinterpret_cast<u32x4*>(nearAcc + 256 * k + 4 * lane) = u32x4{0, 0, 0, 0};
                 }
                 __builtin_amdgcn_wave_barrier();
-                u32x4 e[kOutlierCap / 4];
-#pragma unroll
+                // entries are packed from the front: four at a time, until no row of this board has any left (a net whose rows
+                // carry a few remainders each pays one 16-byte load per lane, not four)
+#pragma unroll 1
                 for (int k = 0; k < kOutlierCap / 4; ++k) {
-                    e[k] = near ? *reinterpret_cast<const u32x4*>(outlierTab + size_t(row) * kOutlierCap + 4 * k)
-                                : u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                }
+                    const u32x4 e = near ? *reinterpret_cast<const u32x4*>(outlierTab + size_t(row) * kOutlierCap + 4 * k)
+                                         : u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    if (!__ballot(e[0] != 0xFFFFFFFFu)) break;
 #pragma unroll
-                for (int k = 0; k < kOutlierCap; ++k) {
-                    const uint32_t entry = e[k / 4][k % 4];
-                    if (entry != 0xFFFFFFFFu) atomicAdd(nearAcc + (entry & 0xFFFFu), int32_t(int16_t(entry >> 16)));
+                    for (int j = 0; j < 4; ++j) {
+                        if (e[j] != 0xFFFFFFFFu) atomicAdd(nearAcc + (e[j] & 0xFFFFu), int32_t(int16_t(e[j] >> 16)));
+                    }
                 }
             }
         }

@@ -171,7 +171,7 @@ class NnueState:
 
     @property
     def near_psq_rows(self):
-        """Piece-square rows with at most 16 weights outside i8: 1 KiB copy + exact remainders in the full-refresh kernel."""
+        """Piece-square rows with at most 32 weights outside i8: 1 KiB copy + exact remainders in the full-refresh kernel."""
         return int(_lib.load().spx_ctx_near_psq_rows(self._h))
 
     def count_rows(self, positions):

@@ -117,12 +117,12 @@ def _mixed_rows_net(sp):
     return blob
 
 
-NEAR_ROW_KIND = np.arange(11264) % 4  # 0: compact, 1: 1-15 wide weights, 2: 17-40 (stays wide), 3: exactly 16
+NEAR_ROW_KIND = np.arange(11264) % 4  # 0: compact, 1: 1-31 wide weights, 2: 33-60 (stays wide), 3: exactly 32
 
 
 def _near_rows_net(sp):
-    """The wild synthetic net with wide weights sprinkled into three quarters of the piece-square rows: 1-15 and exactly 16
-    per row (near-compact: 1 KiB copy + remainders in the full-refresh kernel) and 17-40 (wide rows). Values cover both
+    """The wild synthetic net with wide weights sprinkled into three quarters of the piece-square rows: 1-31 and exactly 32
+    per row (near-compact: 1 KiB copy + remainders in the full-refresh kernel) and 33-60 (wide rows). Values cover both
     signs, the first values outside i8 and the i16 extremes; several land in the same 16-column lane group."""
     blob = np.array(sp.synthetic_net_bytes("wild"), copy=True)
     psq = blob[64 : 64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
@@ -132,7 +132,7 @@ def _near_rows_net(sp):
         kind = NEAR_ROW_KIND[r]
         if kind == 0:
             continue
-        n = int(rng.integers(1, 16)) if kind == 1 else (int(rng.integers(17, 41)) if kind == 2 else 16)
+        n = int(rng.integers(1, 32)) if kind == 1 else (int(rng.integers(33, 61)) if kind == 2 else 32)
         cols = rng.choice(1024, size=n, replace=False)
         if n >= 4:  # neighbours: one lane owns several remainders, columns on both sides of 512
             cols[:4] = [(cols[0] // 8) * 8 + k for k in (0, 1, 6, 7)] if cols[0] % 1024 < 1016 else cols[:4]

@@ -152,9 +152,9 @@ def test_mixed_compact_and_wide_piece_square_rows(sp, oracle, net_blob, states):
 
 
 def test_near_compact_piece_square_rows(sp, oracle, net_blob, states):
-    """Rows with at most 16 weights outside i8 take the 1 KiB path of the full-refresh kernel too: the u8 copy holds those
-    weights clamped, the exact remainders are added from a side table (per-column sums through LDS). A net with 1-15, exactly
-    16 and 17-40 such weights per row (conftest._near_rows_net; values up to the i16 extremes, several in one lane's columns)
+    """Rows with at most 32 weights outside i8 take the 1 KiB path of the full-refresh kernel too: the u8 copy holds those
+    weights clamped, the exact remainders are added from a side table (per-column sums through LDS). A net with 1-31, exactly
+    32 and 33-60 such weights per row (conftest._near_rows_net; values up to the i16 extremes, several in one lane's columns)
     must equal the oracle bit for bit through the full refresh, the arena refresh and the incremental kernels (which read
     such rows from the i16 table)."""
     from conftest import NEAR_ROW_KIND

@@ -57,7 +57,7 @@ def main():
     oracle.spxo_init.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     oracle.spxo_eval_mailboxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     mail, stm = sp.positions_to_mailboxes(pos[:2048])
-    for per_row in (2, 8, 16):
+    for per_row in (2, 8, 16, 32):
         blob = outlier_net(sp, per_row)
         os.environ.pop("SPX_NO_NEAR", None)
         near, s_near, c1, q1 = rate(sp, torch, blob, d_pos, n)
