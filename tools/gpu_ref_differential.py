@@ -111,8 +111,12 @@ def main():
     oracle.spxo_init.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     oracle.spxo_eval_mailboxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     report["port"] = {}
-    for preset in ("wild", "extreme"):
-        blob = sp.synthetic_net_bytes(preset)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest  # the nets with mixed / near-compact piece-square rows are built by the test fixtures
+
+    for preset in ("wild", "extreme", "mixed", "near"):
+        blob = (conftest._mixed_rows_net(sp) if preset == "mixed" else conftest._near_rows_net(sp) if preset == "near"
+                else sp.synthetic_net_bytes(preset))
         assert oracle.spxo_init(blob.ctypes.data, blob.size) == 0
         pos = sp.random_positions(args.port_positions, seed=4242, min_ply=0, max_ply=200, dfrc_every=3)
         mail, stm = sp.positions_to_mailboxes(pos)
