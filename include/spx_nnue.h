@@ -69,6 +69,10 @@ void spx_net_free(spx_net* net);
 const char* spx_net_name(const spx_net* net); /* eval::defaultNetworkName, nnue.h:44 */
 /* FNV-1a 64 of the logical (uncompressed) payload: the same for a net loaded from its plain and from its zstd image */
 uint64_t spx_net_digest(const spx_net* net);
+/* How a context will serve this net's 11 264 piece-square rows (host-side, no device needed): rows whose 1 024 weights all fit
+ * i8 (1 KiB copies), rows with at most 32 weights outside i8 (1 KiB copy + exact remainders in the full-refresh kernel) and
+ * the rest (2 KiB i16 rows). See spx_ctx_compact_psq_rows / spx_ctx_near_psq_rows for what a given context actually did. */
+int spx_net_psq_row_classes(const spx_net* net, uint32_t* fit_i8, uint32_t* near_compact, uint32_t* wide);
 
 /* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
  * 2 extreme (i16 accumulator wraps too). Writes spx_synth_net_bytes() bytes. */

@@ -110,6 +110,7 @@ SYMBOLS = {
     "spx_acc_replay_tree": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_double)]),
     "spx_acc_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "spx_net_digest": (ctypes.c_uint64, [_P]),
+    "spx_net_psq_row_classes": (ctypes.c_int, [_P] + [ctypes.POINTER(ctypes.c_uint32)] * 3),
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_ctx_near_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),

@@ -359,6 +359,27 @@ uint64_t spx_net_digest(const spx_net* net) {
     return net ? fnv1a64(net->blob.data() + kHeaderBytes, net->blob.size() - kHeaderBytes) : 0;
 }
 
+int spx_net_psq_row_classes(const spx_net* net, uint32_t* fit_i8, uint32_t* near_compact, uint32_t* wide) {
+    if (!net || !fit_i8 || !near_compact || !wide) {
+        setError("spx_net_psq_row_classes: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    // the classification spx_ctx_create applies (without its environment switches): how many of the 11 264 piece-square rows
+    // a context will serve as 1 KiB copies (all weights fit i8), as 1 KiB copies + remainders (<= kOutlierCap weights do
+    // not), and as 2 KiB i16 rows
+    const int16_t* psq = reinterpret_cast<const int16_t*>(net->blob.data() + kOffPsqW);
+    uint32_t counts[3] = {0, 0, 0};
+    for (uint32_t r = 0; r < kPsqRows; ++r) {
+        uint32_t outside = 0;
+        for (uint32_t j = 0; j < kL1; ++j) outside += psq[size_t(r) * kL1 + j] < -128 || psq[size_t(r) * kL1 + j] > 127;
+        counts[outside == 0 ? 0 : (outside <= uint32_t(kOutlierCap) ? 1 : 2)] += 1;
+    }
+    *fit_i8 = counts[0];
+    *near_compact = counts[1];
+    *wide = counts[2];
+    return SPX_OK;
+}
+
 size_t spx_synth_net_bytes(void) {
     return synthNetBytes();
 }

@@ -76,6 +76,13 @@ class Network:
         """FNV-1a 64 of the logical payload (identical for the plain and the zstd-compressed image of a net)."""
         return int(_lib.load().spx_net_digest(self._h))
 
+    def psq_row_classes(self):
+        """(rows that fit i8, rows with <= 32 weights outside i8, wide rows) of the 11 264 piece-square rows - how a context
+        will serve them (1 KiB copy / 1 KiB copy + remainders / 2 KiB i16 row). Host-side."""
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        check(_lib.load().spx_net_psq_row_classes(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

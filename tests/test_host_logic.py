@@ -343,3 +343,18 @@ def test_update_kernel_delta_derivation_is_an_exact_feature_difference(sp):
     d = sp.debug_delta(a, flipped, 1)
     assert not d["refresh"] and all(len(d[k]) == 0 for k in ("psq_sub", "psq_add", "thr_sub", "thr_add"))
     assert sp.debug_delta(a, b, 0)["refresh"]
+
+
+def test_piece_square_row_classes_of_a_net(sp, net_blob):
+    """spx_net_psq_row_classes (host-side): which piece-square rows a context serves as 1 KiB copies (all weights fit i8),
+    as 1 KiB copies + exact remainders (<= 32 weights outside i8) and as 2 KiB rows - on the synthetic presets and on the
+    test nets with planted wide weights (conftest)."""
+    from conftest import MIXED_WIDE_ROWS, NEAR_ROW_KIND
+
+    assert sp.Network(net_blob("tame")).psq_row_classes() == (11264, 0, 0)
+    fit, near, wide = sp.Network(net_blob("extreme")).psq_row_classes()
+    assert fit + near + wide == 11264 and wide > 0
+    n_wide = int(MIXED_WIDE_ROWS.sum())
+    assert sp.Network(net_blob("mixed")).psq_row_classes() == (11264 - n_wide, n_wide, 0)  # one planted weight per row
+    kinds = [int((NEAR_ROW_KIND == k).sum()) for k in range(4)]
+    assert sp.Network(net_blob("near")).psq_row_classes() == (kinds[0], kinds[1] + kinds[3], kinds[2])
