@@ -575,8 +575,9 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
     // the update kernel measured on the same sweep (tools/gpu_r02_r.sh, us per ply at 65 536 records):
-    // 16 -> 318.5, 32 -> 318.2, 48 -> 325.2, 64 -> 336.0
-    uint32_t updateBlocksPerCu = 32;
+    // 16 -> 318.5, 32 -> 318.2, 48 -> 325.2, 64 -> 336.0; finer, on the final build (tools/gpu_r02_ag.sh): 12 -> 317.5,
+    // 16 -> 315.8, 20 -> 311.8, 24 -> 309.7, 28 -> 313.3, 32 -> 316.1 (self-play at 4 096 games: +1.6 % at 24 too)
+    uint32_t updateBlocksPerCu = 24;
     if (const char* env = std::getenv("SPX_UPDATE_BLOCKS_PER_CU")) updateBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
     ctx->updateGridCap = uint32_t(prop.multiProcessorCount) * updateBlocksPerCu;
     SPX_HIP(hipDeviceSynchronize());  // the hist memset ran on the null stream, the context's stream does not wait for it
