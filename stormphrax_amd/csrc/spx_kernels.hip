@@ -412,6 +412,9 @@ __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32
 #ifndef SPX_OPT_VOFF
 #define SPX_OPT_VOFF 1
 #endif
+#ifndef SPX_OPT_UPD_VOFF
+#define SPX_OPT_UPD_VOFF 1  // update kernel: u8 row offset in the buffer load's VGPR offset (no v_readfirstlane): +1-1.5 %
+#endif
 __device__ __forceinline__ u32x4 loadGatherRow(const uint8_t* table, const uint8_t* laneBase, uint32_t rowOffset,
                                                uint32_t laneOff) {
 #if SPX_OPT_VOFF
@@ -971,7 +974,11 @@ __device__ __forceinline__ void loadAddRows(const RowTable& table, uint32_t lane
     u32x4 w[kN];
 #pragma unroll
     for (int u = 0; u < kN; ++u) {
+#if SPX_OPT_UPD_VOFF
+        w[u] = loadRow16(table, 0u, list[u] + laneOff);  // row offset folded into the lane's VGPR offset: no v_readfirstlane
+#else
         w[u] = loadRow16(table, uint32_t(__builtin_amdgcn_readfirstlane(list[u])), laneOff);
+#endif
     }
 #pragma unroll
     for (int u = 0; u < kN; ++u) {
