@@ -356,7 +356,26 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
     elapsed = time.perf_counter() - t0
     sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
     prof = (sort_ms, ft_ms, mlp_ms, calls / chunks)  # per-kernel times per STEP (= per batch), as the byte counts are
+    # per-rank view for the report (rank order): each rank's FT-kernel time is its own, free of the barrier wait
+    timed_full_run.per_rank_ft_ms = group.all_floats(ft_ms / max(calls / chunks, 1))
     return group.max_float(elapsed), prof, settle_steps, d_outs[(counter[0] - 1) % len(d_outs)]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run on 127.0.0.1, a free port) with the same arguments, pass their output through and return
+    their exit status - the same command shape works for N = 1 and N > 1."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE in the environment: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -382,17 +401,29 @@ def main():
     ap.add_argument("--device-positions", action="store_true",
                     help="generate the batch with spx_random_positions_gpu (random playouts on the device: move generation + "
                          "uniform move choice kernels) instead of the host chess core - for nodes whose ranks share few CPUs")
+    ap.add_argument("--host-positions", action="store_true",
+                    help="N > 1 generates positions on the device by default; this keeps the host chess core (8 s per rank)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1 all-gathers the last step's scores by default; skip it")
     ap.add_argument("--no-settle", action="store_true", help="skip the time-based clock warm-up before the W warm-up steps")
     ap.add_argument("--no-wide", action="store_true", help="skip the second timed run with SPX_CTX_WIDE_PSQ_ROWS")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: all_gather the per-rank scores of the last step (RCCL) and check the gathered array "
                          "against each rank's own shard checksum (SURVEY 8e's optional result gather; outside the timed region)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (incremental ply, config-3 replay, realistic-weights net, gather ceiling) that "
+                         "the single-GPU run appends to the JSON line after the headline's timed region")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-port-baseline", action="store_true",
                     help="time the scalar C restatement when the compiled reference probe (oracle/_ref) is missing, "
                          "instead of failing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+    if args.gpus > 1:  # ranks of a node share few host CPUs and the point of the run is RCCL: both default on
+        args.device_positions = not args.host_positions
+        args.gather = not args.no_gather
 
     import torch
 
@@ -412,6 +443,11 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
     group = Group(backend=backend, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+    seen_backend, seen_world = group.backend_world()
+    if world > 1:
+        assert seen_world == world, (seen_world, world)
+        assert seen_backend == backend and (backend == "nccl" or "SPX_BENCH_BACKEND" in os.environ), \
+            f"N > 1 runs over RCCL (backend nccl); torch.distributed reports {seen_backend}"
 
     if args.mode == "incremental":
         return incremental_bench(args, sp, torch, group, rank, local_rank, world)
@@ -445,6 +481,7 @@ def main():
     pipelined = not args.no_pipeline
 
     elapsed, (sort_ms, ft_ms, mlp_ms, calls), settle_steps, d_last = timed_full_run(args, torch, group, state, d_pos, pipelined)
+    rank_ft_ms = timed_full_run.per_rank_ft_ms
     # checksum of checksums over all shards (summed in slabs: no 8-byte copy of an HBM-filling score array)
     checksum = group.sum_int(sum(int(d_last[lo:lo + (1 << 26)].sum(dtype=torch.int64).item())
                                  for lo in range(0, args.batch, 1 << 26)))
@@ -550,6 +587,13 @@ def main():
                                + ("steps issued through the pipelined spx_eval_full_device_async (two internal streams: "
                                   "sorts / MLP of a batch overlap the next batch's feature-transformer kernel)"
                                   if pipelined else "steps issued stream-ordered on one HIP stream per GPU"),
+                "ranks": {"backend": seen_backend, "world": seen_world,
+                          "ft_kernel_ms_per_rank": rank_ft_ms,
+                          "evals_per_sec_per_rank_kernel_bound": {
+                              "min": args.batch / (max(rank_ft_ms) / 1e3), "max": args.batch / (min(rank_ft_ms) / 1e3),
+                              "mean": args.batch / (sum(rank_ft_ms) / len(rank_ft_ms) / 1e3)},
+                          "note": "per-rank figures are each rank's own FT-kernel HIP-event time (rank order): a straggler "
+                                  "GPU shows here; `value` uses the MAX-over-ranks wall time"},
                 "net_distribution": (f"rank 0's {blob.size} B net image broadcast to the other ranks over "
                                      f"{backend} in {net_bcast_s * 1e3:.1f} ms (init only)" if world > 1 else "single rank"),
                 "settle_steps": settle_steps,

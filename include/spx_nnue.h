@@ -269,6 +269,18 @@ uint32_t spx_ctx_near_psq_rows(const spx_ctx* ctx);
  * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
 int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
 
+/* Gather-ceiling probe (measurement infrastructure; stormphrax_amd/csrc/spx_probe.hip): replays the row fetches of a
+ * full refresh of `d_positions` (device pointer, n <= spx_ctx_scratch_batch) - same king-bucket order, same grid and XCD
+ * traversal, same rows - with LOADS ONLY (one xor per loaded dword), `iters` launches timed with HIP events on the
+ * context's stream. variant 0 .. spx_debug_gather_probe_variants() - 1 selects the memory path / occupancy
+ * (spx_debug_gather_probe_name); variant -1 times the product feature-transformer kernel in the same way.
+ * `sink_checksum` (optional) receives a checksum of what the loads xor-ed to: equal for every variant >= 0.
+ * No reference counterpart: it measures what bounds nnue_state.cpp:89-145 / input.h:283-293 style row gathers on gfx950. */
+int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
+                           uint64_t* sink_checksum);
+int spx_debug_gather_probe_variants(void);
+const char* spx_debug_gather_probe_name(int variant);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Host helpers (position plumbing for harnesses; counterparts: src/position.cpp FEN parsing, marlinformat pack,
  * src/datagen/datagen.cpp:146-171 random openings).

@@ -17,6 +17,7 @@
 #include "spx_device_math.h"
 #include "spx_internal.h"
 #include "spx_kernels.h"
+#include "spx_probe.h"
 
 namespace spx {
 
@@ -112,16 +113,11 @@ struct spx_ctx {
     bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
     size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = automatic)
-    bool refreshCoop = false;      // SPX_REFRESH_COOP=1: one WORKGROUP per rebuilt perspective (four waves share the gather) -
-                                   // measured slower than one wave each (update + rebuild 327 vs 299 us per 65 536-record ply)
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
-    bool ftPosMajor = false;       // SPX_FT_POS_MAJOR=1: full refresh with one wave per POSITION (extraction shared by the two
-                                   // perspectives, positions sorted by the pair of king buckets)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     uint32_t ftGridCap = 0;
-    uint32_t sortPhaseKeys = 1;    // SPX_SORT_PHASE=1: perspectives ordered by (king bucket, output bucket), 128 keys
     uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
     std::vector<hipEvent_t> profEvents;  // kProfEventsPerCall per recorded call: [0] start, [1] after the sorts, [4] before
@@ -241,12 +237,8 @@ const ZstdApi* zstdApi() {
 void relayoutThreatRow(const int8_t* src, uint8_t* dst) {
     for (uint32_t l = 0; l < 64; ++l) {
         for (uint32_t j = 0; j < 8; ++j) {
-#if SPX_OPT_ANDPERM
             // within a dword: columns (c, c + 2, c + 1, c + 3) - bytes 0, 2 are one accumulator word, bytes 1, 3 the next
             const uint32_t k = (j & 4) | ((j & 1) << 1) | ((j & 2) >> 1);
-#else
-            const uint32_t k = j;
-#endif
             dst[16 * l + k] = uint8_t(src[8 * l + j]) ^ 0x80u;
             dst[16 * l + 8 + k] = uint8_t(src[512 + 8 * l + j]) ^ 0x80u;
         }
@@ -537,8 +529,6 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
-    if (const char* env = std::getenv("SPX_FT_POS_MAJOR")) ctx->ftPosMajor = env[0] == '1';
-    if (const char* env = std::getenv("SPX_SORT_PHASE")) ctx->sortPhaseKeys = env[0] == '1' ? 8u : 1u;
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
@@ -558,7 +548,6 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     ctx->updateSplitMaxV2 = 16384;
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
-    if (const char* env = std::getenv("SPX_REFRESH_COOP")) ctx->refreshCoop = env[0] != '0';
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -617,15 +606,13 @@ void spx_ctx_destroy(spx_ctx* ctx) {
 
 // sort (both keys) on `d_records`, then the MLP over ctx->dFtOut[0..n) -> d_out
 static int runSortAndMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s, bool mlp,
-                         const uint32_t* d_count = nullptr, bool outOnly = false, bool pairMode = false) {
+                         const uint32_t* d_count = nullptr, bool outOnly = false) {
     if (!mlp) {
         SortParams sp{};
         sp.positions = static_cast<const uint64_t*>(d_records);
         sp.nPositions = uint32_t(n);
         sp.nPositionsPtr = d_count;
         sp.outOnly = outOnly;
-        sp.pairMode = pairMode;
-        sp.phaseKeys = ctx->sortPhaseKeys;
         sp.kingKeys = ctx->dKingKeys;
         sp.outKeys = ctx->dOutKeys;
         if (n <= 1024 && !d_count) {  // single-launch path (kSmallSortMax): its own buffer, never needs clearing
@@ -713,8 +700,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         SPX_HIP(hipEventRecord(ev[0], s));
     }
     const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
-    const bool posMajor = ctx->ftPosMajor && ctx->kingSortEnabled && n > 1024 && !tiny;  // (the small single-launch sort has no pair mode)
-    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, false, posMajor);
+    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
@@ -723,10 +709,9 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     fp.positions = d_positions;
     fp.nPositions = uint32_t(n);
     fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
-    fp.posMajor = posMajor;
     fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, posMajor ? n : 2 * n), s));
+    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
     if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
@@ -1004,10 +989,9 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     fp.slots = up.childSlots;
     fp.slotRecords = up.slotRecords;
     ctx->refreshCur ^= 1;
-    // one workgroup per deferred perspective (cooperative gather): ~n / 15 of them in play, grid-stride beyond
-    const bool coop = ctx->refreshCoop;
-    const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : (coop ? std::max<size_t>(1024, n) : std::max<size_t>(256, n / 4));
-    SPX_HIP(launchFt(fp, ftGrid(ctx, waves), s, coop));
+    // one wave per deferred perspective: ~n / 15 of them in play, grid-stride beyond
+    const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : std::max<size_t>(256, n / 4);
+    SPX_HIP(launchFt(fp, ftGrid(ctx, waves), s));
     return SPX_OK;
 }
 
@@ -1679,6 +1663,76 @@ int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out) {
     SPX_HIP(hipDeviceSynchronize());
     SPX_HIP(hipMemcpy(out, ctx->dFtOut, n * size_t(kL1), hipMemcpyDeviceToHost));
     return SPX_OK;
+}
+
+// Gather-ceiling probe (spx_probe.hip): see include/spx_nnue.h. variant -1 = the product feature-transformer kernel itself
+// (stream-ordered, alone), so the probe's numbers and the kernel's come from the same loop on the same device buffers.
+int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
+                           uint64_t* sink_checksum) {
+    if (!ctx || !d_positions || !ms_per_launch || n == 0 || n > ctx->maxBatch || iters <= 0 || variant < -1 ||
+        variant >= probeVariantCount()) {
+        setError("spx_debug_gather_probe: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = runSortAndMlp(ctx, d_positions, n, nullptr, s, false);  // the product path's king-bucket order
+    if (rc != SPX_OK) return rc;
+    ProbeParams pp{};
+    pp.positions = d_positions;
+    pp.nPositions = uint32_t(n);
+    pp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
+    pp.t = tablesOf(ctx);
+    struct Scratch {
+        void *lists = nullptr, *sink = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch() {
+            if (lists) (void)hipFree(lists);
+            if (sink) (void)hipFree(sink);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } scratch;
+    SPX_HIP(hipMalloc(&scratch.lists, 2 * n * size_t(kProbeListWords) * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(&scratch.sink, 2 * n * size_t(512)));
+    SPX_HIP(hipMemsetAsync(scratch.sink, 0, 2 * n * size_t(512), s));
+    SPX_HIP(hipEventCreate(&scratch.e0));
+    SPX_HIP(hipEventCreate(&scratch.e1));
+    pp.lists = static_cast<uint32_t*>(scratch.lists);
+    pp.sink = static_cast<uint8_t*>(scratch.sink);
+    const uint32_t grid = ftGrid(ctx, 2 * n);
+    SPX_HIP(launchProbeLists(pp, grid, s));
+    FtParams fp{};
+    fp.positions = d_positions;
+    fp.nPositions = uint32_t(n);
+    fp.order = pp.order;
+    fp.t = pp.t;
+    fp.ftOut = ctx->dFtOut;
+    auto launch = [&]() -> hipError_t { return variant < 0 ? launchFt(fp, grid, s) : launchProbeGather(pp, variant, grid, s); };
+    for (int i = 0; i < 3; ++i) SPX_HIP(launch());  // warm-up
+    SPX_HIP(hipEventRecord(scratch.e0, s));
+    for (int i = 0; i < iters; ++i) SPX_HIP(launch());
+    SPX_HIP(hipEventRecord(scratch.e1, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    SPX_HIP(hipEventElapsedTime(&ms, scratch.e0, scratch.e1));
+    *ms_per_launch = ms / float(iters);
+    if (sink_checksum) {
+        std::vector<uint64_t> host(variant < 0 ? 0 : 2 * n * 64);
+        if (!host.empty()) SPX_HIP(hipMemcpy(host.data(), scratch.sink, host.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t sum = 0;
+        for (size_t i = 0; i < host.size(); ++i) sum += host[i] * (2 * i + 1);
+        *sink_checksum = sum;
+    }
+    return SPX_OK;
+}
+
+int spx_debug_gather_probe_variants(void) {
+    return probeVariantCount();
+}
+
+const char* spx_debug_gather_probe_name(int variant) {
+    return variant >= 0 && variant < probeVariantCount() ? probeVariant(variant).name : "spx_ft_kernel (the product kernel, alone)";
 }
 
 // ---- host helpers ----

@@ -6,11 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 
-// u8 row table byte order within a dword (host relayout in spx_api.cpp and the kernels' widening must agree):
-// 1 = columns (c, c + 2, c + 1, c + 3): even bytes widen with v_and_b32, odd bytes with v_perm_b32; 0 = natural order
-#ifndef SPX_OPT_ANDPERM
-#define SPX_OPT_ANDPERM 1
-#endif
+// u8 row table byte order within a dword (host relayout in spx_api.cpp and the kernels' widening must agree): columns
+// (c, c + 2, c + 1, c + 3) - even bytes widen with v_and_b32, odd bytes with v_perm_b32.
 
 namespace spx {
 
@@ -32,7 +29,6 @@ struct FtParams {
     const void* positions;   // spx_packed_pos[nPositions] (32 B records)
     uint32_t nPositions;
     const uint32_t* order;   // optional permutation of perspective ids (2*pos + colour), or nullptr
-    bool posMajor;           // `order` holds POSITION ids (pair-sorted): one wave extracts once and gathers both perspectives
     FtTables t;
     uint8_t* ftOut;          // mode A: [nPositions][1024] u8 activations (stm half, then nstm half)
     uint8_t* accOut;         // mode B (ftOut == nullptr): accumulator arena ...
@@ -139,9 +135,6 @@ struct SortParams {
     uint32_t nPositions;
     const uint32_t* nPositionsPtr;  // optional device-resident count (<= nPositions), as in UpdateParams
     bool outOnly;               // large sorts: only the output-bucket order (arena paths: nobody reads the king-bucket order)
-    bool pairMode;              // large sorts: perspOrder receives POSITION ids grouped by the pair of king buckets
-                                // (256 keys) instead of perspective ids grouped by king bucket - the position-major FT kernel
-    uint32_t phaseKeys;         // perspective-major large sorts: sub-keys per king bucket (1 = king bucket alone; 8 = x output bucket)
     uint8_t* kingKeys;          // [2 * nPositions] scratch
     uint8_t* outKeys;           // [nPositions] scratch
     uint32_t* hist;             // [kHistWords] counts + cursors (layout in spx_kernels.hip); all-zero on entry (large sorts)
@@ -167,8 +160,7 @@ struct MlpParams {
     int32_t* out;               // [nPositions]
 };
 
-// cooperative: one workgroup (four waves) per perspective instead of one wave - the latency-bound rebuild pass
-hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, bool cooperative = false);
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,

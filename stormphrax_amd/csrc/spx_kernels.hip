@@ -4,9 +4,12 @@
 //                    One wavefront per (position, perspective); lane l IS square l during extraction and owns
 //                    accumulator columns {8l..8l+7} U {512+8l..512+8l+7} during accumulation, so the pairwise
 //                    product (column j with j+512) is lane-local. A 1 KiB threat row is ONE coalesced 16 B/lane
-//                    wave load, a 2 KiB piece-square row is two. HBM/L2-bound gather: this is the roofline kernel.
+//                    wave load, a 2 KiB piece-square row is two. L2-bound gather: this is the roofline kernel.
 //   spx_mlp_kernel   int8 L1 (1024 -> 32, x8 output buckets) on v_mfma_i32_16x16x64_i8, then the i32 tail
 //                    (dual activation, L2 64x64, L3 + skip, scale). < 1 % of int8 MFMA peak by construction.
+//   spx_update_kernel[_v1|_observed], spx_slot_act_kernel, spx_adjust_kernel, spx_sort_*: see each kernel.
+// The wave-level building blocks (board decode, row lists, gather, activation) live in spx_ft_device.h. Variants that were
+// measured and rejected are kept, unbuilt, under experiments/ (numbers in DESIGN.md 4.1).
 //
 // Reference semantics (paths relative to /root/reference/src/eval):
 //   nnue_state.cpp:612-634 evaluateOnce; :440-449 resetPsqAccumulator; :309-354 addThreatFeatures;
@@ -17,688 +20,9 @@
 
 #include <cstdint>
 
-#include "spx_device_math.h"
-#include "spx_kernels.h"
+#include "spx_ft_device.h"
 
 namespace spx {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-
-namespace {
-
-constexpr int kWavesPerBlock = 4;
-#ifndef SPX_OPT_SADDR
-#define SPX_OPT_SADDR 1
-#endif
-#ifndef SPX_OPT_PSEUDOTAB
-#define SPX_OPT_PSEUDOTAB 1
-#endif
-#ifndef SPX_OPT_RAYTAB
-#define SPX_OPT_RAYTAB 0  // threat targets from LDS ray tables (needs SPX_OPT_PSEUDOTAB): -80 VALU, -14 VGPRs, no gain (see laneTargetsFromTables)
-#endif
-#ifndef SPX_FT_CHUNK
-#define SPX_FT_CHUNK 128  // perspectives per round-robin chunk of the XCD traversal, a power of two (0 = one contiguous eighth per XCD)
-#endif
-#ifndef SPX_FT_WAVES_PER_SIMD
-#define SPX_FT_WAVES_PER_SIMD 5  // launch_bounds 2nd arg = min waves per SIMD. A/B on MI355X: 4 -> 0.557 ms, 5 (96 VGPRs, no spill) -> 0.548, 6 (spills) -> 0.663
-#endif
-#ifndef SPX_STREAM_LOADS
-#define SPX_STREAM_LOADS 0
-#endif
-#ifndef SPX_UPDATE_SPLIT_WAVES
-#define SPX_UPDATE_SPLIT_WAVES 4
-#endif
-#ifndef SPX_MLP_WAVES_PER_SIMD
-#define SPX_MLP_WAVES_PER_SIMD 4  // A/B on MI355X with the batched tail: 3 -> 39.0 us, 4 -> 35.5 us per 65 536 positions (round-1 tail: 38.3)
-#endif
-#ifndef SPX_OPT_MLP_BATCHED
-#define SPX_OPT_MLP_BATCHED 1
-#endif
-constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
-constexpr int kPsqCap = 32;
-constexpr int kU8Cap = kThreatCap + kPsqCap;  // u8-row list: compact piece-square rows first, then <= 256 threat rows
-constexpr int kDeltaCap = 96;  // rows per delta list of the update kernel; a legal move stays far below (<= 64 threat rows
-                               // per board for two changed squares, + pawn pairs); a list that would overflow is rebuilt
-
-__device__ __forceinline__ uint32_t laneId() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-// number of set bits of `mask` strictly below this lane
-__device__ __forceinline__ uint32_t prefixCount(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-__device__ __forceinline__ uint32_t pkAdd16(uint32_t a, uint32_t b) {
-    // two independent wrapping 16-bit adds (v_pk_add_u16): exactly the reference's add_epi16 semantics
-    const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pkSub16(uint32_t a, uint32_t b) {
-    const u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(uint32_t, r);
-}
-// Row fetch: every row load of the gather is `table + wave-uniform row offset + this lane's 16 * lane`. As a BUFFER load the
-// three terms map onto the instruction itself - resource descriptor (table base, SGPRs, built once), soffset (the row
-// offset straight from v_readfirstlane), voffset (the lane's constant) - so a row costs no address arithmetic at all;
-// the flat-global form pays a 64-bit v_lshl_add_u64 (or s_add_u32 + s_addc_u32) per load. Out-of-range offsets (malformed
-// lists cannot produce them; belt and braces) read zeros instead of faulting. Used by the UPDATE kernel (+5 % there);
-// the full-refresh gather keeps global loads (see gatherFull). SPX_OPT_SADDR=0: global loads here too.
-struct RowTable {
-#if SPX_OPT_SADDR
-    __amdgpu_buffer_rsrc_t rsrc;
-#else
-    const uint8_t* base;
-#endif
-};
-__device__ __forceinline__ RowTable makeRowTable(const void* base, uint32_t bytes) {
-    RowTable t;
-#if SPX_OPT_SADDR
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);  // raw buffer, gfx9 DATA_FORMAT_32
-#else
-    t.base = static_cast<const uint8_t*>(base);
-    (void)bytes;
-#endif
-    return t;
-}
-__device__ __forceinline__ u32x4 loadRow16(const RowTable& t, uint32_t rowOffset, uint32_t laneOffset) {
-#if SPX_OPT_SADDR
-    return __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, int(laneOffset), int(rowOffset), 0);
-#else
-    return *reinterpret_cast<const u32x4*>(t.base + rowOffset + laneOffset);
-#endif
-}
-constexpr uint32_t kU8TableBytes = (kThreatRows + kPsqRows) * kL1;  // threat rows + the compact piece-square slots
-
-// The 16 bytes a lane holds of a u8 row are widened into two accumulator words per dword. Storage order of the table
-// (relayoutThreatRow, spx_api.cpp): within a dword the bytes are columns (c, c + 2, c + 1, c + 3) - i.e. the EVEN bytes
-// 0, 2 are one packed-i16 accumulator word (columns c, c + 1) and the ODD bytes 1, 3 the next one (c + 2, c + 3). So:
-//   unpackEven: bytes 0, 2 -> 16-bit fields = x & 0x00FF00FF      (v_and_b32: 2 SIMD cycles, tools/probes/valu_rate_probe)
-//   unpackOdd:  bytes 1, 3 -> 16-bit fields = v_perm_b32          (4 cycles; a shift + and would be 6)
-// Round 1 stored (c, c + 1, c + 2, c + 3) and paid two v_perm_b32 per dword.
-__device__ __forceinline__ uint32_t unpackLo(uint32_t x) {
-#if SPX_OPT_ANDPERM
-    return x & 0x00FF00FFu;
-#else
-    return __builtin_amdgcn_perm(0u, x, 0x0C010C00u);
-#endif
-}
-__device__ __forceinline__ uint32_t unpackHi(uint32_t x) {
-#if SPX_OPT_ANDPERM
-    return __builtin_amdgcn_perm(0u, x, 0x0C030C01u);
-#else
-    return __builtin_amdgcn_perm(0u, x, 0x0C030C02u);
-#endif
-}
-
-// pairwise clipped ReLU of one column pair (multilayer.h:108-145): a = column j, b = column j+512 (i16, wrapped)
-[[maybe_unused]] __device__ __forceinline__ uint32_t pairAct(int32_t a, int32_t b) {
-    const int32_t i1 = min(max(a, 0), 255);
-    const int32_t i2 = min(b, 255);              // NOT clamped at zero
-    const int32_t p = ((i1 << 7) * i2) >> 16;    // mulhi_epi16(i1 << 7, i2): arithmetic shift (floor)
-    return uint32_t(max(p, 0));                  // packus: negatives saturate to 0; p <= 127 always
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Shared wave-level building blocks (one wavefront = one board, lane = square).
-// ---------------------------------------------------------------------------------------------------------------------
-struct LaneBoard {
-    uint64_t occ, kingsBb, whiteBb, pawnsBb;  // wave-uniform bitboards
-    int piece;                                // this lane's piece (type<<1|colour) or kNoPiece
-    int stm;                                  // side to move, 1 = white
-};
-
-#ifndef SPX_OPT_DECODE
-#define SPX_OPT_DECODE 1
-#endif
-__device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
-    LaneBoard b;
-#if SPX_OPT_DECODE
-    // ONE coalesced load for the whole 32-byte record (lane l fetches dword l & 7); the wave-uniform fields come out of
-    // v_readlane into SGPRs - so every mask derived from the occupancy is scalar arithmetic - and a lane's nibble comes
-    // from the lane that holds its dword (ds_bpermute) instead of a second, dependent global load
-    const uint32_t w = reinterpret_cast<const uint32_t*>(rec)[lane & 7];
-    b.occ = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(w), 1))) << 32) | uint32_t(__builtin_amdgcn_readlane(int(w), 0));
-    b.stm = (uint32_t(__builtin_amdgcn_readlane(int(w), 6)) & 0x80u) ? 0 : 1;
-    const bool occupied = (b.occ >> lane) & 1;
-    // malformed records (> 32 pieces) must not index past the 16 nibble bytes: results are unspecified, accesses are not
-    const uint32_t nibIdx = min(prefixCount(b.occ), 31u);
-    const uint32_t word = uint32_t(__shfl(int(w), int(2 + (nibIdx >> 3)), 64));
-    b.piece = occupied ? nibbleToPiece(int((word >> ((nibIdx & 7) * 4)) & 0xF)) : int(kNoPiece);
-#else
-    b.occ = *reinterpret_cast<const uint64_t*>(rec);
-    b.stm = (rec[24] & 0x80) ? 0 : 1;
-    const bool occupied = (b.occ >> lane) & 1;
-    // malformed records (> 32 pieces) must not read past the 32-byte record: results are unspecified, accesses are not
-    const uint32_t nibIdx = min(uint32_t(popc64(b.occ & ((1ull << lane) - 1))), 31u);
-    b.piece = kNoPiece;
-    if (occupied) {
-        const int nib = (rec[8 + (nibIdx >> 1)] >> ((nibIdx & 1) * 4)) & 0xF;
-        b.piece = nibbleToPiece(nib);
-    }
-#endif
-    const int type = b.piece >> 1;  // 6 for empty
-    b.kingsBb = __ballot(type == 5);
-    b.whiteBb = __ballot(occupied && (b.piece & 1) == 1);
-    // pawn-pair ids are (square - 8): pawns on the back ranks exist only in malformed records and are left out of the
-    // pawn-pair features (kPpMasks is empty for those squares anyway, threats.h:109)
-    b.pawnsBb = __ballot(type == 0) & 0x00FFFFFFFFFFFF00ull;
-    return b;
-}
-
-// Appends one threat row per set bit of this lane's `targets` (victims popped one per wave iteration):
-// attacker = this lane's `piece` on square `lane`, victim piece fetched from the lane that owns the target square.
-// Rows the reference excludes (threatFeatureIndex < 0) are dropped. Returns the new list length (capacity kThreatCap).
-template <bool kHaveTable = false>  // true: `pseudoTab` is staged for sure (a null test of an LDS address keeps both forms alive)
-__device__ __forceinline__ uint32_t emitThreatRows(uint32_t* list, uint32_t n, uint64_t targets, int piece,
-                                                   uint32_t lane, int x, int flipColour, const uint32_t* lut,
-                                                   const uint64_t* pseudoTab = nullptr) {
-    const int pieceRel = piece ^ flipColour;
-    const int sqRel = int(lane) ^ x;
-    uint64_t pseudoRel = 0;
-    if (targets) {  // (only non-king pieces have targets)
-        // pseudo-attack set of the attacker in the perspective's frame: one LDS read where the table is staged
-        // (pseudo[k][sq], spx_device_math.h), else the per-lane arithmetic (~40 instructions for the union of piece types)
-        if (kHaveTable || pseudoTab) {
-            pseudoRel = pseudoTab[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
-        } else {
-            pseudoRel = piecePseudoAttacks(pieceRel, sqRel);
-        }
-    }
-    while (__ballot(targets != 0)) {
-        const bool active = targets != 0;
-        const int to = active ? ctz64(targets) : 0;
-        targets &= targets - 1;
-        const int victim = __shfl(piece, to, 64);
-        int32_t row = -1;
-        if (active) {
-            row = threatRow(lut, pieceRel, sqRel, pseudoRel, victim ^ flipColour, to ^ x);
-        }
-        const uint64_t valid = __ballot(row >= 0);
-        const uint32_t slot = n + prefixCount(valid);
-        if (row >= 0 && slot < kThreatCap) {
-            list[slot] = uint32_t(row) * kL1;
-        }
-        n = min(n + uint32_t(popc64(valid)), uint32_t(kThreatCap));
-    }
-    return n;
-}
-
-// Appends one pawn-pair row per set bit of this lane's `partners`; `ownPawns` classifies the partner's side.
-__device__ __forceinline__ uint32_t emitPawnPairRows(uint32_t* list, uint32_t n, uint64_t partners, uint32_t idA,
-                                                     uint64_t ownPawns, int x) {
-    while (__ballot(partners != 0)) {
-        const bool active = partners != 0;
-        const int b = active ? ctz64(partners) : 0;
-        partners &= partners - 1;
-        const bool bEnemy = !((ownPawns >> b) & 1);
-        const uint64_t valid = __ballot(active);
-        const uint32_t slot = n + prefixCount(valid);
-        if (active && slot < kThreatCap) {
-            list[slot] = ppRow(idA, ppId(b ^ x, bEnemy)) * kL1;
-        }
-        n = min(n + uint32_t(popc64(valid)), uint32_t(kThreatCap));
-    }
-    return n;
-}
-
-// this lane's pawn-pair partner set for perspective c (nnue_state.cpp:330-351): own pawns pair with own pawns on
-// higher squares and with every enemy pawn inside kPpMasks; enemy pawns pair with enemy pawns on higher squares
-__device__ __forceinline__ uint64_t pawnPartners(bool isPawn, bool own, uint32_t lane, uint64_t ownPawns,
-                                                 uint64_t theirPawns) {
-    if (!isPawn) {
-        return 0;
-    }
-    const uint64_t above = ~((2ull << lane) - 1);
-    return own ? (((ownPawns & above) | theirPawns) & ppMask(int(lane))) : (theirPawns & above & ppMask(int(lane)));
-}
-
-// One piece-square delta row per `active` lane: rows with a compact (u8) copy are appended at the head of `u8List`,
-// the others go to `wideList` (i16 table). Capacities 8 each. Returns the number of compact rows; nWide by reference.
-__device__ __forceinline__ uint32_t emitPsqDeltaRows(bool active, uint32_t row, const uint32_t* lut, uint32_t* wideList,
-                                                     uint32_t* u8List, uint32_t& nWide) {
-    const bool compact = active && ((lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
-    const uint64_t compactMask = __ballot(compact), wideMask = __ballot(active && !compact);
-    const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
-    if (active && slot < 8) {
-        if (compact) {
-            u8List[slot] = (kThreatRows + row) * kL1;
-        } else {
-            wideList[slot] = row * (kL1 * 2);
-        }
-    }
-    nWide = min(uint32_t(popc64(wideMask)), 8u);
-    return min(uint32_t(popc64(compactMask)), 8u);
-}
-
-// Row lists of one perspective of one board (the full-refresh feature set): psqList (capacity kPsqCap) = byte offsets
-// into the i16 piece-square table, thrList (capacity kU8Cap) = byte offsets into the u8 row table; nThr counts both the
-// compact piece-square rows and the threat / pawn-pair rows in it.
-// this lane's threat targets (perspective independent): the occupied non-king squares its piece attacks
-__device__ __forceinline__ uint64_t laneTargets(const LaneBoard& b, uint32_t lane) {
-    const int type = b.piece >> 1;
-    uint64_t targets = 0;
-    if (b.piece != kNoPiece && type != 5) {
-        targets = pieceAttacks(b.piece, int(lane), b.occ) & b.occ & ~b.kingsBb;
-    }
-    return targets;
-}
-
-// The same set from LDS tables, straight-line for every lane (SPX_OPT_RAYTAB). A slider's targets are exactly the NEAREST
-// occupied square on each of its rays: blockers = ray & occ, nearest = lowest set bit (b & -b) for the four rays that run
-// towards higher squares; the other four are stored bit-reversed (`rays`, staged by the kernel) and met with the reversed
-// occupancy (one s_brev_b64 per board), so they isolate the lowest bit too and ONE 64-bit reversal brings all four back.
-// Pawns and knights read their pseudo-attack set. ~80 VALU instead of ~165 (four hyperbola-quintessence lines, three bit
-// reversals each, plus shifted leaper masks) - and none of the per-lane line masks the arithmetic form keeps hoisted in
-// ~16 VGPRs for the whole kernel (96 -> 82). Bit-exact, and measured: FT kernel 0.4253 ms vs 0.4224 with the arithmetic
-// form in the same run, 0.434 at the 6 waves/SIMD the freed registers allow (profiles/r02_ab_variants.txt) - the kernel is
-// bound by the vector-memory return path, extraction instructions overlap with it for free. Opt-in, off by default.
-__device__ __forceinline__ uint64_t laneTargetsFromTables(const LaneBoard& b, uint32_t lane, const uint64_t* rays,
-                                                          const uint64_t* pseudoTab) {
-    const uint32_t type = uint32_t(b.piece) >> 1;  // 6 = empty
-    const bool diag = type == 2 || type == 4, orth = type == 3 || type == 4;
-    const uint64_t occRev = __builtin_bitreverse64(b.occ);
-    const uint64_t occD = diag ? b.occ : 0, occO = orth ? b.occ : 0;
-    const uint64_t occDr = diag ? occRev : 0, occOr = orth ? occRev : 0;
-    uint64_t up = 0, down = 0;
-#pragma unroll
-    for (int dir = 0; dir < 4; ++dir) {  // N, NE, E, NW | S, SW, W, SE: odd = diagonal
-        const uint64_t bu = rays[dir * 64 + lane] & ((dir & 1) ? occD : occO);
-        up |= bu & (0 - bu);
-        const uint64_t bd = rays[(4 + dir) * 64 + lane] & ((dir & 1) ? occDr : occOr);
-        down |= bd & (0 - bd);
-    }
-    const uint64_t leaper = type <= 1 ? pseudoTab[(type ? 2 : b.piece) * 64 + lane] & b.occ : 0;  // pawns by colour, knight
-    return (up | __builtin_bitreverse64(down) | leaper) & ~b.kingsBb;
-}
-
-// kNear (full-refresh kernel of a net that has near-compact rows): such rows take the 1 KiB path too; the remainders of
-// their <= kOutlierCap wide weights (FtTables::outlierTab) are summed per column into `nearAcc` (this wave's 1 024 i32 in
-// LDS; lane = the row's square, one LDS atomic per remainder) and folded in after the gather. Returns whether any was.
-template <bool kRayTab = false, bool kNear = false>
-__device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
-                                               uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
-                                               const uint64_t* pseudoTab = nullptr, bool haveTargets = false,
-                                               uint64_t sharedTargets = 0, const uint64_t* rayTab = nullptr,
-                                               const uint32_t* outlierTab = nullptr, int32_t* nearAcc = nullptr) {
-    const int piece = b.piece;
-    const bool occupied = piece != kNoPiece;
-    const int type = piece >> 1;
-    const uint64_t ownKing = __ballot(piece == (10 | c));
-    const int kingSq = ownKing ? ctz64(ownKing) : 0;  // a record without that king is malformed: stay in bounds
-    const uint64_t ownPawns = b.pawnsBb & (c ? b.whiteBb : ~b.whiteBb);
-    const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
-    const int x = perspXor(c, kingSq);
-    const int flipColour = (c == 0) ? 1 : 0;
-    bool hasNear = false;
-
-    // piece-square rows: one per occupied square (resetPsqAccumulator, nnue_state.cpp:440-449). Rows whose weights all
-    // fit i8 have a 1 KiB copy in the u8 table: those go to the head of the u8 list, the rest to the i16 list.
-    uint32_t nCompact;
-    {
-        uint32_t row = 0;
-        bool compact = false, near = false;
-        if (occupied) {
-            row = psqRow(c, piece, int(lane), kingSq);
-            compact = (lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u;
-            if constexpr (kNear) {
-                near = (lut[kLutNearBase + (row >> 5)] >> (row & 31)) & 1u;
-                compact = compact || near;
-            }
-        }
-        if constexpr (kNear) {
-            hasNear = __ballot(near) != 0;
-            if (hasNear) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // 1 024 sums back to zero: 4 x 16 bytes per lane
-                    *reinterpret_cast<u32x4*>(nearAcc + 256 * k + 4 * lane) = u32x4{0, 0, 0, 0};
-                }
-                __builtin_amdgcn_wave_barrier();
-                // entries are packed from the front: four at a time, until no row of this board has any left (a net whose rows
-                // carry a few remainders each pays one 16-byte load per lane, not four)
-#pragma unroll 1
-                for (int k = 0; k < kOutlierCap / 4; ++k) {
-                    const u32x4 e = near ? *reinterpret_cast<const u32x4*>(outlierTab + size_t(row) * kOutlierCap + 4 * k)
-                                         : u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    if (!__ballot(e[0] != 0xFFFFFFFFu)) break;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (e[j] != 0xFFFFFFFFu) atomicAdd(nearAcc + (e[j] & 0xFFFFu), int32_t(int16_t(e[j] >> 16)));
-                    }
-                }
-            }
-        }
-        const uint64_t compactMask = __ballot(occupied && compact), wideMask = b.occ & ~compactMask;
-        const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
-        if (occupied && slot < kPsqCap) {
-            if (compact) {
-                thrList[slot] = (kThreatRows + row) * kL1;
-            } else {
-                psqList[slot] = row * (kL1 * 2);
-            }
-        }
-        nCompact = min(uint32_t(popc64(compactMask)), uint32_t(kPsqCap));
-        nPsq = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-    }
-    uint32_t* threatList = thrList + nCompact;  // the reference's <= 256-entry threat list proper
-
-    // threat rows (addThreatFeatures, nnue_state.cpp:309-328); the position-major kernel computes the targets once
-    uint64_t targets = sharedTargets;
-    if (!haveTargets) {
-        if constexpr (kRayTab) {
-            targets = laneTargetsFromTables(b, lane, rayTab, pseudoTab);
-        } else {
-            targets = laneTargets(b, lane);
-        }
-    }
-    nThr = emitThreatRows<kRayTab>(threatList, 0, targets, piece, lane, x, flipColour, lut, pseudoTab);
-
-    // pawn-pair rows (nnue_state.cpp:330-351)
-    const bool isPawn = type == 0;
-    const bool own = isPawn && (piece & 1) == c;
-    nThr = nCompact + emitPawnPairRows(threatList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
-                                       ppId(int(lane) ^ x, !own), ownPawns, x);
-    __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
-    return hasNear;
-}
-
-// One lane's 16 bytes of a table row for the full-refresh gather. The row's byte offset stays in a VGPR (every lane reads
-// the list entry from LDS itself) and goes into the 32-bit offset operand of `global_load_dwordx4 v, voff, s[base]` next to
-// the table's SGPR base: ONE v_add_u32 per row (2.6 SIMD cycles) where round 1 / early round 2 paid v_readfirstlane + a
-// 64-bit per-lane pointer add (v_lshl_add_u64), 4.1-4.2 cycles each (tools/probes/valu_rate_probe). +5.3 % on the whole
-// bench in the same-run A/B (profiles/r02_ab_variants.txt). SPX_OPT_VOFF=0 restores the old form.
-#ifndef SPX_OPT_VOFF
-#define SPX_OPT_VOFF 1
-#endif
-#ifndef SPX_OPT_UPD_VOFF
-#define SPX_OPT_UPD_VOFF 1  // update kernel: u8 row offset in the buffer load's VGPR offset (no v_readfirstlane): +1-1.5 %
-#endif
-__device__ __forceinline__ u32x4 loadGatherRow(const uint8_t* table, const uint8_t* laneBase, uint32_t rowOffset,
-                                               uint32_t laneOff) {
-#if SPX_OPT_VOFF
-    return *reinterpret_cast<const u32x4*>(table + size_t(rowOffset + laneOff));
-#else
-    return *reinterpret_cast<const u32x4*>(laneBase + uint32_t(__builtin_amdgcn_readfirstlane(rowOffset)));
-#endif
-}
-
-// acc = ftBias + sum(piece-square rows) + sum(threat rows), all mod 2^16 per column.
-// acc[r], r < 4: columns 8l+2r, 8l+2r+1 ; acc[4+r]: columns 512+8l+2r, 512+8l+2r+1  (lane l)
-__device__ __forceinline__ void gatherFull(const FtTables& t, uint32_t lane, const uint32_t* psqList, uint32_t nPsq,
-                                           const uint32_t* thrList, uint32_t nThr, uint32_t (&acc)[8],
-                                           bool withBias = true, const int32_t* nearAcc = nullptr) {
-    // Full-refresh rows come in through plain global loads (loadGatherRow). The buffer-load form the update kernel uses
-    // (RowTable: SGPR row offset, no address arithmetic at all) was A/B-measured here too and LOSES 10 % (FT kernel 0.469
-    // -> 0.514 ms, profiles/r02_ab_variants.txt): with 8 x 1 KiB in flight per wave the kernel is bound by the
-    // vector-memory return path, and buffer loads sit longer in it; in the update kernel (4 loads in flight,
-    // latency-bound) they win 5 %.
-    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
-    const uint8_t* thrBase = t.thrW + 16 * lane;
-    const uint8_t* psqTable = reinterpret_cast<const uint8_t*>(t.psqW);
-    const uint32_t laneOff = 16 * lane;
-
-    // (1) u8 rows (threat, pawn-pair and compact piece-square rows, stored +128) FIRST, into their own accumulator while
-    // the packed-i16 one is not live yet (8 VGPRs less in the hot loop): <= 256 rows x 255 never overflow a 16-bit
-    // field, so plain 32-bit adds (v_add3_u32: two rows per add) are exact and no carry crosses fields.
-    const uint32_t nFirst = min(nThr, uint32_t(kThreatCap));
-    uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        uint32_t i = 0;
-        for (; i + 8 <= nFirst; i += 8) {  // 8 x 1 KiB wave loads in flight
-            u32x4 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[u] = loadGatherRow(t.thrW, thrBase, thrList[i + u], laneOff);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    tacc[2 * d] = tacc[2 * d] + unpackLo(w[u][d]) + unpackLo(w[u + 1][d]);
-                    tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w[u][d]) + unpackHi(w[u + 1][d]);
-                }
-            }
-        }
-        for (; i + 2 <= nFirst; i += 2) {
-            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-            const u32x4 w1 = loadGatherRow(t.thrW, thrBase, thrList[i + 1], laneOff);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                tacc[2 * d] = tacc[2 * d] + unpackLo(w0[d]) + unpackLo(w1[d]);
-                tacc[2 * d + 1] = tacc[2 * d + 1] + unpackHi(w0[d]) + unpackHi(w1[d]);
-            }
-        }
-        if (i < nFirst) {
-            const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                tacc[2 * d] += unpackLo(w0[d]);
-                tacc[2 * d + 1] += unpackHi(w0[d]);
-            }
-        }
-    }
-
-    // (2) bias + wide (i16) piece-square rows
-    {   // (withBias = false: a partial sum over a slice of the lists - the cooperative rebuild pass adds the slices up)
-        u32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-        if (withBias) {
-            b0 = *reinterpret_cast<const u32x4*>(t.ftBias + 8 * lane);
-            b1 = *reinterpret_cast<const u32x4*>(t.ftBias + 512 + 8 * lane);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = b0[r];
-            acc[4 + r] = b1[r];
-        }
-    }
-    {
-        uint32_t i = 0;
-        for (; i + 4 <= nPsq; i += 4) {  // 8 x 1 KiB wave loads in flight
-            u32x4 lo[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                lo[u] = loadGatherRow(psqTable, psqBase, psqList[i + u], laneOff);
-                hi[u] = loadGatherRow(psqTable, psqBase, psqList[i + u], laneOff + 1024);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r] = pkAdd16(acc[r], lo[u][r]);
-                    acc[4 + r] = pkAdd16(acc[4 + r], hi[u][r]);
-                }
-            }
-        }
-        for (; i < nPsq; ++i) {
-            const u32x4 lo = loadGatherRow(psqTable, psqBase, psqList[i], laneOff);
-            const u32x4 hi = loadGatherRow(psqTable, psqBase, psqList[i], laneOff + 1024);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r] = pkAdd16(acc[r], lo[r]);
-                acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
-            }
-        }
-    }
-
-    // (3) fold the u8 sums in (mod 2^16), removing the +128 storage bias: every u8 row contributed 128 to every column
-    {
-        const uint32_t corr = (nThr * 128u) & 0xFFFFu;
-        const uint32_t corr2 = corr | (corr << 16);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            acc[r] = pkSub16(pkAdd16(acc[r], tacc[r]), corr2);
-        }
-    }
-    // (3b) remainders of the near-compact rows' wide weights (buildFullLists<.., kNear>): this lane's 16 column sums, mod 2^16
-    if (nearAcc) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const i32x4 lo = *reinterpret_cast<const i32x4*>(nearAcc + 512 * h + 8 * lane);
-            const i32x4 hi = *reinterpret_cast<const i32x4*>(nearAcc + 512 * h + 8 * lane + 4);
-            acc[4 * h + 0] = pkAdd16(acc[4 * h + 0], __builtin_amdgcn_perm(uint32_t(lo[1]), uint32_t(lo[0]), 0x05040100u));
-            acc[4 * h + 1] = pkAdd16(acc[4 * h + 1], __builtin_amdgcn_perm(uint32_t(lo[3]), uint32_t(lo[2]), 0x05040100u));
-            acc[4 * h + 2] = pkAdd16(acc[4 * h + 2], __builtin_amdgcn_perm(uint32_t(hi[1]), uint32_t(hi[0]), 0x05040100u));
-            acc[4 * h + 3] = pkAdd16(acc[4 * h + 3], __builtin_amdgcn_perm(uint32_t(hi[3]), uint32_t(hi[2]), 0x05040100u));
-        }
-    }
-    // (4) rows beyond 256 exist only when compact piece-square rows sit in front of a near-full threat list: one at a
-    // time, straight into the wrapping accumulator
-    for (uint32_t i = nFirst; i < nThr; ++i) {
-        const u32x4 w0 = loadGatherRow(t.thrW, thrBase, thrList[i], laneOff);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            acc[2 * d] = pkAdd16(acc[2 * d], unpackLo(w0[d]));
-            acc[2 * d + 1] = pkAdd16(acc[2 * d + 1], unpackHi(w0[d]));
-        }
-    }
-}
-
-// pairwise activation of one perspective's accumulator -> 8 bytes per lane (columns 8l..8l+7 of the 512 outputs)
-#ifndef SPX_OPT_PKACT
-#define SPX_OPT_PKACT 1
-#endif
-typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
-#if SPX_OPT_PKACT
-    // Two columns per instruction on the packed-16-bit pipe (multilayer.h:108-145): i1 = clamp(a, 0, 255),
-    // i2 = min(b, 255); ((i1 << 7) * i2) >> 16 floors i1 * i2 / 512 and negatives saturate to 0 - and since i1 >= 0 the
-    // product is negative exactly when i2 is, so clamping i2 at 0 first gives the same byte. Then both factors are
-    // 0..255, the product fits 16 bits: v_pk_max/min_i16, v_pk_mul_lo_u16, v_pk_lshrrev_b16.
-    const i16x2 zero = {0, 0}, top = {255, 255};
-    uint32_t q[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const i16x2 a = __builtin_bit_cast(i16x2, acc[r]), b = __builtin_bit_cast(i16x2, acc[4 + r]);
-        const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(a, zero), top));
-        const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top));
-        q[r] = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));  // [col 2r | col 2r + 1 << 16], each 0..127
-    }
-    u32x2 o;  // bytes 0, 2 of each pair of dwords
-    o[0] = __builtin_amdgcn_perm(q[1], q[0], 0x06040200u);
-    o[1] = __builtin_amdgcn_perm(q[3], q[2], 0x06040200u);
-    return o;
-#else
-    uint32_t outLo = 0, outHi = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int32_t a0 = int16_t(acc[r] & 0xFFFF), a1 = int16_t(acc[r] >> 16);
-        const int32_t b0 = int16_t(acc[4 + r] & 0xFFFF), b1 = int16_t(acc[4 + r] >> 16);
-        const uint32_t v = pairAct(a0, b0) | (pairAct(a1, b1) << 8);
-        if (r < 2) {
-            outLo |= v << (16 * r);
-        } else {
-            outHi |= v << (16 * (r - 2));
-        }
-    }
-    u32x2 o;
-    o[0] = outLo;
-    o[1] = outHi;
-    return o;
-#endif
-}
-
-// Accumulator arena slot: [colour 0: i16[1024]][colour 1: i16[1024]] = 4 KiB, natural column order. Lane l owns
-// columns {8l..8l+7} (16 B at 16l) and {512+8l..} (16 B at 1024+16l) - the same split as a piece-square row.
-// kStream: child accumulators of a big batch are written once and, if at all, read much later - non-temporal stores
-// keep those 4 KiB per update from evicting the weight rows out of L2 (65 536 updates: 454 -> 444 us per ply, self-play
-// +3-4 %); small batches (<= 16 384: -4 %) are better off with their slots cached. The parent loads stay cached
-// (SPX_STREAM_LOADS=1 would stream them too: +5 % when every parent has one child, -15 % in self-play where ~35
-// siblings share a parent). Compile-time, because the hint does not survive a run-time select between the two kinds
-// of access.
-template <bool kStream = false>
-__device__ __forceinline__ void storeAcc(uint8_t* arena, uint32_t slot, int c, uint32_t lane, const uint32_t (&acc)[8]) {
-    uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
-    u32x4 lo, hi;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        lo[r] = acc[r];
-        hi[r] = acc[4 + r];
-    }
-    if constexpr (kStream) {
-        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4*>(base));
-        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4*>(base + 1024));
-    } else {
-        *reinterpret_cast<u32x4*>(base) = lo;
-        *reinterpret_cast<u32x4*>(base + 1024) = hi;
-    }
-}
-template <bool kStream = false>
-__device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int c, uint32_t lane, uint32_t (&acc)[8]) {
-    const uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 16 * lane;
-    u32x4 lo, hi;
-    if constexpr (kStream) {
-        lo = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base));
-        hi = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + 1024));
-    } else {
-        lo = *reinterpret_cast<const u32x4*>(base);
-        hi = *reinterpret_cast<const u32x4*>(base + 1024);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        acc[r] = lo[r];
-        acc[4 + r] = hi[r];
-    }
-}
-
-// child accumulator = parent accumulator - removed rows + added rows (updatePsq, nnue_state.cpp:34-87;
-// applyThreatRows, :89-145). Lists hold byte offsets; wrapping i16; threat sums kept in non-overflowing 32-bit fields.
-template <bool kStream = false>
-__device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* arena, uint32_t parentSlot, int c,
-                                           uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
-                                           const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
-                                           uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]) {
-    loadAcc<kStream && SPX_STREAM_LOADS>(arena, parentSlot, c, lane, acc);
-    const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
-    for (uint32_t i = 0; i < nPsqSub; ++i) {
-        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqSub[i]);
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = pkSub16(acc[r], lo[r]);
-            acc[4 + r] = pkSub16(acc[4 + r], hi[r]);
-        }
-    }
-    for (uint32_t i = 0; i < nPsqAdd; ++i) {
-        const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqAdd[i]);
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(row);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(row + 1024);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = pkAdd16(acc[r], lo[r]);
-            acc[4 + r] = pkAdd16(acc[4 + r], hi[r]);
-        }
-    }
-    const uint8_t* thrBase = t.thrW + 16 * lane;
-    uint32_t tadd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tsub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < nAdd; ++i) {
-        const u32x4 w = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrAdd[i]));
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            tadd[2 * d] += unpackLo(w[d]);
-            tadd[2 * d + 1] += unpackHi(w[d]);
-        }
-    }
-    for (uint32_t i = 0; i < nSub; ++i) {
-        const u32x4 w = *reinterpret_cast<const u32x4*>(thrBase + __builtin_amdgcn_readfirstlane(thrSub[i]));
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            tsub[2 * d] += unpackLo(w[d]);
-            tsub[2 * d + 1] += unpackHi(w[d]);
-        }
-    }
-    // +128 storage bias: (nAdd - nSub) * 128 per column, mod 2^16
-    const uint32_t corr = ((nAdd - nSub) * 128u) & 0xFFFFu;
-    const uint32_t corr2 = corr | (corr << 16);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        acc[r] = pkSub16(pkSub16(pkAdd16(acc[r], tadd[r]), tsub[r]), corr2);
-    }
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Feature transformer kernel (full refresh).
@@ -708,51 +32,25 @@ __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* are
 //   ftOut   != nullptr: pairwise-activated u8[512] halves (stm first) for the MLP kernel     == evaluateOnce
 //   accOut  != nullptr: raw i16 accumulators into arena slot slots[position] + the record     == NnueState::reset
 // ---------------------------------------------------------------------------------------------------------------------
-// kCoop = false: one wavefront per perspective (throughput: the full-refresh batches).
-// kCoop = true:  one WORKGROUP per perspective - the rebuild pass behind the update kernel, a few thousand perspectives on
-//                an otherwise idle chip, where the time is the latency of one cold 65-row gather (8 rows per round trip):
-//                all four waves build the lists, each gathers a quarter of them (2-3 round trips instead of 9) and
-//                wave 0 adds the four partial accumulators up through LDS.
 // kNear: the net has near-compact piece-square rows (FtTables::outlierTab): they take the 1 KiB path, their wide weights'
 //        remainders are summed through 4 KiB of LDS per wave (buildFullLists). Nets without such rows run the kNear = false
 //        instantiation - the same code as before the feature existed.
-template <bool kCoop, bool kNear = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
-    static_assert(!(kCoop && kNear), "the cooperative rebuild pass treats near-compact rows as wide rows");
+template <bool kNear>
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ __align__(16) int32_t sNear[kNear ? kWavesPerBlock : 1][kNear ? int(kL1) : 4];  // per-column remainder sums
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // byte offsets into the psq table
-#if SPX_OPT_PSEUDOTAB
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];        // pseudo-attack sets per (piece kind, square), 3 KiB
-#endif
-#if SPX_OPT_RAYTAB
-    __shared__ uint64_t sRays[8 * 64];                     // ray masks per (direction, square), 4 KiB; S, SW, W, SE reversed
-#endif
-    __shared__ uint32_t sPart[kCoop ? kWavesPerBlock : 1][8][64];  // kCoop: the waves' partial accumulators
 
     if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
     if (p.nPerspPtr && *p.nPerspPtr == 0) return;  // nothing was deferred: the refresh pass costs one empty launch
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
         sLut[i] = p.t.lut[i];
     }
-#if SPX_OPT_PSEUDOTAB
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
         sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
     }
-    const uint64_t* pseudoTab = sPseudo;
-#else
-    const uint64_t* pseudoTab = nullptr;
-#endif
-#if SPX_OPT_RAYTAB
-    for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) {
-        const uint64_t ray = p.t.deltaTab[i];
-        sRays[i] = i >= 4 * 64 ? __builtin_bitreverse64(ray) : ray;
-    }
-    const uint64_t* rayTab = sRays;
-#else
-    const uint64_t* rayTab = nullptr;
-#endif
     __syncthreads();
 
     const uint32_t lane = laneId();
@@ -765,22 +63,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
     // current bucket plus the hot threat rows - and every XCD gets the same mix of light and heavy buckets. Round 1 gave
     // each XCD one contiguous eighth: the slices differ in WORK (castled-king buckets average 76 rows per perspective,
     // advanced-king endgame buckets 40-50: the heaviest eighth of the bench batch carries 17 % more rows than the mean)
-    // and the kernel waited for the slowest XCD: FT kernel 0.4407 -> 0.4210 ms. SPX_FT_CHUNK=0: contiguous slices.
+    // and the kernel waited for the slowest XCD: FT kernel 0.4407 -> 0.4210 ms.
     const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
-    const uint32_t stride = kCoop ? blocksPerXcd : blocksPerXcd * kWavesPerBlock;
-#if SPX_FT_CHUNK > 0
+    const uint32_t stride = blocksPerXcd * kWavesPerBlock;
     // (batches too small to give every XCD several chunks are dealt perspective by perspective: chunk = 1)
     const uint32_t chunkShift = nPersp >= 64u * SPX_FT_CHUNK ? uint32_t(__builtin_ctz(SPX_FT_CHUNK)) : 0u;
     const uint32_t nChunks = (nPersp + (1u << chunkShift) - 1) >> chunkShift;
     const uint32_t myItems = ((nChunks + 7 - xcd) / 8) << chunkShift;  // chunks xcd, xcd + 8, ...
-    for (uint32_t t = kCoop ? blockInXcd : blockInXcd * kWavesPerBlock + wave; t < myItems; t += stride) {
+    for (uint32_t t = blockInXcd * kWavesPerBlock + wave; t < myItems; t += stride) {
         const uint32_t it = ((((t >> chunkShift) * 8 + xcd)) << chunkShift) + (t & ((1u << chunkShift) - 1));
-        if (it >= nPersp) continue;  // the last chunk may be partial (`it` is block-uniform in kCoop mode: no barrier is split)
-#else
-    const uint32_t sliceBegin = uint32_t(uint64_t(nPersp) * xcd / 8);
-    const uint32_t sliceEnd = uint32_t(uint64_t(nPersp) * (xcd + 1) / 8);
-    for (uint32_t it = sliceBegin + (kCoop ? blockInXcd : blockInXcd * kWavesPerBlock + wave); it < sliceEnd; it += stride) {
-#endif
+        if (it >= nPersp) continue;  // the last chunk may be partial
         const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
         const uint32_t posIdx = q >> 1;
         const int c = int(q & 1);
@@ -788,29 +80,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kCoop ? 4 : SPX_FT_WAVES_PER_S
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        const bool hasNear = buildFullLists<SPX_OPT_RAYTAB != 0, kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr,
-                                                                        pseudoTab, false, 0, rayTab, p.t.outlierTab, sNear[kNear ? wave : 0]);
+        const bool hasNear = buildFullLists<kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
+                                                   p.t.outlierTab, sNear[kNear ? wave : 0]);
         uint32_t acc[8];
-        if constexpr (kCoop) {
-            // this wave's quarter of both lists (every wave built the same lists)
-            const uint32_t p0 = nPsq * wave / kWavesPerBlock, p1 = nPsq * (wave + 1) / kWavesPerBlock;
-            const uint32_t t0 = nThr * wave / kWavesPerBlock, t1 = nThr * (wave + 1) / kWavesPerBlock;
-            gatherFull(p.t, lane, sPsq[wave] + p0, p1 - p0, sThr[wave] + t0, t1 - t0, acc, wave == 0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) sPart[wave][r][lane] = acc[r];
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int w = 1; w < kWavesPerBlock; ++w) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) acc[r] = pkAdd16(acc[r], sPart[w][r][lane]);
-                }
-            }
-            __syncthreads();  // the partials are consumed before the next item overwrites them
-            if (wave != 0) continue;
-        } else {
-            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, true, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
-        }
+        gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
 
         if (p.accOut) {
             const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
@@ -974,11 +247,7 @@ __device__ __forceinline__ void loadAddRows(const RowTable& table, uint32_t lane
     u32x4 w[kN];
 #pragma unroll
     for (int u = 0; u < kN; ++u) {
-#if SPX_OPT_UPD_VOFF
-        w[u] = loadRow16(table, 0u, list[u] + laneOff);  // row offset folded into the lane's VGPR offset: no v_readfirstlane
-#else
-        w[u] = loadRow16(table, uint32_t(__builtin_amdgcn_readfirstlane(list[u])), laneOff);
-#endif
+        w[u] = loadRow16(table, 0u, list[u] + laneOff);  // row offset folded into the lane's VGPR offset: no v_readfirstlane (+1-1.5 %)
     }
 #pragma unroll
     for (int u = 0; u < kN; ++u) {
@@ -1216,7 +485,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
             const uint32_t na = c ? nAdd[1] : nAdd[0], ns = c ? nSub[1] : nSub[0];
             const uint32_t nws = c ? nWideSub[1] : nWideSub[0], nwa = c ? nWideAdd[1] : nWideAdd[0];
             uint32_t acc[8];
-            loadAcc<kStream && SPX_STREAM_LOADS>(p.arena, parentSlot, c, lane, acc);
+            loadAcc(p.arena, parentSlot, c, lane, acc);
             applyWidePsqDelta(p.t, lane, sWide[wave][c][0], nws, sWide[wave][c][1], nwa, acc);
             applyU8Delta(p.t, lane, sAdd[wave][c], na, sSub[wave][c], ns, acc);
             storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
@@ -1448,7 +717,7 @@ __global__ __launch_bounds__(256) void spx_adjust_kernel(AdjustParams p) {
 // hist layout: see the constants below
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kKingKeys = 16;
-constexpr int kPairKeys = 256;  // position-major full refresh: positions by the PAIR of king buckets (white * 16 + black)
+constexpr int kPairKeys = 256;  // capacity of the first-key histogram (16 king keys in use)
 constexpr int kOutKeys = 8;
 // hist layout (kHistWords u32 words per buffer): [0, 256) first-key counts (16 king keys or 256 pair keys),
 // [256, 264) output-bucket counts, [512, 768) first-key cursors, [768, 776) output-bucket cursors
@@ -1479,16 +748,10 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
             if ((nib & 7) == 5) kingSq[(nib & 8) ? 0 : 1] = sq;
         }
         const uint32_t keyB = uint32_t(kingBucket(kingSq[0] ^ 56)), keyW = uint32_t(kingBucket(kingSq[1]));
-        if (p.pairMode) {  // one key per POSITION: both perspectives are gathered by the same wave
-            p.kingKeys[pos] = uint8_t(keyW * 16 + keyB);
-            atomicAdd(&sHist[keyW * 16 + keyB], 1u);
-        } else {
-            const uint32_t sub = p.phaseKeys > 1 ? outKey : 0u, kB = keyB * p.phaseKeys + sub, kW = keyW * p.phaseKeys + sub;
-            p.kingKeys[2 * pos] = uint8_t(kB);
-            p.kingKeys[2 * pos + 1] = uint8_t(kW);
-            atomicAdd(&sHist[kB], 1u);
-            atomicAdd(&sHist[kW], 1u);
-        }
+        p.kingKeys[2 * pos] = uint8_t(keyB);
+        p.kingKeys[2 * pos + 1] = uint8_t(keyW);
+        atomicAdd(&sHist[keyB], 1u);
+        atomicAdd(&sHist[keyW], 1u);
         p.outKeys[pos] = uint8_t(outKey);
         atomicAdd(&sHist[kPairKeys + outKey], 1u);
     }
@@ -1498,8 +761,7 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
     }
 }
 
-// blocks [0, nb) scatter the first key (perspectives by king key, or positions by pair key); blocks [nb, nb + nb2) scatter
-// positions by output key
+// blocks [0, nb) scatter the first key (perspectives by king key); blocks [nb, nb + nb2) scatter positions by output key
 __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uint32_t firstBlocks) {
     __shared__ uint32_t sCount[kPairKeys];
     __shared__ uint32_t sBase[kPairKeys];
@@ -1507,8 +769,8 @@ __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uin
     const bool first = blockIdx.x < firstBlocks;
     const uint32_t id = (first ? blockIdx.x : blockIdx.x - firstBlocks) * blockDim.x + threadIdx.x;
     const uint32_t nPositions = p.nPositionsPtr ? min(*p.nPositionsPtr, p.nPositions) : p.nPositions;
-    const uint32_t count = (first && !p.pairMode) ? nPositions * 2 : nPositions;
-    const uint32_t nKeys = first ? (p.pairMode ? kPairKeys : kKingKeys * p.phaseKeys) : kOutKeys;
+    const uint32_t count = first ? nPositions * 2 : nPositions;
+    const uint32_t nKeys = first ? kKingKeys : kOutKeys;
     const uint32_t histOff = first ? 0 : kHistOut, cursorOff = first ? kCursorKing : kCursorOut;
     sBase[threadIdx.x] = threadIdx.x < nKeys ? p.hist[histOff + threadIdx.x] : 0u;  // counts, turned into bases below
     __syncthreads();
@@ -1596,7 +858,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(spx_sort_small_kernel, dim3(1), dim3(1024), 0, stream, p);
         return hipGetLastError();
     }
-    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = p.outOnly ? 0u : (p.pairMode ? b1 : (2 * p.nPositions + 255) / 256);
+    const uint32_t b1 = (p.nPositions + 255) / 256, b2 = p.outOnly ? 0u : (2 * p.nPositions + 255) / 256;
     hipLaunchKernelGGL(spx_sort_hist_kernel, dim3(b1), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(spx_sort_scatter_kernel, dim3(b2 + b1), dim3(256), 0, stream, p, b2);
     return hipGetLastError();
@@ -1622,11 +884,7 @@ template <bool kSmallL2W, int kTiling>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
     constexpr bool kShareTile = kTiling == kMlpTileShared;
     __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
-#if SPX_OPT_MLP_BATCHED
     __shared__ __align__(16) int32_t sIn[4][16][kL2Full];  // L2 inputs of the tile's positions (broadcast reads); then L3 terms
-#else
-    __shared__ __align__(16) int32_t sIn[4][kL2Full];  // L2 inputs of the current position (broadcast reads)
-#endif
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
@@ -1709,7 +967,6 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     }
     __builtin_amdgcn_wave_barrier();
 
-#if SPX_OPT_MLP_BATCHED
     // The tile's positions move through the tail TOGETHER, layer by layer (round 1 took them one at a time: per position a
     // store -> barrier -> 16 broadcast reads -> 64-long multiply-add -> 6-step wave reduction, all latency, 16 times):
     //   A  lane = L1 output o: dual activation of every position's sum; L2 inputs to LDS
@@ -1782,103 +1039,14 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
             p.out[kTiling == kMlpTilePerPosition ? sortedBase : p.posOrder[sortedBase + r]] = int32_t(scaled);
         }
     }
-#else
-    for (uint32_t r = kShareTile ? wave : 0u; r < count; r += kShareTile ? 4u : 1u) {
-        const int32_t s = sSum[wave][r][o1];
-        const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
-        const int32_t ts = int32_t(t);
-        const int32_t c0 = min(max(ts, 0), 4096) << kQBits;  // CReLU side, pre-shifted for the skip connection
-        const int32_t sq = int32_t(t * t);                    // mullo wraps BEFORE the signed min
-        const int32_t c1 = min(sq, 1 << 24) >> kQBits;        // SCReLU side
-        const int32_t mine = lane < kL2 ? c0 : c1;            // l1o[lane] = [CReLU(32) | SCReLU(32)]
-        sIn[wave][lane] = mine >> kQBits;                     // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
-        __builtin_amdgcn_wave_barrier();
-        // L2: l2[o] = bias + sum_i in[i] * W2[b][i][o], wrapping i32; in[] broadcast from LDS (same address per lane)
-        // four independent partial sums: a single accumulator is a 64-long dependent multiply-add chain
-        uint32_t part[4] = {uint32_t(l2Bias), 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < int(kL2Full); i += 4) {
-            const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sIn[wave][i]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (kSmallL2W) {
-                    part[j] += uint32_t(__mul24(in4[j], w2[i + j]));
-                } else {
-                    part[j] += uint32_t(in4[j]) * uint32_t(w2[i + j]);
-                }
-            }
-        }
-        const uint32_t acc2 = (part[0] + part[1]) + (part[2] + part[3]);
-        // L3 with skip connection: (clamp(l2, 0, Q^3) + l1o) * W3, wrapping; wave-wide wrapping sum
-        const int32_t l2v = min(max(int32_t(acc2), 0), 262144);
-        uint32_t term = (uint32_t(l2v) + uint32_t(mine)) * uint32_t(l3Weight);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            term += uint32_t(__shfl_xor(int32_t(term), off, 64));
-        }
-        if (lane == 0) {
-            const int32_t l3 = int32_t(term + uint32_t(l3Bias));
-            const int64_t scaled = int64_t(l3) * kScale / (int64_t(1) << (4 * kQBits));  // truncating division
-            p.out[kTiling == kMlpTilePerPosition ? sortedBase : p.posOrder[sortedBase + r]] = int32_t(scaled);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Position-major full refresh ("one extraction per position, not per perspective"): one wavefront per
-// POSITION. The record is decoded and the attack sets are generated once; the two perspectives then build their lists and
-// gather one after the other. `order` holds position ids grouped by the PAIR of king buckets (256 keys), each XCD walking
-// one contiguous eighth, so an XCD's L2 holds one white slab and a slowly changing black slab. Evaluation mode (ftOut) only.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_pos_kernel(FtParams p) {
-    __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
-    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
-    __shared__ uint64_t sPseudo[kDeltaPseudoWords];
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
-        sLut[i] = p.t.lut[i];
-    }
-    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
-        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
-    }
-    __syncthreads();
-    const uint32_t lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t xcd = blockIdx.x & 7, blockInXcd = blockIdx.x >> 3, blocksPerXcd = gridDim.x >> 3;
-    const uint32_t sliceBegin = uint32_t(uint64_t(p.nPositions) * xcd / 8);
-    const uint32_t sliceEnd = uint32_t(uint64_t(p.nPositions) * (xcd + 1) / 8);
-    const uint32_t stride = blocksPerXcd * kWavesPerBlock;
-    for (uint32_t it = sliceBegin + blockInXcd * kWavesPerBlock + wave; it < sliceEnd; it += stride) {
-        const uint32_t posIdx = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
-        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
-        const LaneBoard board = decodeBoard(rec, lane);
-        const uint64_t targets = laneTargets(board, lane);
-#pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
-            uint32_t nPsq, nThr;
-            buildFullLists(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo, true, targets);
-            uint32_t acc[8];
-            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
-            const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
-            *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
-            __builtin_amdgcn_wave_barrier();  // the lists are rebuilt for the other perspective
-        }
-    }
-}
 
-hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream, bool cooperative) {
-    if (p.posMajor) {
-        hipLaunchKernelGGL(spx_ft_pos_kernel, dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
-    } else if (cooperative) {
-        FtParams q = p;
-        q.t.outlierTab = nullptr;  // (near-compact rows: wide rows for this variant)
-        hipLaunchKernelGGL((spx_ft_kernel<true, false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, q);
-    } else if (p.t.outlierTab) {
-        hipLaunchKernelGGL((spx_ft_kernel<false, true>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    if (p.t.outlierTab) {
+        hipLaunchKernelGGL((spx_ft_kernel<true>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((spx_ft_kernel<false, false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((spx_ft_kernel<false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
     }
     return hipGetLastError();
 }

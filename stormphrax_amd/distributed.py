@@ -63,6 +63,23 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_floats(self, x):
+        """Every rank's value of `x`, in rank order, on every rank (per-rank timings for the report: a straggler shows)."""
+        if not self.dist:
+            return [float(x)]
+        import torch
+
+        mine = self._tensor([float(x)], torch.float64)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [float(p.item()) for p in parts]
+
+    def backend_world(self):
+        """(backend name, world size) as torch.distributed reports them - what actually carries the collectives."""
+        if not self.dist:
+            return "none", 1
+        return str(self.dist.get_backend()), int(self.dist.get_world_size())
+
     def sum_int(self, x):
         if not self.dist:
             return int(x)

@@ -287,6 +287,18 @@ class NnueState:
         check(_lib.load().spx_debug_copy_ft(self._h, n, out.ctypes.data))
         return out
 
+    def gather_probe(self, d_positions_ptr, n, variant, iters=20):
+        """Load-only replay of the full refresh's row fetches (spx_debug_gather_probe). variant -1 = the product
+        feature-transformer kernel timed the same way. -> (name, ms per launch, sink checksum)."""
+        lib = _lib.load()
+        ms, sink = ctypes.c_float(0), ctypes.c_uint64(0)
+        check(lib.spx_debug_gather_probe(self._h, d_positions_ptr, n, variant, iters, ctypes.byref(ms), ctypes.byref(sink)))
+        return lib.spx_debug_gather_probe_name(variant).decode(), float(ms.value), int(sink.value)
+
+    @staticmethod
+    def gather_probe_variants():
+        return int(_lib.load().spx_debug_gather_probe_variants())
+
     def __enter__(self):
         return self
 

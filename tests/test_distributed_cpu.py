@@ -41,3 +41,19 @@ def test_two_rank_gloo_sharded_eval_matches_single_process(tmp_path, sp, oracle,
     assert np.array_equal(np.array(res["scores"], dtype=np.int32), want)
     assert res["checksum"] == int(want.astype(np.int64).sum())
     assert res["slowest"] == 2.0
+
+
+def test_bare_bench_command_spawns_its_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks itself instead of refusing.
+    On this GPU-less container the ranks then stop at the "needs a GPU" check - the spawn is what is tested here; the
+    full run is tests/test_gpu_configs.py::test_bare_bench_command_launches_its_own_ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert "launching 2 ranks" in out.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "bench.py needs a GPU" in out.stderr
+        assert "launch with torch.distributed.run" not in out.stderr

@@ -102,6 +102,23 @@ def test_two_rank_control_flow_on_one_gpu(script, tmp_path):
         assert os.path.getsize(tmp_path / "sp.0.vf") > 0 and os.path.getsize(tmp_path / "sp.1.vf") > 0
 
 
+def test_bare_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE (the shape of the driver's N = 1 command) starts its
+    two ranks itself; N > 1 defaults to device-generated positions and the score gather."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SPX_BENCH_SHARE_GPU="1", SPX_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--batch", "16384", "--no-wide", "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "launching 2 ranks" in out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["bit_exact_sample"] is True and line["config"]["gathered_scores_ok"] is True
+    assert "generated on the device" in line["config"]["workload"]
+    ranks = line["config"]["ranks"]
+    assert ranks["world"] == 2 and len(ranks["ft_kernel_ms_per_rank"]) == 2
+
+
 def test_device_group_shards_a_batch_over_its_members(sp, net_blob, oracle):
     """spx_group (the C ABI's multi-device entry): two members on this box's one GPU evaluate contiguous shards on their own
     host threads - scores identical to one context over the whole batch and to the CPU oracle, for ragged and tiny
