@@ -167,7 +167,12 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
                           const void* d_child_positions, size_t n, void* stream);
 int spx_acc_eval_device(spx_ctx* ctx, const void* d_slots, size_t n, void* d_out, void* stream);
 /* update immediately followed by evaluation of the children (== push + applyMove + evaluate, the common search step):
- * one launch fewer and no re-read of the fresh accumulators */
+ * one launch fewer and no re-read of the fresh accumulators.
+ * child_slots == NULL (every spx_acc_update_eval* entry point): EVAL-ONLY children. The children's accumulators exist in
+ * registers only, their activations go straight to the MLP and nothing is written to the arena - what the reference does
+ * for a node it evaluates and immediately unmakes (NnueState::evaluate on the top of the stack, nnue_state.cpp:598-610:
+ * no accumulator outlives the pop). A depth-1 search evaluates ~35 siblings per parent this way and then materialises
+ * only the move it plays (one ordinary spx_acc_update): 97 % of the arena writes of the materialising form disappear. */
 int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32_t* child_slots,
                         const spx_packed_pos* child_positions, size_t n, int32_t* out);
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
@@ -239,6 +244,10 @@ int spx_group_adjust(spx_group* group, const spx_packed_pos* positions, size_t n
 int spx_acc_update_eval_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                        const void* d_child_positions, const void* d_count, size_t capacity, void* d_out,
                                        void* stream);
+/* spx_acc_update_device with a device-resident record count (the self-play driver's materialising update: the seats that
+ * made a move this ply are known only on the device). */
+int spx_acc_update_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                  const void* d_child_positions, const void* d_count, size_t capacity, void* stream);
 
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
@@ -368,19 +377,24 @@ int spx_movegen_device(spx_ctx* ctx, const void* d_positions, size_t n, const vo
 int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_pos* children, int* n, int* in_check);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Batched self-play driver (BASELINE config 4 shape; control flow of src/datagen/datagen.cpp:96-318): n_games concurrent
- * games, per ply every legal move of every game is evaluated in one incremental update+eval batch (score = -eval(child),
- * i.e. a depth-1 "search" - Stormphrax's alpha-beta search is out of scope), random 8-9 ply openings, the reference's
- * adjudication counters, viriformat game records appended to out_path (NULL = discard). As in the reference the recorded
- * scores are from WHITE's point of view (Searcher::runDatagenSearch, src/search.cpp:237; clamped like datagen.cpp:283) and
- * the adjudication counters compare their WDL-normalised form (wdl::normalizeScore at the material of the position the
- * move was played from, src/search.cpp:238, src/datagen/datagen.cpp:224-252); the scores are raw network outputs.
- * Default: the games live on the GPU - legal moves and child records from spx_movegen, openings generated in bulk by the
- * same kernels, the move choice on the device, the two halves of the seats on the context's two lanes; the host keeps
- * the adjudication counters and the records (24 bytes per game and ply come back). SPX_SELFPLAY_HOST_MOVEGEN selects
- * the host chess core for moves and openings instead. Needs a context whose max_batch holds a ply's children
- * (48 * n_games is always enough; smaller contexts fall back to chunked updates); reserves n_games * 193 arena slots
- * (129 with host move generation).
+ * Batched self-play driver (BASELINE config 4 shape; the game loop of src/datagen/datagen.cpp:96-318): n_games concurrent
+ * games, per ply every legal move of every game is evaluated in one incremental batch (score = -staticEval(child), i.e. a
+ * depth-1 "search" - Stormphrax's alpha-beta search is out of scope), viriformat game records appended to out_path (NULL =
+ * discard). The reference's rules, restated once in spx_device_math.h and pinned by tests/_datagen_rules.py:
+ *   random 8-9 ply openings (datagen.cpp:146-171); the opening VERIFICATION filter (:176-190: a first search whose
+ *   normalised score exceeds +-500 discards the opening - here the first ply's own search); scores from WHITE's point of
+ *   view (search.cpp:237), leaves clamped like eval::adjustStatic; the win / loss / draw adjudication counters on the
+ *   WDL-normalised score at the material and plyFromStartpos of the position searched (search.cpp:238,
+ *   datagen.cpp:224-252); Position::isDrawn of the new position (50-move rule unless checkmate, threefold repetition,
+ *   insufficient material; position.cpp:603-667) overriding the adjudication and recording score 0 (datagen.cpp:264-268);
+ *   recorded score 0 when |score| <= 2 (:283); checkmate / stalemate (:213-221). Plus this driver's own ply cap (draw).
+ * Default: the games LIVE ON THE GPU - legal moves and child records from spx_movegen, the ~35 siblings per position
+ * evaluated WITHOUT being stored (eval-only children), one step kernel per ply doing search, bookkeeping, repetition keys,
+ * game records and the seating of new games from a device-side opening pool, one materialising update for the moves
+ * played; the two halves of the seats run on the context's two lanes and the host reads ~100 bytes of counters plus the
+ * finished games per ply. SPX_SELFPLAY_HOST_MOVEGEN selects the host chess core for moves, openings and bookkeeping (the
+ * same rules; the validation path). Needs a context whose max_batch holds a ply's children of half the seats (48 * n_games
+ * is always enough); reserves 2 * n_games + 1 arena slots (129 * n_games with host move generation).
  * Multi-GPU: games are independent - run one process per GPU with its own seed / slice of games.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_selfplay_params {
@@ -390,8 +404,8 @@ typedef struct spx_selfplay_params {
     uint32_t opening_plies;  /* random opening plies before play starts (0 = 8, plus a coin flip as datagen.cpp:153) */
     uint32_t dfrc;           /* 1 = double-Chess960 starts */
     int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
-    uint32_t host_threads;   /* host worker threads; 0 = auto: min(4 with device move generation, 16 with host move generation; usable CPUs
-                              * = cgroup quota / LOCAL_WORLD_SIZE). Phases are short: more threads only add hand-off cost */
+    uint32_t host_threads;   /* host worker threads of the HOST move generation path; 0 = auto: min(16, usable CPUs = cgroup quota /
+                              * LOCAL_WORLD_SIZE). The device-resident games need one host thread */
     uint32_t flags;          /* 0 = moves generated on the device; SPX_SELFPLAY_HOST_MOVEGEN = host chess core instead */
     uint64_t seed;
 } spx_selfplay_params;
@@ -419,6 +433,14 @@ int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, i
 /* Host evaluation of what SPX_ADJUST_WDL computes per position (same source as the kernel): Position::classicalMaterial
  * (src/position.h:515-521) of the record and wdl::normalizeScore (src/wdl.cpp:28-79) of `score` at it. Test-only. */
 int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, int32_t* normalized);
+
+/* Host evaluation of the datagen bookkeeping the device step kernel and the host self-play path share (same source):
+ * counters[3] = the game's win / loss / draw ply counters (src/datagen/datagen.cpp:197-199), advanced by one searched move
+ * with normalised white-point-of-view score `norm_score` at Position::plyFromStartpos `ply` (datagen.cpp:224-252);
+ * *outcome = 0 / 1 / 2 (white loss / draw / win) or 255 = the game goes on. *insufficient = the material part of
+ * Position::isDrawn for `pos` (src/position.cpp:639-666). Either output group may be skipped with NULL. Test-only. */
+int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
+                            const spx_packed_pos* pos, int* insufficient);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,7 @@ SYMBOLS = {
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_ctx_near_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
+    "spx_acc_update_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_ctx_synchronize": (ctypes.c_int, [_P]),
     "spx_viri_expand_gpu": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
@@ -148,6 +149,7 @@ SYMBOLS = {
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
     "spx_debug_delta": (ctypes.c_int, [_P, _P, ctypes.c_int] + [_P, ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int)]),
     "spx_debug_wdl": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "spx_debug_datagen_rules": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), _P, ctypes.POINTER(ctypes.c_int)]),
     "spx_debug_features": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.POINTER(ctypes.c_int), _P, ctypes.POINTER(ctypes.c_int)]),
 }
 

@@ -137,6 +137,10 @@ void* ctxStream(const spx_ctx* ctx) {
 size_t ctxMaxBatch(const spx_ctx* ctx) {
     return ctx->maxBatch;
 }
+
+uint8_t* ctxSlotRecords(const spx_ctx* ctx) {
+    return ctx->dSlotRecords;
+}
 }  // namespace spx
 
 namespace {
@@ -950,6 +954,10 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
                           const void* d_child_positions, size_t n, void* stream) {
     int rc = checkAcc(ctx, n, "spx_acc_update_device");
     if (rc != SPX_OK || n == 0) return rc;
+    if (!d_child_slots) {  // (only the *_eval entry points have an eval-only mode)
+        setError("spx_acc_update_device: null child slots (an update without child slots and without evaluation does nothing)");
+        return SPX_ERR_INVALID_ARG;
+    }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     UpdateParams up{};
     up.nRecords = uint32_t(n);
@@ -965,6 +973,27 @@ int spx_acc_update_device(spx_ctx* ctx, const void* d_parent_slots, const void* 
 static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                             const void* d_child_positions, size_t n, const uint32_t* d_count, void* d_out, void* stream,
                             const char* who);
+
+int spx_acc_update_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
+                                  const void* d_child_positions, const void* d_count, size_t capacity, void* stream) {
+    int rc = checkAcc(ctx, capacity, "spx_acc_update_device_counted");
+    if (rc != SPX_OK || capacity == 0) return rc;
+    if (!d_child_slots || !d_count) {
+        setError("spx_acc_update_device_counted: null child slots or count");
+        return SPX_ERR_INVALID_ARG;
+    }
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    UpdateParams up{};
+    up.nRecords = uint32_t(capacity);
+    up.nRecordsPtr = static_cast<const uint32_t*>(d_count);
+    up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
+    up.childSlots = static_cast<const uint32_t*>(d_child_slots);
+    up.childPositions = d_child_positions;
+    up.t = tablesOf(ctx);
+    up.arena = ctx->dArena;
+    up.slotRecords = ctx->dSlotRecords;
+    return launchUpdateAndRefresh(ctx, up, capacity, s);
+}
 
 // The update kernel proper, followed (second-generation kernel) by the pass that rebuilds the perspectives it deferred:
 // the feature-transformer kernel over the refresh list (ids in dPerspOrder - free until the MLP's sort - and the count in
@@ -985,7 +1014,7 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     fp.clearWord = counters + (ctx->refreshCur ^ 1);
     fp.t = up.t;
     fp.ftOut = up.ftOut;
-    fp.accOut = up.arena;
+    fp.accOut = up.childSlots ? up.arena : nullptr;  // eval-only children: rebuilt perspectives leave through ftOut alone
     fp.slots = up.childSlots;
     fp.slotRecords = up.slotRecords;
     ctx->refreshCur ^= 1;
@@ -1323,12 +1352,12 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
                         const spx_packed_pos* child_positions, size_t n, int32_t* out) {
     int rc = checkAcc(ctx, n, "spx_acc_update_eval");
     if (rc != SPX_OK || n == 0) return rc;
-    if (!parent_slots || !child_slots || !child_positions || !out) {
+    if (!parent_slots || !child_positions || !out) {  // child_slots == NULL: eval-only children (nothing is stored)
         setError("spx_acc_update_eval: null argument");
         return SPX_ERR_INVALID_ARG;
     }
     if ((rc = checkSlots(ctx, parent_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
-    if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
+    if (child_slots && (rc = checkSlots(ctx, child_slots, n, "spx_acc_update_eval")) != SPX_OK) return rc;
     SPX_HIP(hipSetDevice(ctx->device));
     if (n <= ctx->tinyBatchMax && n <= kTinyIoRecords) {
         // push + evaluate of a few nodes (the search's own step): all operands through device-mapped page-locked memory
@@ -1338,13 +1367,13 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
         uint32_t* children = parents + kTinyIoRecords;
         std::memcpy(records, child_positions, n * sizeof(spx_packed_pos));
         std::memcpy(parents, parent_slots, n * sizeof(uint32_t));
-        std::memcpy(children, child_slots, n * sizeof(uint32_t));
+        if (child_slots) std::memcpy(children, child_slots, n * sizeof(uint32_t));
         char* dBase = nullptr;
         SPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dBase), ctx->hTinyIo, 0));
         const size_t offScores = kTinyIoRecords * sizeof(spx_packed_pos), offParents = offScores + kTinyIoRecords * 4,
                      offChildren = offParents + kTinyIoRecords * 4;
-        rc = spx_acc_update_eval_device(ctx, dBase + offParents, dBase + offChildren, dBase, n, dBase + offScores,
-                                        ctx->stream);
+        rc = spx_acc_update_eval_device(ctx, dBase + offParents, child_slots ? dBase + offChildren : nullptr, dBase, n,
+                                        dBase + offScores, ctx->stream);
         if (rc != SPX_OK) return rc;
         SPX_HIP(hipStreamSynchronize(ctx->stream));
         std::memcpy(out, scores, n * sizeof(int32_t));
@@ -1353,8 +1382,9 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
     SPX_HIP(hipMemcpyAsync(ctx->dPositions, child_positions, n * sizeof(spx_packed_pos), hipMemcpyHostToDevice,
                            ctx->stream));
     SPX_HIP(hipMemcpyAsync(ctx->dSlotsA, parent_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    rc = spx_acc_update_eval_device(ctx, ctx->dSlotsA, ctx->dSlotsB, ctx->dPositions, n, ctx->dOut, ctx->stream);
+    if (child_slots) SPX_HIP(hipMemcpyAsync(ctx->dSlotsB, child_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = spx_acc_update_eval_device(ctx, ctx->dSlotsA, child_slots ? ctx->dSlotsB : nullptr, ctx->dPositions, n, ctx->dOut,
+                                    ctx->stream);
     if (rc != SPX_OK) return rc;
     SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
@@ -2413,6 +2443,22 @@ int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, i
     for (int k = 0; k < n; ++k) m += classicalMaterialOfNibble((pos->pieces[k >> 1] >> ((k & 1) * 4)) & 0xF);
     *material = m;
     *normalized = wdlNormalize(score, m);
+    return SPX_OK;
+}
+
+int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
+                            const spx_packed_pos* pos, int* insufficient) {
+    if (counters && outcome) {
+        AdjCounters c{counters[0], counters[1], counters[2]};
+        *outcome = adjudicate(c, norm_score, ply);
+        counters[0] = c.win, counters[1] = c.loss, counters[2] = c.draw;
+    }
+    if (pos && insufficient) {
+        uint64_t lo, hi;
+        std::memcpy(&lo, pos->pieces, 8);
+        std::memcpy(&hi, pos->pieces + 8, 8);
+        *insufficient = insufficientMaterial(pos->occupancy, lo, hi) ? 1 : 0;
+    }
     return SPX_OK;
 }
 

@@ -341,4 +341,70 @@ SPX_HD uint64_t recordKey(uint64_t occ, uint64_t nibLo, uint64_t nibHi, uint32_t
     return h;
 }
 
+// ---- datagen's per-ply bookkeeping (src/datagen/datagen.cpp), shared by the host self-play path and the device step
+//      kernel (spx_game_step_kernel) so both adjudicate identically ----
+// constants: datagen.cpp:82-91
+constexpr int32_t kVerificationScoreLimit = 500, kWinAdjMinScore = 1250, kDrawAdjMaxScore = 10;
+constexpr uint32_t kDrawAdjMinPlies = 70, kWinAdjPlyCount = 5, kDrawAdjPlyCount = 10;
+constexpr uint32_t kNoOutcome = 255;  // else Outcome: 0 = white loss, 1 = draw, 2 = white win (datagen/common.h:24-28)
+
+// eval::adjustStatic with contempt 0 (eval.cpp:24-27): what a search sees of a leaf is the network output clamped to
+// +-(kScoreWin - 1), so a depth-1 score is never "decisive" (core.h:722-724)
+SPX_HD int32_t clampStaticEval(int32_t v) {
+    return v < -(kScoreWin - 1) ? -(kScoreWin - 1) : (v > kScoreWin - 1 ? kScoreWin - 1 : v);
+}
+
+// Position::plyFromStartpos (position.h:511-513) of a record: its fullmove counter and side to move
+SPX_HD uint32_t plyFromStartpos(uint32_t fullmove, bool whiteToMove) {
+    return fullmove * 2u - (whiteToMove ? 1u : 0u) - 1u;
+}
+
+// The win / loss / draw counters of one game (datagen.cpp:197-199) advanced by one searched move (datagen.cpp:224-252):
+// `normScore` = wdl::normalizeScore of the white-point-of-view score at the material of the position searched,
+// `ply` = plyFromStartpos of that position. Returns the adjudicated Outcome or kNoOutcome.
+struct AdjCounters {
+    uint32_t win, loss, draw;
+};
+SPX_HD uint32_t adjudicate(AdjCounters& c, int32_t normScore, uint32_t ply) {
+    if (normScore > kWinAdjMinScore) {
+        ++c.win;
+        c.loss = c.draw = 0;
+    } else if (normScore < -kWinAdjMinScore) {
+        ++c.loss;
+        c.win = c.draw = 0;
+    } else if (ply >= kDrawAdjMinPlies && (normScore < 0 ? -normScore : normScore) < kDrawAdjMaxScore) {
+        ++c.draw;
+        c.win = c.loss = 0;
+    } else {
+        c.win = c.loss = c.draw = 0;
+    }
+    if (c.win >= kWinAdjPlyCount) return 2;
+    if (c.loss >= kWinAdjPlyCount) return 0;
+    if (c.draw >= kDrawAdjPlyCount) return 1;
+    return kNoOutcome;
+}
+
+// The material part of Position::isDrawn (position.cpp:639-666) on a record: no pawns and no rooks / queens, and then
+// KK, KNK / KBK, or one bishop each on squares of opposite colour (the reference's "KBKB OCB" test, restated as written)
+SPX_HD bool insufficientMaterial(uint64_t occ, uint64_t nibLo, uint64_t nibHi) {
+    uint64_t minors[2] = {0, 0}, bishops[2] = {0, 0};  // [black, white]
+    uint32_t idx = 0;
+    while (occ) {
+        const int sq = ctz64(occ);
+        occ &= occ - 1;
+        const uint32_t nib = uint32_t(((idx < 16 ? nibLo : nibHi) >> ((idx & 15) * 4)) & 0xF);
+        ++idx;
+        const uint32_t type = nib & 7u, side = (nib & 8u) ? 0u : 1u;
+        if (type == 0 || type == 3 || type == 4 || type == 6) return false;  // pawn, rook, queen, rook with castling right
+        if (type == 1 || type == 2) minors[side] |= 1ull << sq;
+        if (type == 2) bishops[side] |= 1ull << sq;
+    }
+    const int nb = popc64(minors[0]), nw = popc64(minors[1]);
+    if (nb + nw == 0) return true;                                   // KK
+    if ((nb == 0 && nw == 1) || (nw == 0 && nb == 1)) return true;   // KNK, KBK
+    constexpr uint64_t kLightSquares = 0x55AA55AA55AA55AAull;
+    return nb == 1 && nw == 1 && bishops[0] == minors[0] && bishops[1] == minors[1] &&
+           ((bishops[0] & kLightSquares) == 0) != ((bishops[1] & kLightSquares) == 0);
+}
+
 }  // namespace spx

@@ -22,6 +22,7 @@ namespace spx {
 size_t ctxMaxBatch(const spx_ctx* ctx);
 int ctxDevice(const spx_ctx* ctx);
 void* ctxStream(const spx_ctx* ctx);  // the context's own hipStream_t (what a NULL stream argument means)
+uint8_t* ctxSlotRecords(const spx_ctx* ctx);  // device pointer: the arena's [nSlots][32] record store (after spx_acc_reserve)
 // lanes: see spx_api.cpp (two scratch sets + streams; big kernels chained by events)
 int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream);
 void ctxLaneEnd(spx_ctx* ctx, int laneIndex);

@@ -43,7 +43,8 @@ struct UpdateParams {
     const uint32_t* nRecordsPtr;   // optional: the actual record count lives on the device (<= nRecords, which then
                                    // only sizes the grid) - lets a producer kernel feed this one without a host sync
     const uint32_t* parentSlots;   // [nRecords] materialised slots
-    const uint32_t* childSlots;    // [nRecords] slots to write (distinct from every parent of this batch)
+    const uint32_t* childSlots;    // [nRecords] slots to write (distinct from every parent of this batch); nullptr (with
+                                   // ftOut set) = eval-only children: nothing is stored in the arena
     const void* childPositions;    // spx_packed_pos[nRecords]: the boards after the move
     FtTables t;
     uint8_t* arena;                // [nSlots][kAccSlotBytes]
@@ -119,6 +120,57 @@ struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)
     int32_t temperature;            // pick uniformly among the moves within this margin of the best (0 = first best)
 };
 
+// ---- device-resident self-play (spx_game_step_kernel, spx_movegen.hip): the per-game bookkeeping of
+//      src/datagen/datagen.cpp:153-300 for every seat of one half, one wavefront per seat ----
+struct SeatState {          // one per seat
+    uint32_t plies;         // moves recorded in the current game
+    uint32_t win, loss, draw;  // adjudication counters (datagen.cpp:197-199)
+    uint32_t startPly;      // Position::plyFromStartpos of the game's initial position
+    uint32_t active;        // a game is in progress on this seat
+    uint32_t pendingFifty;  // the last move took the halfmove clock to 100: draw unless this ply finds a checkmate ...
+    uint32_t reserved;      // ... in which case the result adjudicated with that move (+ 1; 0 = none) stands
+};
+
+struct SelfplayCounters {   // one per run, device memory; a copy travels to the host after every ply
+    unsigned long long streamWords;  // 4-byte words of viriformat output written so far (ring position = mod ringWords)
+    unsigned long long games, positions, outcomes[3], discarded;
+    uint32_t started;       // games counted towards the target (begun and not discarded by the verification filter)
+    uint32_t poolCursor;    // openings taken from the pool so far
+    uint32_t poolSize;      // openings the host has published so far (ring: entry i lives at i % poolCap)
+    uint32_t reserved;
+};
+
+struct GameStepParams {
+    uint32_t nSeats;                // seats of this half; every pointer below is already offset to its first seat
+    uint32_t seatBase, nSeatsTotal; // global index of the half's first seat; G (slots: seat / G + seat, null slot 2 G)
+    const uint32_t* first;          // movegen outputs for the seats' current positions
+    const uint32_t* count;
+    const uint8_t* inCheck;
+    const int32_t* evals;           // per child (side to move of the child)
+    const uint16_t* moves;
+    const uint64_t* children;       // records as u64[4]
+    uint64_t* positions;            // [nSeats] current records
+    uint32_t* slots;                // [nSeats] accumulator slot of the current position
+    uint64_t* rng;                  // [nSeats] splitmix64 state of the game's move choice
+    SeatState* state;               // [nSeats]
+    uint64_t* initial;              // [nSeats] records the games started from
+    uint32_t* gameMoves;            // [nSeats][maxPlies] viriformat move | recorded score << 16
+    uint64_t* keys;                 // [nSeats][maxPlies] keys of the positions played through (repetition detection)
+    uint32_t maxPlies;
+    int32_t temperature;
+    uint32_t targetGames;
+    const uint64_t* poolRecords;    // [poolCap] opening records as u64[4]
+    const uint64_t* poolSeeds;      // [poolCap]
+    uint32_t poolCap;
+    SelfplayCounters* counters;
+    uint32_t* ring;                 // [ringWords] viriformat output (page-locked host memory mapped into the device)
+    uint32_t ringWords;
+    uint32_t* updParents;           // materialising update of the seats that go on: parent slot (or the null slot for a new game) ...
+    uint32_t* updChildren;          // ... child slot ...
+    uint64_t* updPositions;         // ... and the new current record, compacted; their number in *halfCounters
+    uint32_t* halfCounters;         // [0] update records, [1] seats with a game in progress after this step (zero on entry)
+};
+
 struct ViriExpandParams {          // spx_viri_expand_kernel (spx_movegen.hip)
     const uint8_t* data;            // the viriformat stream
     uint32_t nGames;
@@ -169,6 +221,7 @@ hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipS
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);
+hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream);
 // seats[k] of the self-play state receive record k, slot = seat id, RNG state k (games that start this ply)
 hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,
                            uint64_t* positions, uint32_t* slots, uint64_t* rng, hipStream_t stream);

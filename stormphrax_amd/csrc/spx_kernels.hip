@@ -140,7 +140,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
         const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
-        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+        // childSlots == nullptr: EVAL-ONLY children - the activations leave through ftOut, no accumulator and no record is
+        // stored (the reference never keeps accumulators of nodes it only evaluates, nnue_state.cpp:598-610)
+        const uint32_t childSlot = p.childSlots ? __builtin_amdgcn_readfirstlane(p.childSlots[it]) : 0u;
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
         const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
         const LaneBoard pb = decodeBoard(parentRec, lane);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
                 applyDelta<kStream>(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1],
                                     nPsqAdd, sThr[wave], nAdd + nAddCompact, sSub[wave], nSub + nSubCompact, acc);
             }
-            storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
+            if (p.childSlots) storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
             if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
                 const uint32_t half = (c == cb.stm) ? 0u : 1u;
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
         }
         if (lane < 8 && cFirst == 0) {
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
-            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            if (p.childSlots) reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
             if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
         }
     }
@@ -376,7 +378,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
-        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+        // childSlots == nullptr: EVAL-ONLY children - the activations leave through ftOut, no accumulator and no record is
+        // stored (the reference never keeps accumulators of nodes it only evaluates, nnue_state.cpp:598-610)
+        const uint32_t childSlot = p.childSlots ? __builtin_amdgcn_readfirstlane(p.childSlots[it]) : 0u;
         const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
         const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
 
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
             loadAcc(p.arena, parentSlot, c, lane, acc);
             applyWidePsqDelta(p.t, lane, sWide[wave][c][0], nws, sWide[wave][c][1], nwa, acc);
             applyU8Delta(p.t, lane, sAdd[wave][c], na, sSub[wave][c], ns, acc);
-            storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
+            if (p.childSlots) storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
             if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
                 const uint32_t half = (c == childStm) ? 0u : 1u;
                 *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
         __builtin_amdgcn_wave_barrier();  // this record's lists are dead before the next record's are written
         if (lane < 8 && cFirst == 0) {
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
-            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            if (p.childSlots) reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
             if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
         }
     }

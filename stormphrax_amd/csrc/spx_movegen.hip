@@ -443,6 +443,233 @@ __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
     if (p.results && lane == 0) p.results[g] = r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One ply of device-resident self-play for every seat of one half - the body of datagen's game loop
+// (src/datagen/datagen.cpp:153-300) with the depth-1 "search" of spx_pick_kernel, one wavefront per seat:
+//   * terminal positions: checkmate / stalemate (datagen.cpp:213-221); the 50-move rule of Position::isDrawn
+//     (position.cpp:622-633: draw unless the position is checkmate - known one ply later, hence SeatState::pendingFifty);
+//   * search: score(move) = -staticEval(child) (network output clamped like eval.cpp:24-27), uniformly among the moves
+//     within `temperature` of the best; white-point-of-view score and its wdl::normalizeScore at the material of the
+//     position searched (search.cpp:237-238);
+//   * opening verification (datagen.cpp:176-190): on a game's first ply the search doubles as the verification search - a
+//     normalised best score beyond +-500 discards the opening (not counted, nothing written) and the seat draws another;
+//   * adjudication counters (datagen.cpp:224-252, spx_device_math.h:adjudicate), key history push, the move, then
+//     Position::isDrawn of the new position - repetition (position.cpp:603-619 with ply 0: two earlier occurrences within
+//     the halfmove window), insufficient material (:639-666), plus this driver's own ply cap - which overrides an
+//     adjudicated result and records the move with score 0 (datagen.cpp:264-268); otherwise the recorded score is the
+//     white-point-of-view score, 0 when |score| <= 2 (datagen.cpp:283-284);
+//   * a finished game is written as viriformat (viriformat.cpp:28-63: 32-byte initial record with the outcome, 4 bytes per
+//     move, 4 zero bytes) straight into the output ring; its seat takes the next opening from the pool while the run's
+//     target allows;
+//   * every seat that goes on (move made / new game) appends one record to the half's materialising update: parent slot
+//     (the null slot - an empty board - for a new game, which the update kernel therefore rebuilds from scratch), child
+//     slot (the seat's other slot), new current record. The ~35 siblings of the chosen move were evaluated without ever
+//     being stored (eval-only children, spx_update_kernel with childSlots == nullptr).
+// The host sees one SelfplayCounters copy per ply and the ring: O(1) work per ply.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uniform(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+}
+
+// nWords move words: gm[0 .. nWords - 2] from the seat's buffer, the last one from a register (it may never have been stored)
+__device__ void writeGame(const GameStepParams& p, uint32_t g, uint32_t lane, const uint32_t* gm, uint32_t nWords,
+                          uint32_t lastWord, uint32_t outcome) {
+    unsigned long long base = 0;
+    if (lane == 0) {
+        SelfplayCounters* c = p.counters;
+        base = atomicAdd(&c->streamWords, static_cast<unsigned long long>(8u + nWords + 1u));
+        atomicAdd(&c->games, 1ull);
+        atomicAdd(&c->positions, static_cast<unsigned long long>(nWords));
+        atomicAdd(&c->outcomes[outcome], 1ull);
+    }
+    base = (static_cast<unsigned long long>(uniform(uint32_t(base >> 32))) << 32) | uniform(uint32_t(base));
+    const uint32_t at = uint32_t(base % p.ringWords);
+    if (lane < 8) {
+        uint32_t w = reinterpret_cast<const uint32_t*>(p.initial + size_t(g) * 4)[lane];
+        if (lane == 7) w = (w & 0xFF00FFFFu) | (outcome << 16);  // byte 30 = wdl (marlinformat.h:32-84)
+        p.ring[(at + lane) % p.ringWords] = w;
+    }
+    for (uint32_t k = lane; k <= nWords; k += 64) {  // k == nWords: the null terminator
+        const uint32_t w = k == nWords ? 0u : (k + 1 == nWords ? lastWord : gm[k]);
+        p.ring[(at + 8 + k) % p.ringWords] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
+    const uint32_t lane = laneId();
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.nSeats) return;
+    SeatState st = p.state[g];
+    uint64_t* pos = p.positions + size_t(g) * 4;
+    uint32_t* gm = p.gameMoves + size_t(g) * p.maxPlies;
+    uint64_t* keys = p.keys + size_t(g) * p.maxPlies;
+    const uint32_t seat = p.seatBase + g;
+    const uint32_t oldSlot = uniform(p.slots[g]);
+    const uint32_t otherSlot = oldSlot == seat ? p.nSeatsTotal + seat : seat;
+
+    uint32_t outcome = kNoOutcome;  // the current game ended with this outcome
+    bool discard = false;           // ... or was discarded by the verification filter
+    bool moved = false;
+    uint32_t nWords = 0, lastWord = 0;
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen child
+    if (st.active) {
+        const uint32_t count = uniform(p.count[g]);
+        const bool inCheck = uniform(p.inCheck[g]) != 0;
+        const uint64_t p0 = pos[0], p1 = pos[1], p2 = pos[2], p3 = pos[3];
+        const bool whiteToMove = !(p3 & 0x80u);
+        if (st.pendingFifty && !(count == 0 && inCheck)) {
+            outcome = 1;
+            nWords = st.plies;
+            lastWord = st.plies ? (gm[st.plies - 1] & 0xFFFFu) : 0u;  // that move led to a drawn position: score 0
+        } else if (st.pendingFifty && st.reserved) {
+            outcome = st.reserved - 1;  // checkmate on the board, so not drawn: the result adjudicated with that move stands
+            nWords = st.plies;
+            lastWord = st.plies ? gm[st.plies - 1] : 0u;
+        } else if (count == 0) {
+            outcome = inCheck ? (whiteToMove ? 0u : 2u) : 1u;
+            nWords = st.plies;
+            lastWord = st.plies ? gm[st.plies - 1] : 0u;
+        } else {
+            const uint32_t lo = uniform(p.first[g]);
+            int32_t best = INT32_MIN;
+            for (uint32_t k = lane; k < count; k += 64) best = max(best, clampStaticEval(-p.evals[lo + k]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+            uint32_t nCandidates = 0;
+            for (uint32_t base = 0; base < count; base += 64) {
+                const uint32_t k = base + lane;
+                const bool cand = k < count && clampStaticEval(-p.evals[lo + k]) >= best - p.temperature;
+                nCandidates += uint32_t(popc64(__ballot(cand)));
+            }
+            const uint64_t rngState = p.rng[g] + 0x9E3779B97F4A7C15ull;
+            uint64_t z = rngState;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            uint32_t target = p.temperature == 0 ? 0u : uint32_t(z >> 32) % nCandidates;
+            uint32_t pick = 0;
+            for (uint32_t base = 0; base < count; base += 64) {
+                const uint32_t k = base + lane;
+                const bool cand = k < count && clampStaticEval(-p.evals[lo + k]) >= best - p.temperature;
+                const uint64_t mask = __ballot(cand);
+                const uint32_t here = uint32_t(popc64(mask));
+                if (target < here) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+                    pick = base + uint32_t(ctz64(__ballot(cand && rank == target)));
+                    break;
+                }
+                target -= here;
+            }
+            const uint32_t c = lo + pick;
+            const uint64_t* child = p.children + size_t(c) * 4;
+            c0 = child[0], c1 = child[1], c2 = child[2], c3 = child[3];
+            // Position::classicalMaterial of the position searched (lane k sums nibble k)
+            int32_t material = 0;
+            {
+                const uint32_t pieces = min(uint32_t(popc64(p0)), 32u);
+                if (lane < pieces) material = classicalMaterialOfNibble(int(((lane < 16 ? p1 : p2) >> ((lane & 15) * 4)) & 0xF));
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) material += __shfl_xor(material, off, 64);
+            }
+            const int32_t score = clampStaticEval(-p.evals[c]);
+            const int32_t whiteScore = whiteToMove ? score : -score;
+            const int32_t normScore = wdlNormalize(whiteScore, material);
+            const int32_t normBest = wdlNormalize(whiteToMove ? best : -best, material);
+            if (st.plies == 0 && (normBest > kVerificationScoreLimit || normBest < -kVerificationScoreLimit)) {
+                discard = true;
+            } else {
+                AdjCounters adj{st.win, st.loss, st.draw};
+                outcome = adjudicate(adj, normScore, st.startPly + st.plies);
+                st.win = adj.win, st.loss = adj.loss, st.draw = adj.draw;
+                const uint64_t newKey = recordKey(c0, c1, c2, uint32_t(c3));
+                const uint32_t halfmove = uint32_t((c3 >> 8) & 0xFFu);
+                // key history: the position searched is pushed, then the new position is looked for (isDrawnByRepetition, ply 0)
+                const uint32_t size = st.plies + 1;
+                if (lane == 0) keys[st.plies] = recordKey(p0, p1, p2, uint32_t(p3));
+                const int32_t limit = max(0, int32_t(size) - int32_t(halfmove) - 2);
+                const int32_t i = int32_t(size) - 4 - 2 * int32_t(lane);
+                const bool hit = i >= limit && keys[i] == newKey;
+                const bool repetition = popc64(__ballot(hit)) >= 2;
+                // halfmove clock at 100: Position::isDrawn looks at nothing else (position.cpp:622-633) and the answer - a
+                // draw unless checkmate - needs the next move generation: the seat goes on for one ply (pendingFifty) with
+                // the adjudicated result, if any, parked in `reserved`
+                const bool fifty = halfmove >= 100;
+                const bool capped = st.plies + 1 >= p.maxPlies;
+                const bool drawn = capped || (!fifty && (repetition || insufficientMaterial(c0, c1, c2)));
+                if (drawn) outcome = 1;
+                const int32_t recorded = drawn ? 0 : (whiteScore >= -2 && whiteScore <= 2 ? 0 : whiteScore);
+                lastWord = uint32_t(p.moves[c]) | (uint32_t(uint16_t(int16_t(recorded))) << 16);
+                nWords = st.plies + 1;
+                st.pendingFifty = 0;
+                st.reserved = 0;
+                if (fifty && !drawn) {
+                    st.pendingFifty = 1;
+                    st.reserved = outcome == kNoOutcome ? 0u : outcome + 1;
+                    outcome = kNoOutcome;
+                }
+                if (outcome == kNoOutcome) {
+                    moved = true;
+                    if (lane == 0) {
+                        gm[st.plies] = lastWord;
+                        p.rng[g] = rngState;
+                    }
+                    st.plies += 1;
+                }
+            }
+        }
+    }
+
+    if (outcome != kNoOutcome) writeGame(p, g, lane, gm, nWords, lastWord, outcome);
+    bool started = false;
+    uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, seed = 0;
+    if (!st.active || outcome != kNoOutcome || discard) {
+        // the seat is free: take the next opening while the run's target allows. A discarded game hands its ticket on; the
+        // host keeps the pool ahead of every claim a step can make (spx_selfplay.cpp), so a claim beyond it only idles the seat.
+        uint32_t claim = 0xFFFFFFFFu;
+        if (lane == 0) {
+            SelfplayCounters* c = p.counters;
+            if (discard) atomicAdd(&c->discarded, 1ull);
+            const bool ticket = discard || atomicAdd(&c->started, 1u) < p.targetGames;
+            if (ticket) {
+                const uint32_t k = atomicAdd(&c->poolCursor, 1u);
+                if (k < *reinterpret_cast<volatile uint32_t*>(&c->poolSize)) claim = k;
+            }
+        }
+        claim = uniform(claim);
+        st = SeatState{};
+        if (claim != 0xFFFFFFFFu) {
+            const uint64_t* rec = p.poolRecords + size_t(claim % p.poolCap) * 4;
+            r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            seed = p.poolSeeds[claim % p.poolCap];
+            started = true;
+            st.active = 1;
+            st.startPly = plyFromStartpos(uint32_t((r3 >> 16) & 0xFFFFu), !(r3 & 0x80u));
+        }
+    }
+    if (lane == 0) p.state[g] = st;
+    if (started || moved) {
+        const uint64_t n0 = started ? r0 : c0, n1 = started ? r1 : c1, n2 = started ? r2 : c2, n3 = started ? r3 : c3;
+        uint32_t idx = 0;
+        if (lane == 0) {
+            idx = atomicAdd(&p.halfCounters[0], 1u);
+            atomicAdd(&p.halfCounters[1], 1u);
+            p.updParents[idx] = started ? 2u * p.nSeatsTotal : oldSlot;
+            p.updChildren[idx] = otherSlot;
+            p.slots[g] = otherSlot;
+            if (started) p.rng[g] = seed;
+        }
+        idx = uniform(idx);
+        if (lane < 4) {
+            const uint64_t w = lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3));
+            pos[lane] = w;
+            p.updPositions[size_t(idx) * 4 + lane] = w;
+            if (started) p.initial[size_t(g) * 4 + lane] = w;
+        }
+    } else if (lane < 4) {
+        pos[lane] = 0;  // idle seat: an empty record generates no moves
+    }
+}
+
 __global__ __launch_bounds__(256) void spx_seat_games_kernel(uint32_t n, const uint32_t* seats, const uint64_t* records,
                                                              const uint64_t* rngStates, uint64_t* positions,
                                                              uint32_t* slots, uint64_t* rng) {
@@ -554,6 +781,11 @@ __global__ __launch_bounds__(256) void spx_viri_expand_kernel(ViriExpandParams p
 
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_viri_expand_kernel, dim3((p.nGames + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_game_step_kernel, dim3((p.nSeats + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ namespace spx {
 
 namespace {
 
-constexpr uint32_t kListStride = 328;  // words per perspective: [0] nThr, [1] nPsq, [4 .. 292) u8 rows, [292 .. 324) i16 rows
+constexpr uint32_t kListStride = 328;  // words per perspective: [0] nThr, [1] nPsq, [2] perspective id, [4 .. 292) u8 rows, [292 .. 324) i16 rows
 constexpr uint32_t kListThr = 4, kListPsq = 4 + kU8Cap;
 
 // the product kernel's traversal (spx_ft_kernel): perspective order dealt to the XCDs in round-robin chunks
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         if (lane == 0) {
             out[0] = nThr;
             out[1] = nPsq;
+            out[2] = q;  // the sort's order within a bucket varies from run to run: results are stored by perspective id
         }
         for (uint32_t i = lane; i < nThr; i += 64) out[kListThr + i] = sThr[wave][i];
         if (lane < nPsq) out[kListPsq + lane] = sPsq[wave][lane];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kWaves) void spx_probe_gather_
         if (it >= nPersp) continue;
         const uint32_t* in = p.lists + size_t(it) * kListStride;
         const uint32_t nThr = __builtin_amdgcn_readfirstlane(in[0]), nPsq = __builtin_amdgcn_readfirstlane(in[1]);
+        const uint32_t q = __builtin_amdgcn_readfirstlane(in[2]);
 #pragma unroll 1
         for (uint32_t i = lane; i < nThr; i += 64) sThr[wave][i] = in[kListThr + i];
         if (lane < nPsq) sPsq[wave][lane] = in[kListPsq + lane];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kWaves) void spx_probe_gather_
         u32x2 o;
         o[0] = x[0] ^ x[2];
         o[1] = x[1] ^ x[3];
-        *reinterpret_cast<u32x2*>(p.sink + size_t(it) * 512 + 8 * lane) = o;
+        *reinterpret_cast<u32x2*>(p.sink + size_t(q) * 512 + 8 * lane) = o;
         __builtin_amdgcn_wave_barrier();
     }
 }

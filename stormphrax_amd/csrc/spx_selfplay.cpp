@@ -39,9 +39,7 @@ namespace spx {
 
 namespace {
 
-// adjudication constants of the reference (datagen.cpp:78-88); scores here are raw network outputs
-constexpr int kWinAdjMinScore = 1250, kDrawAdjMaxScore = 10;
-constexpr uint32_t kDrawAdjMinPlies = 70, kWinAdjPlyCount = 5, kDrawAdjPlyCount = 10;
+// (adjudication constants and the counter ladder of datagen.cpp:78-88,224-252: spx_device_math.h, shared with the device)
 
 struct Rng {
     uint64_t s;
@@ -103,6 +101,8 @@ struct Game {
     std::vector<Move> legal;
     size_t firstChild = 0;
     uint8_t outcome = 255;   // set by a worker when the game ended this step (255 = still running)
+    bool discard = false;    // the opening failed the verification filter (datagen.cpp:176-190)
+    uint32_t startPly = 0;   // Position::plyFromStartpos of the initial position
     bool needsFix = false;   // the chosen child's scratch slot was recycled: re-materialise into the home slot
     spx_packed_pos fixPos;
 };
@@ -122,6 +122,8 @@ void startGame(Game& g, Rng& rng, bool dfrc, uint32_t baseOpeningPlies) {
         if (!dead && !moves.empty()) break;
     }
     packBoard(g.board, g.initial);
+    g.startPly = plyFromStartpos(g.initial.fullmove, g.board.stm == 1);
+    g.discard = false;
     g.moves.clear();
     g.scores.clear();
     g.history.clear();
@@ -410,19 +412,19 @@ static int runHostMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char
         forGames(h, [&](Game& g, uint32_t i) {
             if (!g.active || g.legal.empty()) return;
             const int32_t* evals = h.evals.data() + g.firstChild;
+            // the leaves as a search sees them: network output clamped like eval::adjustStatic (eval.cpp:24-27)
             int best = INT32_MIN;
-            for (size_t k = 0; k < g.legal.size(); ++k) best = std::max(best, -evals[k]);
+            for (size_t k = 0; k < g.legal.size(); ++k) best = std::max(best, clampStaticEval(-evals[k]));
             // exploration: uniformly among the moves within temperature_cp of the best (0 = greedy, first best)
             size_t pick = 0, seen = 0;
             for (size_t k = 0; k < g.legal.size(); ++k) {
-                if (-evals[k] >= best - p->temperature_cp) {
+                if (clampStaticEval(-evals[k]) >= best - p->temperature_cp) {
                     ++seen;
                     if (g.rng.below(uint32_t(seen)) == 0) pick = k;
                     if (p->temperature_cp == 0) break;
                 }
             }
-            const int score = -evals[pick];
-            g.moves.push_back(viriMove(g.legal[pick]));
+            const int score = clampStaticEval(-evals[pick]);
             // white-point-of-view score (what the reference records) and its WDL-normalised form (what its adjudication
             // counters compare): search.cpp:237-238, datagen.cpp:224-252,283-284
             const int whiteScore = g.board.stm ? score : -score;
@@ -432,27 +434,42 @@ static int runHostMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char
                 if (g.board.mailbox[sq] != kNoPiece) material += kValue[g.board.mailbox[sq] >> 1];
             }
             const int normScore = wdlNormalize(whiteScore, material);
-            g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(whiteScore) <= 2 ? 0 : whiteScore))));
-            uint8_t outcome = 255;
-            if (normScore > kWinAdjMinScore) {
-                ++g.winPlies;
-                g.lossPlies = g.drawPlies = 0;
-            } else if (normScore < -kWinAdjMinScore) {
-                ++g.lossPlies;
-                g.winPlies = g.drawPlies = 0;
-            } else if (g.plies >= kDrawAdjMinPlies && std::abs(normScore) < kDrawAdjMaxScore) {
-                ++g.drawPlies;
-                g.winPlies = g.lossPlies = 0;
-            } else {
-                g.winPlies = g.lossPlies = g.drawPlies = 0;
+            if (g.plies == 0) {  // opening verification (datagen.cpp:176-190): this search doubles as the verification search
+                const int normBest = wdlNormalize(g.board.stm ? best : -best, material);
+                if (std::abs(normBest) > kVerificationScoreLimit) {
+                    g.discard = true;
+                    return;
+                }
             }
-            if (g.winPlies >= kWinAdjPlyCount) outcome = 2;
-            else if (g.lossPlies >= kWinAdjPlyCount) outcome = 0;
-            else if (g.drawPlies >= kDrawAdjPlyCount) outcome = 1;
+            AdjCounters adj{g.winPlies, g.lossPlies, g.drawPlies};
+            uint32_t outcome = adjudicate(adj, normScore, g.startPly + g.plies);
+            g.winPlies = adj.win, g.lossPlies = adj.loss, g.drawPlies = adj.draw;
 
             g.history.push_back(boardHash(g.board));
             makeMove(g.board, g.legal[pick]);
             ++g.plies;
+            // Position::isDrawn of the new position (position.cpp:621-667; datagen.cpp:264-268): it overrides an
+            // adjudicated result and the move is recorded with score 0
+            bool drawn = g.plies >= p->max_plies;  // (this driver's own ply cap)
+            if (g.board.halfmove >= 100) {  // 50-move rule, and nothing else is looked at: a draw unless checkmate
+                std::vector<Move> replies;
+                generateLegal(g.board, replies);
+                drawn = drawn || !(g.board.inCheck() && replies.empty());
+            } else if (!drawn) {
+                const uint64_t hash = boardHash(g.board);
+                drawn = std::count(g.history.begin(), g.history.end(), hash) >= 2;
+                if (!drawn) {
+                    spx_packed_pos rec;
+                    packBoard(g.board, rec);
+                    uint64_t lo, hi;
+                    std::memcpy(&lo, rec.pieces, 8);
+                    std::memcpy(&hi, rec.pieces + 8, 8);
+                    drawn = insufficientMaterial(rec.occupancy, lo, hi);
+                }
+            }
+            if (drawn) outcome = 1;
+            g.moves.push_back(viriMove(g.legal[pick]));
+            g.scores.push_back(int16_t(drawn || std::abs(whiteScore) <= 2 ? 0 : whiteScore));
             const size_t idx = g.firstChild + pick;
             if (h.slotValid[idx]) {
                 g.slot = h.children[idx];
@@ -461,18 +478,17 @@ static int runHostMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char
                 g.fixPos = h.childPos[idx];
                 g.slot = i;  // the game's home slot
             }
-            // draws: 50-move rule, threefold repetition, ply cap (Position::isDrawn analogue, datagen.cpp:264-268)
-            const uint64_t hash = boardHash(g.board);
-            const size_t reps = size_t(std::count(g.history.begin(), g.history.end(), hash));
-            if (outcome == 255 && (g.board.halfmove >= 100 || reps >= 2 || g.plies >= p->max_plies)) outcome = 1;
-            g.outcome = outcome;
+            g.outcome = uint8_t(outcome);
         });
         refreshSlots.clear();
         refreshPos.clear();
         for (uint32_t i = h.begin; i < h.end; ++i) {
             Game& g = games[i];
             if (!g.active) continue;
-            if (g.outcome != 255) {
+            if (g.discard) {  // the verification filter dropped this opening: not counted, nothing written
+                g.active = g.discard = false;
+                --started;
+            } else if (g.outcome != 255) {
                 finishGame(g, g.outcome);
             } else if (g.needsFix) {  // through the record alone (full refresh of the home slot)
                 refreshSlots.push_back(i);
@@ -549,26 +565,6 @@ struct PinnedBuffers {
         return static_cast<T*>(q);
     }
 };
-
-struct DeviceGame {
-    spx_packed_pos initial;
-    std::vector<uint16_t> moves;
-    std::vector<int16_t> scores;
-    std::vector<uint64_t> history;  // keys of the positions played through
-    uint64_t key = 0;               // key of the current position
-    uint32_t winPlies = 0, lossPlies = 0, drawPlies = 0, plies = 0;
-    uint8_t stm = 1;
-    bool active = false;
-    bool blank = true;              // the seat's device record is empty (generates no moves)
-    uint8_t outcome = 255;
-};
-
-uint64_t keyOfRecord(const spx_packed_pos& r) {
-    uint64_t lo, hi;
-    std::memcpy(&lo, r.pieces, 8);
-    std::memcpy(&hi, r.pieces + 8, 8);
-    return recordKey(r.occupancy, lo, hi, r.stm_ep);
-}
 
 #define SPX_SP_HIP(call)                                                                      \
     do {                                                                                      \
@@ -801,44 +797,46 @@ extern "C" int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t coun
 
 namespace {
 
-// One half of the seats: its own child buffers and scratch-slot regions. The halves alternate so that the host's
-// bookkeeping for one half runs while the GPU evaluates the children of the other.
+// One half of the seats: its own child buffers, update list and status mirror. The two halves run on the context's two
+// lanes and are both kept in flight: the small kernels of one half's ply overlap the other half's update kernel.
+struct HalfStatus {              // what the host reads back per ply (page-locked)
+    SelfplayCounters counters;   // run-wide counters as of the end of this half's step kernel
+    uint32_t total;              // children generated this ply (must fit `cap`)
+    uint32_t half[2];            // update records, seats with a game in progress
+};
+
 struct DeviceHalf {
     uint32_t begin = 0, end = 0;     // seats
     size_t cap = 0;                  // children per ply
-    uint32_t slotBase = 0;           // first scratch slot; two regions of cap, alternating per ply
-    uint32_t step = 0;
     uint64_t* dChildren = nullptr;
     uint16_t* dMoves = nullptr;
     uint32_t* dParents = nullptr;
     int32_t* dEvals = nullptr;
-    uint32_t* dChildSlots = nullptr; // [2][cap] slot ids
     uint32_t* dTotal = nullptr;
-    uint32_t* hTotal = nullptr;      // pinned
-    PickResult* hResults = nullptr;  // pinned, [end - begin]
-    // staging for games that start this ply (pinned host + device)
-    uint32_t* hSeats = nullptr;
-    spx_packed_pos* hRecords = nullptr;
-    uint64_t* hRng = nullptr;
-    uint32_t* dSeats = nullptr;
-    uint64_t* dRecords = nullptr;
-    uint64_t* dRngNew = nullptr;
-    hipEvent_t done = nullptr;       // recorded after the ply's results are on their way to the host
-    bool inFlight = false;
+    uint32_t *dUpdParents = nullptr, *dUpdChildren = nullptr, *dHalfCounters = nullptr;
+    uint64_t* dUpdPositions = nullptr;
+    HalfStatus* hStatus = nullptr;   // pinned
+    hipEvent_t done = nullptr;
+    bool inFlight = false, everRan = false;
     uint32_t index = 0;              // which lane of the context this half runs on
 };
 
-int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
+// The games live on the device: per ply and half the host enqueues one fixed chain of launches, waits for its event and
+// reads 100 bytes of counters plus whatever finished games the step kernel wrote into the output ring - O(1) host work per
+// ply, whatever the number of seats (round 2 kept counters, repetition keys and the records on the host: 24 bytes and a
+// few hundred instructions per game and ply, and the GPU idled half of the wall time at 4 096 games).
+int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
     const uint32_t G = p->n_games;
     const uint32_t nHalves = G >= 2 ? 2 : 1;
-    const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
-    if (size_t(G) * (1 + 2 * perSeat) > 0xFFFFFFFFull) {
+    const uint32_t maxPlies = std::max(8u, std::min(p->max_plies ? p->max_plies : 300u, 4096u));
+    if (uint64_t(G) * 2 + 1 > 0x7FFFFFFFull) {
         setError("spx_selfplay_run: too many games for 32-bit slot ids");
         return SPX_ERR_INVALID_ARG;
     }
-    int rc = spx_acc_reserve(ctx, size_t(G) * (1 + 2 * perSeat));
+    int rc = spx_acc_reserve(ctx, size_t(G) * 2 + 1);  // two slots per seat (current / next position) + the null slot
     if (rc != SPX_OK) return rc;
     SPX_SP_HIP(hipSetDevice(ctxDevice(ctx)));
+    SPX_SP_HIP(hipMemset(ctxSlotRecords(ctx) + size_t(G) * 2 * 32, 0, 32));  // the null slot holds the empty board
     FILE* out = nullptr;
     if (out_path && out_path[0]) {
         out = std::fopen(out_path, "wb");
@@ -855,6 +853,9 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     } closer{out};
     std::memset(stats, 0, sizeof(*stats));
 
+    const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
+    const uint32_t poolCap = 4 * G + 32768;
+    const uint32_t ringWords = uint32_t(std::max<uint64_t>(1u << 20, uint64_t(G) * 2 * (maxPlies + 9)));
     DeviceBuffers dev;
     PinnedBuffers pinned;
     auto* dPositions = dev.get<uint64_t>(size_t(G) * 4);
@@ -863,38 +864,52 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
     auto* dFirst = dev.get<uint32_t>(G);
     auto* dCount = dev.get<uint32_t>(G);
     auto* dInCheck = dev.get<uint8_t>(G);
-    auto* dResults = dev.get<PickResult>(G);
-    bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dResults;
+    auto* dState = dev.get<SeatState>(G);
+    auto* dInitial = dev.get<uint64_t>(size_t(G) * 4);
+    auto* dGameMoves = dev.get<uint32_t>(size_t(G) * maxPlies);
+    auto* dKeys = dev.get<uint64_t>(size_t(G) * maxPlies);
+    auto* dPoolRecords = dev.get<uint64_t>(size_t(poolCap) * 4);
+    auto* dPoolSeeds = dev.get<uint64_t>(poolCap);
+    auto* dCounters = dev.get<SelfplayCounters>(1);
+    auto* hPoolRecords = pinned.get<spx_packed_pos>(16384);
+    auto* hPoolSeeds = pinned.get<uint64_t>(16384);
+    auto* hPoolSize = pinned.get<uint32_t>(1);
+    // the output ring: page-locked host memory the step kernel writes through its device mapping
+    uint32_t* hRing = nullptr;
+    uint32_t* dRing = nullptr;
+    struct RingCloser {
+        uint32_t*& r;
+        ~RingCloser() {
+            if (r) (void)hipHostFree(r);
+        }
+    } ringCloser{hRing};
+    bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dState && dInitial && dGameMoves && dKeys &&
+              dPoolRecords && dPoolSeeds && dCounters && hPoolRecords && hPoolSeeds && hPoolSize &&
+              hipHostMalloc(reinterpret_cast<void**>(&hRing), size_t(ringWords) * 4, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&dRing), hRing, 0) == hipSuccess;
     std::vector<DeviceHalf> halves(nHalves);
-    uint32_t nextSlot = G;
     for (uint32_t h = 0; h < nHalves && ok; ++h) {
         DeviceHalf& hf = halves[h];
         hf.index = h;
         hf.begin = uint32_t(uint64_t(G) * h / nHalves);
         hf.end = uint32_t(uint64_t(G) * (h + 1) / nHalves);
         const uint32_t seats = hf.end - hf.begin;
-        hf.cap = size_t(seats) * perSeat;
-        hf.slotBase = nextSlot;
-        nextSlot += uint32_t(2 * hf.cap);
+        hf.cap = std::min(size_t(seats) * perSeat, ctxMaxBatch(ctx));
         hf.dChildren = dev.get<uint64_t>(hf.cap * 4);
         hf.dMoves = dev.get<uint16_t>(hf.cap);
         hf.dParents = dev.get<uint32_t>(hf.cap);
         hf.dEvals = dev.get<int32_t>(hf.cap);
-        hf.dChildSlots = dev.get<uint32_t>(2 * hf.cap);
         hf.dTotal = dev.get<uint32_t>(1);
-        hf.dSeats = dev.get<uint32_t>(seats);
-        hf.dRecords = dev.get<uint64_t>(size_t(seats) * 4);
-        hf.dRngNew = dev.get<uint64_t>(seats);
-        hf.hTotal = pinned.get<uint32_t>(1);
-        hf.hResults = pinned.get<PickResult>(seats);
-        hf.hSeats = pinned.get<uint32_t>(seats);
-        hf.hRecords = pinned.get<spx_packed_pos>(seats);
-        hf.hRng = pinned.get<uint64_t>(seats);
-        ok = hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dChildSlots && hf.dTotal && hf.dSeats &&
-             hf.dRecords && hf.dRngNew && hf.hTotal && hf.hResults && hf.hSeats && hf.hRecords && hf.hRng;
+        hf.dUpdParents = dev.get<uint32_t>(seats);
+        hf.dUpdChildren = dev.get<uint32_t>(seats);
+        hf.dUpdPositions = dev.get<uint64_t>(size_t(seats) * 4);
+        hf.dHalfCounters = dev.get<uint32_t>(2);
+        hf.hStatus = pinned.get<HalfStatus>(1);
+        ok = hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
+             hf.dUpdPositions && hf.dHalfCounters && hf.hStatus && seats <= ctxMaxBatch(ctx);
     }
     if (!ok) {
-        setError("spx_selfplay_run: out of device or page-locked memory");
+        setError("spx_selfplay_run: out of device or page-locked memory (or a context smaller than half the seats)");
         return SPX_ERR_HIP;
     }
     hipStream_t stream;
@@ -914,53 +929,59 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
             }
         }
     } eventCloser{halves};
-    for (DeviceHalf& hf : halves) {
-        SPX_SP_HIP(hipEventCreateWithFlags(&hf.done, hipEventDisableTiming));
-        std::vector<uint32_t> iota(2 * hf.cap);
-        for (size_t k = 0; k < iota.size(); ++k) iota[k] = uint32_t(hf.slotBase + k);
-        SPX_SP_HIP(hipMemcpy(hf.dChildSlots, iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
+    for (DeviceHalf& hf : halves) SPX_SP_HIP(hipEventCreateWithFlags(&hf.done, hipEventDisableTiming));
+    {
+        std::vector<uint32_t> iota(G);
+        for (uint32_t i = 0; i < G; ++i) iota[i] = i;  // every seat starts on its home slot
+        SPX_SP_HIP(hipMemcpy(dSlots, iota.data(), size_t(G) * 4, hipMemcpyHostToDevice));
     }
     SPX_SP_HIP(hipMemset(dPositions, 0, size_t(G) * 32));  // empty records generate no moves
+    SPX_SP_HIP(hipMemset(dState, 0, size_t(G) * sizeof(SeatState)));
+    SPX_SP_HIP(hipMemset(dRng, 0, size_t(G) * 8));
+    SPX_SP_HIP(hipMemset(dCounters, 0, sizeof(SelfplayCounters)));
+    SPX_SP_HIP(hipDeviceSynchronize());
 
     Rng rng{p->seed};
-    std::vector<DeviceGame> games(G);
-    // the host only keeps records and adjudication counters here: a few workers are plenty
-    Pool pool(std::max(1u, std::min(p->host_threads ? p->host_threads : std::min(4u, usableCpus()), G)));
     OpeningPool openings(ctx, stream, p->dfrc != 0, p->opening_plies ? p->opening_plies : 8);
-    std::vector<uint8_t> retire;
     const auto t0 = std::chrono::steady_clock::now();
-    double gpuWait = 0.0;
-    uint64_t started = 0;
+    double gpuWait = 0.0, enqueueSeconds = 0.0;
+    SelfplayCounters latest{};       // newest counters seen
+    uint64_t consumedWords = 0;      // ring words already written to the file
+    uint32_t published = 0;          // openings handed to the device so far
+    uint64_t evals = 0, steps = 0;
 
-    auto finishGame = [&](DeviceGame& g, uint8_t outcome) {
-        g.initial.wdl = outcome;
-        if (out) {
-            std::fwrite(&g.initial, sizeof(g.initial), 1, out);
-            for (size_t i = 0; i < g.moves.size(); ++i) {
-                std::fwrite(&g.moves[i], 2, 1, out);
-                std::fwrite(&g.scores[i], 2, 1, out);
+    // Openings: generated in bulk on the device (OpeningPool), published to the device-side ring ahead of every claim the
+    // step kernels in flight can make: a step claims at most one opening per seat, two steps may have run since the
+    // counters were last seen.
+    auto ensurePool = [&](hipStream_t s) -> int {
+        const uint32_t want = 2 * G + G / 2 + 64;
+        while (published - latest.poolCursor < want) {
+            const uint32_t room = poolCap - (published - latest.poolCursor);
+            const uint32_t n = std::min<uint32_t>({16384u, room, want + G - (published - latest.poolCursor)});
+            if (n == 0) break;
+            if (openings.available() < n) {
+                const int r = openings.refill(n, rng);
+                if (r != SPX_OK) return r;
             }
-            const uint32_t zero = 0;
-            std::fwrite(&zero, 4, 1, out);
+            for (uint32_t k = 0; k < n; ++k) openings.pop(hPoolRecords[k], hPoolSeeds[k]);
+            for (uint32_t k = 0; k < n;) {  // ring: at most two contiguous pieces
+                const uint32_t at = (published + k) % poolCap, m = std::min(n - k, poolCap - at);
+                SPX_SP_HIP(hipMemcpyAsync(dPoolRecords + size_t(at) * 4, hPoolRecords + k, size_t(m) * 32, hipMemcpyHostToDevice, s));
+                SPX_SP_HIP(hipMemcpyAsync(dPoolSeeds + at, hPoolSeeds + k, size_t(m) * 8, hipMemcpyHostToDevice, s));
+                k += m;
+            }
+            published += n;
+            *hPoolSize = published;
+            SPX_SP_HIP(hipMemcpyAsync(&dCounters->poolSize, hPoolSize, 4, hipMemcpyHostToDevice, s));
+            SPX_SP_HIP(hipStreamSynchronize(s));  // the staging buffers are reused (a refill happens every few dozen plies)
         }
-        stats->games += 1;
-        stats->positions += g.moves.size();
-        stats->outcomes[outcome] += 1;
-        g.active = false;
-        g.outcome = 255;
+        return SPX_OK;
     };
 
-    // With the whole ply's children fitting the context's batch capacity the chain below needs no host round trip: the
-    // update reads its record count on the device (spx_acc_update_eval_device_counted). Otherwise the count is fetched
-    // and the update is issued in chunks.
-    const bool counted = halves[0].cap <= ctxMaxBatch(ctx) && halves[nHalves - 1].cap <= ctxMaxBatch(ctx);
-
-    // One ply of a half, enqueued back to back: (re)start games in its idle seats (openings from the device-generated
-    // pool, one RNG stream per game; NnueState::reset of their accumulators), move generation, fused update+eval of the
-    // children, move choice, and the per-game results on their way back. Ends with the half's event.
+    // One ply of a half, enqueued back to back on its lane: move generation, eval-only update + evaluation of the
+    // children, the step kernel (search, bookkeeping, game records, new games), the materialising update of the seats
+    // that go on, and the counters on their way back. Ends with the half's event.
     auto enqueuePly = [&](DeviceHalf& hf) -> int {
-        // everything of this half runs on its own lane of the context (scratch set + stream): the small kernels of one
-        // half's chain overlap the other half's update kernel, the update kernels themselves are chained
         void* laneStream = nullptr;
         int lr = ctxLaneBegin(ctx, int(hf.index), &laneStream);
         if (lr != SPX_OK) return lr;
@@ -971,180 +992,102 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
                 ctxLaneEnd(c, i);
             }
         } laneGuard{ctx, int(hf.index)};
-        hipStream_t stream = static_cast<hipStream_t>(laneStream);  // shadows the driver's own stream inside this ply
-        uint32_t n = 0, fresh = 0;
-        retire.clear();
-        for (uint32_t i = hf.begin; i < hf.end; ++i) {
-            DeviceGame& g = games[i];
-            if (g.active) continue;
-            if (started < p->target_games) {
-                ++started;
-                ++fresh;
-                hf.hSeats[n++] = i;
-                retire.push_back(0);
-            } else if (!g.blank) {  // no successor for this seat: blank its record so that it stops generating children
-                g.blank = true;
-                hf.hSeats[n++] = i;
-                retire.push_back(1);
-            }
-        }
-        if (n) {
-            if (openings.available() < fresh) {
-                const size_t ahead = std::min<size_t>(p->target_games - started, 16384);
-                const int r = openings.refill(fresh + ahead, rng);
-                if (r != SPX_OK) return r;
-            }
-            for (uint32_t k = 0; k < n; ++k) {
-                DeviceGame& g = games[hf.hSeats[k]];
-                if (retire[k]) {
-                    std::memset(&hf.hRecords[k], 0, sizeof(spx_packed_pos));
-                    hf.hRng[k] = 0;
-                    continue;
-                }
-                openings.pop(g.initial, hf.hRng[k]);
-                g.moves.clear();
-                g.scores.clear();
-                g.history.clear();
-                g.key = keyOfRecord(g.initial);
-                g.winPlies = g.lossPlies = g.drawPlies = g.plies = 0;
-                g.stm = (g.initial.stm_ep & 0x80) ? 0 : 1;
-                g.active = true;
-                g.blank = false;
-                hf.hRecords[k] = g.initial;
-            }
-            SPX_SP_HIP(hipMemcpyAsync(hf.dSeats, hf.hSeats, size_t(n) * 4, hipMemcpyHostToDevice, stream));
-            SPX_SP_HIP(hipMemcpyAsync(hf.dRecords, hf.hRecords, size_t(n) * 32, hipMemcpyHostToDevice, stream));
-            SPX_SP_HIP(hipMemcpyAsync(hf.dRngNew, hf.hRng, size_t(n) * 8, hipMemcpyHostToDevice, stream));
-            SPX_SP_HIP(launchSeatGames(n, hf.dSeats, hf.dRecords, hf.dRngNew, dPositions, dSlots, dRng, stream));
-            // accumulators of the new games: full refresh into the seats' home slots (a blanked seat gets the
-            // accumulator of the empty board - never used)
-            for (size_t lo = 0; lo < n; lo += ctxMaxBatch(ctx)) {
-                const size_t m = std::min<size_t>(ctxMaxBatch(ctx), n - lo);
-                const int r = spx_acc_refresh_device(ctx, hf.dRecords + lo * 4, hf.dSeats + lo, m, stream);
-                if (r != SPX_OK) return r;
-            }
-        }
-        const uint32_t seats = hf.end - hf.begin;
-        int r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren,
-                                   hf.dMoves, hf.dParents, dFirst + hf.begin, dCount + hf.begin, dInCheck + hf.begin,
-                                   hf.cap, hf.dTotal, stream);
+        hipStream_t s = static_cast<hipStream_t>(laneStream);
+        int r = ensurePool(s);
         if (r != SPX_OK) return r;
-        SPX_SP_HIP(hipMemcpyAsync(hf.hTotal, hf.dTotal, 4, hipMemcpyDeviceToHost, stream));
-        const uint32_t* childSlots = hf.dChildSlots + size_t(hf.step & 1) * hf.cap;
-        if (counted) {
-            r = spx_acc_update_eval_device_counted(ctx, hf.dParents, childSlots, hf.dChildren, hf.dTotal, hf.cap,
-                                                   hf.dEvals, stream);
-            if (r != SPX_OK) return r;
-        } else {
-            SPX_SP_HIP(hipStreamSynchronize(stream));
-            const size_t total = std::min<size_t>(*hf.hTotal, hf.cap);
-            for (size_t lo = 0; lo < total; lo += ctxMaxBatch(ctx)) {
-                const size_t m = std::min(ctxMaxBatch(ctx), total - lo);
-                r = spx_acc_update_eval_device(ctx, hf.dParents + lo, childSlots + lo, hf.dChildren + lo * 4, m,
-                                               hf.dEvals + lo, stream);
-                if (r != SPX_OK) return r;
-            }
-        }
-        PickParams pk{};
-        pk.nGames = seats;
-        pk.first = dFirst + hf.begin;
-        pk.count = dCount + hf.begin;
-        pk.inCheck = dInCheck + hf.begin;
-        pk.evals = hf.dEvals;
-        pk.moves = hf.dMoves;
-        pk.children = hf.dChildren;
-        pk.childSlots = childSlots;
-        pk.positions = dPositions + size_t(hf.begin) * 4;
-        pk.slots = dSlots + hf.begin;
-        pk.rng = dRng + hf.begin;
-        pk.results = dResults + hf.begin;
-        pk.temperature = p->temperature_cp;
-        SPX_SP_HIP(launchPick(pk, stream));
-        SPX_SP_HIP(hipMemcpyAsync(hf.hResults, dResults + hf.begin, size_t(seats) * sizeof(PickResult),
-                                  hipMemcpyDeviceToHost, stream));
-        SPX_SP_HIP(hipEventRecord(hf.done, stream));
-        hf.inFlight = true;
-        ++hf.step;
-        stats->steps += 1;
+        const uint32_t seats = hf.end - hf.begin;
+        r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren, hf.dMoves,
+                               hf.dParents, dFirst + hf.begin, dCount + hf.begin, dInCheck + hf.begin, hf.cap, hf.dTotal, s);
+        if (r != SPX_OK) return r;
+        // eval-only children (child slots NULL): ~35 siblings per seat evaluated, none stored
+        r = spx_acc_update_eval_device_counted(ctx, hf.dParents, nullptr, hf.dChildren, hf.dTotal, hf.cap, hf.dEvals, s);
+        if (r != SPX_OK) return r;
+        SPX_SP_HIP(hipMemsetAsync(hf.dHalfCounters, 0, 8, s));
+        GameStepParams gp{};
+        gp.nSeats = seats;
+        gp.seatBase = hf.begin;
+        gp.nSeatsTotal = G;
+        gp.first = dFirst + hf.begin;
+        gp.count = dCount + hf.begin;
+        gp.inCheck = dInCheck + hf.begin;
+        gp.evals = hf.dEvals;
+        gp.moves = hf.dMoves;
+        gp.children = hf.dChildren;
+        gp.positions = dPositions + size_t(hf.begin) * 4;
+        gp.slots = dSlots + hf.begin;
+        gp.rng = dRng + hf.begin;
+        gp.state = dState + hf.begin;
+        gp.initial = dInitial + size_t(hf.begin) * 4;
+        gp.gameMoves = dGameMoves + size_t(hf.begin) * maxPlies;
+        gp.keys = dKeys + size_t(hf.begin) * maxPlies;
+        gp.maxPlies = maxPlies;
+        gp.temperature = p->temperature_cp;
+        gp.targetGames = p->target_games;
+        gp.poolRecords = dPoolRecords;
+        gp.poolSeeds = dPoolSeeds;
+        gp.poolCap = poolCap;
+        gp.counters = dCounters;
+        gp.ring = dRing;
+        gp.ringWords = ringWords;
+        gp.updParents = hf.dUpdParents;
+        gp.updChildren = hf.dUpdChildren;
+        gp.updPositions = hf.dUpdPositions;
+        gp.halfCounters = hf.dHalfCounters;
+        SPX_SP_HIP(launchGameStep(gp, s));
+        // the one accumulator per seat that has to exist next ply: the move played (parent -> the seat's other slot) or
+        // the new game's opening (null slot -> rebuilt from scratch by the update kernel's deferred pass)
+        r = spx_acc_update_device_counted(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, hf.dHalfCounters, seats, s);
+        if (r != SPX_OK) return r;
+        SPX_SP_HIP(hipMemcpyAsync(&hf.hStatus->counters, dCounters, sizeof(SelfplayCounters), hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(hipMemcpyAsync(&hf.hStatus->total, hf.dTotal, 4, hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(hipMemcpyAsync(hf.hStatus->half, hf.dHalfCounters, 8, hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(hipEventRecord(hf.done, s));
+        hf.inFlight = hf.everRan = true;
+        ++steps;
         return SPX_OK;
     };
-    // wait for a half's ply; its child count must have fitted the buffers
+    // wait for a half's ply; append what the step kernels finished since the last look to the file
     auto awaitPly = [&](DeviceHalf& hf) -> int {
         const auto g0 = std::chrono::steady_clock::now();
         SPX_SP_HIP(hipEventSynchronize(hf.done));
         gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
         hf.inFlight = false;
-        const size_t total = *hf.hTotal;
-        if (total > hf.cap) {
-            setError("spx_selfplay_run: " + std::to_string(total) + " children in one ply exceed the buffer of " +
-                     std::to_string(hf.cap));
+        const HalfStatus& st = *hf.hStatus;
+        if (st.total > hf.cap) {
+            setError("spx_selfplay_run: " + std::to_string(st.total) + " children in one ply exceed the buffer of " +
+                     std::to_string(hf.cap) + " (context max_batch too small for this many seats?)");
             return SPX_ERR_CAPACITY;
         }
-        stats->evals += total;
+        evals += st.total;
+        {   // every counter only grows: the newest view is the element-wise maximum of the halves' snapshots
+            const SelfplayCounters& c = st.counters;
+            latest.streamWords = std::max(latest.streamWords, c.streamWords);
+            latest.games = std::max(latest.games, c.games);
+            latest.positions = std::max(latest.positions, c.positions);
+            for (int k = 0; k < 3; ++k) latest.outcomes[k] = std::max(latest.outcomes[k], c.outcomes[k]);
+            latest.discarded = std::max(latest.discarded, c.discarded);
+            latest.started = std::max(latest.started, c.started);
+            latest.poolCursor = std::max(latest.poolCursor, c.poolCursor);
+        }
+        if (latest.streamWords - consumedWords > ringWords) {
+            setError("spx_selfplay_run: the output ring overflowed");
+            return SPX_ERR_CAPACITY;
+        }
+        while (consumedWords < latest.streamWords) {
+            const uint32_t at = uint32_t(consumedWords % ringWords);
+            const uint64_t m = std::min<uint64_t>(latest.streamWords - consumedWords, ringWords - at);
+            if (out && std::fwrite(hRing + at, 4, size_t(m), out) != size_t(m)) {
+                setError("spx_selfplay_run: short write to the output file");
+                return SPX_ERR_INVALID_ARG;
+            }
+            consumedWords += m;
+        }
         return SPX_OK;
     };
-    // host bookkeeping of one ply of a half: records, adjudication (datagen.cpp:224-252), draws
-    auto processResults = [&](DeviceHalf& hf) {
-        pool.run([&](uint32_t t) {
-            const uint32_t seats = hf.end - hf.begin, per = (seats + pool.size() - 1) / pool.size();
-            for (uint32_t s = std::min(seats, t * per); s < std::min(seats, (t + 1) * per); ++s) {
-                DeviceGame& g = games[hf.begin + s];
-                if (!g.active) continue;
-                const PickResult& r = hf.hResults[s];
-                if (r.count == 0) {  // mate / stalemate (datagen.cpp:213-221)
-                    g.outcome = r.inCheck ? (g.stm == 0 ? 2 : 0) : 1;
-                    continue;
-                }
-                // what runDatagenSearch hands to datagen (search.cpp:237-238): the score from WHITE's point of view - this
-                // is what the reference records (datagen.cpp:283-284) - and its WDL-normalised form, which the
-                // adjudication counters compare (datagen.cpp:224-252)
-                const int whiteScore = g.stm ? r.score : -r.score;
-                const int normScore = r.normScore;
-                g.moves.push_back(r.move);
-                g.scores.push_back(int16_t(std::max(-32000, std::min(32000, std::abs(whiteScore) <= 2 ? 0 : whiteScore))));
-                uint8_t outcome = 255;
-                if (normScore > kWinAdjMinScore) {
-                    ++g.winPlies;
-                    g.lossPlies = g.drawPlies = 0;
-                } else if (normScore < -kWinAdjMinScore) {
-                    ++g.lossPlies;
-                    g.winPlies = g.drawPlies = 0;
-                } else if (g.plies >= kDrawAdjMinPlies && std::abs(normScore) < kDrawAdjMaxScore) {
-                    ++g.drawPlies;
-                    g.winPlies = g.lossPlies = 0;
-                } else {
-                    g.winPlies = g.lossPlies = g.drawPlies = 0;
-                }
-                if (g.winPlies >= kWinAdjPlyCount) outcome = 2;
-                else if (g.lossPlies >= kWinAdjPlyCount) outcome = 0;
-                else if (g.drawPlies >= kDrawAdjPlyCount) outcome = 1;
-                g.history.push_back(g.key);
-                g.key = r.key;
-                g.stm ^= 1;
-                ++g.plies;
-                // draws: 50-move rule, threefold repetition, ply cap. A repetition can only reach back as far as the
-                // halfmove clock (irreversible moves cut the history).
-                size_t reps = 0;
-                const size_t window = std::min<size_t>(g.history.size(), r.halfmove);
-                for (size_t k = g.history.size() - window; k < g.history.size(); ++k) reps += g.history[k] == g.key;
-                if (outcome == 255 && (r.halfmove >= 100 || reps >= 2 || g.plies >= p->max_plies)) outcome = 1;
-                g.outcome = outcome;
-            }
-        });
-        for (uint32_t i = hf.begin; i < hf.end; ++i) {
-            DeviceGame& g = games[i];
-            if (g.active && g.outcome != 255) finishGame(g, g.outcome);
-        }
-    };
     auto halfHasWork = [&](const DeviceHalf& hf) {
-        for (uint32_t i = hf.begin; i < hf.end; ++i) {
-            if (games[i].active || !games[i].blank) return true;
-        }
-        return started < p->target_games;
+        return !hf.everRan || hf.hStatus->half[1] != 0 || latest.started < p->target_games;
     };
 
-    // both halves are kept in flight: while the host does the bookkeeping of one, the GPU works on the other
-    double phase[2] = {0, 0};  // bookkeeping, starts + enqueue
     for (DeviceHalf& hf : halves) {
         if ((rc = enqueuePly(hf)) != SPX_OK) break;
     }
@@ -1157,21 +1100,22 @@ int runDeviceMovegen(spx_ctx* ctx, const spx_selfplay_params* p, const char* out
             continue;
         }
         if ((rc = awaitPly(hf)) != SPX_OK) break;
-        const auto a0 = std::chrono::steady_clock::now();
-        processResults(hf);
         const auto a1 = std::chrono::steady_clock::now();
         if (halfHasWork(hf)) rc = enqueuePly(hf);
-        const auto a2 = std::chrono::steady_clock::now();
-        phase[0] += std::chrono::duration<double>(a1 - a0).count();
-        phase[1] += std::chrono::duration<double>(a2 - a1).count();
+        enqueueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
     }
     (void)spx_ctx_synchronize(ctx);  // nothing may still reference the staging buffers on an error exit
-    stats->steps = (stats->steps + nHalves - 1) / nHalves;
+    stats->games = latest.games;
+    stats->positions = latest.positions;
+    for (int k = 0; k < 3; ++k) stats->outcomes[k] = latest.outcomes[k];
+    stats->evals = evals;
+    stats->steps = (steps + nHalves - 1) / nHalves;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
     if (std::getenv("SPX_SELFPLAY_TRACE")) {
-        std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, bookkeeping %.3f, starts + enqueue %.3f (%s)\n",
-                     stats->seconds, gpuWait, phase[0], phase[1], counted ? "device-counted update" : "chunked update");
+        std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, enqueue + openings %.3f; %llu openings discarded by "
+                     "the verification filter, %u published\n", stats->seconds, gpuWait, enqueueSeconds,
+                     static_cast<unsigned long long>(latest.discarded), published);
     }
     return rc;
 }
@@ -1186,5 +1130,5 @@ extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, cons
         return SPX_ERR_INVALID_ARG;
     }
     return (p->flags & SPX_SELFPLAY_HOST_MOVEGEN) ? runHostMovegen(ctx, p, out_path, stats)
-                                                  : runDeviceMovegen(ctx, p, out_path, stats);
+                                                  : runDeviceGames(ctx, p, out_path, stats);
 }

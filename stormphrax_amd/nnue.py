@@ -232,13 +232,14 @@ class NnueState:
         check(_lib.load().spx_acc_update(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data, pos.shape[0]))
 
     def update_evaluate(self, parent_slots, child_slots, child_positions):
-        """update() followed by evaluate(child_slots) in one fused call (push + applyMove + evaluate)."""
+        """update() followed by evaluate(child_slots) in one fused call (push + applyMove + evaluate).
+        child_slots=None: eval-only children - evaluated from registers, nothing stored in the arena."""
         pos = np.ascontiguousarray(child_positions, dtype=PACKED_DTYPE)
         ps = np.ascontiguousarray(parent_slots, dtype=np.uint32)
-        cs = np.ascontiguousarray(child_slots, dtype=np.uint32)
+        cs = None if child_slots is None else np.ascontiguousarray(child_slots, dtype=np.uint32)
         out = np.empty(pos.shape[0], dtype=np.int32)
-        check(_lib.load().spx_acc_update_eval(self._h, ps.ctypes.data, cs.ctypes.data, pos.ctypes.data, pos.shape[0],
-                                              out.ctypes.data))
+        check(_lib.load().spx_acc_update_eval(self._h, ps.ctypes.data, None if cs is None else cs.ctypes.data,
+                                              pos.ctypes.data, pos.shape[0], out.ctypes.data))
         return out
 
     def update_observed(self, parent_slots, child_slots, child_positions, deltas, evaluate=True):

@@ -358,3 +358,51 @@ def test_piece_square_row_classes_of_a_net(sp, net_blob):
     assert sp.Network(net_blob("mixed")).psq_row_classes() == (11264 - n_wide, n_wide, 0)  # one planted weight per row
     kinds = [int((NEAR_ROW_KIND == k).sum()) for k in range(4)]
     assert sp.Network(net_blob("near")).psq_row_classes() == (kinds[0], kinds[1] + kinds[3], kinds[2])
+
+
+def test_datagen_rules_shared_by_host_and_device_match_the_python_restatement(sp):
+    """The counter ladder (datagen.cpp:224-252) and the material part of Position::isDrawn (position.cpp:639-666) that the
+    device step kernel and the host self-play path share (spx_device_math.h) against tests/_datagen_rules.py, which is
+    written from the reference's text independently: random score sequences around the thresholds, and endgame records
+    with every combination of up to two minor pieces per side (incl. same / opposite coloured bishops)."""
+    import ctypes
+
+    import _datagen_rules as rules
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        counters = (ctypes.c_uint32 * 3)(0, 0, 0)
+        win = loss = draw = 0
+        start = int(rng.integers(0, 90))
+        for k in range(40):
+            norm = int(rng.choice([-1300, -1251, -1250, -11, -10, -9, 0, 9, 10, 11, 1250, 1251, 2000]))
+            if rng.random() < 0.6:
+                norm = int(np.sign(norm or 1)) * abs(norm) if k % 7 else norm
+            out = ctypes.c_uint32()
+            lib.spx_debug_datagen_rules(counters, norm, start + k, ctypes.byref(out), None, None)
+            if norm > rules.WIN_ADJ_MIN_SCORE:
+                win, loss, draw = win + 1, 0, 0
+            elif norm < -rules.WIN_ADJ_MIN_SCORE:
+                win, loss, draw = 0, loss + 1, 0
+            elif start + k >= rules.DRAW_ADJ_MIN_PLIES and abs(norm) < rules.DRAW_ADJ_MAX_SCORE:
+                win, loss, draw = 0, 0, draw + 1
+            else:
+                win = loss = draw = 0
+            want = 2 if win >= 5 else (0 if loss >= 5 else (1 if draw >= 10 else 255))
+            assert (list(counters), out.value) == ([win, loss, draw], want), (trial, k)
+            if want != 255:
+                break
+    fens = ["4k3/8/8/8/8/8/8/4K3 w - - 0 1", "4k3/8/8/8/8/8/8/4KN2 w - - 0 1", "4kb2/8/8/8/8/8/8/4K3 w - - 0 1",
+            "4kb2/8/8/8/8/8/8/4KB2 w - - 0 1", "4kb2/8/8/8/8/8/8/2B1K3 w - - 0 1", "4kn2/8/8/8/8/8/8/4KB2 w - - 0 1",
+            "4k3/8/8/8/8/8/8/3NKN2 w - - 0 1", "4k3/8/8/8/8/8/8/3BKB2 w - - 0 1", "4k3/p7/8/8/8/8/8/4K3 w - - 0 1",
+            "4k3/8/8/8/8/8/8/R3K3 w Q - 0 1", "4k3/8/8/8/8/8/8/3QK3 w - - 0 1", "2b1kb2/8/8/8/8/8/8/4KB2 w - - 0 1",
+            "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"]
+    recs = sp.positions_from_fens(fens)
+    for i, fen in enumerate(fens):
+        flag = ctypes.c_int(-1)
+        lib.spx_debug_datagen_rules(None, 0, 0, None, recs[i:i + 1].ctypes.data, ctypes.byref(flag))
+        assert flag.value in (0, 1) and bool(flag.value) == rules.insufficient_material(recs[i]), fen
+    assert [rules.insufficient_material(r) for r in recs] == [True, True, True, True, False, False, False, False, False, False,
+                                                              False, False, False]
