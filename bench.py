@@ -318,7 +318,7 @@ def incremental_bench(args, sp, torch, group, rank, local_rank, world):
     group.close()
 
 
-def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
+def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2, settle_seconds=1.0):
     """Settle, W warm-up steps, then exactly K timed steps of the full-refresh path on `state`.
     -> (elapsed max over ranks, per-kernel ms (sort, ft, mlp, calls), settle steps, the output tensor of the last step)."""
     # (a batch above the scratch capacity is pipelined chunk by chunk inside ONE call: a second output buffer buys nothing)
@@ -339,7 +339,7 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2):
         state.synchronize()
         torch.cuda.synchronize()
 
-    settle_steps = 0 if args.no_settle else settle(step, sync, chunk=10 if args.batch <= (1 << 22) else 1)
+    settle_steps = 0 if args.no_settle else settle(step, sync, min_seconds=settle_seconds, chunk=10 if args.batch <= (1 << 22) else 1)
     for _ in range(args.warmup):
         step()
     sync()
@@ -378,13 +378,164 @@ def self_launch(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def gather_ceiling(state, d_pos, n, iters=30):
+    """roofline.ceiling: the load-only replay of this batch's row fetches (spx_probe.hip; the product kernel's own lists, grid
+    and traversal, global_load_dwordx4 at 5 waves/SIMD - the fastest of the probe's variants, profiles/r03_gather_ceiling.json)
+    next to the product kernel timed the same way (alone, stream-ordered)."""
+    name, probe_ms, _ = state.gather_probe(d_pos.data_ptr(), n, 0, iters)
+    _, ft_ms, _ = state.gather_probe(d_pos.data_ptr(), n, -1, iters)
+    return {"probe": name, "probe_us": probe_ms * 1e3, "ft_kernel_alone_us": ft_ms * 1e3, "frac_of_probe": probe_ms / ft_ms,
+            "note": "frac_of_probe = load-only replay time / feature-transformer kernel time, both alone on the stream: what the "
+                    "kernel reaches of the rate this chip sustains for the same row fetches with no extraction, no widening, "
+                    "no activation (a measured ceiling for this access pattern, unlike the guide's streaming L2 figure)"}
+
+
+def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
+    """Third headline: the same timed run on the `realistic` preset (heavy-tailed weights: ~42 % of the piece-square rows fit
+    i8, ~38 % have <= 32 weights outside it, ~20 % are wide) - what a trained net should expect rather than the all-compact
+    best case of the uniform presets. Scores checked against the CPU oracle on a sample."""
+    blob = sp.synthetic_net_bytes("realistic")
+    net = sp.Network(blob)
+    st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch)
+    try:
+        elapsed, (_, ft_ms, _, calls), _, last = timed_full_run(args, torch, group, st, d_pos, pipelined, settle_seconds=0.4)
+        n_sample = min(1024, len(positions))
+        exact = oracle_sample_check(sp, blob, positions[:n_sample], last[:n_sample].cpu().numpy())
+        wide_rows, compact_rows, thr_rows = st.count_rows(positions)
+        fit, near, wide = net.psq_row_classes()
+        return {"value": args.batch * args.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "ft_kernel_ms": ft_ms / max(calls, 1), "bit_exact_sample": bool(exact),
+                "psq_row_classes": {"fit_i8": fit, "near_compact_le_32_outliers": near, "wide": wide},
+                "rows_per_launch": {"psq_wide_2KiB": wide_rows, "psq_1KiB_compact_or_near": compact_rows, "threat_1KiB": thr_rows},
+                "net": f"synthetic CBNF '{net.name}': two-sided geometric (Laplace-like) weights with heavy tails, the shape of a "
+                       "trained QA = 255 net (spx_synth.cpp preset 3); reference goldens in tests/golden/evals.jsonl"}
+    finally:
+        st.close()
+
+
+def incremental_leg(sp, torch, net, device, games=65536, chain=6, seconds=0.6):
+    """secondary.incremental (BASELINE configs[2] shape): `games` concurrent games, one fused update + eval batch per ply,
+    pipelined plies. Boards are generated on the device: spx_random_positions_gpu is deterministic per seed, so the same
+    call with one more ply yields each position's successor; four material phases (10 / 30 / 60 / 100 plies)."""
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    st = sp.NnueState(net, device=device, max_batch=games)
+    try:
+        boards = []
+        quarter = games // 4
+        for k in range(chain):
+            t = torch.empty((games, 32), dtype=torch.uint8, device="cuda")
+            for q, base in enumerate((10, 30, 60, 100)):
+                cnt = quarter if q < 3 else games - 3 * quarter
+                st.random_positions_device(t[q * quarter:].data_ptr(), cnt, seed=4242 + q, min_ply=base + k, max_ply=base + k,
+                                           dfrc_every=4)
+            boards.append(t)
+        sample = [b[:: max(1, games // 256)].cpu().numpy().reshape(-1).view(sp.PACKED_DTYPE) for b in boards[:2]]
+        changed = [int(np.count_nonzero(sp.positions_to_mailboxes(sample[0][i:i + 1])[0] != sp.positions_to_mailboxes(sample[1][i:i + 1])[0]))
+                   for i in range(len(sample[0]))]
+        st.reserve_slots(2 * games)
+        slots = [torch.arange(games, dtype=torch.int32, device="cuda"), torch.arange(games, 2 * games, dtype=torch.int32, device="cuda")]
+        outs = [torch.empty(games, dtype=torch.int32, device="cuda") for _ in range(2)]
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.spx_acc_refresh_device(st._h, boards[0].data_ptr(), slots[0].data_ptr(), games, stream))
+        torch.cuda.synchronize()
+        L, no = chain, [0]
+
+        def board_index(step):  # 0, 1, .., L-1, L-2, .., 0, 1, ..: an unmake is a one-move delta too
+            k = step % (2 * L - 2)
+            return k if k < L else 2 * L - 2 - k
+
+        def step():
+            s_ = no[0]
+            _lib.check(lib.spx_acc_update_eval_device_async(st._h, slots[s_ & 1].data_ptr(), slots[(s_ + 1) & 1].data_ptr(),
+                                                            boards[board_index(s_ + 1)].data_ptr(), games,
+                                                            outs[s_ & 1].data_ptr(), None))
+            no[0] = s_ + 1
+
+        def sync():
+            st.synchronize()
+            torch.cuda.synchronize()
+
+        settle(step, sync, min_seconds=0.3, max_seconds=2.0)
+        steps = 0
+        st.profile_begin(4096)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds and steps < 4000:
+            for _ in range(20):
+                step()
+            steps += 20
+            sync()
+        elapsed = time.perf_counter() - t0
+        _, update_ms, mlp_ms, calls = st.profile_end()
+        full = torch.empty(games, dtype=torch.int32, device="cuda")
+        st.evaluate_once_device(boards[board_index(no[0])].data_ptr(), games, full.data_ptr(), stream)
+        torch.cuda.synchronize()
+        exact = bool(torch.equal(full, outs[(no[0] - 1) & 1]))
+        compulsory = 2 * 4096 + 72
+        update_s = update_ms / max(calls, 1) / 1e3
+        return {"value": games * steps / elapsed, "unit": "updates+evals/s", "games": games, "steps": steps,
+                "ms_per_step": elapsed / steps * 1e3, "update_kernel_ms": update_s * 1e3, "sort_mlp_ms": mlp_ms / max(calls, 1),
+                "bit_exact_vs_full_refresh": exact, "squares_changed_per_move_sample_max": max(changed),
+                "roofline": {"kernel": "spx_update_kernel (+ its rebuild pass)", "bound": "hbm",
+                             "achieved": compulsory * games / update_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": compulsory * games / update_s / 1e9 / HBM_PEAK_GBS,
+                             "note": "compulsory bytes (parent accumulators in, child accumulators out, records) x records / "
+                                     "HIP-event time of the update kernel and its rebuild pass; PMC traffic: profiles/"}}
+    finally:
+        st.close()
+
+
+def config3_leg(sp, net, device):
+    """secondary.config3_replay: the recorded 65 536-EVAL reference trace (tests/golden, BASELINE configs[2]) through ONE
+    native spx_acc_replay_tree call; every EVAL must equal what the reference's NnueState::evaluate recorded."""
+    from stormphrax_amd.trace import Trace, replay_native
+
+    path = os.path.join(ROOT, "tests", "golden", "trace_startpos_tame_64k.txt.gz")
+    trace = Trace(path)
+    st = sp.NnueState(net, device=device, max_batch=65536)
+    try:
+        pos = trace.positions()
+        got, want, ms = replay_native(st, trace, pos)
+        got2, _, ms2 = replay_native(st, trace, pos)
+        return {"device_ms": min(ms, ms2), "updates": trace.n_nodes - 1, "evals": len(want),
+                "updates_plus_evals_per_sec": (trace.n_nodes - 1 + len(want)) / (min(ms, ms2) / 1e3),
+                "every_eval_equals_the_reference": bool(np.array_equal(got, want) and np.array_equal(got2, want)),
+                "trace": "tests/golden/trace_startpos_tame_64k.txt.gz (recorded from the compiled reference: depth-12 "
+                         "make/unmake walk from the start position through NnueState::push / pop / evaluate)"}
+    finally:
+        st.close()
+
+
+def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelined, device):
+    """Outside the headline's timed region, single-GPU runs only: puts the other configurations on the driver's clock
+    (VERDICT r2 item 6). A leg that fails reports its error instead of taking the headline down."""
+    out = {}
+
+    def run(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001 - reported, not swallowed
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        out[name]["leg_seconds"] = time.perf_counter() - t0
+
+    if args.batch <= state.scratch_batch:
+        run("gather_ceiling", lambda: gather_ceiling(state, d_pos, args.batch))
+    run("realistic_rows", lambda: realistic_leg(args, sp, torch, group, d_pos, positions, pipelined))
+    if args.preset == "tame":  # (the trace was recorded on the tame net)
+        run("incremental", lambda: incremental_leg(sp, torch, net, device))
+        run("config3_replay", lambda: config3_leg(sp, net, device))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="positions per GPU per step")
-    ap.add_argument("--preset", default="tame", choices=["tame", "wild", "extreme"])
+    ap.add_argument("--preset", default="tame", choices=["tame", "wild", "extreme", "realistic"])
     ap.add_argument("--net", default=None,
                     help="CBNF net file (plain or zstd-compressed, e.g. Stormphrax's net093_255_128_q6.nnue) instead of the "
                          "synthetic preset; the compiled-reference CPU leg embeds the synthetic net, so it is skipped")
@@ -512,6 +663,10 @@ def main():
                         "as its 2 KiB i16 row (what a net whose piece-square weights do not fit i8 gets)"}
         wstate.close()
 
+    secondary = None
+    if world == 1 and not args.no_secondary and not args.net:
+        secondary = secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelined, local_rank)
+
     if rank == 0:
         wide_rows, compact_rows, thr_rows = state.count_rows(distinct)  # host-side count; tiled batches scale the distinct block
         if n_distinct < args.batch:
@@ -607,6 +762,14 @@ def main():
         }
         if wide:
             line["wide_psq_rows"] = wide
+        if secondary:
+            ceiling = secondary.pop("gather_ceiling", None)
+            if ceiling:
+                roofline["ceiling"] = ceiling
+            realistic = secondary.pop("realistic_rows", None)
+            if realistic:
+                line["realistic_rows"] = realistic
+            line["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1 and not args.net:  # the CPU leg is timed on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(sp, distinct, blob, args.cpu_seconds, args.allow_port_baseline)
         print(json.dumps(line), flush=True)

@@ -75,7 +75,10 @@ uint64_t spx_net_digest(const spx_net* net);
 int spx_net_psq_row_classes(const spx_net* net, uint32_t* fit_i8, uint32_t* near_compact, uint32_t* wide);
 
 /* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
- * 2 extreme (i16 accumulator wraps too). Writes spx_synth_net_bytes() bytes. */
+ * 2 extreme (i16 accumulator wraps too) - uniform random weights; 3 realistic: the weight SHAPE of a trained QA = 255 net
+ * (src/eval/arch.h:36-50) - heavy-tailed piece-square rows of which about 40 % fit i8, 40 % have a handful of weights
+ * beyond it and 20 % are densely wide, Laplace-like i8 threat and L1 weights - so that the measured rate does not rest on
+ * every piece-square row being compact. Writes spx_synth_net_bytes() bytes. */
 size_t spx_synth_net_bytes(void);
 int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
 uint64_t spx_fnv1a64(const void* data, size_t nbytes);
@@ -177,6 +180,13 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
                         const spx_packed_pos* child_positions, size_t n, int32_t* out);
 int spx_acc_update_eval_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                const void* d_child_positions, size_t n, void* d_out, void* stream);
+/* NnueState::ensureUpToDate (nnue_state.cpp:636-697) over a pending PATH, then evaluate (:598-610): ply 0's parent is the
+ * materialised `parent_slot`, ply k's parent is ply k - 1; every ply's accumulators are written to child_slots[k] (the
+ * reference leaves every stack entry on the path clean) and *out (may be NULL) receives the evaluation of the last
+ * position. One kernel launch whatever the length - the accumulator travels in registers from ply to ply - instead of
+ * one synchronous call per pending ply. Host buffers, synchronous; n <= 8192. */
+int spx_acc_update_chain_eval(spx_ctx* ctx, uint32_t parent_slot, const uint32_t* child_slots,
+                              const spx_packed_pos* child_positions, size_t n, int32_t* out);
 
 /* A recorded make/unmake TREE (BASELINE config 3: the PUSH / POP / EVAL stream of a search, src/thread.cpp:46-67,
  * src/thread.h:116-122) replayed natively: node 0 is the root (NnueState::reset), node k > 0 was reached from node
@@ -244,11 +254,6 @@ int spx_group_adjust(spx_group* group, const spx_packed_pos* positions, size_t n
 int spx_acc_update_eval_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                        const void* d_child_positions, const void* d_count, size_t capacity, void* d_out,
                                        void* stream);
-/* spx_acc_update_device with a device-resident record count (the self-play driver's materialising update: the seats that
- * made a move this ply are known only on the device). */
-int spx_acc_update_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
-                                  const void* d_child_positions, const void* d_count, size_t capacity, void* stream);
-
 /* Per-kernel GPU timing of subsequent spx_eval_full* calls (HIP events recorded on the stream the kernels run on,
  * at most max_calls calls). spx_profile_end waits for the last recorded call and returns the summed durations of the
  * sort kernels, the feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */

@@ -4,9 +4,10 @@
 // src/eval/nnue.h:38-63 and class eval::NnueState (src/eval/nnue_state.h:85-116: reset / push / pop / evaluate /
 // evaluateOnce), used by one search thread each over a shared read-only network (src/thread.h:147). The classes below
 // keep those names and that discipline - an accumulator *stack* with lazy updates - and map it onto the library's
-// arena: stack depth d lives in slot d, push() only records the child position, evaluate() materialises the pending
-// plies (one spx_acc_update per ply, like ensureUpToDate walks back to the last clean ancestor,
-// src/eval/nnue_state.cpp:636-697) and evaluates the top. Positions cross the boundary as marlinformat PackedBoard
+// arena: stack depth d lives in an arena slot, push() only records the child position, evaluate() materialises ALL
+// pending plies in one launch (spx_acc_update_chain_eval: like ensureUpToDate walks forward from the last clean
+// ancestor, src/eval/nnue_state.cpp:636-697) and evaluates the top; applyImmediately() advances the root in place from an
+// observer delta (datagen's use, src/datagen/datagen.cpp:257-262). Positions cross the boundary as marlinformat PackedBoard
 // records (src/datagen/marlinformat.h:32-84 == spx_packed_pos), which Stormphrax already produces.
 //
 // Errors: the reference's calls cannot fail (asserts only); here a failing library call throws spx_nnue::Error with
@@ -71,12 +72,15 @@ public:
     explicit NnueState(const Network& net, int device = 0, size_t maxBatch = 4096) {
         check(spx_ctx_create(net.handle(), device, maxBatch, &ctx_));
         try {
-            check(spx_acc_reserve(ctx_, kMaxDepth));
+            check(spx_acc_reserve(ctx_, kMaxDepth + 1));  // one slot per stack entry + a spare for applyImmediately
         } catch (...) {
             spx_ctx_destroy(ctx_);
             throw;
         }
         stack_.reserve(kMaxDepth);
+        slotOf_.resize(kMaxDepth);
+        for (uint32_t d = 0; d < kMaxDepth; ++d) slotOf_[d] = d;
+        spare_ = kMaxDepth;
     }
     NnueState(const NnueState&) = delete;
     NnueState& operator=(const NnueState&) = delete;
@@ -88,8 +92,7 @@ public:
     void reset(const spx_packed_pos& pos) {
         stack_.assign(1, pos);
         clean_ = 0;
-        const uint32_t slot = 0;
-        check(spx_acc_refresh(ctx_, &pos, &slot, 1));
+        check(spx_acc_refresh(ctx_, &pos, &slotOf_[0], 1));
     }
     // NnueState::push + Position::applyMove (src/thread.cpp:46-67): `child` is the position after the move. Nothing is
     // computed yet - the entry is dirty until the next evaluate(), exactly like the reference's lazy UpdateContext
@@ -110,18 +113,25 @@ public:
         if (stack_.empty()) throw Error(SPX_ERR_INVALID_ARG, "NnueState::evaluate before reset");
         const uint32_t top = uint32_t(stack_.size() - 1);
         int32_t out = 0;
-        while (clean_ < top) {  // pending plies: each child is the next one's parent, so one record per call ...
-            const uint32_t parent = clean_, child = clean_ + 1;
-            if (child == top) {  // ... and the last one is fused with the evaluation
-                check(spx_acc_update_eval(ctx_, &parent, &child, &stack_[child], 1, &out));
-                clean_ = child;
-                return out;
-            }
-            check(spx_acc_update(ctx_, &parent, &child, &stack_[child], 1));
-            clean_ = child;
+        if (clean_ < top) {  // pending plies clean_ + 1 .. top: one launch for the whole path, fused with the evaluation
+            check(spx_acc_update_chain_eval(ctx_, slotOf_[clean_], &slotOf_[clean_ + 1], &stack_[clean_ + 1], top - clean_, &out));
+            clean_ = top;
+            return out;
         }
-        check(spx_acc_eval(ctx_, &top, 1, &out));
+        check(spx_acc_eval(ctx_, &slotOf_[top], 1, &out));
         return out;
+    }
+    // NnueState::applyImmediately (nnue_state.cpp:572-591; datagen.cpp:257-262): the move has been made with an observer -
+    // `delta` is the UpdateContext it captured (spx_pos_apply_uci_observed, or the host's own BoardObserver), `child` the
+    // position after it. The TOP of the stack becomes `child`, its accumulators updated at once from the old top's (no push:
+    // the stack depth is unchanged, nothing stays pending).
+    void applyImmediately(const spx_move_delta& delta, const spx_packed_pos& child) {
+        if (stack_.empty()) throw Error(SPX_ERR_INVALID_ARG, "NnueState::applyImmediately before reset");
+        evaluateIfPending();
+        const uint32_t top = uint32_t(stack_.size() - 1);
+        check(spx_acc_update_observed(ctx_, &slotOf_[top], &spare_, &child, &delta, 1, nullptr));
+        std::swap(slotOf_[top], spare_);  // the old top's slot is the next spare
+        stack_[top] = child;
     }
     // NnueState::evaluateOnce (nnue_state.cpp:612-634): from scratch, no state touched
     int32_t evaluateOnce(const spx_packed_pos& pos) {
@@ -162,6 +172,9 @@ public:
     size_t depth() const {
         return stack_.empty() ? 0 : stack_.size() - 1;
     }
+    size_t pending() const {  // stack entries whose accumulators are not materialised yet
+        return stack_.empty() ? 0 : stack_.size() - 1 - clean_;
+    }
     const spx_packed_pos& position() const {
         return stack_.back();
     }
@@ -170,8 +183,17 @@ public:
     }
 
 private:
+    void evaluateIfPending() {
+        const uint32_t top = uint32_t(stack_.size() - 1);
+        if (clean_ < top) {
+            check(spx_acc_update_chain_eval(ctx_, slotOf_[clean_], &slotOf_[clean_ + 1], &stack_[clean_ + 1], top - clean_, nullptr));
+            clean_ = top;
+        }
+    }
     spx_ctx* ctx_ = nullptr;
-    std::vector<spx_packed_pos> stack_;  // position at every stack depth; slot index == depth
+    std::vector<spx_packed_pos> stack_;  // position at every stack depth
+    std::vector<uint32_t> slotOf_;       // arena slot of every stack depth (a permutation: applyImmediately swaps with the spare)
+    uint32_t spare_ = 0;
     uint32_t clean_ = 0;                 // deepest stack entry whose slot holds up-to-date accumulators
 };
 

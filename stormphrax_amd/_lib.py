@@ -105,6 +105,7 @@ SYMBOLS = {
     "spx_acc_refresh_device": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_eval": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "spx_acc_update_chain_eval": (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_eval_device": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "spx_acc_update_eval_device_async": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_acc_replay_tree": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_double)]),
@@ -114,7 +115,6 @@ SYMBOLS = {
     "spx_ctx_compact_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_ctx_near_psq_rows": (ctypes.c_uint32, [_P]),
     "spx_acc_update_eval_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),
-    "spx_acc_update_device_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device_async": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(ctypes.c_void_p)]),
     "spx_ctx_synchronize": (ctypes.c_int, [_P]),
     "spx_viri_expand_gpu": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),

@@ -974,27 +974,6 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
                             const void* d_child_positions, size_t n, const uint32_t* d_count, void* d_out, void* stream,
                             const char* who);
 
-int spx_acc_update_device_counted(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
-                                  const void* d_child_positions, const void* d_count, size_t capacity, void* stream) {
-    int rc = checkAcc(ctx, capacity, "spx_acc_update_device_counted");
-    if (rc != SPX_OK || capacity == 0) return rc;
-    if (!d_child_slots || !d_count) {
-        setError("spx_acc_update_device_counted: null child slots or count");
-        return SPX_ERR_INVALID_ARG;
-    }
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    UpdateParams up{};
-    up.nRecords = uint32_t(capacity);
-    up.nRecordsPtr = static_cast<const uint32_t*>(d_count);
-    up.parentSlots = static_cast<const uint32_t*>(d_parent_slots);
-    up.childSlots = static_cast<const uint32_t*>(d_child_slots);
-    up.childPositions = d_child_positions;
-    up.t = tablesOf(ctx);
-    up.arena = ctx->dArena;
-    up.slotRecords = ctx->dSlotRecords;
-    return launchUpdateAndRefresh(ctx, up, capacity, s);
-}
-
 // The update kernel proper, followed (second-generation kernel) by the pass that rebuilds the perspectives it deferred:
 // the feature-transformer kernel over the refresh list (ids in dPerspOrder - free until the MLP's sort - and the count in
 // one of two alternating device words; the pass clears the other one for the next update).
@@ -1388,6 +1367,56 @@ int spx_acc_update_eval(spx_ctx* ctx, const uint32_t* parent_slots, const uint32
     if (rc != SPX_OK) return rc;
     SPX_HIP(hipMemcpyAsync(out, ctx->dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SPX_HIP(hipStreamSynchronize(ctx->stream));
+    return SPX_OK;
+}
+
+// NnueState::ensureUpToDate over a whole pending path + evaluate of its last position: ONE launch of the chain kernel (the
+// accumulator stays in registers from ply to ply), one tiny MLP launch, one synchronisation.
+int spx_acc_update_chain_eval(spx_ctx* ctx, uint32_t parent_slot, const uint32_t* child_slots,
+                              const spx_packed_pos* child_positions, size_t n, int32_t* out) {
+    int rc = checkAcc(ctx, n, "spx_acc_update_chain_eval");
+    if (rc != SPX_OK || n == 0) return rc;
+    if (!child_slots || !child_positions || n > kTinyIoRecords) {
+        setError("spx_acc_update_chain_eval: null argument or a path longer than 8192 plies");
+        return SPX_ERR_INVALID_ARG;
+    }
+    if ((rc = checkSlots(ctx, &parent_slot, 1, "spx_acc_update_chain_eval")) != SPX_OK) return rc;
+    if ((rc = checkSlots(ctx, child_slots, n, "spx_acc_update_chain_eval")) != SPX_OK) return rc;
+    // operands through the device-mapped page-locked staging buffer (as the other latency-bound host calls)
+    auto* records = static_cast<spx_packed_pos*>(ctx->hTinyIo);
+    auto* scores = reinterpret_cast<int32_t*>(records + kTinyIoRecords);
+    uint32_t* head = reinterpret_cast<uint32_t*>(scores + kTinyIoRecords);  // [0] parent slot, [1] first, [2] count
+    uint32_t* children = head + kTinyIoRecords;
+    std::memcpy(records, child_positions, n * sizeof(spx_packed_pos));
+    std::memcpy(children, child_slots, n * sizeof(uint32_t));
+    head[0] = parent_slot;
+    head[1] = 0;
+    head[2] = uint32_t(n);
+    char* dBase = nullptr;
+    SPX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dBase), ctx->hTinyIo, 0));
+    const size_t offScores = kTinyIoRecords * sizeof(spx_packed_pos), offHead = offScores + kTinyIoRecords * 4,
+                 offChildren = offHead + kTinyIoRecords * 4;
+    ChainParams cp{};
+    cp.nChains = 1;
+    cp.parentSlots = reinterpret_cast<const uint32_t*>(dBase + offHead);
+    cp.first = cp.parentSlots + 1;
+    cp.count = cp.parentSlots + 2;
+    cp.childSlots = reinterpret_cast<const uint32_t*>(dBase + offChildren);
+    cp.childPositions = dBase;
+    cp.t = tablesOf(ctx);
+    cp.arena = ctx->dArena;
+    cp.slotRecords = ctx->dSlotRecords;
+    if (out) {
+        cp.ftOut = ctx->dFtOut;
+        cp.stagedRecords = ctx->dStaged;
+    }
+    SPX_HIP(launchUpdateChain(cp, ctx->stream));
+    if (out) {
+        rc = runTinyMlp(ctx, ctx->dStaged, 1, dBase + offScores, ctx->stream);
+        if (rc != SPX_OK) return rc;
+    }
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    if (out) *out = scores[0];
     return SPX_OK;
 }
 

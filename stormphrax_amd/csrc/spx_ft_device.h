@@ -504,12 +504,21 @@ __device__ __forceinline__ void loadAcc(const uint8_t* arena, uint32_t slot, int
 
 // child accumulator = parent accumulator - removed rows + added rows (updatePsq, nnue_state.cpp:34-87;
 // applyThreatRows, :89-145). Lists hold byte offsets; wrapping i16; threat sums kept in non-overflowing 32-bit fields.
+// (applyDeltaRows: the parent accumulator is already in `acc` - the chain kernel carries it from ply to ply in registers)
+__device__ __forceinline__ void applyDeltaRows(const FtTables& t, uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
+                                               const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
+                                               uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]);
 template <bool kStream = false>
 __device__ __forceinline__ void applyDelta(const FtTables& t, const uint8_t* arena, uint32_t parentSlot, int c,
                                            uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
                                            const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
                                            uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]) {
     loadAcc(arena, parentSlot, c, lane, acc);
+    applyDeltaRows(t, lane, psqSub, nPsqSub, psqAdd, nPsqAdd, thrAdd, nAdd, thrSub, nSub, acc);
+}
+__device__ __forceinline__ void applyDeltaRows(const FtTables& t, uint32_t lane, const uint32_t* psqSub, uint32_t nPsqSub,
+                                               const uint32_t* psqAdd, uint32_t nPsqAdd, const uint32_t* thrAdd,
+                                               uint32_t nAdd, const uint32_t* thrSub, uint32_t nSub, uint32_t (&acc)[8]) {
     const uint8_t* psqBase = reinterpret_cast<const uint8_t*>(t.psqW) + 16 * lane;
     for (uint32_t i = 0; i < nPsqSub; ++i) {
         const uint8_t* row = psqBase + __builtin_amdgcn_readfirstlane(psqSub[i]);

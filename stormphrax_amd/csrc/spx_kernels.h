@@ -56,6 +56,20 @@ struct UpdateParams {
     uint32_t* refreshCount;        // ... and their number (zero on entry); the FT kernel launched next consumes both
 };
 
+struct ChainParams {               // spx_update_chain_kernel: whole pending PATHS (NnueState::ensureUpToDate) in one launch
+    uint32_t nChains;
+    const uint32_t* parentSlots;   // [nChains] the materialised slot each path starts from
+    const uint32_t* first;         // [nChains] index of the path's first ply in the arrays below
+    const uint32_t* count;         // [nChains] plies of the path (>= 1): ply k's parent is ply k - 1
+    const uint32_t* childSlots;    // [total plies] slot every ply's accumulators are written to
+    const void* childPositions;    // spx_packed_pos[total plies]
+    FtTables t;
+    uint8_t* arena;
+    uint8_t* slotRecords;
+    uint8_t* ftOut;                // optional: [nChains][1024] activations of each path's LAST position ...
+    uint8_t* stagedRecords;        // ... and [nChains][32] its record
+};
+
 struct SlotActParams {
     uint32_t nSlots;
     const uint32_t* slots;
@@ -165,10 +179,9 @@ struct GameStepParams {
     SelfplayCounters* counters;
     uint32_t* ring;                 // [ringWords] viriformat output (page-locked host memory mapped into the device)
     uint32_t ringWords;
-    uint32_t* updParents;           // materialising update of the seats that go on: parent slot (or the null slot for a new game) ...
-    uint32_t* updChildren;          // ... child slot ...
-    uint64_t* updPositions;         // ... and the new current record, compacted; their number in *halfCounters
-    uint32_t* halfCounters;         // [0] update records, [1] seats with a game in progress after this step (zero on entry)
+    uint32_t* updParents;           // [nSeats] the half's materialising update, one record per seat: parent slot (the null
+    uint32_t* updChildren;          //          slot for a new game or an idle seat), child slot (the seat's other slot) ...
+    uint64_t* updPositions;         // [nSeats] ... and the seat's new current record (empty for an idle seat)
 };
 
 struct ViriExpandParams {          // spx_viri_expand_kernel (spx_movegen.hip)
@@ -218,6 +231,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
                         bool legacy, hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
+hipError_t launchUpdateChain(const ChainParams& p, hipStream_t stream);
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);

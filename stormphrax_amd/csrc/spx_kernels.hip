@@ -227,6 +227,105 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// A whole pending PATH per wavefront pair: NnueState::ensureUpToDate (nnue_state.cpp:636-697) walks forward from the last
+// clean ancestor and applies one ply after the other; here one wavefront per (path, perspective) does the same inside ONE
+// launch, the accumulator staying in registers from ply to ply (updatePsq :34-87, applyThreatUpdates :356-394, rebuilds
+// :458-536 inline) and every ply's accumulator written to its slot on the way, as the reference leaves every stack entry on
+// the path clean. The drop-in stack (include/spx_nnue.hpp) used to pay one ~29 us synchronous call per pending ply.
+// Delta derivation as in spx_update_kernel_v1 (two attack generations per ply: this path is latency-, not
+// throughput-bound).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_chain_kernel(ChainParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint32_t sSub[kWavesPerBlock][kU8Cap];
+    __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
+    __syncthreads();
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
+    if (item >= 2 * p.nChains) return;
+    const uint32_t chain = item >> 1;
+    const int c = int(item & 1);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(p.first[chain]);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(p.count[chain]);
+    const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[chain]);
+    uint32_t acc[8];
+    loadAcc(p.arena, parentSlot, c, lane, acc);
+    LaneBoard pb = decodeBoard(p.slotRecords + size_t(parentSlot) * 32, lane);
+    int childStm = pb.stm;
+#pragma unroll 1
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(first + k) * 32;
+        const LaneBoard cb = decodeBoard(childRec, lane);
+        childStm = cb.stm;
+        const bool changedSq = pb.piece != cb.piece;
+        const uint64_t changed = __ballot(changedSq);
+        const uint64_t kingMaskP = __ballot(pb.piece == (10 | c)), kingMaskC = __ballot(cb.piece == (10 | c));
+        const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
+        const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
+        const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) ||
+                             popc64(changed) > 4;
+        if (refresh) {
+            uint32_t nPsq, nThr;
+            buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+        } else {
+            uint64_t tP = 0, tC = 0;
+            if (pb.piece != kNoPiece && (pb.piece >> 1) != 5) tP = pieceAttacks(pb.piece, int(lane), pb.occ) & pb.occ & ~pb.kingsBb;
+            if (cb.piece != kNoPiece && (cb.piece >> 1) != 5) tC = pieceAttacks(cb.piece, int(lane), cb.occ) & cb.occ & ~cb.kingsBb;
+            const uint64_t keep = changedSq ? 0 : (tP & tC & ~changed);
+            const int x = perspXor(c, kingC);
+            const int flipColour = (c == 0) ? 1 : 0;
+            uint32_t nPsqSub, nPsqAdd;
+            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
+            uint32_t* subList = sSub[wave];
+            uint32_t* addList = sThr[wave];
+            const uint32_t nSubCompact = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC) : 0u, sLut,
+                                                          sPsqDelta[wave][0], subList, nPsqSub);
+            const uint32_t nAddCompact = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC) : 0u, sLut,
+                                                          sPsqDelta[wave][1], addList, nPsqAdd);
+            subList += nSubCompact;
+            addList += nAddCompact;
+            uint32_t nSub = emitThreatRows(subList, 0, tP & ~keep, pb.piece, lane, x, flipColour, sLut);
+            uint32_t nAdd = emitThreatRows(addList, 0, tC & ~keep, cb.piece, lane, x, flipColour, sLut);
+            {
+                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
+                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
+                const bool pawnP = (pb.piece >> 1) == 0, pawnC = (cb.piece >> 1) == 0;
+                const bool ownSideP = pawnP && (pb.piece & 1) == c, ownSideC = pawnC && (cb.piece & 1) == c;
+                const uint64_t partP = pawnPartners(pawnP, ownSideP, lane, ownP, theirP);
+                const uint64_t partC = pawnPartners(pawnC, ownSideC, lane, ownC, theirC);
+                const uint64_t unchangedPawns = pb.pawnsBb & cb.pawnsBb & ~changed;
+                const uint64_t kept = (pawnP && pawnC && !changedSq) ? (partP & partC & unchangedPawns) : 0;
+                nSub = emitPawnPairRows(subList, nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
+                nAdd = emitPawnPairRows(addList, nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
+            }
+            __builtin_amdgcn_wave_barrier();
+            applyDeltaRows(p.t, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd, sThr[wave], nAdd + nAddCompact,
+                           sSub[wave], nSub + nSubCompact, acc);
+        }
+        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[first + k]);
+        storeAcc(p.arena, childSlot, c, lane, acc);
+        if (lane < 8 && c == 0) {
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = reinterpret_cast<const uint32_t*>(childRec)[lane];
+        }
+        __builtin_amdgcn_wave_barrier();  // this ply's lists are dead before the next ply's are written
+        pb = cb;
+    }
+    if (p.ftOut && n) {
+        const uint32_t half = (c == childStm) ? 0u : 1u;
+        *reinterpret_cast<u32x2*>(p.ftOut + size_t(chain) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+        if (lane < 8 && c == 0) {
+            const uint8_t* last = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(first + n - 1) * 32;
+            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(chain) * 32)[lane] = reinterpret_cast<const uint32_t*>(last)[lane];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Incremental update kernel, second generation (round 2): same contract as spx_update_kernel_v1 above - child
 // accumulator = parent accumulator + added rows - removed rows, delta derived on the device from the two boards - but
 // the threat delta comes from RAY WALKS around the changed squares (deltaCandidates, spx_device_math.h: one lane per
@@ -1079,6 +1178,12 @@ hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPe
     } else {
         hipLaunchKernelGGL((spx_update_kernel<false, false>), grid, block, 0, stream, p);
     }
+    return hipGetLastError();
+}
+
+hipError_t launchUpdateChain(const ChainParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_update_chain_kernel, dim3((2 * p.nChains + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock),
+                       0, stream, p);
     return hipGetLastError();
 }
 

@@ -647,26 +647,23 @@ __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
         }
     }
     if (lane == 0) p.state[g] = st;
-    if (started || moved) {
-        const uint64_t n0 = started ? r0 : c0, n1 = started ? r1 : c1, n2 = started ? r2 : c2, n3 = started ? r3 : c3;
-        uint32_t idx = 0;
-        if (lane == 0) {
-            idx = atomicAdd(&p.halfCounters[0], 1u);
-            atomicAdd(&p.halfCounters[1], 1u);
-            p.updParents[idx] = started ? 2u * p.nSeatsTotal : oldSlot;
-            p.updChildren[idx] = otherSlot;
-            p.slots[g] = otherSlot;
-            if (started) p.rng[g] = seed;
-        }
-        idx = uniform(idx);
-        if (lane < 4) {
-            const uint64_t w = lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3));
-            pos[lane] = w;
-            p.updPositions[size_t(idx) * 4 + lane] = w;
-            if (started) p.initial[size_t(g) * 4 + lane] = w;
-        }
-    } else if (lane < 4) {
-        pos[lane] = 0;  // idle seat: an empty record generates no moves
+    // The half's materialising update has one record per SEAT, at the seat's own index (no compaction: thousands of atomic
+    // adds on one counter per launch cost more than the whole ply - ~116 ns each on this chip): the move played (parent =
+    // old slot), a new game (parent = the null slot's empty board: the update kernel rebuilds the child from scratch), or,
+    // for an idle seat, empty board -> empty board into the seat's spare slot (no rows, nothing read back).
+    const bool live = started || moved;
+    const uint64_t n0 = started ? r0 : c0, n1 = started ? r1 : c1, n2 = started ? r2 : c2, n3 = started ? r3 : c3;
+    if (lane == 0) {
+        p.updParents[g] = moved ? oldSlot : 2u * p.nSeatsTotal;
+        p.updChildren[g] = otherSlot;
+        if (live) p.slots[g] = otherSlot;
+        if (started) p.rng[g] = seed;
+    }
+    if (lane < 4) {
+        const uint64_t w = !live ? 0ull : (lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3)));
+        pos[lane] = w;  // (idle seat: an empty record generates no moves)
+        p.updPositions[size_t(g) * 4 + lane] = w;
+        if (started) p.initial[size_t(g) * 4 + lane] = w;
     }
 }
 

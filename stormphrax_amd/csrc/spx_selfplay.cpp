@@ -802,8 +802,9 @@ namespace {
 struct HalfStatus {              // what the host reads back per ply (page-locked)
     SelfplayCounters counters;   // run-wide counters as of the end of this half's step kernel
     uint32_t total;              // children generated this ply (must fit `cap`)
-    uint32_t half[2];            // update records, seats with a game in progress
 };
+
+constexpr uint32_t kPliesInFlight = 2;  // per half: the host enqueues this far ahead of the results it has seen
 
 struct DeviceHalf {
     uint32_t begin = 0, end = 0;     // seats
@@ -813,18 +814,19 @@ struct DeviceHalf {
     uint32_t* dParents = nullptr;
     int32_t* dEvals = nullptr;
     uint32_t* dTotal = nullptr;
-    uint32_t *dUpdParents = nullptr, *dUpdChildren = nullptr, *dHalfCounters = nullptr;
+    uint32_t *dUpdParents = nullptr, *dUpdChildren = nullptr;
     uint64_t* dUpdPositions = nullptr;
-    HalfStatus* hStatus = nullptr;   // pinned
-    hipEvent_t done = nullptr;
-    bool inFlight = false, everRan = false;
+    HalfStatus* hStatus = nullptr;   // pinned, [kPliesInFlight]
+    hipEvent_t done[kPliesInFlight] = {};
+    uint64_t enqueued = 0, acked = 0;  // plies enqueued / plies whose results the host has read
     uint32_t index = 0;              // which lane of the context this half runs on
 };
 
-// The games live on the device: per ply and half the host enqueues one fixed chain of launches, waits for its event and
-// reads 100 bytes of counters plus whatever finished games the step kernel wrote into the output ring - O(1) host work per
-// ply, whatever the number of seats (round 2 kept counters, repetition keys and the records on the host: 24 bytes and a
-// few hundred instructions per game and ply, and the GPU idled half of the wall time at 4 096 games).
+// The games live on the device: per ply and half the host enqueues one fixed chain of launches and, kPliesInFlight plies
+// later, reads 100 bytes of counters plus whatever finished games the step kernels wrote into the output ring - O(1) host
+// work per ply, whatever the number of seats, and never on the GPU's critical path (round 2 kept counters, repetition keys
+// and the records on the host: 24 bytes and a few hundred instructions per game and ply, one host round trip per ply, and
+// the GPU idled half of the wall time at 4 096 games).
 int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path, spx_selfplay_stats* stats) {
     const uint32_t G = p->n_games;
     const uint32_t nHalves = G >= 2 ? 2 : 1;
@@ -854,7 +856,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     std::memset(stats, 0, sizeof(*stats));
 
     const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
-    const uint32_t poolCap = 4 * G + 32768;
+    const uint32_t poolCap = (kPliesInFlight + 3) * G + 32768;
     const uint32_t ringWords = uint32_t(std::max<uint64_t>(1u << 20, uint64_t(G) * 2 * (maxPlies + 9)));
     DeviceBuffers dev;
     PinnedBuffers pinned;
@@ -903,10 +905,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         hf.dUpdParents = dev.get<uint32_t>(seats);
         hf.dUpdChildren = dev.get<uint32_t>(seats);
         hf.dUpdPositions = dev.get<uint64_t>(size_t(seats) * 4);
-        hf.dHalfCounters = dev.get<uint32_t>(2);
-        hf.hStatus = pinned.get<HalfStatus>(1);
+        hf.hStatus = pinned.get<HalfStatus>(kPliesInFlight);
         ok = hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
-             hf.dUpdPositions && hf.dHalfCounters && hf.hStatus && seats <= ctxMaxBatch(ctx);
+             hf.dUpdPositions && hf.hStatus && seats <= ctxMaxBatch(ctx);
     }
     if (!ok) {
         setError("spx_selfplay_run: out of device or page-locked memory (or a context smaller than half the seats)");
@@ -925,11 +926,15 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         std::vector<DeviceHalf>& hs;
         ~EventCloser() {
             for (DeviceHalf& hf : hs) {
-                if (hf.done) (void)hipEventDestroy(hf.done);
+                for (hipEvent_t e : hf.done) {
+                    if (e) (void)hipEventDestroy(e);
+                }
             }
         }
     } eventCloser{halves};
-    for (DeviceHalf& hf : halves) SPX_SP_HIP(hipEventCreateWithFlags(&hf.done, hipEventDisableTiming));
+    for (DeviceHalf& hf : halves) {
+        for (hipEvent_t& e : hf.done) SPX_SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     {
         std::vector<uint32_t> iota(G);
         for (uint32_t i = 0; i < G; ++i) iota[i] = i;  // every seat starts on its home slot
@@ -951,10 +956,10 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     uint64_t evals = 0, steps = 0;
 
     // Openings: generated in bulk on the device (OpeningPool), published to the device-side ring ahead of every claim the
-    // step kernels in flight can make: a step claims at most one opening per seat, two steps may have run since the
-    // counters were last seen.
+    // step kernels in flight can make: a step claims at most one opening per seat, and 2 * kPliesInFlight half-steps may
+    // have run since the counters were last seen.
     auto ensurePool = [&](hipStream_t s) -> int {
-        const uint32_t want = 2 * G + G / 2 + 64;
+        const uint32_t want = (kPliesInFlight + 1) * G + 64;
         while (published - latest.poolCursor < want) {
             const uint32_t room = poolCap - (published - latest.poolCursor);
             const uint32_t n = std::min<uint32_t>({16384u, room, want + G - (published - latest.poolCursor)});
@@ -1002,7 +1007,6 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         // eval-only children (child slots NULL): ~35 siblings per seat evaluated, none stored
         r = spx_acc_update_eval_device_counted(ctx, hf.dParents, nullptr, hf.dChildren, hf.dTotal, hf.cap, hf.dEvals, s);
         if (r != SPX_OK) return r;
-        SPX_SP_HIP(hipMemsetAsync(hf.dHalfCounters, 0, 8, s));
         GameStepParams gp{};
         gp.nSeats = seats;
         gp.seatBase = hf.begin;
@@ -1032,27 +1036,26 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         gp.updParents = hf.dUpdParents;
         gp.updChildren = hf.dUpdChildren;
         gp.updPositions = hf.dUpdPositions;
-        gp.halfCounters = hf.dHalfCounters;
         SPX_SP_HIP(launchGameStep(gp, s));
         // the one accumulator per seat that has to exist next ply: the move played (parent -> the seat's other slot) or
-        // the new game's opening (null slot -> rebuilt from scratch by the update kernel's deferred pass)
-        r = spx_acc_update_device_counted(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, hf.dHalfCounters, seats, s);
+        // the new game's opening (null slot -> rebuilt from scratch by the update kernel)
+        r = spx_acc_update_device(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, seats, s);
         if (r != SPX_OK) return r;
-        SPX_SP_HIP(hipMemcpyAsync(&hf.hStatus->counters, dCounters, sizeof(SelfplayCounters), hipMemcpyDeviceToHost, s));
-        SPX_SP_HIP(hipMemcpyAsync(&hf.hStatus->total, hf.dTotal, 4, hipMemcpyDeviceToHost, s));
-        SPX_SP_HIP(hipMemcpyAsync(hf.hStatus->half, hf.dHalfCounters, 8, hipMemcpyDeviceToHost, s));
-        SPX_SP_HIP(hipEventRecord(hf.done, s));
-        hf.inFlight = hf.everRan = true;
+        HalfStatus* status = hf.hStatus + hf.enqueued % kPliesInFlight;
+        SPX_SP_HIP(hipMemcpyAsync(&status->counters, dCounters, sizeof(SelfplayCounters), hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(hipMemcpyAsync(&status->total, hf.dTotal, 4, hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(hipEventRecord(hf.done[hf.enqueued % kPliesInFlight], s));
+        ++hf.enqueued;
         ++steps;
         return SPX_OK;
     };
-    // wait for a half's ply; append what the step kernels finished since the last look to the file
+    // wait for a half's oldest ply in flight; append what the step kernels finished since the last look to the file
     auto awaitPly = [&](DeviceHalf& hf) -> int {
         const auto g0 = std::chrono::steady_clock::now();
-        SPX_SP_HIP(hipEventSynchronize(hf.done));
+        SPX_SP_HIP(hipEventSynchronize(hf.done[hf.acked % kPliesInFlight]));
         gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
-        hf.inFlight = false;
-        const HalfStatus& st = *hf.hStatus;
+        const HalfStatus& st = hf.hStatus[hf.acked % kPliesInFlight];
+        ++hf.acked;
         if (st.total > hf.cap) {
             setError("spx_selfplay_run: " + std::to_string(st.total) + " children in one ply exceed the buffer of " +
                      std::to_string(hf.cap) + " (context max_batch too small for this many seats?)");
@@ -1069,6 +1072,10 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
             latest.started = std::max(latest.started, c.started);
             latest.poolCursor = std::max(latest.poolCursor, c.poolCursor);
         }
+        if (latest.poolCursor > published) {
+            setError("spx_selfplay_run: the opening pool ran dry (internal: the publishing margin was too small)");
+            return SPX_ERR_CAPACITY;
+        }
         if (latest.streamWords - consumedWords > ringWords) {
             setError("spx_selfplay_run: the output ring overflowed");
             return SPX_ERR_CAPACITY;
@@ -1084,25 +1091,28 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         }
         return SPX_OK;
     };
-    auto halfHasWork = [&](const DeviceHalf& hf) {
-        return !hf.everRan || hf.hStatus->half[1] != 0 || latest.started < p->target_games;
-    };
-
-    for (DeviceHalf& hf : halves) {
-        if ((rc = enqueuePly(hf)) != SPX_OK) break;
-    }
-    for (uint32_t cur = 0; rc == SPX_OK; cur = (cur + 1) % nHalves) {
-        DeviceHalf& hf = halves[cur];
-        if (!hf.inFlight) {
-            bool any = false;
-            for (const DeviceHalf& other : halves) any = any || other.inFlight;
-            if (!any) break;
-            continue;
+    // Every game that gets a ticket finishes (a discarded opening hands its ticket on), so the run is over when the target
+    // number of games has been written. The host sees that up to kPliesInFlight plies late: the extra plies run on seats that
+    // have gone idle one after the other (empty records generate no moves).
+    for (;;) {
+        if (latest.games < p->target_games) {
+            for (uint32_t round = 0; round < kPliesInFlight && rc == SPX_OK; ++round) {
+                for (DeviceHalf& hf : halves) {
+                    if (rc == SPX_OK && hf.enqueued - hf.acked < kPliesInFlight && hf.enqueued == hf.acked + round) {
+                        const auto a1 = std::chrono::steady_clock::now();
+                        rc = enqueuePly(hf);
+                        enqueueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+                    }
+                }
+            }
         }
-        if ((rc = awaitPly(hf)) != SPX_OK) break;
-        const auto a1 = std::chrono::steady_clock::now();
-        if (halfHasWork(hf)) rc = enqueuePly(hf);
-        enqueueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+        if (rc != SPX_OK) break;
+        DeviceHalf* oldest = nullptr;  // the half whose oldest ply in flight was enqueued first
+        for (DeviceHalf& hf : halves) {
+            if (hf.enqueued > hf.acked && (!oldest || hf.acked < oldest->acked)) oldest = &hf;
+        }
+        if (!oldest) break;
+        if ((rc = awaitPly(*oldest)) != SPX_OK) break;
     }
     (void)spx_ctx_synchronize(ctx);  // nothing may still reference the staging buffers on an error exit
     stats->games = latest.games;

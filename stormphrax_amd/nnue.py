@@ -26,7 +26,7 @@ PACKED_DTYPE = np.dtype(
 )
 assert PACKED_DTYPE.itemsize == 32
 
-PRESETS = {"tame": 0, "wild": 1, "extreme": 2}
+PRESETS = {"tame": 0, "wild": 1, "extreme": 2, "realistic": 3}
 DEFAULT_SEED = 20260927
 
 

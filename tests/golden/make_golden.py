@@ -7,7 +7,7 @@ Drives oracle/_ref/sp_ref_probe_tame and oracle/_ref_build/sp_ref_probe_{wild,ex
 sources compiled where they lie under /root/reference and linked with oracle/ref_probe.cpp - and records what the
 reference itself computes:
 
-  evals.jsonl     {"fen", "src", "tame", "wild", "extreme"}: NnueState::evaluateOnce (unclamped raw eval) per preset of
+  evals.jsonl     {"fen", "src", "tame", "wild", "extreme", "realistic"}: NnueState::evaluateOnce (unclamped raw eval) per preset of
                   the repo's synthetic net, for (a) the 52 `bench` FENs of src/bench.cpp:36-93 + startpos, (b) positions
                   from the repo's own seeded generator, (c) positions the reference's own move generator produced
   features.jsonl  {"fen", "bucket", "stm", "psq": [black, white], "thr": [black, white]}: per-perspective row ids in the
@@ -46,6 +46,7 @@ PROBES = {
     "tame": os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame"),
     "wild": os.path.join(ROOT, "oracle", "_ref_build", "sp_ref_probe_wild"),
     "extreme": os.path.join(ROOT, "oracle", "_ref_build", "sp_ref_probe_extreme"),
+    "realistic": os.path.join(ROOT, "oracle", "_ref_build", "sp_ref_probe_realistic"),
 }
 STARTPOS = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
 
@@ -153,7 +154,25 @@ def make_wire():
     print("wire goldens written:", len(fens), "packs,", len(games), "games")
 
 
+def add_preset_column(preset):
+    """evals.jsonl gains (or refreshes) the column of one preset without touching the others: `make_golden.py column realistic`."""
+    path = os.path.join(HERE, "evals.jsonl")
+    recs = [json.loads(line) for line in open(path)]
+    probe = Probe(PROBES[preset])
+    for rec in recs:
+        (line,) = probe.cmd("eval " + rec["fen"])
+        assert line.startswith("E "), (rec["fen"], line)
+        rec[preset] = int(line.split()[1])
+    probe.close()
+    with open(path, "w") as f:
+        for rec in recs:
+            f.write(json.dumps(rec) + "\n")
+    print(f"evals.jsonl: column '{preset}' written for {len(recs)} positions")
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "column":
+        return add_preset_column(sys.argv[2])
     if sys.argv[1:] == ["wire"]:
         return make_wire()
     if sys.argv[1:] == ["adjust"]:

@@ -23,7 +23,7 @@ def states(sp, net_blob):
         s.close()
 
 
-@pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
+@pytest.mark.parametrize("preset", ["tame", "wild", "extreme", "realistic"])
 def test_random_positions_bit_exact(sp, oracle, net_blob, states, preset):
     pos = sp.random_positions(4096, seed=101, min_ply=0, max_ply=160, dfrc_every=3)
     mail, stm = sp.positions_to_mailboxes(pos)
@@ -72,7 +72,7 @@ def test_startpos_and_bare_kings(sp, oracle, net_blob, states):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
+@pytest.mark.parametrize("preset", ["tame", "wild", "extreme", "realistic"])
 def test_reference_golden_vectors(sp, net_blob, states, preset):
     """GPU vs the COMPILED REFERENCE directly (tests/golden/evals.jsonl), without going through the oracle."""
     import json

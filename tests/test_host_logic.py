@@ -81,11 +81,14 @@ def test_kernel_feature_extraction_matches_oracle(sp, oracle, net_blob):
 
 
 def test_synthetic_net_is_reproducible(sp):
-    """Digest pins of the three presets (seed 20260927): the GPU box regenerates bit-identical files."""
+    """Digest pins of the presets (seed 20260927): the GPU box regenerates bit-identical files. "realistic" also pins how its
+    piece-square rows split (fit i8 / <= 32 weights outside i8 / wide) - the property the third bench headline is about."""
     from stormphrax_amd import _lib
 
     lib = _lib.load()
     want = {"tame": 0x4177798691D12739, "wild": 0xAE32025FCF2471C1}
+    real = sp.Network(sp.synthetic_net_bytes("realistic"))
+    assert (real.name, real.psq_row_classes()) == ("spx_synth_realistic", (4711, 4328, 2225))
     for preset, digest in want.items():
         blob = sp.synthetic_net_bytes(preset)
         assert blob.size == 89381984

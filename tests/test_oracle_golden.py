@@ -14,7 +14,7 @@ def load_jsonl(name):
         return [json.loads(line) for line in f]
 
 
-@pytest.mark.parametrize("preset", ["tame", "wild", "extreme"])
+@pytest.mark.parametrize("preset", ["tame", "wild", "extreme", "realistic"])
 def test_oracle_matches_reference_evals(oracle, net_blob, preset):
     recs = load_jsonl("evals.jsonl")
     assert len(recs) >= 2000

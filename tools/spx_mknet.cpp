@@ -1,5 +1,5 @@
 // spx_mknet: write the repo's synthetic CBNF network to a file.
-//   usage: spx_mknet <seed> <preset 0|1|2> <out.nnue>
+//   usage: spx_mknet <seed> <preset 0|1|2|3> <out.nnue>
 // Used by oracle/Makefile to give the compiled reference an embeddable net (the default net is not obtainable
 // offline); the same bytes are generated in-process by spx_synth_net() on the GPU box.
 #include <cstdio>
