@@ -486,12 +486,14 @@ def incremental_leg(sp, torch, net, device, games=65536, chain=6, seconds=0.6):
         st.close()
 
 
-def config3_leg(sp, net, device):
-    """secondary.config3_replay: the recorded 65 536-EVAL reference trace (tests/golden, BASELINE configs[2]) through ONE
+def config3_leg(sp, net, device, name="trace_startpos_tame_64k.txt.gz",
+                what="recorded from the compiled reference: depth-12 make/unmake walk from the start position through "
+                     "NnueState::push / pop / evaluate"):
+    """secondary.config3_replay: a recorded 65 536-EVAL reference trace (tests/golden, BASELINE configs[2]) through ONE
     native spx_acc_replay_tree call; every EVAL must equal what the reference's NnueState::evaluate recorded."""
     from stormphrax_amd.trace import Trace, replay_native
 
-    path = os.path.join(ROOT, "tests", "golden", "trace_startpos_tame_64k.txt.gz")
+    path = os.path.join(ROOT, "tests", "golden", name)
     trace = Trace(path)
     st = sp.NnueState(net, device=device, max_batch=65536)
     try:
@@ -501,8 +503,7 @@ def config3_leg(sp, net, device):
         return {"device_ms": min(ms, ms2), "updates": trace.n_nodes - 1, "evals": len(want),
                 "updates_plus_evals_per_sec": (trace.n_nodes - 1 + len(want)) / (min(ms, ms2) / 1e3),
                 "every_eval_equals_the_reference": bool(np.array_equal(got, want) and np.array_equal(got2, want)),
-                "trace": "tests/golden/trace_startpos_tame_64k.txt.gz (recorded from the compiled reference: depth-12 "
-                         "make/unmake walk from the start position through NnueState::push / pop / evaluate)"}
+                "tree_levels": int(max(trace.depth)), "trace": f"tests/golden/{name} ({what})"}
     finally:
         st.close()
 
@@ -526,6 +527,9 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
     if args.preset == "tame":  # (the trace was recorded on the tame net)
         run("incremental", lambda: incremental_leg(sp, torch, net, device))
         run("config3_replay", lambda: config3_leg(sp, net, device))
+        run("config3_alpha_beta_replay", lambda: config3_leg(
+            sp, net, device, "trace_search_startpos_tame_64k.txt.gz",
+            "the reference's own alpha-beta search, depth <= 12 from the start position, recorded through link-time interposition"))
     return out
 
 

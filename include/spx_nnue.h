@@ -157,6 +157,9 @@ int spx_ctx_synchronize(spx_ctx* ctx);
  *                       derived on the device from the parent slot's record and the child record
  *   spx_acc_eval     == evaluateNetwork on materialised slots (nnue_state.cpp:396-438); stm comes from the slot's record
  * Host-buffer variants synchronise; *_device variants take device pointers and enqueue on `stream` (NULL = context's).
+ * A context is single-threaded and STREAM-ORDERED: the *_device calls of one context share its scratch (sort buffers,
+ * refresh counters, activations), so calls on different streams must be ordered against each other by the caller (events);
+ * the *_async entry points do that ordering themselves on the context's two internal lanes.
  * ---------------------------------------------------------------------------------------------------------------- */
 /* spx_acc_reserve sizes the arena (never shrinks). Growing it keeps every materialised slot: accumulators and records are
  * copied into the new allocation (both arenas exist for the duration of the call). */
@@ -421,6 +424,11 @@ typedef struct spx_selfplay_stats {
     double seconds, gpu_seconds;
 } spx_selfplay_stats;
 int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* params, const char* out_path, spx_selfplay_stats* stats);
+/* The same over a device group (BASELINE configs[3]: "games sharded 2/4/8 MI355X") from ONE native process: member r plays
+ * its contiguous share of n_games / target_games on its own device and host thread (seed + r, output <out_path>.<r>.vf);
+ * no exchange step; stats are summed (seconds: the slowest member). Members need spx_selfplay_run's context capacity for
+ * their share. */
+int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, const char* out_path, spx_selfplay_stats* stats);
 
 /* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):
  * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */

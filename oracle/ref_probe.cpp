@@ -16,6 +16,15 @@
 //   feat <fen>                 -> "F <raw> <bucket> <stm>" + 4 lines "R <colour> <psq|thr> <n> ids..."
 //   playout <seed> <count> <minPly> <maxPly> <dfrc>  -> count lines "P <raw> <fen>"
 //   trace <seed> <maxEvals> <depth> <fen>            -> opcode stream of a DFS make/unmake walk with evaluate() values
+//   searchtrace <maxEvals> <depth> <hardNodes> <fen> -> the same opcode stream recorded from the reference's own ALPHA-BETA
+//                                 SEARCH (Searcher::runDatagenSearch: PVS + qsearch, null moves, reductions, TT): every
+//                                 Position::applyMove<BoardObserver> the search makes (thread.cpp:46-67) is a PUSH, every
+//                                 NnueState::pop (thread.h:116-122) a POP, every NnueState::evaluate (search.cpp:782,1520)
+//                                 an EVAL. The three functions are reached through link-time interposition (oracle/Makefile
+//                                 renames the reference's definitions in copies of two of ITS object files; the wrappers
+//                                 below log and forward) - no reference source is touched or copied. PUSH and EVAL carry
+//                                 the side to move of the position they act on: after a null move (no NNUE push,
+//                                 thread.cpp:28-44) it differs from the stack's, which is how the replayer sees null moves.
 //   deltas <seed> <count> <dfrc>                     -> per played move the BoardObserver's UpdateContext
 //   adjust <cB> <cW> <oB> <oW> <fen>                 -> "A <staticEvalOnce(contempt)> <adjustEval<false>(optimism, static)>"
 //   add <fen> / bench <threads> <seconds>            -> timing of evaluateOnce over the added positions
@@ -44,11 +53,18 @@
 #include "movegen.h"
 #include "opts.h"
 #include "position.h"
+#include "search.h"
 #include "tunable.h"
 #include "util/numa/numa.h"
 #include "wdl.h"
 
 using namespace stormphrax;
+
+namespace stormphrax {
+    // defined near the end of this file: the logging wrapper that `searchtrace` interposes (declared before any use)
+    template <>
+    Position Position::applyMove<eval::BoardObserver>(Move move, eval::BoardObserver observer) const;
+} // namespace stormphrax
 
 namespace {
     struct SplitMix64 {
@@ -171,6 +187,44 @@ namespace {
         }
     };
 } // namespace
+
+// ---- link-time interposition for `searchtrace` (see the header comment and oracle/Makefile) ----
+namespace {
+    bool g_tracing = false;
+    u64 g_traceEvals = 0, g_traceMaxEvals = 0;
+    bool tracing() {
+        return g_tracing && g_traceEvals < g_traceMaxEvals;
+    }
+} // namespace
+// the reference's own definitions, under the names oracle/Makefile gave them in its copies of position.o / nnue_state.o
+// (Itanium ABI: a non-static member function is a free function taking `this` first)
+Position spxOrigApplyMove(const Position* self, Move move, eval::BoardObserver observer) asm("spx_orig_apply_move_observed");
+void spxOrigPop(eval::NnueState* self) asm("spx_orig_nnue_pop");
+i32 spxOrigEvaluate(eval::NnueState* self, const Position& pos, Color stm) asm("spx_orig_nnue_evaluate");
+
+namespace stormphrax {
+    template <>
+    Position Position::applyMove<eval::BoardObserver>(Move move, eval::BoardObserver observer) const {
+        if (tracing()) {
+            std::printf("PUSH %s %c\n", fmt::format("{}", move).c_str(), stm() == Colors::kWhite ? 'w' : 'b');
+        }
+        return spxOrigApplyMove(this, move, observer);
+    }
+    void eval::NnueState::pop() {
+        if (tracing()) {
+            std::printf("POP\n");
+        }
+        spxOrigPop(this);
+    }
+    i32 eval::NnueState::evaluate(const Position& pos, Color stm) {
+        const auto v = spxOrigEvaluate(this, pos, stm);
+        if (tracing()) {
+            std::printf("EVAL %d %d %c\n", v, eval::NnueState::evaluateOnce(pos, stm), pos.stm() == Colors::kWhite ? 'w' : 'b');
+            ++g_traceEvals;
+        }
+        return v;
+    }
+} // namespace stormphrax
 
 int main() {
     if (!numa::init()) {
@@ -401,6 +455,42 @@ int main() {
             tracer.state.reset(*pos);
             std::printf("ROOT %s\n", pos->toFen().c_str());
             tracer.walk(*pos, depth);
+        } else if (cmd == "searchtrace") {
+            u64 maxEvals, hardNodes;
+            i32 depth;
+            in >> maxEvals >> depth >> hardNodes;
+            std::string fen;
+            std::getline(in, fen);
+            const auto pos = Position::fromFen(fen);
+            if (!pos) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            // the set-up of datagen's searches (src/datagen/datagen.cpp:112-135,177-184): one searcher, its thread data taken
+            // over, a hard node limit, a depth limit
+            search::Searcher searcher{16};
+            searcher.setSilent(true);
+            auto& thread = searcher.take(0);
+            thread.datagen = true;
+            limit::SearchLimiter limiter{util::Instant::now()};
+            limiter.setHardNodes(hardNodes);
+            searcher.setLimiter(limiter);
+            searcher.setMaxDepth(depth);
+            searcher.newGame();
+            thread.search = search::SearchData{};
+            thread.keyHistory.clear();
+            thread.rootPos = *pos;
+            thread.nnueState.reset(thread.rootPos);
+            std::printf("ROOT %s\n", pos->toFen().c_str());
+            g_traceEvals = 0;
+            g_traceMaxEvals = maxEvals;
+            g_tracing = true;
+            const auto [score, norm] = searcher.runDatagenSearch();
+            g_tracing = false;
+            std::printf("# searched to depth <= %d, %llu nodes, score %d (white point of view), %llu evaluates recorded\n", depth,
+                        static_cast<unsigned long long>(thread.search.loadNodes()), score,
+                        static_cast<unsigned long long>(g_traceEvals));
         } else if (cmd == "bench") {
             u32 threads;
             double seconds;

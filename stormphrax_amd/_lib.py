@@ -146,6 +146,7 @@ SYMBOLS = {
     "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
+    "spx_group_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),
     "spx_perft": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_int]),
     "spx_debug_delta": (ctypes.c_int, [_P, _P, ctypes.c_int] + [_P, ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int)]),
     "spx_debug_wdl": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),

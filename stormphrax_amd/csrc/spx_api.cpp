@@ -73,6 +73,8 @@ struct spx_ctx {
     uint32_t* dHist = nullptr;     // 3 sort-histogram buffers of kHistWords + 64 words of counters
     uint32_t* dPerspOrder = nullptr;  // perspective ids grouped by king bucket
     uint32_t* dPosOrder = nullptr;    // position ids grouped by output bucket
+    uint32_t* dRefreshList = nullptr; // update kernel: perspectives deferred to the rebuild pass (its own buffer: the king sort
+                                      // of a full refresh on another stream must not overwrite a list that is being consumed)
     // accumulator arena (incremental path): nSlots x (4 KiB accumulators + 32 B record)
     uint8_t* dArena = nullptr;
     uint8_t* dSlotRecords = nullptr;
@@ -90,7 +92,7 @@ struct spx_ctx {
     // chained by events (they never overlap each other - two of them thrash the caches)
     struct EvalLane {
         uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr, *dStaged = nullptr;
-        uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *histUsed = nullptr;
+        uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *dRefreshList = nullptr, *histUsed = nullptr;
         int histCur = 0, refreshCur = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ftDone = nullptr, done = nullptr;
@@ -439,7 +441,16 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     // (default 4 Mi): a context created for an HBM-filling batch (BASELINE config 5: 36 bytes per resident position -
     // record in, score out) walks it in chunks of that size instead of reserving ~1.1 KB of scratch per position
     size_t scratchCap = size_t(1) << 22;
-    if (const char* env = std::getenv("SPX_SCRATCH_CAP")) scratchCap = std::max<size_t>(1024, size_t(std::atoll(env)));
+    if (const char* env = std::getenv("SPX_SCRATCH_CAP")) {
+        // launch parameters are 32-bit (2 * n perspective ids, n * 1024 activation offsets are 64-bit): positions per chunk
+        // stay at or below 2^30; a non-positive or unparsable value is refused rather than turned into a huge size_t
+        const long long v = std::atoll(env);
+        if (v <= 0 || v > (1ll << 30)) {
+            setError("SPX_SCRATCH_CAP must be in [1, 2^30]");
+            return SPX_ERR_INVALID_ARG;
+        }
+        scratchCap = std::max<size_t>(1024, size_t(v));
+    }
     ctx->callLimit = max_batch;
     ctx->maxBatch = std::min(max_batch, scratchCap);
     max_batch = ctx->maxBatch;
@@ -529,6 +540,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMemset(ctx->dHist, 0, (3 * kHistWords + 64) * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
+    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dRefreshList), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
@@ -583,7 +595,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dOutlierTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
-                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder,
+                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder, ctx->dRefreshList,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
@@ -594,7 +606,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
-                            lane.dPosOrder, lane.dIn, lane.dOutStage};
+                            lane.dPosOrder, lane.dRefreshList, lane.dIn, lane.dOutStage};
         if (lane.hIn) (void)hipHostFree(lane.hIn);
         if (lane.hOut) (void)hipHostFree(lane.hOut);
         for (void* q : lanePtrs) {
@@ -733,6 +745,7 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
     std::swap(ctx->dHist, lane.dHist);
     std::swap(ctx->dPerspOrder, lane.dPerspOrder);
     std::swap(ctx->dPosOrder, lane.dPosOrder);
+    std::swap(ctx->dRefreshList, lane.dRefreshList);
     std::swap(ctx->histUsed, lane.histUsed);
     std::swap(ctx->histCur, lane.histCur);
     std::swap(ctx->refreshCur, lane.refreshCur);
@@ -754,6 +767,7 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipMemset(lane.dHist, 0, (3 * kHistWords + 64) * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
+        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dRefreshList), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking,
                                             laneIndex++ == 0 ? leastPriority : greatestPriority));
         SPX_HIP(hipEventCreateWithFlags(&lane.ftDone, hipEventDisableTiming));
@@ -768,7 +782,7 @@ static void releaseLanes(spx_ctx* ctx) {
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
-                            lane.dPosOrder, lane.dIn, lane.dOutStage};
+                            lane.dPosOrder, lane.dRefreshList, lane.dIn, lane.dOutStage};
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
@@ -922,7 +936,9 @@ static int checkAcc(spx_ctx* ctx, size_t n, const char* who) {
         return SPX_ERR_INVALID_ARG;
     }
     if (n > ctx->maxBatch) {
-        setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->maxBatch));
+        setError(std::string(who) + ": batch of " + std::to_string(n) + " exceeds what one arena call accepts (" +
+                 std::to_string(ctx->maxBatch) + " = min(max_batch, SPX_SCRATCH_CAP): spx_ctx_scratch_batch); only "
+                 "spx_eval_full* walk larger batches in chunks");
         return SPX_ERR_CAPACITY;
     }
     SPX_HIP(hipSetDevice(ctx->device));  // every arena entry point passes through here: contexts on other GPUs stay independent
@@ -975,13 +991,13 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
                             const char* who);
 
 // The update kernel proper, followed (second-generation kernel) by the pass that rebuilds the perspectives it deferred:
-// the feature-transformer kernel over the refresh list (ids in dPerspOrder - free until the MLP's sort - and the count in
-// one of two alternating device words; the pass clears the other one for the next update).
+// the feature-transformer kernel over the refresh list (ids in the context's dRefreshList, the count in one of two alternating
+// device words behind the sort histograms; the pass clears the other one for the next update).
 static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipStream_t s) {
     const bool legacy = ctx->updateLegacyForced ? ctx->updateLegacy : (n <= ctx->tinyBatchMax && !up.nRecordsPtr);
     const bool split = n <= (legacy ? ctx->updateSplitMax : ctx->updateSplitMaxV2);  // one wave per (record, perspective)
     uint32_t* counters = ctx->dHist + 3 * kHistWords;
-    up.refreshList = ctx->dPerspOrder;
+    up.refreshList = ctx->dRefreshList;
     up.refreshCount = counters + ctx->refreshCur;
     SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));
     if (legacy) return SPX_OK;

@@ -136,4 +136,39 @@ int spx_group_adjust(spx_group* group, const spx_packed_pos* positions, size_t n
     });
 }
 
+// BASELINE config 4 from a native host: the concurrent games are dealt to the members (contiguous shares of n_games and of
+// target_games, sizes differing by at most one; member r's RNG stream is seed + r, its games go to <out_path>.<r>.vf),
+// every member runs the ordinary spx_selfplay_run on its own host thread against its own device - games never cross
+// devices, there is no exchange step - and the statistics are summed (seconds / gpu_seconds: the slowest member's).
+int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, const char* out_path, spx_selfplay_stats* stats) {
+    if (!group || !params || !stats || params->n_games == 0 || params->target_games == 0) {
+        spx::setError("spx_group_selfplay_run: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const size_t world = group->members.size();
+    std::vector<spx_selfplay_stats> part(world);
+    const int rc = forEachShard(group, params->n_games, "spx_group_selfplay_run", [&](size_t r, size_t lo, size_t hi) {
+        spx_selfplay_params mine = *params;
+        mine.n_games = uint32_t(hi - lo);
+        size_t tLo, tHi;
+        shardBounds(params->target_games, r, world, tLo, tHi);
+        mine.target_games = uint32_t(std::max<size_t>(1, tHi - tLo));
+        mine.seed = params->seed + r;
+        const std::string path = (out_path && out_path[0]) ? std::string(out_path) + "." + std::to_string(r) + ".vf" : std::string();
+        return spx_selfplay_run(group->members[r], &mine, path.empty() ? nullptr : path.c_str(), &part[r]);
+    });
+    if (rc != SPX_OK) return rc;
+    *stats = spx_selfplay_stats{};
+    for (const spx_selfplay_stats& s : part) {
+        stats->games += s.games;
+        stats->positions += s.positions;
+        stats->evals += s.evals;
+        stats->steps = std::max(stats->steps, s.steps);
+        for (int k = 0; k < 3; ++k) stats->outcomes[k] += s.outcomes[k];
+        stats->seconds = std::max(stats->seconds, s.seconds);
+        stats->gpu_seconds = std::max(stats->gpu_seconds, s.gpu_seconds);
+    }
+    return SPX_OK;
+}
+
 }  // extern "C"

@@ -153,6 +153,7 @@ struct SelfplayCounters {   // one per run, device memory; a copy travels to the
     uint32_t poolSize;      // openings the host has published so far (ring: entry i lives at i % poolCap)
     uint32_t reserved;
 };
+static_assert(sizeof(SelfplayCounters) % 4 == 0 && sizeof(SelfplayCounters) / 4 < 63, "spx_game_status_kernel copies it word by word");
 
 struct GameStepParams {
     uint32_t nSeats;                // seats of this half; every pointer below is already offset to its first seat
@@ -236,6 +237,8 @@ hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream);
+// hostStatus: device view of page-locked host memory laid out as { SelfplayCounters, uint32_t total }
+hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, void* hostStatus, hipStream_t stream);
 // seats[k] of the self-play state receive record k, slot = seat id, RNG state k (games that start this ply)
 hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,
                            uint64_t* positions, uint32_t* slots, uint64_t* rng, hipStream_t stream);

@@ -377,6 +377,7 @@ __device__ __forceinline__ void accumulateRows(const RowTable& table, uint32_t l
     }
 }
 
+static_assert(2 * kDeltaCap <= 256, "applyU8Delta sums add + sub rows in 16-bit fields: at most 256 rows x 255");
 __device__ __forceinline__ void applyU8Delta(const FtTables& t, uint32_t lane, const uint32_t* addList, uint32_t nAdd,
                                              const uint32_t* subList, uint32_t nSub, uint32_t (&acc)[8]) {
     const RowTable table = makeRowTable(t.thrW, kU8TableBytes);
@@ -572,7 +573,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
                                             lane, x[c]);
                 nAdd[c] = emitPawnPairDelta(sAdd[wave][c], nAdd[c], (ownC & ~ownP) | (theirC & ~theirP), cb.pawnsBb, ownC,
                                             lane, x[c]);
-                if (nSub[c] > uint32_t(kDeltaCap) || nAdd[c] > uint32_t(kDeltaCap)) refresh[c] = true;  // never in legal play
+            }
+            // every emitter above has run: a list that outgrew its capacity (never in legal play) is not applied - its
+            // perspective is rebuilt instead (applyU8Delta relies on nAdd + nSub <= 2 * kDeltaCap <= 256 rows)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (nSub[c] > uint32_t(kDeltaCap) || nAdd[c] > uint32_t(kDeltaCap)) refresh[c] = true;
             }
             __builtin_amdgcn_wave_barrier();
         }

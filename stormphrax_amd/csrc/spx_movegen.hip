@@ -781,6 +781,23 @@ hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// End of a half's ply: the run-wide counters and this ply's child count go to the host (page-locked memory mapped into the
+// device: no blit kernels on the stream) and the child cursor is zeroed for the half's next move generation.
+__global__ __launch_bounds__(64) void spx_game_status_kernel(const SelfplayCounters* counters, uint32_t* total, uint32_t* hostStatus) {
+    constexpr uint32_t kWords = sizeof(SelfplayCounters) / 4;
+    const uint32_t t = threadIdx.x;
+    if (t < kWords) hostStatus[t] = reinterpret_cast<const uint32_t*>(counters)[t];
+    if (t == kWords) {
+        hostStatus[kWords] = *total;
+        *total = 0;
+    }
+}
+
+hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, void* hostStatus, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_game_status_kernel, dim3(1), dim3(64), 0, stream, counters, total, static_cast<uint32_t*>(hostStatus));
+    return hipGetLastError();
+}
+
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_game_step_kernel, dim3((p.nSeats + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();

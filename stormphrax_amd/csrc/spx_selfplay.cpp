@@ -564,6 +564,14 @@ struct PinnedBuffers {
         if (q) ptrs.push_back(q);
         return static_cast<T*>(q);
     }
+    template <typename T>
+    T* getMapped(size_t count, T** deviceView) {  // page-locked AND mapped into the device: kernels write it directly
+        void* q = nullptr;
+        if (hipHostMalloc(&q, std::max<size_t>(count * sizeof(T), 16), hipHostMallocMapped) != hipSuccess) return nullptr;
+        ptrs.push_back(q);
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(deviceView), q, 0) != hipSuccess) return nullptr;
+        return static_cast<T*>(q);
+    }
 };
 
 #define SPX_SP_HIP(call)                                                                      \
@@ -816,7 +824,8 @@ struct DeviceHalf {
     uint32_t* dTotal = nullptr;
     uint32_t *dUpdParents = nullptr, *dUpdChildren = nullptr;
     uint64_t* dUpdPositions = nullptr;
-    HalfStatus* hStatus = nullptr;   // pinned, [kPliesInFlight]
+    HalfStatus* hStatus = nullptr;   // page-locked and mapped into the device, [kPliesInFlight] ...
+    HalfStatus* dStatus = nullptr;   // ... and its device view
     hipEvent_t done[kPliesInFlight] = {};
     uint64_t enqueued = 0, acked = 0;  // plies enqueued / plies whose results the host has read
     uint32_t index = 0;              // which lane of the context this half runs on
@@ -905,8 +914,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         hf.dUpdParents = dev.get<uint32_t>(seats);
         hf.dUpdChildren = dev.get<uint32_t>(seats);
         hf.dUpdPositions = dev.get<uint64_t>(size_t(seats) * 4);
-        hf.hStatus = pinned.get<HalfStatus>(kPliesInFlight);
-        ok = hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
+        hf.hStatus = pinned.getMapped<HalfStatus>(kPliesInFlight, &hf.dStatus);
+        ok = hf.hStatus && hf.dStatus && hf.dTotal && hipMemset(hf.dTotal, 0, 4) == hipSuccess;
+        ok = ok && hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
              hf.dUpdPositions && hf.hStatus && seats <= ctxMaxBatch(ctx);
     }
     if (!ok) {
@@ -1001,9 +1011,21 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         int r = ensurePool(s);
         if (r != SPX_OK) return r;
         const uint32_t seats = hf.end - hf.begin;
-        r = spx_movegen_device(ctx, dPositions + size_t(hf.begin) * 4, seats, dSlots + hf.begin, hf.dChildren, hf.dMoves,
-                               hf.dParents, dFirst + hf.begin, dCount + hf.begin, dInCheck + hf.begin, hf.cap, hf.dTotal, s);
-        if (r != SPX_OK) return r;
+        {   // (spx_movegen_device without its cursor memset: the status kernel of the half's previous ply zeroed it)
+            MovegenParams mp{};
+            mp.positions = dPositions + size_t(hf.begin) * 4;
+            mp.nPositions = seats;
+            mp.parentValues = dSlots + hf.begin;
+            mp.children = hf.dChildren;
+            mp.moves = hf.dMoves;
+            mp.parents = hf.dParents;
+            mp.first = dFirst + hf.begin;
+            mp.count = dCount + hf.begin;
+            mp.inCheck = dInCheck + hf.begin;
+            mp.cursor = hf.dTotal;
+            mp.capacity = uint32_t(hf.cap);
+            SPX_SP_HIP(launchMovegen(mp, (seats + 3) / 4, s));
+        }
         // eval-only children (child slots NULL): ~35 siblings per seat evaluated, none stored
         r = spx_acc_update_eval_device_counted(ctx, hf.dParents, nullptr, hf.dChildren, hf.dTotal, hf.cap, hf.dEvals, s);
         if (r != SPX_OK) return r;
@@ -1041,9 +1063,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         // the new game's opening (null slot -> rebuilt from scratch by the update kernel)
         r = spx_acc_update_device(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, seats, s);
         if (r != SPX_OK) return r;
-        HalfStatus* status = hf.hStatus + hf.enqueued % kPliesInFlight;
-        SPX_SP_HIP(hipMemcpyAsync(&status->counters, dCounters, sizeof(SelfplayCounters), hipMemcpyDeviceToHost, s));
-        SPX_SP_HIP(hipMemcpyAsync(&status->total, hf.dTotal, 4, hipMemcpyDeviceToHost, s));
+        SPX_SP_HIP(launchGameStatus(dCounters, hf.dTotal, hf.dStatus + hf.enqueued % kPliesInFlight, s));
         SPX_SP_HIP(hipEventRecord(hf.done[hf.enqueued % kPliesInFlight], s));
         ++hf.enqueued;
         ++steps;

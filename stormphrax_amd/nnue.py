@@ -102,7 +102,10 @@ class NnueState:
         check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
         self._h = handle
         self._net = network
-        self.max_batch = max_batch
+        # what one arena call (reset / update / evaluate) accepts: the scratch capacity (SPX_SCRATCH_CAP, 4 Mi positions by
+        # default) when the context was created for a larger full-refresh batch - trace.replay chunks by this
+        self.max_batch = min(max_batch, int(lib.spx_ctx_scratch_batch(handle)))
+        self.call_limit = max_batch
 
     def evaluate_once(self, positions):
         """Batched NnueState::evaluateOnce: packed positions (PACKED_DTYPE array) -> int32 raw evals (stm view)."""
@@ -357,6 +360,16 @@ class DeviceGroup:
         check(_lib.load().spx_group_adjust(self._h, pos.ctypes.data, pos.shape[0], ctypes.byref(params),
                                            None if corr is None else corr.ctypes.data, out.ctypes.data))
         return out
+
+    def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1):
+        """spx_group_selfplay_run: the games dealt to the members, one host thread and one device each; output files
+        <out_path>.<member>.vf; summed stats."""
+        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, 0, 0, seed)
+        stats = _lib.SelfplayStats()
+        check(_lib.load().spx_group_selfplay_run(self._h, ctypes.byref(params), out_path.encode() if out_path else None,
+                                                 ctypes.byref(stats)))
+        return {"games": stats.games, "positions": stats.positions, "evals": stats.evals, "steps": stats.steps,
+                "outcomes": list(stats.outcomes), "seconds": stats.seconds, "gpu_seconds": stats.gpu_seconds}
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -6,6 +6,12 @@ Trace format (tests/golden/trace_*.txt, recorded from the compiled reference by 
     POP                 the guard's NnueState::pop (src/thread.h:116-122)
     EVAL <inc> <once>   NnueState::evaluate at the current node (lazy multi-ply update, nnue_state.cpp:636-697) and
                         evaluateOnce of the same position, as computed by the reference
+Traces recorded from the reference's own alpha-beta SEARCH (`searchtrace`, tests/golden/trace_search_*.txt.gz) carry one
+more field on PUSH and EVAL: the side to move (w / b) of the position the call acted on. A search also makes NULL moves,
+which do not touch the NNUE stack (src/thread.cpp:28-44): below one, the side to move is the other one while the
+accumulators are the parent's. The parser turns that into an explicit node - same board, side to move flipped, en-passant
+square cleared - entered when a PUSH / EVAL names the other side and left when one names the stack's side again (or on the
+POP that leaves its parent), so the replay sees an ordinary tree (a null node is an update with an empty delta).
 
 The reference walks the tree depth-first with ONE accumulator stack. On the GPU every visited node gets an arena slot
 and the tree is processed level by level: all (parent -> child) updates of depth d form one spx_acc_update batch.
@@ -22,8 +28,31 @@ class Trace:
         self.depth = [0]
         self.moves = [None]
         self.evals = []             # (node, incremental value, evaluateOnce value) as recorded by the reference
-        stack = [0]
+        stack = [0]                 # node ids; a null-move node sits above the node the null move was made from
+        self.null = [False]         # node -> entered by a null move (its record: the parent's with the side to move flipped)
+        stm = [None]                # node -> side to move where known ('w' / 'b'), from the recorded fields
         import gzip
+
+        def enter_null():
+            self.parent.append(stack[-1])
+            self.depth.append(len(stack))
+            self.moves.append(None)
+            self.null.append(True)
+            stm.append({"w": "b", "b": "w"}.get(stm[stack[-1]]))
+            stack.append(len(self.parent) - 1)
+
+        def settle(side):
+            """Make the top of the stack the position the recorded call acted on (side to move `side`)."""
+            if side is None:
+                return
+            if stm[stack[-1]] is None:
+                stm[stack[-1]] = side
+            elif stm[stack[-1]] != side:
+                if self.null[stack[-1]]:
+                    stack.pop()       # back from the null move's subtree
+                else:
+                    enter_null()
+                assert stm[stack[-1]] == side, "trace: side to move does not fit the stack"
 
         with (gzip.open(path, "rt") if str(path).endswith(".gz") else open(path)) as f:
             for line in f:
@@ -32,14 +61,21 @@ class Trace:
                     continue
                 if t[0] == "ROOT":
                     self.root_fen = " ".join(t[1:])
+                    stm[0] = t[2] if len(t) > 2 else None
                 elif t[0] == "PUSH":
+                    settle(t[2] if len(t) > 2 else None)
                     self.parent.append(stack[-1])
                     self.depth.append(len(stack))
                     self.moves.append(t[1])
+                    self.null.append(False)
+                    stm.append({"w": "b", "b": "w"}.get(t[2]) if len(t) > 2 else None)
                     stack.append(len(self.parent) - 1)
                 elif t[0] == "POP":
+                    if self.null[stack[-1]]:
+                        stack.pop()   # the null node does not occupy an NNUE stack entry
                     stack.pop()
                 elif t[0] == "EVAL":
+                    settle(t[3] if len(t) > 3 else None)
                     self.evals.append((stack[-1], int(t[1]), int(t[2])))
         self.n_nodes = len(self.parent)
 
@@ -48,7 +84,11 @@ class Trace:
         pos = np.zeros(self.n_nodes, dtype=nnue.PACKED_DTYPE)
         pos[0] = nnue.positions_from_fens([self.root_fen])[0]
         for node in range(1, self.n_nodes):  # nodes are numbered in visiting order: parents come first
-            pos[node] = nnue.apply_uci(pos[self.parent[node]], self.moves[node])
+            if self.null[node]:  # Position::applyNullMove: same board, other side to move, no en-passant square
+                pos[node] = pos[self.parent[node]]
+                pos[node]["stm_ep"] = ((pos[node]["stm_ep"] & 0x80) ^ 0x80) | 64
+            else:
+                pos[node] = nnue.apply_uci(pos[self.parent[node]], self.moves[node])
         return pos
 
     def levels(self):

@@ -18,6 +18,9 @@ reference itself computes:
                   regenerate alone with `make_golden.py adjust`
   trace_startpos_tame_64k.txt.gz   the same kind of stream at BASELINE config-3 scale (65 536 EVALs, depth cap 12);
                   regenerate alone with `make_golden.py bigtrace`
+  trace_search_startpos_tame_64k.txt.gz   config 3 as worded - "a recorded alpha-beta make/unmake trace": the reference's
+                  own search (depth <= 12 from the start position), PUSH / EVAL with the side to move (null moves);
+                  regenerate alone with `make_golden.py searchtrace`
   pack.txt        "<fen> | <64 hex>": the 32 bytes of datagen::marlinformat::PackedBoard::pack(pos, 0)
                   (src/datagen/marlinformat.h:32-84) - castling-rook code 6, relative ep square (only when an en passant
                   capture is legal: Position::filterEp), clocks, zero eval / wdl / extra
@@ -110,6 +113,23 @@ def make_big_trace():
     print("big trace written:", sum(1 for ln in out if ln.startswith("EVAL")), "evals")
 
 
+def make_search_trace():
+    """BASELINE config 3 as the north star words it: a recorded ALPHA-BETA make/unmake trace - the reference's own search
+    (Searcher::runDatagenSearch: PVS + quiescence, reductions, TT; depth <= 12 from the start position, 3 M nodes), its
+    first 65 536 NnueState::evaluate calls with every applyMove / pop in between (oracle/ref_probe.cpp `searchtrace`)."""
+    import gzip
+
+    probe = Probe(PROBES["tame"])
+    out = probe.cmd(f"searchtrace 65536 12 3000000 {STARTPOS}")
+    probe.close()
+    with gzip.open(os.path.join(HERE, "trace_search_startpos_tame_64k.txt.gz"), "wt", compresslevel=9) as f:
+        f.write("# preset tame; the reference's own alpha-beta search (Searcher::runDatagenSearch, depth <= 12) recorded by "
+                "oracle/ref_probe.cpp `searchtrace 65536 12 3000000`\n")
+        f.write("\n".join(out) + "\n")
+    print("search trace written:", sum(1 for ln in out if ln.startswith("EVAL")), "evals,",
+          sum(1 for ln in out if ln.startswith("PUSH")), "moves")
+
+
 def make_wire():
     """Wire-format and WDL goldens: bytes written by the reference's own marlinformat / viriformat code."""
     import random
@@ -179,6 +199,8 @@ def main():
         return make_adjust()
     if sys.argv[1:] == ["bigtrace"]:
         return make_big_trace()
+    if sys.argv[1:] == ["searchtrace"]:
+        return make_search_trace()
     probes = {k: Probe(v) for k, v in PROBES.items()}
     fens = [(STARTPOS, "startpos")]
     fens += [(f.strip(), "bench") for f in open(os.path.join(HERE, "bench_fens.txt")) if f.strip()]

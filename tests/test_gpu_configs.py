@@ -137,3 +137,24 @@ def test_device_group_shards_a_batch_over_its_members(sp, net_blob, oracle):
     with sp.DeviceGroup(net, max_batch_per_device=4096) as grp:
         assert len(grp) == sp.device_count() >= 1
         assert np.array_equal(grp.evaluate_once(pos[:5000]), want[:5000])
+
+
+def test_device_group_plays_its_games_on_every_member(sp, net_blob, oracle, tmp_path):
+    """spx_group_selfplay_run (configs[3] from one native process): two members on this box's one GPU play their shares of
+    the games concurrently on their own host threads; every member's file obeys the datagen rules and the totals add up."""
+    from _datagen_rules import verify_selfplay_file
+
+    net = sp.Network(net_blob("tame"))
+    oracle.use(net_blob("tame"), "tame")
+    with sp.DeviceGroup(net, devices=[0, 0], max_batch_per_device=16384) as grp:
+        stats = grp.selfplay(n_games=257, target_games=401, out_path=str(tmp_path / "g"), max_plies=150, dfrc=True,
+                             temperature_cp=15, seed=21)
+    assert stats["games"] == 401 and sum(stats["outcomes"]) == 401
+    with sp.NnueState(net, max_batch=16384) as st:
+        checked = 0
+        for member, games in ((0, 201), (1, 200)):
+            blob = open(tmp_path / f"g.{member}.vf", "rb").read()
+            positions, n = sp.viri_expand(blob)
+            assert n == games
+            checked += verify_selfplay_file(sp, st, oracle, blob, max_plies=150, oracle_sample=512)
+    assert checked == stats["positions"]

@@ -406,3 +406,24 @@ def test_native_tree_replay_of_the_config3_trace(sp, net_blob):
         assert min(ms, ms2) < 8.0
     finally:
         st.close()
+
+
+def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob):
+    """BASELINE config 3 as the north star words it: the make/unmake trace of the reference's own ALPHA-BETA search (depth <= 12
+    from the start position: 84 066 moves, 65 536 evaluates, lines down to ply 249 with the random-weight net) through
+    spx_acc_replay_tree - every EVAL equals the reference's lazily updated NnueState::evaluate."""
+    from stormphrax_amd.trace import Trace, replay_native
+
+    path = os.path.join(GOLDEN, "trace_search_startpos_tame_64k.txt.gz")
+    trace = Trace(path)
+    st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=65536)
+    try:
+        pos = trace.positions()
+        got, want, ms = replay_native(st, trace, pos)
+        assert len(want) == 65536 and np.array_equal(got, want)
+        got2, _, ms2 = replay_native(st, trace, pos)
+        assert np.array_equal(got2, want)
+        print(f"alpha-beta trace: {trace.n_nodes - 1} updates + {len(want)} evals over {max(trace.depth)} levels in "
+              f"{min(ms, ms2):.2f} ms on the device")
+    finally:
+        st.close()

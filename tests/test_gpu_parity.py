@@ -32,7 +32,7 @@ def test_random_positions_bit_exact(sp, oracle, net_blob, states, preset):
     got = states(preset).evaluate_once(pos)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, f"{bad.size} mismatches, first: {sp.position_to_fen(pos[bad[0]])} got {got[bad[0]]} want {want[bad[0]]}"
-    assert len(set(want.tolist())) > 1000  # the batch is not degenerate
+    assert len(set(want.tolist())) > (500 if preset == "realistic" else 1000)  # the batch is not degenerate (the heavy-tailed net spreads evals less)
 
 
 def test_ft_activations_bit_exact(sp, oracle, net_blob, states):

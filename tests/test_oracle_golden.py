@@ -72,3 +72,60 @@ def test_oracle_adjust_matches_reference(oracle, net_blob, sp, preset):
         assert oracle.adjust(mail, stm, halfmove, stat, r["contempt"], r["optimism"], stages=2) == r["adjusted"], r
         # both stages in one call == adjustedStaticEval<false> (eval.cpp:81-91)
         assert oracle.adjust(mail, stm, halfmove, raw, r["contempt"], r["optimism"], stages=3) == r["adjusted"], r
+
+
+def test_alpha_beta_search_trace_matches_the_oracle(oracle, net_blob, sp):
+    """tests/golden/trace_search_startpos_tame_64k.txt.gz: the reference's own alpha-beta search (depth <= 12 from the start
+    position, recorded through link-time interposition by oracle/ref_probe.cpp `searchtrace`) as a PUSH / POP / EVAL stream.
+    The host replay of the moves reaches positions whose oracle evaluation equals what the reference's evaluateOnce recorded at
+    every sampled EVAL, and the reference's lazily updated evaluate() equalled its evaluateOnce() everywhere."""
+    from stormphrax_amd.trace import Trace
+
+    trace = Trace(os.path.join(GOLDEN, "trace_search_startpos_tame_64k.txt.gz"))
+    assert len(trace.evals) == 65536 and trace.n_nodes > 80000 and max(trace.depth) > 100
+    pos = trace.positions()
+    nodes = np.array([e[0] for e in trace.evals])
+    inc = np.array([e[1] for e in trace.evals])
+    once = np.array([e[2] for e in trace.evals])
+    assert np.array_equal(inc, once)
+    idx = np.random.default_rng(1).choice(len(nodes), 12000, replace=False)
+    oracle.use(net_blob("tame"), "tame")
+    mail, stm = sp.positions_to_mailboxes(pos[nodes[idx]])
+    assert np.array_equal(oracle.eval_mailboxes(mail, stm), once[idx])
+
+
+def test_trace_parser_turns_null_moves_into_nodes(tmp_path, sp):
+    """A search's null move does not touch the NNUE stack (src/thread.cpp:28-44): below it PUSH / EVAL name the other side
+    to move. The parser makes it a node of its own (same board, side flipped, en-passant square cleared) and leaves it when
+    the stack's side is named again or its parent is popped."""
+    from stormphrax_amd.trace import Trace
+
+    text = "\n".join([
+        "ROOT rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1",
+        "EVAL 1 1 w",
+        "PUSH e2e4 w",        # node 1 (black to move)
+        "EVAL 2 2 b",
+        "EVAL 3 3 w",         # null move made at node 1: node 2 = null node (white to move, same board)
+        "PUSH d2d4 w",        # node 3 under the null node
+        "EVAL 4 4 b",
+        "POP",                # back on the null node
+        "PUSH e7e5 b",        # names node 1's side again: the null subtree is left, node 4 under node 1
+        "EVAL 5 5 w",
+        "POP",
+        "EVAL 6 6 w",         # another null move at node 1: node 5
+        "POP",                # leaves node 1 (and the null node on top of it)
+        "PUSH g1f3 w",        # node 6 under the root
+        "EVAL 7 7 b",
+    ]) + "\n"
+    path = tmp_path / "mini.txt"
+    path.write_text(text)
+    trace = Trace(str(path))
+    assert trace.parent == [-1, 0, 1, 2, 1, 1, 0] and trace.null == [False, False, True, False, False, True, False]
+    assert [e[0] for e in trace.evals] == [0, 1, 2, 3, 4, 5, 6]
+    pos = trace.positions()
+    fens = [sp.position_to_fen(p) for p in pos]
+    assert fens[1].split()[:2] == ["rnbqkbnr/pppppppp/8/8/4P3/8/PPPP1PPP/RNBQKBNR", "b"]
+    assert fens[2].split()[:2] == ["rnbqkbnr/pppppppp/8/8/4P3/8/PPPP1PPP/RNBQKBNR", "w"] and fens[2].split()[3] == "-"
+    assert fens[3].split()[:2] == ["rnbqkbnr/pppppppp/8/8/3PP3/8/PPP2PPP/RNBQKBNR", "b"]
+    assert fens[4].split()[:2] == ["rnbqkbnr/pppp1ppp/8/4p3/4P3/8/PPPP1PPP/RNBQKBNR", "w"]
+    assert fens[5] == fens[2] and fens[6].split()[1] == "b"

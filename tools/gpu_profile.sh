@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-settle --no-wide $*"
+BENCH="python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-settle --no-wide --no-secondary $*"
 # 1) kernel trace + stats (no counters)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o t -- $BENCH > $OUT/stats.log 2>&1
 # 2) counters, one group per pass (TCC: FETCH_SIZE costs 3 of 4 slots, WRITE_SIZE 2), kernel-trace only
