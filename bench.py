@@ -42,7 +42,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
 N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
-PMC_FILES = {"full": "r02_pmc_full_refresh.json", "incremental": "r02_pmc_incremental.json"}
+# committed rocprofv3 PMC passes of this command, newest round first (tools/gpu_final.sh puts this round's in place before the
+# bench lines are taken; the kernels these counters describe did not change in round 3)
+PMC_FILES = {"full": ["r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
+             "incremental": ["r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
 
 
 def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):
@@ -68,15 +71,17 @@ def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):
 
 
 def load_pmc(mode, **match):
-    """Counters of the committed rocprofv3 PMC passes of this command (profiles/r02_pmc_*.json, written by
+    """Counters of the committed rocprofv3 PMC passes of this command (profiles/r0N_pmc_*.json, written by
     tools/pmc_to_json.py from the passes of tools/gpu_profile.sh). None when this run's configuration was not profiled."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[mode])))
-    except (OSError, ValueError):
-        return None
-    if any(rec.get("config", {}).get(k) != v for k, v in match.items()):
-        return None
-    return rec
+    for name in PMC_FILES[mode]:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if all(rec.get("config", {}).get(k) == v for k, v in match.items()):
+            rec["file"] = "profiles/" + name
+            return rec
+    return None
 
 
 def kernel_pmc(rec, name):

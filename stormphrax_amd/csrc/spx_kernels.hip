@@ -117,6 +117,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // kSplit = false: one wavefront per record does both perspectives (board decoding and attack generation shared);
 // kSplit = true: one wavefront per (record, perspective) - twice the waves, half the serial latency - for batches too
 // small to fill the chip (the kernel is latency-bound there: 4 096 records = 36 us unsplit).
+// Workgroup b runs on XCD b % 8 (observed dispatch order; speed only). The update kernels deal their items to the XCDs in
+// round-robin CHUNKS of 64 consecutive items (as the feature-transformer kernel deals perspectives): the ~35 children of one
+// parent - contiguous in self-play's batches - then meet in one private L2, so the parent's accumulators cross the fabric
+// once instead of up to eight times and the delta rows siblings share (the moved piece leaving its square) hit; every XCD
+// gets the same share whatever the (possibly device-resident) item count. Independent records are unaffected.
+// Measured (profiles/r03_ab_update_xcd_chunks.txt): self-play at 4 096 seats +1.5 %, 16 384 seats and independent records
+// unchanged. The single-launch kernel for tiny batches keeps the plain order (kChunked = false).
+template <bool kChunked>
+struct ItemWalk {
+    uint32_t t, tEnd, stride, xcd;
+    __device__ ItemWalk(uint32_t nItems, uint32_t wave) {
+        if constexpr (kChunked) {
+            xcd = blockIdx.x & 7u;
+            t = (blockIdx.x >> 3) * kWavesPerBlock + wave;
+            stride = (gridDim.x >> 3) * kWavesPerBlock;  // gridDim.x is a multiple of 8 (cappedGrid)
+            tEnd = ((nItems + 511u) >> 9) << 6;          // per-XCD index space: chunks of 64, one chunk in eight is this XCD's
+        } else {
+            xcd = 0;
+            t = blockIdx.x * kWavesPerBlock + wave;
+            stride = gridDim.x * kWavesPerBlock;
+            tEnd = nItems;
+        }
+    }
+    __device__ uint32_t item() const {
+        if constexpr (kChunked) return ((((t >> 6) << 3) + xcd) << 6) | (t & 63u);
+        return t;
+    }
+};
+
 template <bool kSplit, bool kStream>
 __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel_v1(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
@@ -132,11 +161,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
 
     const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
     const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
-    for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < nItems; item += wavesTotal) {
+    for (ItemWalk<false> walk(nItems, wave); walk.t < walk.tEnd; walk.t += walk.stride) {
+        const uint32_t item = walk.item();
+        if (item >= nItems) continue;  // (the last chunk round may be partial)
         const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
@@ -470,11 +500,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock;
 
     const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
     const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
-    for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < nItems; item += wavesTotal) {
+    for (ItemWalk<true> walk(nItems, wave); walk.t < walk.tEnd; walk.t += walk.stride) {
+        const uint32_t item = walk.item();
+        if (item >= nItems) continue;  // (the last chunk round may be partial)
         const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);

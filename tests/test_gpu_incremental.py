@@ -427,3 +427,18 @@ def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob):
               f"{min(ms, ms2):.2f} ms on the device")
     finally:
         st.close()
+
+
+def test_selfplay_plays_the_same_games_for_the_same_seed(sp, net_blob, tmp_path):
+    """The device-resident games draw their openings from a pool in claim order and carry their RNG stream with the opening:
+    a seed fixes the SET of games (their order in the file is the order in which seats finish, which is timing)."""
+    from _datagen_rules import parse_games
+
+    runs = []
+    for k in range(2):
+        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=16384) as st:
+            path = str(tmp_path / f"g{k}.vf")
+            stats = st.selfplay(n_games=200, target_games=500, out_path=path, max_plies=100, dfrc=True, temperature_cp=25, seed=77)
+            assert stats["games"] == 500
+            runs.append(sorted((h, m.tobytes(), s.tobytes()) for h, m, s, _ in parse_games(open(path, "rb").read())))
+    assert runs[0] == runs[1] and len(runs[0]) == 500

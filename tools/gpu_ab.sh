@@ -9,7 +9,7 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, SPX_LIB=os.path.abspath(l))
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "100", "--warmup", "10", "--no-cpu-baseline"] + extra,
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "100", "--warmup", "10", "--no-cpu-baseline", "--no-secondary", "--no-wide"] + extra,
                              env=env, capture_output=True, text=True)
         try:
             j = json.loads(out.stdout.strip().splitlines()[-1])

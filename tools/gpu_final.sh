@@ -1,6 +1,6 @@
 # Round-end measurement set (GPU box): bench lines, secondary measurements, rocprofv3 stats + counters.
 # usage: bash tools/gpu_final.sh <tag>   -> gpurun_out/final_<tag>/   (copy what is quoted into profiles/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -26,9 +26,14 @@ SPX_UPDATE_V1=1 python bench.py --mode incremental --no-pipeline --no-cpu-baseli
 python bench.py --mode incremental --batch 262144 --steps 100 --no-cpu-baseline > $OUT/bench_incremental_n1_262144.json 2>> $OUT/bench_incremental_n1.err
 python bench.py --batch 4194304 --steps 20 --warmup 3 --no-cpu-baseline --no-wide > $OUT/bench_n1_batch4M.json 2> $OUT/bench_4m.err
 python tools/gpu_measure.py > $OUT/secondary.json 2> $OUT/secondary.err
-python tools/spx_selfplay.py --games 4096 --target 8192 > $OUT/selfplay_4096.json 2> $OUT/selfplay.err
-python tools/spx_selfplay.py --games 16384 --target 32768 > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
-python tools/spx_selfplay.py --games 1024 --target 2048 > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 4096 --target 8192 --dfrc > $OUT/selfplay_4096.json 2> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 4096 --target 65536 --dfrc > $OUT/selfplay_4096_long.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 16384 --target 32768 --dfrc > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 1024 --target 2048 --dfrc > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
+python tools/gpu_gather_ceiling.py --out $OUT/gather_ceiling.json > /dev/null 2>> $OUT/selfplay.err
+python tools/gpu_gather_ceiling.py --wide --rounds 3 --out $OUT/gather_ceiling_wide_psq_rows.json > /dev/null 2>> $OUT/selfplay.err
+./stormphrax_amd/spx_raweval --preset tame --walk 7 6000 rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 > $OUT/raweval_walk.txt 2>&1
+bash tools/gpu_selfplay_busy.sh 4096 32768 > $OUT/selfplay_gpu_busy.txt 2>&1
 python tools/gpu_movegen_rate.py > $OUT/movegen_rate.json 2>> $OUT/selfplay.err
 python tools/gpu_latency.py > $OUT/latency.txt 2>&1
 python tools/gpu_replay_rate.py > $OUT/config3_replay.json 2> $OUT/replay.err

@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"final_{TAG}")
 DST = os.path.join(ROOT, "profiles")
@@ -17,7 +17,8 @@ def last(name):
 
 
 secondary = {"secondary_gpu_measure_py": last("secondary.json")}
-for key, name in [("selfplay_4096", "selfplay_4096.json"), ("selfplay_16384", "selfplay_16384.json"),
+for key, name in [("selfplay_4096", "selfplay_4096.json"), ("selfplay_4096_long", "selfplay_4096_long.json"),
+                  ("selfplay_16384", "selfplay_16384.json"),
                   ("selfplay_1024", "selfplay_1024.json"), ("config3_replay", "config3_replay.json"),
                   ("movegen_rate", "movegen_rate.json")]:
     secondary[key] = last(name)
@@ -35,6 +36,8 @@ names = {
     "rocprofv3_summary_incremental.txt": "rocprofv3_summary_incremental.txt",
     "rocprofv3_kernel_stats_default_cmd.txt": "rocprofv3_kernel_stats_default_cmd.txt",
     "rocprofv3_incremental_kernel_stats.txt": "rocprofv3_incremental_kernel_stats.txt",
+    "gather_ceiling.json": "gather_ceiling.json", "gather_ceiling_wide_psq_rows.json": "gather_ceiling_wide_psq_rows.json",
+    "raweval_walk.txt": "raweval_walk_evaluate_by_pending_plies.txt", "selfplay_gpu_busy.txt": "selfplay_gpu_busy_4096_seats.txt",
 }
 for src, dst in names.items():
     target = os.path.join(DST, f"{TAG}_{dst}")
@@ -48,7 +51,7 @@ for f in sorted(glob.glob(os.path.join(DST, f"{TAG}_bench*.json"))):
     print(os.path.basename(f), "%.4e" % j["value"], "ms/step %.4f" % j["ms_per_step"], "frac %.3f" % r.get("frac", 0),
           "wide", (j.get("wide_psq_rows") or {}).get("value"), "cpu", (j.get("cpu_baseline") or {}).get("value"),
           "kernel_ms", j["config"].get("kernel_ms"), "update", r.get("update_kernel_ms"), "traffic/hbm", r.get("traffic_over_hbm_peak"))
-print("selfplay", secondary["selfplay_4096"]["value"], secondary["selfplay_16384"]["value"], secondary["selfplay_1024"]["value"],
+print("selfplay", secondary["selfplay_4096"]["value"], secondary["selfplay_4096_long"]["value"], secondary["selfplay_16384"]["value"], secondary["selfplay_1024"]["value"],
       "replay ms", secondary["config3_replay"]["native_device_ms"])
 print(secondary["latency_txt"])
 print(json.dumps(secondary["secondary_gpu_measure_py"]))
