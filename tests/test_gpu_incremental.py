@@ -442,3 +442,16 @@ def test_selfplay_plays_the_same_games_for_the_same_seed(sp, net_blob, tmp_path)
             assert stats["games"] == 500
             runs.append(sorted((h, m.tobytes(), s.tobytes()) for h, m, s, _ in parse_games(open(path, "rb").read())))
     assert runs[0] == runs[1] and len(runs[0]) == 500
+
+
+@pytest.mark.parametrize("n_games,target", [(1, 3), (3, 7), (64, 64)])
+def test_selfplay_edge_sizes(sp, net_blob, oracle, tmp_path, n_games, target):
+    """One seat (a single half), an odd number of seats, and a target equal to the seats (no seat ever restarts)."""
+    from _datagen_rules import verify_selfplay_file
+
+    with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192) as st:
+        path = str(tmp_path / "g.vf")
+        stats = st.selfplay(n_games=n_games, target_games=target, out_path=path, max_plies=80, dfrc=False, temperature_cp=10, seed=5)
+        assert stats["games"] == target and sum(stats["outcomes"]) == target
+        oracle.use(net_blob("tame"), "tame")
+        assert verify_selfplay_file(sp, st, oracle, open(path, "rb").read(), max_plies=80, oracle_sample=256) == stats["positions"]

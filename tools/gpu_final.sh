@@ -39,6 +39,24 @@ python tools/gpu_latency.py > $OUT/latency.txt 2>&1
 python tools/gpu_replay_rate.py > $OUT/config3_replay.json 2> $OUT/replay.err
 # (the TA/TD/TCP counter groups are NOT collected here: on 2026-09-28 rocprofv3 aborted inside hipMemcpy with them and
 #  then hung in its signal handler until the timeout - every rocprofv3 call in tools/ runs under `timeout 300`)
+# differential runs against the COMPILED REFERENCE on the final binary (its probe travels in oracle/_ref/)
+python tools/gpu_ref_differential.py --positions 4000000 --pack-positions 500000 > $OUT/reference_differential.json 2> $OUT/differential.err
+python tools/gpu_ref_trace_differential.py --roots 64 > $OUT/reference_trace_differential.json 2>> $OUT/differential.err
+# counters of the self-play's eval-only update kernel (what crosses the fabric per child now)
+( cd /tmp && export TMPDIR=/tmp
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
+    timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/sp_pmc_$(echo $grp | cut -d' ' -f1) -o c -- python $REPO/tools/spx_selfplay.py --games 4096 --target 8192 --dfrc > /dev/null 2>&1
+  done )
+python3 - <<PY > $OUT/pmc_selfplay_4096_seats.txt 2>&1
+import glob, sqlite3
+print("rocprofv3 --pmc <group> --kernel-trace -- python tools/spx_selfplay.py --games 4096 --target 8192 --dfrc  (mean per dispatch)")
+for f in sorted(glob.glob("$OUT/sp_pmc_*/*.db")):
+    c = sqlite3.connect(f).cursor()
+    for r in c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"):
+        if "rocclr" in r[0]: continue
+        print("   %-44s %-18s mean/dispatch %16.1f  dispatches %d" % (r[0].replace("spx::", "")[:44], r[1], r[2], r[3]))
+PY
+rm -rf $OUT/sp_pmc_*
 bash tools/gpu_stats.sh default_$TAG --no-wide > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
 bash tools/gpu_stats.sh inc_$TAG --mode incremental > $OUT/rocprofv3_incremental_kernel_stats.txt 2>&1
 rm -rf $REPO/gpurun_out/stats_default_$TAG $REPO/gpurun_out/stats_inc_$TAG

@@ -36,6 +36,8 @@ names = {
     "rocprofv3_summary_incremental.txt": "rocprofv3_summary_incremental.txt",
     "rocprofv3_kernel_stats_default_cmd.txt": "rocprofv3_kernel_stats_default_cmd.txt",
     "rocprofv3_incremental_kernel_stats.txt": "rocprofv3_incremental_kernel_stats.txt",
+    "reference_differential.json": "reference_differential.json", "reference_trace_differential.json": "reference_trace_differential.json",
+    "pmc_selfplay_4096_seats.txt": "pmc_selfplay_4096_seats.txt",
     "gather_ceiling.json": "gather_ceiling.json", "gather_ceiling_wide_psq_rows.json": "gather_ceiling_wide_psq_rows.json",
     "raweval_walk.txt": "raweval_walk_evaluate_by_pending_plies.txt", "selfplay_gpu_busy.txt": "selfplay_gpu_busy_4096_seats.txt",
 }
