@@ -600,6 +600,8 @@ def main():
     #   SPX_BENCH_SHARE_GPU=1 maps every rank to GPU 0, SPX_BENCH_BACKEND=gloo swaps RCCL for gloo (CPU tensors).
     if os.environ.get("SPX_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES per rank) leaves one visible device
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
     group = Group(backend=backend, device=torch.device("cuda", local_rank) if backend == "nccl" else None)

@@ -40,7 +40,7 @@ def main():
     from stormphrax_amd.distributed import env_rank
 
     # SPX_BENCH_SHARE_GPU=1 (debug, as in bench.py): every rank on GPU 0, to exercise the N > 1 control flow on one GPU
-    device = 0 if os.environ.get("SPX_BENCH_SHARE_GPU") == "1" else env_rank()[1]
+    device = 0 if os.environ.get("SPX_BENCH_SHARE_GPU") == "1" else env_rank()[1] % max(1, torch.cuda.device_count())
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
     if backend == "nccl":
         torch.cuda.set_device(device)
