@@ -146,13 +146,15 @@ int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, 
         return SPX_ERR_INVALID_ARG;
     }
     const size_t world = group->members.size();
+    // (fewer seats than members: the first n_games members get one seat each and share the whole target)
+    const size_t active = std::min<size_t>(world, params->n_games);
     std::vector<spx_selfplay_stats> part(world);
     const int rc = forEachShard(group, params->n_games, "spx_group_selfplay_run", [&](size_t r, size_t lo, size_t hi) {
         spx_selfplay_params mine = *params;
         mine.n_games = uint32_t(hi - lo);
         size_t tLo, tHi;
-        shardBounds(params->target_games, r, world, tLo, tHi);
-        mine.target_games = uint32_t(std::max<size_t>(1, tHi - tLo));
+        shardBounds(std::max<size_t>(params->target_games, active), r, active, tLo, tHi);
+        mine.target_games = uint32_t(tHi - tLo);
         mine.seed = params->seed + r;
         const std::string path = (out_path && out_path[0]) ? std::string(out_path) + "." + std::to_string(r) + ".vf" : std::string();
         return spx_selfplay_run(group->members[r], &mine, path.empty() ? nullptr : path.c_str(), &part[r]);

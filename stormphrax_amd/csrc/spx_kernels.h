@@ -106,32 +106,14 @@ struct MovegenParams {              // spx_movegen_kernel (spx_movegen.hip)
     uint32_t capacity;
 };
 
-struct PickResult {   // per game, read back by the self-play driver after every ply (24 bytes)
-    uint64_t key;     // recordKey of the position after the chosen move
-    int32_t score;    // -eval(chosen child), from the mover's point of view
-    uint32_t count;   // legal moves in the position (0: mate or stalemate, see inCheck)
-    uint16_t move;    // viriformat word of the chosen move
-    uint8_t inCheck;
-    uint8_t halfmove; // halfmove clock after the move
-    int32_t normScore; // wdl::normalizeScore of the WHITE-point-of-view score at the material of the position the move was
-                       // played from: what datagen's adjudication counters compare (search.cpp:237-238, datagen.cpp:224-252)
-};
-
-struct PickParams {                 // spx_pick_kernel (spx_movegen.hip)
+struct PickParams {                 // spx_pick_kernel (spx_movegen.hip): one uniformly random legal move per position
     uint32_t nGames;
-    const uint32_t* first;          // per game: block of children (spx_movegen_kernel)
+    const uint32_t* first;          // per position: block of children (spx_movegen_kernel)
     const uint32_t* count;
-    const uint8_t* inCheck;
-    const int32_t* evals;           // per child, side to move of the child; NULL = all equal (uniformly random move)
-    const uint8_t* enable;          // optional per game: 0 = leave this game alone
-    const uint16_t* moves;
+    const uint8_t* enable;          // optional per position: 0 = leave this one alone
     const uint64_t* children;       // records as u64[4]
-    const uint32_t* childSlots;     // per child: the accumulator slot its update was written to (NULL with slots)
     uint64_t* positions;            // [nGames] records as u64[4]: replaced by the chosen child
-    uint32_t* slots;                // [nGames] accumulator slot of the game's current position: replaced likewise; or NULL
     uint64_t* rng;                  // [nGames] splitmix64 state
-    PickResult* results;            // [nGames]
-    int32_t temperature;            // pick uniformly among the moves within this margin of the best (0 = first best)
 };
 
 // ---- device-resident self-play (spx_game_step_kernel, spx_movegen.hip): the per-game bookkeeping of
@@ -239,9 +221,6 @@ hipError_t launchPick(const PickParams& p, hipStream_t stream);
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream);
 // hostStatus: device view of page-locked host memory laid out as { SelfplayCounters, uint32_t total }
 hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, void* hostStatus, hipStream_t stream);
-// seats[k] of the self-play state receive record k, slot = seat id, RNG state k (games that start this ply)
-hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,
-                           uint64_t* positions, uint32_t* slots, uint64_t* rng, hipStream_t stream);
 hipError_t launchAdjust(const AdjustParams& p, hipStream_t stream);
 hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();

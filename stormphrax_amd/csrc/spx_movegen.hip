@@ -367,80 +367,24 @@ __global__ __launch_bounds__(256) void spx_movegen_kernel(MovegenParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Move choice of the depth-1 self-play policy, one wavefront per game (lanes = its children): score(move) =
-// -eval(child); uniformly among the moves within `temperature` of the best (one splitmix64 draw per game and ply; the
-// host path of spx_selfplay.cpp draws per candidate - same distribution); the chosen child's record and accumulator
-// slot become the game's current ones.
+// A uniformly random legal move for every position (one thread each): the random plies of datagen's openings
+// (src/datagen/datagen.cpp:153-171) and of spx_random_positions_gpu's playouts. The position's record is replaced by the
+// chosen child; one splitmix64 draw per position and ply.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spx_pick_kernel(PickParams p) {
-    const uint32_t lane = laneId();
-    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per game, lanes = its children
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.nGames) return;
-    PickResult r{};
-    r.count = p.count[g];
-    r.inCheck = p.inCheck[g];
-    if (r.count != 0 && (!p.enable || p.enable[g])) {
-        const uint32_t lo = p.first[g];
-        int32_t best = INT32_MIN;
-        for (uint32_t k = lane; k < r.count; k += 64) best = max(best, p.evals ? -p.evals[lo + k] : 0);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
-        // candidates = moves within the margin of the best; one draw picks uniformly among them (0 margin: the first)
-        uint32_t nCandidates = 0;
-        for (uint32_t base = 0; base < r.count; base += 64) {
-            const uint32_t k = base + lane;
-            const bool cand = k < r.count && (p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature;
-            nCandidates += uint32_t(popc64(__ballot(cand)));
-        }
-        uint64_t state = p.rng[g] + 0x9E3779B97F4A7C15ull;
-        uint64_t z = state;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z ^= z >> 31;
-        uint32_t target = p.temperature == 0 ? 0u : uint32_t(z >> 32) % nCandidates;
-        uint32_t pick = 0;
-        for (uint32_t base = 0; base < r.count; base += 64) {
-            const uint32_t k = base + lane;
-            const bool cand = k < r.count && (p.evals ? -p.evals[lo + k] : 0) >= best - p.temperature;
-            const uint64_t mask = __ballot(cand);
-            const uint32_t here = uint32_t(popc64(mask));
-            if (target < here) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-                const uint64_t hit = __ballot(cand && rank == target);
-                pick = base + uint32_t(ctz64(hit));
-                break;
-            }
-            target -= here;
-        }
-        const uint32_t c = lo + pick;
-        const uint64_t* child = p.children + size_t(c) * 4;
-        const uint64_t w0 = child[0], w1 = child[1], w2 = child[2], w3 = child[3];
-        // Position::classicalMaterial of the position the move is played FROM (lane k sums nibble k), before it is replaced
-        int32_t material = 0;
-        {
-            const uint64_t* parent = p.positions + size_t(g) * 4;
-            const uint32_t pieces = min(uint32_t(popc64(parent[0])), 32u);
-            if (lane < pieces) {
-                material = classicalMaterialOfNibble(int((parent[1 + (lane >> 4)] >> ((lane & 15) * 4)) & 0xF));
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) material += __shfl_xor(material, off, 64);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 4) p.positions[size_t(g) * 4 + lane] = child[lane];
-        if (lane == 0) {
-            p.rng[g] = state;
-            if (p.slots) p.slots[g] = p.childSlots[c];
-        }
-        r.key = recordKey(w0, w1, w2, uint32_t(w3));
-        r.score = p.evals ? -p.evals[c] : 0;
-        // the child has the OTHER side to move: bit 7 of its stm byte set = black to move = white made this move
-        const bool whiteMoved = (w3 & 0x80u) != 0;
-        r.normScore = wdlNormalize(whiteMoved ? r.score : -r.score, material);
-        r.move = p.moves[c];
-        r.halfmove = uint8_t((w3 >> 8) & 0xFF);
-    }
-    if (p.results && lane == 0) p.results[g] = r;
+    const uint32_t count = p.count[g];
+    if (count == 0 || (p.enable && !p.enable[g])) return;
+    const uint64_t state = p.rng[g] + 0x9E3779B97F4A7C15ull;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const uint64_t* child = p.children + size_t(p.first[g] + uint32_t(z >> 32) % count) * 4;
+    uint64_t* pos = p.positions + size_t(g) * 4;
+    for (int w = 0; w < 4; ++w) pos[w] = child[w];
+    p.rng[g] = state;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -667,24 +611,6 @@ __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void spx_seat_games_kernel(uint32_t n, const uint32_t* seats, const uint64_t* records,
-                                                             const uint64_t* rngStates, uint64_t* positions,
-                                                             uint32_t* slots, uint64_t* rng) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t seat = seats[k];
-    for (int w = 0; w < 4; ++w) positions[size_t(seat) * 4 + w] = records[size_t(k) * 4 + w];
-    slots[seat] = seat;
-    rng[seat] = rngStates[k];
-}
-
-hipError_t launchSeatGames(uint32_t n, const uint32_t* seats, const uint64_t* records, const uint64_t* rngStates,
-                           uint64_t* positions, uint32_t* slots, uint64_t* rng, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_seat_games_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, seats, records, rngStates,
-                       positions, slots, rng);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // viriformat game streams -> one record per played move, on the device (src/datagen/viriformat.cpp:28-63; what
 // Marlinformat::push would have stored, marlinformat.cpp:31-36): one THREAD per game replays its moves on the packed
@@ -804,7 +730,7 @@ hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream) {
 }
 
 hipError_t launchPick(const PickParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 3) / 4), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_pick_kernel, dim3((p.nGames + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -664,13 +664,10 @@ private:
             pk.nGames = uint32_t(b);
             pk.first = dFirst_;
             pk.count = dCount_;
-            pk.inCheck = dInCheck_;
             pk.enable = ply == basePlies_ ? dExtra_ : nullptr;
-            pk.moves = dMoves_;
             pk.children = dChildren_;
             pk.positions = dPositions_;
             pk.rng = dRng_;
-            pk.temperature = 0x3FFFFFFF;  // no evaluations: every legal move is within the margin
             SPX_SP_HIP(launchPick(pk, stream_));
         }
         std::vector<spx_packed_pos> done(b);
@@ -782,13 +779,10 @@ extern "C" int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t coun
             pk.nGames = uint32_t(b);
             pk.first = dFirst;
             pk.count = dCount;
-            pk.inCheck = dInCheck;
             pk.enable = dEnable;
-            pk.moves = dMoves;
             pk.children = dChildren;
             pk.positions = dPositions;
             pk.rng = dRng;
-            pk.temperature = 0x3FFFFFFF;  // no evaluations: every legal move is within the margin
             SPX_SP_HIP(launchPick(pk, stream));
             SPX_SP_HIP(hipStreamSynchronize(stream));  // the host rewrites `enable` for the next ply
         }
