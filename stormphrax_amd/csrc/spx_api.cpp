@@ -999,7 +999,9 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     uint32_t* counters = ctx->dHist + 3 * kHistWords;
     up.refreshList = ctx->dRefreshList;
     up.refreshCount = counters + ctx->refreshCur;
-    SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, n >= ctx->streamAccMin, legacy, s));
+    // streaming (non-temporal) arena accesses only where accumulators are written: eval-only children keep cached parents
+    const bool streamAcc = n >= ctx->streamAccMin && up.childSlots != nullptr;
+    SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, legacy, s));
     if (legacy) return SPX_OK;
     FtParams fp{};
     fp.positions = up.childPositions;

@@ -124,6 +124,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 // gets the same share whatever the (possibly device-resident) item count. Independent records are unaffected.
 // Measured (profiles/r03_ab_update_xcd_chunks.txt): self-play at 4 096 seats +1.5 %, 16 384 seats and independent records
 // unchanged. The single-launch kernel for tiny batches keeps the plain order (kChunked = false).
+// kStream launches (materialising batches from 32 768 records on) read the parent accumulators with non-temporal loads
+// too: each is used once, and streaming them keeps the 4 KiB per record from evicting weight rows (round 2 measured +5 % for
+// one child per parent but -15 % in self-play, whose ~35 siblings share a parent; since round 3 self-play's big update is
+// eval-only and never a kStream launch, so the hint is on). SPX_UPDATE_STREAM_PARENTS=0: cached parent loads.
+#ifndef SPX_UPDATE_STREAM_PARENTS
+#define SPX_UPDATE_STREAM_PARENTS 1
+#endif
 template <bool kChunked>
 struct ItemWalk {
     uint32_t t, tEnd, stride, xcd;
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
             const uint32_t na = c ? nAdd[1] : nAdd[0], ns = c ? nSub[1] : nSub[0];
             const uint32_t nws = c ? nWideSub[1] : nWideSub[0], nwa = c ? nWideAdd[1] : nWideAdd[0];
             uint32_t acc[8];
-            loadAcc(p.arena, parentSlot, c, lane, acc);
+            loadAcc<kStream && SPX_UPDATE_STREAM_PARENTS>(p.arena, parentSlot, c, lane, acc);
             applyWidePsqDelta(p.t, lane, sWide[wave][c][0], nws, sWide[wave][c][1], nwa, acc);
             applyU8Delta(p.t, lane, sAdd[wave][c], na, sSub[wave][c], ns, acc);
             if (p.childSlots) storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
