@@ -866,15 +866,15 @@ namespace spx {
 // Internal (spx_internal.h): run a sequence of *_device calls of this context on one of its two lanes - the lane's
 // scratch set and stream - so that two independent sequences (the two halves of the self-play seats) overlap. The
 // lane's big kernel (FT / update) first waits for the other lane's latest one.
-int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream) {
+int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream, bool gates) {
     const int rc = ensureLanes(ctx);
     if (rc != SPX_OK) return rc;
     spx_ctx::EvalLane& lane = ctx->lanes[laneIndex & 1];
     spx_ctx::EvalLane& other = ctx->lanes[(laneIndex & 1) ^ 1];
     swapLane(ctx, lane);
-    ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
-    ctx->ftGateRecord = lane.ftDone;
-    lane.ftRecorded = true;  // conservatively: an unrecorded event counts as complete for hipStreamWaitEvent
+    ctx->ftGateWait = (gates && other.ftRecorded) ? other.ftDone : nullptr;
+    ctx->ftGateRecord = gates ? lane.ftDone : nullptr;
+    if (gates) lane.ftRecorded = true;  // conservatively: an unrecorded event counts as complete for hipStreamWaitEvent
     *stream = lane.stream;
     return SPX_OK;
 }

@@ -24,7 +24,9 @@ int ctxDevice(const spx_ctx* ctx);
 void* ctxStream(const spx_ctx* ctx);  // the context's own hipStream_t (what a NULL stream argument means)
 uint8_t* ctxSlotRecords(const spx_ctx* ctx);  // device pointer: the arena's [nSlots][32] record store (after spx_acc_reserve)
 // lanes: see spx_api.cpp (two scratch sets + streams; big kernels chained by events)
-int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream);
+// gates = false: the lane's big kernels are NOT chained to the other lane's by events (a stream that is being captured
+// into a graph cannot wait on events recorded outside the capture)
+int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream, bool gates = true);
 void ctxLaneEnd(spx_ctx* ctx, int laneIndex);
 
 // error plumbing (spx_api): thread-local last error string, returned by spx_last_error()

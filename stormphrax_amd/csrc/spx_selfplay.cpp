@@ -806,7 +806,11 @@ struct HalfStatus {              // what the host reads back per ply (page-locke
     uint32_t total;              // children generated this ply (must fit `cap`)
 };
 
-constexpr uint32_t kPliesInFlight = 2;  // per half: the host enqueues this far ahead of the results it has seen
+constexpr uint32_t kPliesInFlight = 2;  // direct launches, per half: the host enqueues this far ahead of the results it has seen
+constexpr uint32_t kGraphPlies = 2;     // graph mode: consecutive plies of a half per captured graph (even: see enqueue) ...
+constexpr uint32_t kGraphsInFlight = 2; // ... and graph launches per half in flight (each with its own status slots)
+constexpr uint32_t kStatusSlots = kGraphPlies * kGraphsInFlight;  // (>= kPliesInFlight)
+constexpr int kRetryUngraphed = -1000;  // internal: the graph capture was refused before anything ran
 
 struct DeviceHalf {
     uint32_t begin = 0, end = 0;     // seats
@@ -818,10 +822,11 @@ struct DeviceHalf {
     uint32_t* dTotal = nullptr;
     uint32_t *dUpdParents = nullptr, *dUpdChildren = nullptr;
     uint64_t* dUpdPositions = nullptr;
-    HalfStatus* hStatus = nullptr;   // page-locked and mapped into the device, [kPliesInFlight] ...
+    HalfStatus* hStatus = nullptr;   // page-locked and mapped into the device, [kStatusSlots] ...
     HalfStatus* dStatus = nullptr;   // ... and its device view
-    hipEvent_t done[kPliesInFlight] = {};
+    hipEvent_t done[kStatusSlots] = {};
     uint64_t enqueued = 0, acked = 0;  // plies enqueued / plies whose results the host has read
+    hipGraphExec_t graph[kGraphsInFlight] = {};  // graph mode: kGraphPlies consecutive plies of this half each, captured once
     uint32_t index = 0;              // which lane of the context this half runs on
 };
 
@@ -859,7 +864,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     std::memset(stats, 0, sizeof(*stats));
 
     const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
-    const uint32_t poolCap = (kPliesInFlight + 3) * G + 32768;
+    const uint32_t poolCap = (kStatusSlots + 3) * G + 32768;
     const uint32_t ringWords = uint32_t(std::max<uint64_t>(1u << 20, uint64_t(G) * 2 * (maxPlies + 9)));
     DeviceBuffers dev;
     PinnedBuffers pinned;
@@ -908,7 +913,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         hf.dUpdParents = dev.get<uint32_t>(seats);
         hf.dUpdChildren = dev.get<uint32_t>(seats);
         hf.dUpdPositions = dev.get<uint64_t>(size_t(seats) * 4);
-        hf.hStatus = pinned.getMapped<HalfStatus>(kPliesInFlight, &hf.dStatus);
+        hf.hStatus = pinned.getMapped<HalfStatus>(kStatusSlots, &hf.dStatus);
         ok = hf.hStatus && hf.dStatus && hf.dTotal && hipMemset(hf.dTotal, 0, 4) == hipSuccess;
         ok = ok && hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
              hf.dUpdPositions && hf.hStatus && seats <= ctxMaxBatch(ctx);
@@ -932,6 +937,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
             for (DeviceHalf& hf : hs) {
                 for (hipEvent_t e : hf.done) {
                     if (e) (void)hipEventDestroy(e);
+                }
+                for (hipGraphExec_t g : hf.graph) {
+                    if (g) (void)hipGraphExecDestroy(g);
                 }
             }
         }
@@ -960,10 +968,10 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     uint64_t evals = 0, steps = 0;
 
     // Openings: generated in bulk on the device (OpeningPool), published to the device-side ring ahead of every claim the
-    // step kernels in flight can make: a step claims at most one opening per seat, and 2 * kPliesInFlight half-steps may
+    // step kernels in flight can make: a step claims at most one opening per seat, and up to 2 * kStatusSlots half-steps may
     // have run since the counters were last seen.
     auto ensurePool = [&](hipStream_t s) -> int {
-        const uint32_t want = (kPliesInFlight + 1) * G + 64;
+        const uint32_t want = (kStatusSlots + 1) * G + 64;
         while (published - latest.poolCursor < want) {
             const uint32_t room = poolCap - (published - latest.poolCursor);
             const uint32_t n = std::min<uint32_t>({16384u, room, want + G - (published - latest.poolCursor)});
@@ -987,23 +995,12 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         return SPX_OK;
     };
 
-    // One ply of a half, enqueued back to back on its lane: move generation, eval-only update + evaluation of the
+    // One ply of a half, enqueued back to back on its lane stream: move generation, eval-only update + evaluation of the
     // children, the step kernel (search, bookkeeping, game records, new games), the materialising update of the seats
-    // that go on, and the counters on their way back. Ends with the half's event.
-    auto enqueuePly = [&](DeviceHalf& hf) -> int {
-        void* laneStream = nullptr;
-        int lr = ctxLaneBegin(ctx, int(hf.index), &laneStream);
-        if (lr != SPX_OK) return lr;
-        struct LaneGuard {
-            spx_ctx* c;
-            int i;
-            ~LaneGuard() {
-                ctxLaneEnd(c, i);
-            }
-        } laneGuard{ctx, int(hf.index)};
-        hipStream_t s = static_cast<hipStream_t>(laneStream);
-        int r = ensurePool(s);
-        if (r != SPX_OK) return r;
+    // that go on, and the status kernel. Launches only (no copies, no events, no waits): the same sequence is what graph
+    // mode captures.
+    auto plyBody = [&](DeviceHalf& hf, hipStream_t s, uint32_t statusSlot) -> int {
+        int r = SPX_OK;
         const uint32_t seats = hf.end - hf.begin;
         {   // (spx_movegen_device without its cursor memset: the status kernel of the half's previous ply zeroed it)
             MovegenParams mp{};
@@ -1057,31 +1054,87 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         // the new game's opening (null slot -> rebuilt from scratch by the update kernel)
         r = spx_acc_update_device(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, seats, s);
         if (r != SPX_OK) return r;
-        SPX_SP_HIP(launchGameStatus(dCounters, hf.dTotal, hf.dStatus + hf.enqueued % kPliesInFlight, s));
+        SPX_SP_HIP(launchGameStatus(dCounters, hf.dTotal, hf.dStatus + statusSlot, s));
+        return SPX_OK;
+    };
+    // The per-ply chain is a fixed sequence of ~9 launches with fixed arguments: a launch-bound inner loop at small seat
+    // counts (1 024 seats: the host's enqueue time exceeded the GPU's). GRAPH MODE captures kGraphPlies consecutive plies of
+    // a half ONCE per status-slot group (two plies, so that the context's alternating sort / refresh buffers are back in
+    // phase at the end of a graph) and relaunches the instantiated graphs in turn, kGraphsInFlight of them ahead: one host
+    // call per two plies. The lanes' cross-stream event gates cannot be part of a capture, so graph mode runs the lanes
+    // ungated. SPX_SELFPLAY_NO_GRAPH=1, or a HIP runtime that refuses the capture, means direct launches (one ply at a
+    // time, kPliesInFlight plies ahead).
+    bool useGraph = std::getenv("SPX_SELFPLAY_NO_GRAPH") == nullptr;
+    auto enqueue = [&](DeviceHalf& hf) -> int {
+        void* laneStream = nullptr;
+        int lr = ctxLaneBegin(ctx, int(hf.index), &laneStream, /*gates=*/!useGraph);
+        if (lr != SPX_OK) return lr;
+        struct LaneGuard {
+            spx_ctx* c;
+            int i;
+            ~LaneGuard() {
+                ctxLaneEnd(c, i);
+            }
+        } laneGuard{ctx, int(hf.index)};
+        hipStream_t s = static_cast<hipStream_t>(laneStream);
+        int r = ensurePool(s);
+        if (r != SPX_OK) return r;
+        const uint32_t which = uint32_t(hf.enqueued / kGraphPlies) % kGraphsInFlight;  // graph mode: the graph / slot group due
+        if (useGraph && !hf.graph[which]) {
+            hipGraph_t captured = nullptr;
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            for (uint32_t k = 0; ok && k < kGraphPlies; ++k) ok = plyBody(hf, s, which * kGraphPlies + k) == SPX_OK;
+            const bool ended = hipStreamEndCapture(s, &captured) == hipSuccess && captured != nullptr;
+            ok = ok && ended && hipGraphInstantiate(&hf.graph[which], captured, nullptr, nullptr, 0) == hipSuccess;
+            if (captured) (void)hipGraphDestroy(captured);
+            if (!ok) {  // this HIP runtime cannot capture the chain
+                (void)hipGetLastError();
+                hf.graph[which] = nullptr;
+                if (steps != 0) {
+                    setError("spx_selfplay_run: graph capture failed after the run had started");
+                    return SPX_ERR_HIP;
+                }
+                useGraph = false;  // nothing has run yet: direct launches for the whole run
+                return kRetryUngraphed;
+            }
+        }
+        if (useGraph) {
+            SPX_SP_HIP(hipGraphLaunch(hf.graph[which], s));
+            SPX_SP_HIP(hipEventRecord(hf.done[which], s));
+            hf.enqueued += kGraphPlies;
+            steps += kGraphPlies;
+            return SPX_OK;
+        }
+        r = plyBody(hf, s, uint32_t(hf.enqueued % kPliesInFlight));
+        if (r != SPX_OK) return r;
         SPX_SP_HIP(hipEventRecord(hf.done[hf.enqueued % kPliesInFlight], s));
         ++hf.enqueued;
         ++steps;
         return SPX_OK;
     };
-    // wait for a half's oldest ply in flight; append what the step kernels finished since the last look to the file
-    auto awaitPly = [&](DeviceHalf& hf) -> int {
+    // wait for a half's oldest unit in flight (one ply; in graph mode the kGraphPlies plies of one graph launch); append
+    // what the step kernels finished since the last look to the file
+    auto awaitUnit = [&](DeviceHalf& hf) -> int {
+        const uint32_t plies = useGraph ? kGraphPlies : 1;
+        const uint32_t slots = useGraph ? kStatusSlots : kPliesInFlight;
         const auto g0 = std::chrono::steady_clock::now();
-        SPX_SP_HIP(hipEventSynchronize(hf.done[hf.acked % kPliesInFlight]));
+        SPX_SP_HIP(hipEventSynchronize(hf.done[useGraph ? (hf.acked / kGraphPlies) % kGraphsInFlight : hf.acked % kPliesInFlight]));
         gpuWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
-        const HalfStatus& st = hf.hStatus[hf.acked % kPliesInFlight];
-        ++hf.acked;
-        if (st.total > hf.cap) {
-            setError("spx_selfplay_run: " + std::to_string(st.total) + " children in one ply exceed the buffer of " +
-                     std::to_string(hf.cap) + " (context max_batch too small for this many seats?)");
-            return SPX_ERR_CAPACITY;
-        }
-        evals += st.total;
-        {   // every counter only grows: the newest view is the element-wise maximum of the halves' snapshots
+        for (uint32_t k = 0; k < plies; ++k) {
+            const HalfStatus& st = hf.hStatus[hf.acked % slots];
+            ++hf.acked;
+            if (st.total > hf.cap) {
+                setError("spx_selfplay_run: " + std::to_string(st.total) + " children in one ply exceed the buffer of " +
+                         std::to_string(hf.cap) + " (context max_batch too small for this many seats?)");
+                return SPX_ERR_CAPACITY;
+            }
+            evals += st.total;
+            // every counter only grows: the newest view is the element-wise maximum of the halves' snapshots
             const SelfplayCounters& c = st.counters;
             latest.streamWords = std::max(latest.streamWords, c.streamWords);
             latest.games = std::max(latest.games, c.games);
             latest.positions = std::max(latest.positions, c.positions);
-            for (int k = 0; k < 3; ++k) latest.outcomes[k] = std::max(latest.outcomes[k], c.outcomes[k]);
+            for (int o = 0; o < 3; ++o) latest.outcomes[o] = std::max(latest.outcomes[o], c.outcomes[o]);
             latest.discarded = std::max(latest.discarded, c.discarded);
             latest.started = std::max(latest.started, c.started);
             latest.poolCursor = std::max(latest.poolCursor, c.poolCursor);
@@ -1106,27 +1159,36 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         return SPX_OK;
     };
     // Every game that gets a ticket finishes (a discarded opening hands its ticket on), so the run is over when the target
-    // number of games has been written. The host sees that up to kPliesInFlight plies late: the extra plies run on seats that
+    // number of games has been written. The host sees that up to kStatusSlots plies late: the extra plies run on seats that
     // have gone idle one after the other (empty records generate no moves).
     for (;;) {
         if (latest.games < p->target_games) {
-            for (uint32_t round = 0; round < kPliesInFlight && rc == SPX_OK; ++round) {
+            // keep every half its quota of plies ahead, the halves taking turns (A0 B0 A1 B1 ... / graph mode: A01 B01 A23 B23)
+            const uint32_t unit = useGraph ? kGraphPlies : 1, ahead = useGraph ? kStatusSlots : kPliesInFlight;
+            bool retry = false;
+            for (uint32_t round = 0; round < ahead && rc == SPX_OK && !retry; round += unit) {
                 for (DeviceHalf& hf : halves) {
-                    if (rc == SPX_OK && hf.enqueued - hf.acked < kPliesInFlight && hf.enqueued == hf.acked + round) {
-                        const auto a1 = std::chrono::steady_clock::now();
-                        rc = enqueuePly(hf);
-                        enqueueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+                    const uint64_t inFlight = hf.enqueued - hf.acked;
+                    if (rc != SPX_OK || inFlight != round) continue;
+                    const auto a1 = std::chrono::steady_clock::now();
+                    rc = enqueue(hf);
+                    enqueueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+                    if (rc == kRetryUngraphed) {  // the capture was refused before anything ran: direct launches from the top
+                        rc = SPX_OK;
+                        retry = true;
+                        break;
                     }
                 }
             }
+            if (retry) continue;
         }
         if (rc != SPX_OK) break;
-        DeviceHalf* oldest = nullptr;  // the half whose oldest ply in flight was enqueued first
+        DeviceHalf* oldest = nullptr;  // the half whose oldest unit in flight was enqueued first
         for (DeviceHalf& hf : halves) {
             if (hf.enqueued > hf.acked && (!oldest || hf.acked < oldest->acked)) oldest = &hf;
         }
         if (!oldest) break;
-        if ((rc = awaitPly(*oldest)) != SPX_OK) break;
+        if ((rc = awaitUnit(*oldest)) != SPX_OK) break;
     }
     (void)spx_ctx_synchronize(ctx);  // nothing may still reference the staging buffers on an error exit
     stats->games = latest.games;
@@ -1138,8 +1200,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     stats->gpu_seconds = gpuWait;
     if (std::getenv("SPX_SELFPLAY_TRACE")) {
         std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, enqueue + openings %.3f; %llu openings discarded by "
-                     "the verification filter, %u published\n", stats->seconds, gpuWait, enqueueSeconds,
-                     static_cast<unsigned long long>(latest.discarded), published);
+                     "the verification filter, %u published; %s\n", stats->seconds, gpuWait, enqueueSeconds,
+                     static_cast<unsigned long long>(latest.discarded), published,
+                     useGraph ? "graph mode: two plies per launch, two launches ahead" : "direct launches");
     }
     return rc;
 }

@@ -158,3 +158,8 @@ def test_device_group_plays_its_games_on_every_member(sp, net_blob, oracle, tmp_
             assert n == games
             checked += verify_selfplay_file(sp, st, oracle, blob, max_plies=150, oracle_sample=512)
     assert checked == stats["positions"]
+    # fewer seats than members: the first members get one seat each and share the whole target; the third member sits out
+    with sp.DeviceGroup(net, devices=[0, 0, 0], max_batch_per_device=4096) as grp:
+        stats = grp.selfplay(n_games=2, target_games=5, out_path=str(tmp_path / "few"), max_plies=60, seed=3)
+    assert stats["games"] == 5 and os.path.exists(tmp_path / "few.0.vf") and os.path.exists(tmp_path / "few.1.vf")
+    assert not os.path.exists(tmp_path / "few.2.vf")
