@@ -115,6 +115,9 @@ struct spx_ctx {
     bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
     size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = automatic)
+    size_t teamMaxPersp = 512;     // SPX_FT_TEAM_MAX: full refreshes of at most this many perspectives run one workgroup per
+                                   // perspective (spx_ft_team_kernel): evaluate_once of 64 / 256 positions 30.8 -> 27.5 / 33.6 -> 28.8 us,
+                                   // 1 024 positions 43.3 -> 44.6 (profiles/r03_ab_rebuild_pass_team_kernel.txt); 0 = never
     uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
@@ -564,6 +567,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     ctx->updateSplitMaxV2 = 16384;
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_FT_TEAM_MAX")) ctx->teamMaxPersp = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -669,6 +673,12 @@ static uint32_t cappedGrid(size_t waves, uint32_t cap) {
 }
 static uint32_t ftGrid(const spx_ctx* ctx, size_t waves) { return cappedGrid(waves, ctx->ftGridCap); }
 static uint32_t updateGrid(const spx_ctx* ctx, size_t waves) { return cappedGrid(waves, ctx->updateGridCap); }
+// full refresh of nPersp perspectives: one wave each, or - launches too small to fill the wave slots, which are bound by the
+// latency of a single perspective - one workgroup each (spx_ft_team_kernel)
+static hipError_t launchFullFt(const spx_ctx* ctx, const FtParams& fp, size_t nPersp, hipStream_t s) {
+    if (nPersp <= ctx->teamMaxPersp) return launchFtTeam(fp, ftGrid(ctx, nPersp * ftWavesPerBlock()), s);
+    return launchFt(fp, ftGrid(ctx, nPersp), s);
+}
 
 // MLP of a handful of positions without any sort: every position is its own tile and finds its bucket from its record
 static int runTinyMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out, hipStream_t s) {
@@ -727,7 +737,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
     fp.t = tablesOf(ctx);
     fp.ftOut = ctx->dFtOut;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
+    SPX_HIP(launchFullFt(ctx, fp, 2 * n, s));
     if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
@@ -960,7 +970,7 @@ int spx_acc_refresh_device(spx_ctx* ctx, const void* d_positions, const void* d_
     fp.accOut = ctx->dArena;
     fp.slots = static_cast<const uint32_t*>(d_slots);
     fp.slotRecords = ctx->dSlotRecords;
-    SPX_HIP(launchFt(fp, ftGrid(ctx, 2 * n), s));
+    SPX_HIP(launchFullFt(ctx, fp, 2 * n, s));
     return SPX_OK;
 }
 
@@ -1015,7 +1025,10 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     fp.slots = up.childSlots;
     fp.slotRecords = up.slotRecords;
     ctx->refreshCur ^= 1;
-    // one wave per deferred perspective: ~n / 15 of them in play, grid-stride beyond
+    // one wave per deferred perspective: ~n / 15 of them in play, grid-stride beyond. (One WORKGROUP per perspective - the team
+    // kernel - was measured here and loses: 4 456 items are more than the resident workgroups, so the pass runs in rounds and
+    // pays table staging and list building four times over: update + rebuild 0.291 -> 0.319 ms per 65 536-record ply,
+    // profiles/r03_ab_rebuild_pass_team_kernel.txt.)
     const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : std::max<size_t>(256, n / 4);
     SPX_HIP(launchFt(fp, ftGrid(ctx, waves), s));
     return SPX_OK;

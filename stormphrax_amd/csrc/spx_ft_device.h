@@ -256,7 +256,7 @@ __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32
         }
         if constexpr (kNear) {
             hasNear = __ballot(near) != 0;
-            if (hasNear) {
+            if (hasNear && nearAcc) {  // (nearAcc == nullptr: another wave of the team sums the remainders)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // 1 024 sums back to zero: 4 x 16 bytes per lane
                     *reinterpret_cast<u32x4*>(nearAcc + 256 * k + 4 * lane) = u32x4{0, 0, 0, 0};

@@ -209,6 +209,8 @@ struct MlpParams {
 };
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
+// one WORKGROUP per perspective (spx_ft_team_kernel): launches with fewer perspectives than wave slots
+hipError_t launchFtTeam(const FtParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,

@@ -101,6 +101,85 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Team variant of the feature-transformer kernel, for full refreshes of fewer perspectives than the chip has resident
+// workgroups (<= 512: evaluate_once of up to 256 positions). Such a launch is bound by the LATENCY of one perspective's serial
+// chain (lists, then ~65 rows in bursts of 8), so here the kWavesPerBlock waves of a workgroup share ONE perspective: every
+// wave builds the (identical) row lists for itself - no barrier before the gather -, fetches its quarter of the rows, and
+// wave 0 adds the partial accumulators up through LDS. A partial accumulator is ftBias + its rows - 128 per u8 row
+// (gatherFull), so the sum of kWavesPerBlock of them carries the bias kWavesPerBlock times: the surplus is taken off again;
+// everything is mod 2^16 per column, hence bit-identical to the one-wave kernel (test_team_kernel_matches_the_wave_kernel).
+// NOT used for the update kernels' rebuild pass: with more items than resident workgroups the pass runs in rounds and pays
+// table staging and list building four times over (measured: 44 -> 72 us, profiles/r03_ab_rebuild_pass_team_kernel.txt).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool kNear>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_ft_team_kernel(FtParams p) {  // (5 waves/SIMD: 96 VGPRs spill)
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ __align__(16) int32_t sNear[kNear ? int(kL1) : 4];  // remainders of near-compact rows: summed by wave 0 alone
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint64_t sPseudo[kDeltaPseudoWords];
+    __shared__ uint32_t sPart[kWavesPerBlock - 1][8][64];  // partial accumulators of waves 1.., 2 KiB each
+
+    if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
+    const uint32_t nPersp = p.nPerspPtr ? min(*p.nPerspPtr, p.nPositions * 2) : p.nPositions * 2;
+    if (blockIdx.x >= nPersp) return;  // (a device-produced list is usually much shorter than the grid)
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
+        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x; it < nPersp; it += gridDim.x) {  // (block-uniform trip count: the barriers below are safe)
+        const uint32_t q = __builtin_amdgcn_readfirstlane(p.order ? p.order[it] : it);
+        const uint32_t posIdx = q >> 1;
+        const int c = int(q & 1);
+        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
+        const LaneBoard board = decodeBoard(rec, lane);
+        uint32_t nPsq, nThr;
+        const bool hasNear = buildFullLists<kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
+                                                   p.t.outlierTab, wave == 0 ? sNear : nullptr);
+        // this wave's slice of both lists (the near-compact rows' remainders go in once: wave 0)
+        const uint32_t p0 = nPsq * wave / kWavesPerBlock, p1 = nPsq * (wave + 1) / kWavesPerBlock;
+        const uint32_t t0 = nThr * wave / kWavesPerBlock, t1 = nThr * (wave + 1) / kWavesPerBlock;
+        uint32_t acc[8];
+        gatherFull(p.t, lane, sPsq[wave] + p0, p1 - p0, sThr[wave] + t0, t1 - t0, acc,
+                   (kNear && hasNear && wave == 0) ? sNear : nullptr);
+        if (wave != 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sPart[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(p.t.ftBias + 8 * lane);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(p.t.ftBias + 512 + 8 * lane);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t bias = r < 4 ? b0[r & 3] : b1[r & 3];
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock - 1; ++w) acc[r] = pkSub16(pkAdd16(acc[r], sPart[w][r][lane]), bias);
+            }
+            if (p.accOut) {
+                const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
+                storeAcc(p.accOut, slot, c, lane, acc);
+                if (c == 0 && lane < 8) {
+                    reinterpret_cast<uint32_t*>(p.slotRecords + size_t(slot) * 32)[lane] =
+                        reinterpret_cast<const uint32_t*>(rec)[lane];
+                }
+            }
+            if (p.ftOut) {
+                const uint32_t half = (c == board.stm) ? 0u : 1u;
+                *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            }
+        }
+        __syncthreads();  // the partial sums are consumed before the next perspective's are written
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Incremental update kernel: child accumulator = parent accumulator + added rows - removed rows.
 // One wavefront per (parent slot -> child slot) record, both perspectives. Replaces, for a batch of independent
 // records, what the reference does per ply in ensureUpToDate (nnue_state.cpp:636-697): updatePsq (:34-87),
@@ -399,11 +478,25 @@ __device__ __forceinline__ void loadAddRows(const RowTable& table, uint32_t lane
     }
 }
 
+#ifndef SPX_UPDATE_BURST
+#define SPX_UPDATE_BURST 4  // rows in flight per wave in the delta gather. 5 / 6 / 8 (28-64 B of spills at 96 VGPRs) and 8 at
+                            // 4 waves/SIMD all LOSE: update + rebuild 0.318 -> 0.333 / 0.336 / 0.361 / 0.333 ms per ply
+                            // (profiles/r03_ab_update_burst_depth.txt) - the kernel is not short of loads in flight
+#endif
 __device__ __forceinline__ void accumulateRows(const RowTable& table, uint32_t laneOff, const uint32_t* list, uint32_t n,
                                                uint32_t flip, uint32_t (&tacc)[8]) {
     uint32_t i = 0;
+    if constexpr (SPX_UPDATE_BURST > 4) {
 #pragma unroll 1
-    for (; i + 4 <= n; i += 4) loadAddRows<4>(table, laneOff, list + i, flip, tacc);
+        for (; i + SPX_UPDATE_BURST <= n; i += SPX_UPDATE_BURST) loadAddRows<SPX_UPDATE_BURST>(table, laneOff, list + i, flip, tacc);
+        if (i + 4 <= n) {
+            loadAddRows<4>(table, laneOff, list + i, flip, tacc);
+            i += 4;
+        }
+    } else {
+#pragma unroll 1
+        for (; i + 4 <= n; i += 4) loadAddRows<4>(table, laneOff, list + i, flip, tacc);
+    }
     const uint32_t rest = n - i;  // wave-uniform
     if (rest == 3) {
         loadAddRows<3>(table, laneOff, list + i, flip, tacc);
@@ -1188,6 +1281,15 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     }
 }
 
+
+hipError_t launchFtTeam(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
+    if (p.t.outlierTab) {
+        hipLaunchKernelGGL((spx_ft_team_kernel<true>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((spx_ft_team_kernel<false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
     if (p.t.outlierTab) {

@@ -182,6 +182,42 @@ def test_near_compact_piece_square_rows(sp, oracle, net_blob, states):
     assert np.array_equal(got, oracle.eval_mailboxes(m2, s2))
 
 
+@pytest.mark.parametrize("preset", ["tame", "extreme", "mixed", "near"])
+def test_team_kernel_matches_the_wave_kernel(sp, oracle, net_blob, preset):
+    """Full refreshes of at most 512 perspectives run one WORKGROUP per perspective (spx_ft_team_kernel: four waves fetch a
+    quarter of the rows each, partial accumulators summed through LDS), larger ones one wave per perspective. Both kernels,
+    forced onto the same batches through SPX_FT_TEAM_MAX (read when a context is created), must agree with the oracle and with
+    each other: evaluations, u8 activations, and the accumulators they leave in the arena."""
+    import os
+
+    def make(team_max):
+        old = os.environ.get("SPX_FT_TEAM_MAX")
+        os.environ["SPX_FT_TEAM_MAX"] = str(team_max)
+        try:
+            return sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
+        finally:
+            if old is None:
+                os.environ.pop("SPX_FT_TEAM_MAX", None)
+            else:
+                os.environ["SPX_FT_TEAM_MAX"] = old
+
+    pos = sp.random_positions(3000, seed=404, min_ply=0, max_ply=160, dfrc_every=3)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    oracle.use(net_blob(preset), preset)
+    want = oracle.eval_mailboxes(mail, stm)
+    with make(0) as wave, make(1 << 20) as team:
+        for n in (1, 2, 63, 200, 256, 257, 3000):
+            a, b = wave.evaluate_once(pos[:n]), team.evaluate_once(pos[:n])
+            assert np.array_equal(a, want[:n]) and np.array_equal(b, want[:n]), n
+            assert np.array_equal(wave.debug_ft(n), team.debug_ft(n)), n
+        slots = np.arange(3000, dtype=np.uint32)
+        for st in (wave, team):
+            st.reserve_slots(3000)
+            st.reset(pos, slots)
+            assert np.array_equal(st.evaluate(slots), want)
+    # the default context takes the team kernel up to 256 positions and the wave kernel beyond: covered by every other test
+
+
 @pytest.mark.parametrize("preset", ["tame", "wild"])
 def test_adjust_on_device_matches_reference_and_oracle(sp, oracle, net_blob, states, preset):
     """spx_adjust (device post-processing, rows a18 / f-4): golden staticEvalOnce / adjustEval<false> values of the
