@@ -363,6 +363,15 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
 int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, uint8_t* unfiltered,
                         size_t capacity, size_t* n_positions, size_t* n_games, size_t* bad_games);
 int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
+/* datagen's two other output formats (datagen.cpp:340-346), converted from a viriformat stream - what the reference would
+ * have written for the same games had it been started with "marlinformat" / "fen":
+ *   spx_viri_to_marlinformat: the unfiltered positions as PackedBoard records with eval = the recorded score and wdl = the
+ *     game's outcome, back to back (Marlinformat::push / writeAllWithOutcome, marlinformat.cpp:32-57);
+ *   spx_viri_to_fen: one text line per unfiltered position, "<fen> | <score> | <0.0 / 0.5 / 1.0>" + '\n' (fen.cpp:32-66).
+ * out = NULL counts only (*n_records / *n_bytes); SPX_ERR_CAPACITY when `capacity` (records / bytes) is too small. */
+int spx_viri_to_marlinformat(const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity, size_t* n_records,
+                             size_t* n_games);
+int spx_viri_to_fen(const void* data, size_t nbytes, char* out, size_t capacity, size_t* n_bytes, size_t* n_games);
 uint64_t spx_perft(const char* fen, int depth);
 
 /* ---- legal move generation + make-move on the device (takes the host out of the self-play loop) ----

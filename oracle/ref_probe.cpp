@@ -31,7 +31,8 @@
 //   pack <fen>                 -> "K <64 hex digits>": the 32 bytes of datagen::marlinformat::PackedBoard::pack(pos, 0)
 //   viri <seed> <plies> <dfrc> -> a random game pushed through datagen::Viriformat: per ply "M <fen before> | <uci> |
 //                                 <score> | <filtered> | <pack hex of the position before>", then "V <hex of the stream
-//                                 writeAllWithOutcome wrote>" (marlinformat.h:32-84, viriformat.cpp:28-63)
+//                                 writeAllWithOutcome wrote>" (marlinformat.h:32-84, viriformat.cpp:28-63); then "F <kept> <hex>" =
+//                                 datagen::Marlinformat's file bytes and "T <lines joined by ;>" = datagen::Fen's, same game
 //   wdl <score> <fen>          -> "W <classicalMaterial> <wdl::normalizeScore(score, material)>" (wdl.cpp:28-79) at
 //                                 datagen's evalSharpness of 100 (datagen.cpp:353)
 #include <atomic>
@@ -45,6 +46,8 @@
 
 #include "attacks/attacks.h"
 #include "cuckoo.h"
+#include "datagen/marlinformat.h"
+#include "datagen/fen.h"
 #include "datagen/marlinformat.h"
 #include "datagen/viriformat.h"
 #include "eval/eval.h"
@@ -332,7 +335,11 @@ int main() {
             SplitMix64 rng{seed};
             auto pos = dfrc ? *Position::fromDfrcIndex(rng.below(960 * 960)) : Position::startpos();
             datagen::Viriformat format{};
+            datagen::Marlinformat marlin{};  // the other two output formats of datagen.cpp:340-346 see the same pushes
+            datagen::Fen fenLines{};
             format.start(pos);
+            marlin.start(pos);
+            fenLines.start(pos);
             for (u32 ply = 0; ply < plies; ++ply) {
                 const auto moves = legalMoves(pos);
                 if (moves.empty()) {
@@ -352,13 +359,25 @@ int main() {
                 std::printf("M %s | %s | %d | %d | %s\n", pos.toFen().c_str(), fmt::format("{}", move).c_str(), score,
                             filtered ? 1 : 0, hexOf(&packed, sizeof(packed)).c_str());
                 format.push(filtered, move, score);
+                marlin.push(filtered, move, score);
+                fenLines.push(filtered, move, score);
                 pos = pos.applyMove(move);
             }
-            std::ostringstream stream;
+            std::ostringstream stream, marlinStream, fenStream;
             const auto outcome = static_cast<datagen::Outcome>(rng.below(3));
             format.writeAllWithOutcome(stream, outcome);
             const auto bytes = stream.str();
             std::printf("V %s\n", hexOf(bytes.data(), bytes.size()).c_str());
+            // datagen::Marlinformat (marlinformat.cpp:32-57) and datagen::Fen (fen.cpp:32-66) of the same game
+            const auto kept = marlin.writeAllWithOutcome(marlinStream, outcome);
+            const auto marlinBytes = marlinStream.str();
+            std::printf("F %zu %s\n", static_cast<size_t>(kept), hexOf(marlinBytes.data(), marlinBytes.size()).c_str());
+            fenLines.writeAllWithOutcome(fenStream, outcome);
+            auto text = fenStream.str();
+            for (auto& ch : text) {
+                if (ch == '\n') ch = ';';
+            }
+            std::printf("T %s\n", text.c_str());
         } else if (cmd == "playout") {
             u64 seed;
             u32 count, minPly, maxPly, dfrc;

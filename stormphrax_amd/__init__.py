@@ -27,5 +27,7 @@ from .nnue import (  # noqa: F401
     random_successors,
     synthetic_net_bytes,
     viri_expand,
+    viri_to_fen,
+    viri_to_marlinformat,
     viri_random_game,
 )

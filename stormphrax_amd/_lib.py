@@ -143,6 +143,8 @@ SYMBOLS = {
     "spx_random_positions": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_random_positions_gpu": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "spx_random_successors": (ctypes.c_int, [ctypes.c_uint64, _P, ctypes.c_size_t, _P, _P]),
+    "spx_viri_to_marlinformat": (ctypes.c_int, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "spx_viri_to_fen": (ctypes.c_int, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_expand": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_viri_random_game": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_selfplay_run": (ctypes.c_int, [_P, _P, ctypes.c_char_p, _P]),

@@ -2173,6 +2173,78 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
     return SPX_OK;
 }
 
+// datagen's other output formats from a viriformat stream (include/spx_nnue.h): the expansion above, filtered
+static int expandFiltered(const void* data, size_t nbytes, std::vector<spx_packed_pos>& kept, size_t* n_games, const char* who) {
+    size_t n = 0, games = 0;
+    int rc = spx_viri_expand(data, nbytes, nullptr, nullptr, nullptr, 0, &n, &games);
+    if (rc != SPX_OK) return rc;
+    std::vector<spx_packed_pos> all(n);
+    std::vector<uint8_t> keep(n);
+    rc = spx_viri_expand(data, nbytes, all.data(), nullptr, keep.data(), n, &n, &games);
+    if (rc != SPX_OK) return rc;
+    kept.clear();
+    for (size_t i = 0; i < n; ++i) {
+        if (keep[i]) kept.push_back(all[i]);
+    }
+    if (n_games) *n_games = games;
+    (void)who;
+    return SPX_OK;
+}
+
+int spx_viri_to_marlinformat(const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity, size_t* n_records,
+                             size_t* n_games) {
+    if (!data || !n_records) {
+        setError("spx_viri_to_marlinformat: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    std::vector<spx_packed_pos> kept;
+    const int rc = expandFiltered(data, nbytes, kept, n_games, "spx_viri_to_marlinformat");
+    if (rc != SPX_OK) return rc;
+    *n_records = kept.size();
+    if (!out) return SPX_OK;
+    if (kept.size() > capacity) {
+        setError("spx_viri_to_marlinformat: output capacity exceeded");
+        return SPX_ERR_CAPACITY;
+    }
+    if (!kept.empty()) std::memcpy(out, kept.data(), kept.size() * sizeof(spx_packed_pos));
+    return SPX_OK;
+}
+
+int spx_viri_to_fen(const void* data, size_t nbytes, char* out, size_t capacity, size_t* n_bytes, size_t* n_games) {
+    if (!data || !n_bytes) {
+        setError("spx_viri_to_fen: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    std::vector<spx_packed_pos> kept;
+    int rc = expandFiltered(data, nbytes, kept, n_games, "spx_viri_to_fen");
+    if (rc != SPX_OK) return rc;
+    std::string text;
+    text.reserve(kept.size() * 80);
+    static const char* const kOutcome[3] = {"0.0", "0.5", "1.0"};  // Outcome: white loss, draw, white win (fen.cpp:47-59)
+    char fen[128];
+    for (const spx_packed_pos& rec : kept) {
+        if ((rc = spx_pos_to_fen(&rec, fen, sizeof(fen))) != SPX_OK) return rc;
+        if (rec.wdl > 2) {
+            setError("spx_viri_to_fen: outcome byte " + std::to_string(rec.wdl) + " is not 0, 1 or 2");
+            return SPX_ERR_BAD_POSITION;
+        }
+        text += fen;
+        text += " | ";
+        text += std::to_string(int(rec.eval));
+        text += " | ";
+        text += kOutcome[rec.wdl];
+        text += '\n';
+    }
+    *n_bytes = text.size();
+    if (!out) return SPX_OK;
+    if (text.size() > capacity) {
+        setError("spx_viri_to_fen: output capacity exceeded");
+        return SPX_ERR_CAPACITY;
+    }
+    std::memcpy(out, text.data(), text.size());
+    return SPX_OK;
+}
+
 // viriformat expansion on the device: the host only finds the game boundaries (one linear scan for the 4-byte null
 // terminators), a thread per game replays the moves (spx_viri_expand_kernel)
 int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, uint8_t* unfiltered,

@@ -462,6 +462,30 @@ def viri_expand(data, with_filter=False):
     return (out, g.value, keep.astype(bool)) if with_filter else (out, g.value)
 
 
+def viri_to_marlinformat(data):
+    """viriformat stream -> the bytes datagen's marlinformat output holds for the same games (spx_viri_to_marlinformat):
+    unfiltered positions as PackedBoard records, eval = recorded score, wdl = outcome. -> (records, n_games)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n, g = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.spx_viri_to_marlinformat(buf.ctypes.data, buf.size, None, 0, ctypes.byref(n), ctypes.byref(g)))
+    out = np.zeros(n.value, dtype=PACKED_DTYPE)
+    check(lib.spx_viri_to_marlinformat(buf.ctypes.data, buf.size, out.ctypes.data, n.value, ctypes.byref(n), ctypes.byref(g)))
+    return out, g.value
+
+
+def viri_to_fen(data):
+    """viriformat stream -> the text datagen's "fen" output holds for the same games (spx_viri_to_fen):
+    "<fen> | <score> | <0.0 / 0.5 / 1.0>" per unfiltered position. -> (text, n_games)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n, g = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.spx_viri_to_fen(buf.ctypes.data, buf.size, None, 0, ctypes.byref(n), ctypes.byref(g)))
+    out = ctypes.create_string_buffer(max(1, n.value))
+    check(lib.spx_viri_to_fen(buf.ctypes.data, buf.size, out, n.value, ctypes.byref(n), ctypes.byref(g)))
+    return out.raw[: n.value].decode(), g.value
+
+
 def viri_random_game(seed, plies=80, dfrc=False):
     lib = _lib.load()
     buf = np.zeros(32 + 4 * (plies + 1), dtype=np.uint8)

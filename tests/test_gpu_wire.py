@@ -34,6 +34,30 @@ def test_device_viriformat_expansion_reproduces_the_reference_records(sp, state)
             k += 1
 
 
+def test_marlinformat_of_device_played_games(sp, state, tmp_path):
+    """datagen's marlinformat / fen outputs of games the DEVICE played: the device expander's unfiltered records are the
+    bytes of the host conversion (whose output is pinned to the reference writers in test_wire_golden.py), the reference's
+    golden games give the same through the device expander, and the fen text has one line per record."""
+    games = load_games()
+    blob = b"".join(g["stream"] for g in games)
+    records, _, _, keep = state.viri_expand(blob, with_filter=True)
+    assert records[keep].tobytes() == b"".join(g["marlin"] for g in games)
+    path = str(tmp_path / "games.vf")
+    stats = state.selfplay(64, 200, out_path=path, max_plies=120, dfrc=True, seed=31)
+    played = open(path, "rb").read()
+    records, n_games, bad, keep = state.viri_expand(played, with_filter=True)
+    assert (n_games, bad) == (stats["games"], 0) and len(records) == stats["positions"]
+    marlin, g2 = sp.viri_to_marlinformat(played)
+    assert g2 == n_games and records[keep].tobytes() == marlin.tobytes() and 0 < len(marlin) < len(records)
+    text, _ = sp.viri_to_fen(played)
+    lines = text.splitlines()
+    assert len(lines) == len(marlin)
+    for k in (0, len(lines) // 2, len(lines) - 1):
+        fen, score, wdl = lines[k].split(" | ")
+        assert fen == sp.position_to_fen(marlin[k]) and int(score) == int(marlin[k]["eval"])
+        assert wdl == ("0.0", "0.5", "1.0")[int(marlin[k]["wdl"])]
+
+
 def test_device_move_generator_writes_the_reference_child_records(sp, state):
     """For every position of the reference's games the kernel's children contain the move the reference played, under the
     reference's own 16-bit viriformat word, and the child's 32 bytes are PackedBoard::pack of the reference's next

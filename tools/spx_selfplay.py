@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--preset", default="tame")
     ap.add_argument("--net")
     ap.add_argument("--out")
+    ap.add_argument("--format", default="viriformat", choices=["viriformat", "marlinformat", "fen"],
+                    help="datagen's output formats (datagen.cpp:340-346). The games are always recorded as viriformat "
+                         "(<out>.<rank>.vf); marlinformat / fen convert that file afterwards into what the reference would have "
+                         "written for the same games (<out>.<rank>.bin / .txt: unfiltered positions only) and remove it")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     import numpy as np
@@ -54,6 +58,18 @@ def main():
     stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
                            temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads,
                            host_movegen=args.host_movegen)
+    written = None
+    if out and args.format != "viriformat":
+        data = open(out, "rb").read()
+        if args.format == "marlinformat":
+            records, _ = sp.viri_to_marlinformat(data)
+            written = f"{args.out}.{group.rank}.bin"
+            records.tofile(written)
+        else:
+            text, _ = sp.viri_to_fen(data)
+            written = f"{args.out}.{group.rank}.txt"
+            open(written, "w").write(text)
+        os.remove(out)
     slowest = group.max_float(stats["seconds"])
     total = {k: group.sum_int(stats[k]) for k in ("games", "positions", "evals", "steps")}
     gpu_seconds = group.max_float(stats["gpu_seconds"])
@@ -64,7 +80,7 @@ def main():
             "n_gpus": group.world, "collectives": backend, "net_digest": "%016x" % net.digest, "games_per_gpu": args.games, "games": total["games"], "positions": total["positions"],
             "positions_per_sec": total["positions"] / slowest, "games_per_sec": total["games"] / slowest,
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
-            "outcomes_white_loss_draw_win": outcomes, "host_threads": args.threads or "auto",
+            "outcomes_white_loss_draw_win": outcomes, "host_threads": args.threads or "auto", "format": args.format,
             "move_generation": "host chess core" if args.host_movegen else "device (spx_movegen_kernel)",
             "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
         }))
