@@ -885,6 +885,9 @@ int ctxLaneBegin(spx_ctx* ctx, int laneIndex, void** stream, bool gates) {
     ctx->ftGateWait = (gates && other.ftRecorded) ? other.ftDone : nullptr;
     ctx->ftGateRecord = gates ? lane.ftDone : nullptr;
     if (gates) lane.ftRecorded = true;  // conservatively: an unrecorded event counts as complete for hipStreamWaitEvent
+    // an ungated lane may be under stream capture: spx_profile_* timing events have no place in a graph (a profile that was
+    // left open ends here)
+    if (!gates) ctx->profUsed = ctx->profEvents.size();
     *stream = lane.stream;
     return SPX_OK;
 }

@@ -28,8 +28,8 @@ python bench.py --batch 4194304 --steps 20 --warmup 3 --no-cpu-baseline --no-wid
 python tools/gpu_measure.py > $OUT/secondary.json 2> $OUT/secondary.err
 python tools/spx_selfplay.py --games 4096 --target 8192 --dfrc > $OUT/selfplay_4096.json 2> $OUT/selfplay.err
 python tools/spx_selfplay.py --games 4096 --target 65536 --dfrc > $OUT/selfplay_4096_long.json 2>> $OUT/selfplay.err
-python tools/spx_selfplay.py --games 16384 --target 32768 --dfrc > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
-python tools/spx_selfplay.py --games 1024 --target 2048 --dfrc > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 16384 --target 65536 --dfrc > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 1024 --target 8192 --dfrc > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
 python tools/gpu_gather_ceiling.py --out $OUT/gather_ceiling.json > /dev/null 2>> $OUT/selfplay.err
 python tools/gpu_gather_ceiling.py --wide --rounds 3 --out $OUT/gather_ceiling_wide_psq_rows.json > /dev/null 2>> $OUT/selfplay.err
 ./stormphrax_amd/spx_raweval --preset tame --walk 7 6000 rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 > $OUT/raweval_walk.txt 2>&1
@@ -40,7 +40,7 @@ python tools/gpu_replay_rate.py > $OUT/config3_replay.json 2> $OUT/replay.err
 # (the TA/TD/TCP counter groups are NOT collected here: on 2026-09-28 rocprofv3 aborted inside hipMemcpy with them and
 #  then hung in its signal handler until the timeout - every rocprofv3 call in tools/ runs under `timeout 300`)
 # differential runs against the COMPILED REFERENCE on the final binary (its probe travels in oracle/_ref/)
-python tools/gpu_ref_differential.py --positions 4000000 --pack-positions 500000 > $OUT/reference_differential.json 2> $OUT/differential.err
+python tools/gpu_ref_differential.py --positions 10000000 --pack-positions 1000000 > $OUT/reference_differential.json 2> $OUT/differential.err
 python tools/gpu_ref_trace_differential.py --roots 64 > $OUT/reference_trace_differential.json 2>> $OUT/differential.err
 # counters of the self-play's eval-only update kernel (what crosses the fabric per child now)
 ( cd /tmp && export TMPDIR=/tmp
