@@ -27,13 +27,14 @@ def shard_bounds(n, rank, world):
 
 
 class Group:
-    """Thin wrapper over torch.distributed that degrades to a no-op for world size 1."""
+    """Thin wrapper over torch.distributed that degrades to a no-op for world size 1 (SPX_FORCE_DIST=1 initialises the
+    process group even then: a single-GPU box can put every collective below through the real RCCL once)."""
 
     def __init__(self, backend="nccl", device=None):
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("SPX_FORCE_DIST") == "1":
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -112,6 +112,29 @@ def test_bare_bench_command_launches_its_own_ranks():
     assert ranks["world"] == 2 and len(ranks["ft_kernel_ms_per_rank"]) == 2
 
 
+def test_every_collective_once_through_rccl(tmp_path):
+    """No multi-GPU node has been available to any round, and the 2-rank tests share one GPU over gloo: RCCL itself would
+    otherwise meet this code for the first time on the driver's 8-GPU lease. SPX_FORCE_DIST=1 initialises the process group
+    at world size 1, so every collective the N > 1 runs use - the net broadcast (89 MB, uint8), MAX / SUM all_reduce (f64,
+    i64), the per-rank all_gather (f64) and the score all_gather (i32), barriers - goes through the real RCCL library once,
+    on device tensors, in bench.py and in the self-play tool."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SPX_FORCE_DIST="1", MASTER_PORT="29641")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--gather",
+                          "--device-positions", "--no-wide", "--no-secondary", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["ranks"]["backend"] == "nccl" and line["config"]["ranks"]["world"] == 1
+    assert line["bit_exact_sample"] is True and line["config"]["gathered_scores_ok"] is True
+    env["MASTER_PORT"] = "29642"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spx_selfplay.py"), "--games", "256", "--target", "300",
+                          "--out", str(tmp_path / "g")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["collectives"] == "nccl" and line["games"] == 300 and os.path.getsize(str(tmp_path / "g.0.vf")) > 0
+
+
 def test_device_group_shards_a_batch_over_its_members(sp, net_blob, oracle):
     """spx_group (the C ABI's multi-device entry): two members on this box's one GPU evaluate contiguous shards on their own
     host threads - scores identical to one context over the whole batch and to the CPU oracle, for ragged and tiny
