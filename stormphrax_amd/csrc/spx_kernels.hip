@@ -478,25 +478,14 @@ __device__ __forceinline__ void loadAddRows(const RowTable& table, uint32_t lane
     }
 }
 
-#ifndef SPX_UPDATE_BURST
-#define SPX_UPDATE_BURST 4  // rows in flight per wave in the delta gather. 5 / 6 / 8 (28-64 B of spills at 96 VGPRs) and 8 at
-                            // 4 waves/SIMD all LOSE: update + rebuild 0.318 -> 0.333 / 0.336 / 0.361 / 0.333 ms per ply
-                            // (profiles/r03_ab_update_burst_depth.txt) - the kernel is not short of loads in flight
-#endif
+// Four rows in flight per wave. 5 / 6 / 8 at a time (28-64 B of spills at 96 VGPRs) and 8 at 4 waves/SIMD were measured and
+// all LOSE: update + rebuild pass per 65 536-record ply +4.6 % / +5.8 % / +13 % / +4.8 % (profiles/r03_ab_update_burst_depth.txt) -
+// the kernel is bound by its L2-miss traffic, not short of loads in flight.
 __device__ __forceinline__ void accumulateRows(const RowTable& table, uint32_t laneOff, const uint32_t* list, uint32_t n,
                                                uint32_t flip, uint32_t (&tacc)[8]) {
     uint32_t i = 0;
-    if constexpr (SPX_UPDATE_BURST > 4) {
 #pragma unroll 1
-        for (; i + SPX_UPDATE_BURST <= n; i += SPX_UPDATE_BURST) loadAddRows<SPX_UPDATE_BURST>(table, laneOff, list + i, flip, tacc);
-        if (i + 4 <= n) {
-            loadAddRows<4>(table, laneOff, list + i, flip, tacc);
-            i += 4;
-        }
-    } else {
-#pragma unroll 1
-        for (; i + 4 <= n; i += 4) loadAddRows<4>(table, laneOff, list + i, flip, tacc);
-    }
+    for (; i + 4 <= n; i += 4) loadAddRows<4>(table, laneOff, list + i, flip, tacc);
     const uint32_t rest = n - i;  // wave-uniform
     if (rest == 3) {
         loadAddRows<3>(table, laneOff, list + i, flip, tacc);
