@@ -44,17 +44,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];        // pseudo-attack sets per (piece kind, square), 3 KiB
 
     if (p.clearWord && blockIdx.x == 0 && threadIdx.x == 0) *p.clearWord = 0;
-    if (p.nPerspPtr && *p.nPerspPtr == 0) return;  // nothing was deferred: the refresh pass costs one empty launch
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
-        sLut[i] = p.t.lut[i];
-    }
-    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
-        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
-    }
-    __syncthreads();
-
-    const uint32_t lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6;
     // nPerspPtr: the list in `order` was produced on the device (deferred refreshes of the update kernel) and so was its length
     const uint32_t nPersp = p.nPerspPtr ? min(*p.nPerspPtr, p.nPositions * 2) : p.nPositions * 2;
     // XCD-aware traversal: workgroup b runs on XCD b % 8 (observed dispatch order; affects speed only). The (king-bucket
@@ -70,6 +59,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
     const uint32_t chunkShift = nPersp >= 64u * SPX_FT_CHUNK ? uint32_t(__builtin_ctz(SPX_FT_CHUNK)) : 0u;
     const uint32_t nChunks = (nPersp + (1u << chunkShift) - 1) >> chunkShift;
     const uint32_t myItems = ((nChunks + 7 - xcd) / 8) << chunkShift;  // chunks xcd, xcd + 8, ...
+    // A workgroup without items leaves BEFORE staging the tables: the grid of a rebuild pass is sized on the host for a list
+    // whose length only the device knows (3-4 % of the perspectives in play - in self-play 90 % of its 12 288 workgroups find
+    // nothing, and each read 14 KB of tables and sat at a barrier beside the other half's kernels): self-play +3.4 % at 4 096
+    // seats, +2.3 % at 1 024; the incremental bench (a quarter of the grid, nothing running beside it) unchanged
+    // (profiles/r03_ab_idle_workgroups_exit_before_staging.txt).
+    if (blockInXcd * kWavesPerBlock >= myItems) return;
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
+        sLut[i] = p.t.lut[i];
+    }
+    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) {
+        sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t t = blockInXcd * kWavesPerBlock + wave; t < myItems; t += stride) {
         const uint32_t it = ((((t >> chunkShift) * 8 + xcd)) << chunkShift) + (t & ((1u << chunkShift) - 1));
         if (it >= nPersp) continue;  // the last chunk may be partial
@@ -579,6 +584,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
     __shared__ uint32_t sWide[kWavesPerBlock][2][2][8];        // per perspective: wide piece-square rows to subtract / add
     __shared__ uint8_t sMail[kWavesPerBlock][2][64];           // piece per square of the parent / child board
 
+    const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
+    const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
+    // (a counted launch is sized for its capacity: workgroups beyond the count leave before staging 19 KB of tables)
+    if (ItemWalk<true>(nItems, 0).t >= ItemWalk<true>(nItems, 0).tEnd) return;
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
         sLut[i] = p.t.lut[i];
     }
@@ -590,8 +599,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
 
-    const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
-    const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
     for (ItemWalk<true> walk(nItems, wave); walk.t < walk.tEnd; walk.t += walk.stride) {
         const uint32_t item = walk.item();
         if (item >= nItems) continue;  // (the last chunk round may be partial)

@@ -57,7 +57,8 @@ for f in sorted(glob.glob("$OUT/sp_pmc_*/*.db")):
         print("   %-44s %-18s mean/dispatch %16.1f  dispatches %d" % (r[0].replace("spx::", "")[:44], r[1], r[2], r[3]))
 PY
 rm -rf $OUT/sp_pmc_*
-bash tools/gpu_stats.sh default_$TAG --no-wide > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
+bash tools/gpu_stats.sh default_$TAG > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
+bash tools/gpu_stats.sh headline_$TAG --no-secondary --no-wide > $OUT/rocprofv3_kernel_stats_headline_only.txt 2>&1
 bash tools/gpu_stats.sh inc_$TAG --mode incremental > $OUT/rocprofv3_incremental_kernel_stats.txt 2>&1
-rm -rf $REPO/gpurun_out/stats_default_$TAG $REPO/gpurun_out/stats_inc_$TAG
+rm -rf $REPO/gpurun_out/stats_default_$TAG $REPO/gpurun_out/stats_headline_$TAG $REPO/gpurun_out/stats_inc_$TAG
 ls -la $OUT
