@@ -1032,7 +1032,11 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     // kernel - was measured here and loses: 4 456 items are more than the resident workgroups, so the pass runs in rounds and
     // pays table staging and list building four times over: update + rebuild 0.291 -> 0.319 ms per 65 536-record ply,
     // profiles/r03_ab_rebuild_pass_team_kernel.txt.)
-    const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : std::max<size_t>(256, n / 4);
+    // Grid: 4 096 waves at most, grid-stride beyond (SPX_REFRESH_WAVES overrides). Round 2 launched n / 4 waves - up to the
+    // full 12 288-workgroup grid for self-play's capacity-sized batches; measured now (profiles/r03_ab_rebuild_pass_grid.txt):
+    // 16 384 / 8 192 / 4 096 / 2 048 / 1 024 waves = self-play at 4 096 seats 2.39 / 2.39 / 2.41 / 2.43 / 2.37 x 10^8 and the
+    // incremental bench's update + rebuild 0.290 / 0.291 / 0.290 / 0.297 / 0.320 ms: 4 096 suits both.
+    const size_t waves = ctx->refreshWaves ? ctx->refreshWaves : std::min<size_t>(4096, std::max<size_t>(256, n / 4));
     SPX_HIP(launchFt(fp, ftGrid(ctx, waves), s));
     return SPX_OK;
 }
