@@ -807,9 +807,9 @@ struct HalfStatus {              // what the host reads back per ply (page-locke
 };
 
 constexpr uint32_t kPliesInFlight = 2;  // direct launches, per half: the host enqueues this far ahead of the results it has seen
-constexpr uint32_t kGraphPlies = 2;     // graph mode: consecutive plies of a half per captured graph (even: see enqueue) ...
+constexpr uint32_t kGraphPliesMax = 16; // graph mode: consecutive plies of a half per captured graph (even: see enqueue) ...
 constexpr uint32_t kGraphsInFlight = 2; // ... and graph launches per half in flight (each with its own status slots)
-constexpr uint32_t kStatusSlots = kGraphPlies * kGraphsInFlight;  // (>= kPliesInFlight)
+constexpr uint32_t kStatusSlotsMax = kGraphPliesMax * kGraphsInFlight;
 constexpr int kRetryUngraphed = -1000;  // internal: the graph capture was refused before anything ran
 
 struct DeviceHalf {
@@ -824,7 +824,7 @@ struct DeviceHalf {
     uint64_t* dUpdPositions = nullptr;
     HalfStatus* hStatus = nullptr;   // page-locked and mapped into the device, [kStatusSlots] ...
     HalfStatus* dStatus = nullptr;   // ... and its device view
-    hipEvent_t done[kStatusSlots] = {};
+    hipEvent_t done[kStatusSlotsMax] = {};
     uint64_t enqueued = 0, acked = 0;  // plies enqueued / plies whose results the host has read
     hipGraphExec_t graph[kGraphsInFlight] = {};  // graph mode: kGraphPlies consecutive plies of this half each, captured once
     uint32_t index = 0;              // which lane of the context this half runs on
@@ -864,8 +864,22 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     std::memset(stats, 0, sizeof(*stats));
 
     const size_t perSeat = 96;  // children per seat and ply (mean ~35; a ply that needs more is reported as an error)
+    // Plies per captured graph. Between two graph launches on a stream this runtime leaves ~80-100 us (rocprofv3 kernel trace,
+    // profiles/r03_selfplay_lane_chain.txt: no gap between the kernels of a graph), 8-11 % of a lane's time at two plies per
+    // graph; more plies per graph halve that but idle longer at the end of a run and want a deeper opening pool. Measured
+    // (profiles/r03_ab_selfplay_plies_per_graph.txt; 2 / 4 / 8 / 16 plies): 4 096 seats x 65 536 games 2.42 / 2.46 / 2.46 / 2.41
+    // x 10^8, 1 024 x 8 192 1.45 / 1.49 / 1.46 / 1.43, but 4 096 x 8 192 1.85 / 1.81 / 1.71 / 1.53 and 16 384 x 65 536 2.58 /
+    // 2.56 / 2.44 / 2.25: four for runs of at least eight games per seat, else two. SPX_SELFPLAY_GRAPH_PLIES overrides (even, 2..16).
+    uint32_t kGraphPlies = p->target_games >= 8ull * G ? 4 : 2;
+    if (const char* env = std::getenv("SPX_SELFPLAY_GRAPH_PLIES")) {
+        const long v = std::atol(env);
+        if (v >= 2 && v <= long(kGraphPliesMax) && v % 2 == 0) kGraphPlies = uint32_t(v);
+    }
+    const uint32_t kStatusSlots = kGraphPlies * kGraphsInFlight;  // (>= kPliesInFlight)
     const uint32_t poolCap = (kStatusSlots + 3) * G + 32768;
-    const uint32_t ringWords = uint32_t(std::max<uint64_t>(1u << 20, uint64_t(G) * 2 * (maxPlies + 9)));
+    // (a seat writes 9 + plies words per finished game; with very short ply caps up to ~10 words per ply in flight)
+    const uint32_t ringWords = uint32_t(std::max<uint64_t>(
+        1u << 20, uint64_t(G) * std::max<uint64_t>(2 * (maxPlies + 9), 10 * (kStatusSlots + 2))));
     DeviceBuffers dev;
     PinnedBuffers pinned;
     auto* dPositions = dev.get<uint64_t>(size_t(G) * 4);
@@ -1202,7 +1216,10 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, enqueue + openings %.3f; %llu openings discarded by "
                      "the verification filter, %u published; %s\n", stats->seconds, gpuWait, enqueueSeconds,
                      static_cast<unsigned long long>(latest.discarded), published,
-                     useGraph ? "graph mode: two plies per launch, two launches ahead" : "direct launches");
+                     useGraph ? (kGraphPlies == 2 ? "graph mode: two plies per launch, two launches ahead"
+                                                  : kGraphPlies == 4 ? "graph mode: four plies per launch, two launches ahead"
+                                                                     : "graph mode: SPX_SELFPLAY_GRAPH_PLIES plies per launch, two launches ahead")
+                              : "direct launches");
     }
     return rc;
 }
