@@ -36,6 +36,7 @@ names = {
     "rocprofv3_summary_incremental.txt": "rocprofv3_summary_incremental.txt",
     "rocprofv3_kernel_stats_default_cmd.txt": "rocprofv3_kernel_stats_default_cmd.txt",
     "rocprofv3_incremental_kernel_stats.txt": "rocprofv3_incremental_kernel_stats.txt",
+    "rocprofv3_kernel_stats_headline_only.txt": "rocprofv3_kernel_stats_headline_only.txt",
     "reference_differential.json": "reference_differential.json", "reference_trace_differential.json": "reference_trace_differential.json",
     "pmc_selfplay_4096_seats.txt": "pmc_selfplay_4096_seats.txt",
     "gather_ceiling.json": "gather_ceiling.json", "gather_ceiling_wide_psq_rows.json": "gather_ceiling_wide_psq_rows.json",
