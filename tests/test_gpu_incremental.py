@@ -444,9 +444,30 @@ def test_selfplay_plays_the_same_games_for_the_same_seed(sp, net_blob, tmp_path)
     assert runs[0] == runs[1] and len(runs[0]) == 500
 
 
-@pytest.mark.parametrize("n_games,target", [(1, 3), (3, 7), (64, 64)])
+def test_selfplay_direct_launch_fallback(sp, net_blob, oracle, tmp_path, monkeypatch):
+    """SPX_SELFPLAY_NO_GRAPH=1 (what a HIP runtime that refuses the stream capture falls back to): the per-ply chain enqueued
+    launch by launch, lanes gated. Same rules, same verification; and the same SET of games as graph mode for the same seed."""
+    from _datagen_rules import parse_games, verify_selfplay_file
+
+    sets = {}
+    for mode in ("graph", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("SPX_SELFPLAY_NO_GRAPH", "1")
+        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192) as st:
+            path = str(tmp_path / f"{mode}.vf")
+            stats = st.selfplay(n_games=48, target_games=120, out_path=path, max_plies=90, dfrc=True, temperature_cp=20, seed=123)
+            assert stats["games"] == 120
+            blob = open(path, "rb").read()
+            oracle.use(net_blob("tame"), "tame")
+            assert verify_selfplay_file(sp, st, oracle, blob, max_plies=90, oracle_sample=512) == stats["positions"]
+            sets[mode] = sorted((h, m.tobytes(), s_.tobytes()) for h, m, s_, _ in parse_games(blob))
+    assert sets["graph"] == sets["direct"]
+
+
+@pytest.mark.parametrize("n_games,target", [(1, 3), (3, 7), (64, 64), (24, 300)])
 def test_selfplay_edge_sizes(sp, net_blob, oracle, tmp_path, n_games, target):
-    """One seat (a single half), an odd number of seats, and a target equal to the seats (no seat ever restarts)."""
+    """One seat (a single half), an odd number of seats, a target equal to the seats (no seat ever restarts), and a long run
+    (at least eight games per seat: the driver then captures four plies per graph instead of two)."""
     from _datagen_rules import verify_selfplay_file
 
     with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192) as st:
