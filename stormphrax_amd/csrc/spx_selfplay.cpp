@@ -1096,16 +1096,20 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         const uint32_t which = uint32_t(hf.enqueued / kGraphPlies) % kGraphsInFlight;  // graph mode: the graph / slot group due
         if (useGraph && !hf.graph[which]) {
             hipGraph_t captured = nullptr;
-            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            for (uint32_t k = 0; ok && k < kGraphPlies; ++k) ok = plyBody(hf, s, which * kGraphPlies + k) == SPX_OK;
-            const bool ended = hipStreamEndCapture(s, &captured) == hipSuccess && captured != nullptr;
+            const bool began = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            uint32_t bodies = 0;
+            bool ok = began;
+            for (; ok && bodies < kGraphPlies; ++bodies) ok = plyBody(hf, s, which * kGraphPlies + bodies) == SPX_OK;
+            const bool ended = !began || (hipStreamEndCapture(s, &captured) == hipSuccess && captured != nullptr);
             ok = ok && ended && hipGraphInstantiate(&hf.graph[which], captured, nullptr, nullptr, 0) == hipSuccess;
             if (captured) (void)hipGraphDestroy(captured);
             if (!ok) {  // this HIP runtime cannot capture the chain
                 (void)hipGetLastError();
                 hf.graph[which] = nullptr;
-                if (steps != 0) {
-                    setError("spx_selfplay_run: graph capture failed after the run had started");
+                // (a ply that failed HALFWAY through its launches has advanced the context's alternating refresh buffers by an
+                // odd count without running anything: not a state to go on from)
+                if (steps != 0 || (began && bodies != 0 && bodies != kGraphPlies)) {
+                    setError("spx_selfplay_run: graph capture failed after the run had started or in the middle of a ply");
                     return SPX_ERR_HIP;
                 }
                 useGraph = false;  // nothing has run yet: direct launches for the whole run
