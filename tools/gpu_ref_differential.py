@@ -55,6 +55,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=262144)
     ap.add_argument("--procs", type=int, default=16)
     ap.add_argument("--port-positions", type=int, default=65536, help="positions per wrapping preset against the C restatement")
+    ap.add_argument("--preset", default="tame",
+                    help="net preset: its compiled-reference probe oracle/_ref/sp_ref_probe_<preset> must be there (only the tame "
+                         "probe is kept in oracle/_ref by default - each embeds 89 MB of net; copy the others from "
+                         "oracle/_ref_build/ for a one-off run)")
+    ap.add_argument("--no-port", action="store_true", help="skip the C-restatement leg on the wrapping presets")
     ap.add_argument("--pack-positions", type=int, default=1000000,
                     help="leading positions whose 32-byte records are also compared with the reference's PackedBoard::pack")
     args = ap.parse_args()
@@ -63,10 +68,10 @@ def main():
 
     import stormphrax_amd as sp
 
-    probe = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame")
-    assert os.path.exists(probe), "oracle/_ref/sp_ref_probe_tame is missing (built in the authoring container: make -C oracle ref)"
-    report = {"reference": "compiled Stormphrax 8.0.2 (oracle/_ref/sp_ref_probe_tame), NnueState::evaluateOnce", "chunks": []}
-    net = sp.Network.synthetic("tame")
+    probe = os.path.join(ROOT, "oracle", "_ref", f"sp_ref_probe_{args.preset}")
+    assert os.path.exists(probe), f"{probe} is missing (built in the authoring container: make -C oracle ref)"
+    report = {"reference": f"compiled Stormphrax 8.0.2 (oracle/_ref/sp_ref_probe_{args.preset}), NnueState::evaluateOnce", "chunks": []}
+    net = sp.Network.synthetic(args.preset)
     mismatches, pack_mismatches, packed, done, t0 = 0, 0, 0, 0, time.time()
     distinct_scores = set()
     with sp.NnueState(net, max_batch=args.chunk) as st:
@@ -114,7 +119,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conftest  # the nets with mixed / near-compact piece-square rows are built by the test fixtures
 
-    for preset in ("wild", "extreme", "mixed", "near"):
+    for preset in (() if args.no_port else ("wild", "extreme", "mixed", "near")):
         blob = (conftest._mixed_rows_net(sp) if preset == "mixed" else conftest._near_rows_net(sp) if preset == "near"
                 else sp.synthetic_net_bytes(preset))
         assert oracle.spxo_init(blob.ctypes.data, blob.size) == 0
