@@ -27,13 +27,14 @@ def main():
     ap.add_argument("--evals", type=int, default=16384)
     ap.add_argument("--depth", type=int, default=14)
     ap.add_argument("--procs", type=int, default=16)
+    ap.add_argument("--preset", default="tame", help="net preset; needs oracle/_ref/sp_ref_probe_<preset> (see gpu_ref_differential.py)")
     args = ap.parse_args()
 
     import stormphrax_amd as sp
     from stormphrax_amd import trace as tr
 
-    probe = os.path.join(ROOT, "oracle", "_ref", "sp_ref_probe_tame")
-    assert os.path.exists(probe), "oracle/_ref/sp_ref_probe_tame is missing (built in the authoring container: make -C oracle ref)"
+    probe = os.path.join(ROOT, "oracle", "_ref", f"sp_ref_probe_{args.preset}")
+    assert os.path.exists(probe), f"{probe} is missing (built in the authoring container: make -C oracle ref)"
     roots = sp.random_positions(args.roots, seed=777, min_ply=0, max_ply=140, dfrc_every=3)
     fens = [sp.position_to_fen(p) for p in roots]
     t0 = time.time()
@@ -53,8 +54,8 @@ def main():
         p.wait()
     recorded_s = time.time() - t0
 
-    net = sp.Network.synthetic("tame")
-    report = {"reference": "compiled Stormphrax 8.0.2 (oracle/_ref/sp_ref_probe_tame): NnueState::reset/push/pop/evaluate on random DFS walks",
+    net = sp.Network.synthetic(args.preset)
+    report = {"reference": f"compiled Stormphrax 8.0.2 (oracle/_ref/sp_ref_probe_{args.preset}): NnueState::reset/push/pop/evaluate on random DFS walks",
               "roots": args.roots, "depth": args.depth, "traces": []}
     total_evals = total_updates = mismatches = once_mismatches = 0
     gpu_ms = 0.0
