@@ -409,7 +409,8 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * evaluated WITHOUT being stored (eval-only children), one step kernel per ply doing search, bookkeeping, repetition keys,
  * game records and the seating of new games from a device-side opening pool, one materialising update for the moves
  * played; the two halves of the seats run on the context's two lanes, each half's per-ply launch chain captured once as a
- * hipGraph (two plies per graph launch; environment SPX_SELFPLAY_NO_GRAPH=1 = direct launches), and the host reads ~100
+ * hipGraph (two plies per graph launch, four on runs of >= 8 games per seat; environment SPX_SELFPLAY_NO_GRAPH=1 = direct
+ * launches, SPX_SELFPLAY_GRAPH_PLIES = plies per graph), and the host reads ~100
  * bytes of counters plus the finished games per ply. SPX_SELFPLAY_HOST_MOVEGEN selects the host chess core for moves, openings and bookkeeping (the
  * same rules; the validation path). Needs a context whose max_batch holds a ply's children of half the seats (48 * n_games
  * is always enough); reserves 2 * n_games + 1 arena slots (129 * n_games with host move generation).
