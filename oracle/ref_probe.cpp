@@ -33,6 +33,8 @@
 //                                 <score> | <filtered> | <pack hex of the position before>", then "V <hex of the stream
 //                                 writeAllWithOutcome wrote>" (marlinformat.h:32-84, viriformat.cpp:28-63); then "F <kept> <hex>" =
 //                                 datagen::Marlinformat's file bytes and "T <lines joined by ;>" = datagen::Fen's, same game
+//   drawn <seed> <plies> <undo permille> <fen> -> "S <fen>", then per move "X <uci> | <Position::isDrawn(0, keyHistory) of the
+//                                 new position, as datagen.cpp:258-265 asks it> | <fen after>" (position.cpp:603-667)
 //   wdl <score> <fen>          -> "W <classicalMaterial> <wdl::normalizeScore(score, material)>" (wdl.cpp:28-79) at
 //                                 datagen's evalSharpness of 100 (datagen.cpp:353)
 #include <atomic>
@@ -378,6 +380,62 @@ int main() {
                 if (ch == '\n') ch = ';';
             }
             std::printf("T %s\n", text.c_str());
+        } else if (cmd == "drawn") {
+            // `drawn <seed> <plies> <undo permille> <fen>`: a game whose movers like to take their last move back (repetitions)
+            // and to capture (bare material); after every move what datagen asks (datagen.cpp:258-265): the key of the
+            // position moved from is pushed, the move made, then Position::isDrawn(0, keyHistory) of the new position
+            // (position.cpp:603-667: 50-move rule unless checkmate, threefold repetition, insufficient material). The game goes
+            // on after a "drawn" answer - the point is the flags, not the game.
+            u64 seed;
+            u32 plies, undo;
+            in >> seed >> plies >> undo;
+            std::string fen;
+            std::getline(in, fen);
+            const auto start = Position::fromFen(fen);
+            if (!start) {
+                std::printf("ERR bad fen\nOK\n");
+                std::fflush(stdout);
+                continue;
+            }
+            SplitMix64 rng{seed};
+            auto pos = *start;
+            std::vector<u64> keyHistory;
+            std::array<Move, 2> last{kNullMove, kNullMove};  // by colour of the mover
+            std::printf("S %s\n", pos.toFen().c_str());
+            for (u32 ply = 0; ply < plies; ++ply) {
+                const auto moves = legalMoves(pos);
+                if (moves.empty()) {
+                    break;
+                }
+                const auto us = pos.stm().idx();
+                Move move = kNullMove;
+                if (last[us] != kNullMove && rng.below(1000) < undo) {
+                    for (const auto mv : moves) {
+                        if (mv.type() == MoveType::kStandard && mv.fromSq() == last[us].toSq() && mv.toSq() == last[us].fromSq()) {
+                            move = mv;
+                        }
+                    }
+                }
+                if (move == kNullMove && rng.below(10) < 3) {
+                    std::vector<Move> captures;
+                    for (const auto mv : moves) {
+                        if (pos.isNoisy(mv)) {
+                            captures.push_back(mv);
+                        }
+                    }
+                    if (!captures.empty()) {
+                        move = captures[rng.below(static_cast<u32>(captures.size()))];
+                    }
+                }
+                if (move == kNullMove) {
+                    move = moves[rng.below(static_cast<u32>(moves.size()))];
+                }
+                last[us] = move;
+                keyHistory.push_back(pos.key());
+                pos = pos.applyMove(move);
+                const bool drawn = pos.isDrawn(0, keyHistory);
+                std::printf("X %s | %d | %s\n", fmt::format("{}", move).c_str(), drawn ? 1 : 0, pos.toFen().c_str());
+            }
         } else if (cmd == "playout") {
             u64 seed;
             u32 count, minPly, maxPly, dfrc;

@@ -190,7 +190,66 @@ def add_preset_column(preset):
     print(f"evals.jsonl: column '{preset}' written for {len(recs)} positions")
 
 
+def make_drawn():
+    """Position::isDrawn as datagen asks it (datagen.cpp:258-265, position.cpp:603-667), answered by the compiled reference
+    move by move on games built to hit it: movers that take their moves back (threefold repetition inside and across the
+    halfmove window), bare-material endings (KK, KNK, KBK, KBKB with like and unlike bishops, and near misses: KNNK, KBNK,
+    KBBK, a pawn left), and halfmove clocks that reach 100 - with and without check, and with checkmate on the 100th
+    half-move (not a draw). One line per game: start FEN | final FEN | uci:flag ..."""
+    probe = Probe(PROBES["tame"])
+    games = []
+
+    def play(seed, plies, undo, fen):
+        out = probe.cmd(f"drawn {seed} {plies} {undo} {fen}")
+        assert out[0].startswith("S "), out[:2]
+        moves = []
+        for ln in out[1:]:
+            uci, flag, after = ln[2:].split(" | ")
+            moves.append((uci, int(flag), after))
+        return out[0][2:], moves
+
+    dfrc = [ln.split(" | ")[0][2:] for ln in open(os.path.join(HERE, "viri_games.txt")) if ln.startswith("M ") and " 0 1 | " in ln]
+    starts = [STARTPOS] + dfrc[:7]
+    for k, fen in enumerate(starts * 3):
+        games.append(play(100 + k, 120, (800, 900, 960)[k % 3], fen))
+    sparse = [
+        "8/8/4k3/8/8/3K4/8/8 w - - 0 1", "8/8/4k3/8/8/3KN3/8/8 w - - 0 1", "8/8/4k3/8/8/3KB3/8/8 b - - 0 1",
+        "8/5b2/4k3/8/8/3KB3/8/8 w - - 0 1", "8/4b3/4k3/8/8/3KB3/8/8 w - - 0 1", "8/8/4k3/8/8/3KNN2/8/8 w - - 0 1",
+        "8/8/4k3/8/8/3KBN2/8/8 b - - 0 1", "8/8/4k3/8/8/3KBB2/8/8 w - - 0 1", "8/8/4k3/4p3/8/3KB3/8/8 w - - 0 1",
+        "8/5n2/4k3/8/8/3KB3/8/8 w - - 0 1", "8/8/4k3/8/8/3K4/4R3/8 b - - 0 1", "8/5n2/4k3/8/8/3KN3/8/8 w - - 0 1",
+        "8/5p2/4k3/8/8/3KN3/4P3/8 w - - 0 1", "3b4/5b2/4k3/8/8/3KB3/8/8 w - - 0 1",
+    ]
+    for k, fen in enumerate(sparse * 2):
+        games.append(play(300 + k, 40, (0, 300)[k % 2], fen))
+    clocks = ["7k/8/5K2/8/8/8/8/Q7 w - - 97 80", "6k1/8/6K1/8/8/8/8/R7 w - - 99 80", "6k1/8/6K1/8/8/8/8/R7 w - - 98 80",
+              "r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 96 70", "8/8/4k3/8/8/3KB3/4P3/8 w - - 95 60"]
+    mates = others = 0
+    for seed in range(500, 900):
+        fen = clocks[seed % len(clocks)]
+        start, moves = play(seed, 12, 0, fen)
+        # the interesting games: the clock passes 100; keep every game where the reference said "not drawn" at >= 100
+        # (checkmate on the spot) and a bounded number of the others
+        late = [(u, f, a) for u, f, a in moves if int(a.split()[4]) >= 100]
+        if any(f == 0 for _, f, _ in late):
+            mates += 1
+            games.append((start, moves))
+        elif late and others < 12:
+            others += 1
+            games.append((start, moves))
+    assert mates >= 3, mates
+    with open(os.path.join(HERE, "drawn_games.txt"), "w") as f:
+        f.write("# oracle/ref_probe.cpp `drawn <seed> <plies> <undo permille> <fen>`: <start fen> | <final fen> | <uci>:<Position::isDrawn(0, keyHistory) after the move> ...\n")
+        for start, moves in games:
+            if moves:
+                f.write(f"{start} | {moves[-1][2]} | " + " ".join(f"{u}:{fl}" for u, fl, _ in moves) + "\n")
+    flags = [fl for _, ms in games for _, fl, _ in ms]
+    probe.close()
+    print("drawn goldens written:", len(games), "games,", len(flags), "moves,", sum(flags), "drawn flags,", mates, "games with checkmate at the 100th half-move")
+
+
 def main():
+    if sys.argv[1:] == ["drawn"]:
+        return make_drawn()
     if len(sys.argv) == 3 and sys.argv[1] == "column":
         return add_preset_column(sys.argv[2])
     if sys.argv[1:] == ["wire"]:

@@ -411,6 +411,51 @@ def test_datagen_rules_shared_by_host_and_device_match_the_python_restatement(sp
                                                               False, False, False]
 
 
+def test_position_is_drawn_equals_the_compiled_reference(sp):
+    """Position::isDrawn as datagen asks it (datagen.cpp:258-265, position.cpp:603-667), answered move by move by the COMPILED
+    reference on 76 games built to hit it (tests/golden/drawn_games.txt: take-back games for threefold repetition, bare-material
+    endings and their near misses, halfmove clocks passing 100 incl. checkmate on the 100th half-move). The plain-Python
+    restatement the self-play files are judged by (tests/_datagen_rules.py) and the C++ helper the device step kernel and the
+    host path share (spx_device_math.h:insufficientMaterial through spx_debug_datagen_rules) must give the reference's flag
+    after every move."""
+    import ctypes
+    import os
+
+    import _datagen_rules as rules
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    path = os.path.join(os.path.dirname(__file__), "golden", "drawn_games.txt")
+    games = [ln.rstrip("\n").split(" | ") for ln in open(path) if not ln.startswith("#")]
+    assert len(games) >= 70
+    seen = {"repetition": 0, "material": 0, "fifty": 0, "mate_at_100": 0, "not_drawn": 0}
+    flag = ctypes.c_int(-1)
+    for start, final, line in games:
+        rec = sp.positions_from_fens([start])[0]
+        history = []
+        for item in line.split():
+            uci, want = item.rsplit(":", 1)
+            history.append(rules.identity(rec))
+            rec = sp.apply_uci(rec, uci)
+            halfmove = int(rec["halfmove"])
+            lib.spx_debug_datagen_rules(None, 0, 0, None, np.ascontiguousarray(rec).reshape(1).ctypes.data, ctypes.byref(flag))
+            material = rules.insufficient_material(rec)
+            assert bool(flag.value) == material, (start, uci)
+            if halfmove >= 100:   # a draw unless checkmate; nothing else is looked at
+                moves, _, in_check = sp.legal_moves(rec)
+                got = not (in_check and len(moves) == 0)
+                seen["fifty" if got else "mate_at_100"] += 1
+            else:
+                rep = rules.is_drawn_by_repetition(rules.identity(rec), history, halfmove)
+                got = rep or material
+                seen["repetition"] += int(rep)
+                seen["material"] += int(material)
+            seen["not_drawn"] += int(not got)
+            assert got == bool(int(want)), (start, uci, halfmove)
+        assert sp.position_to_fen(rec) == final, start
+    assert seen["repetition"] > 300 and seen["material"] > 200 and seen["fifty"] > 50 and seen["mate_at_100"] >= 3 and seen["not_drawn"] > 1000, seen
+
+
 def test_wdl_normalisation_does_not_depend_on_fp_contraction(sp, oracle):
     """wdl::normalizeScore (wdl.cpp:28-79) is an f64 cubic; the device / host source evaluates it with fused multiply-adds
     (what the reference's x86-64 clang builds contract to), the oracle's plain-C restatement is built with -ffp-contract=off
