@@ -93,12 +93,18 @@ def is_drawn_by_repetition(key, history, halfmove):
     return False
 
 
-def replay_game(before, after_last, mover_scores, normalize, max_plies, final_is_mate, final_has_moves):
+def replay_game(before, after_last, mover_scores, normalize, max_plies, final_is_mate, final_has_moves, tally=None):
     """before[k]: record before move k (k < n); after_last: record after the last move; mover_scores[k]: the search score of
     move k from the mover's point of view (already clamped like a static eval); normalize(white_score, material) =
     wdl::normalizeScore. final_is_mate / final_has_moves describe after_last (checkmate? any legal move?).
-    -> (outcome, plies played when the loop stopped, recorded scores the reference would have written)."""
+    -> (outcome, plies played when the loop stopped, recorded scores the reference would have written).
+    `tally` (optional dict) counts how games end: which branch of the rules stopped the loop."""
     n = len(before)
+
+    def count(what):
+        if tally is not None:
+            tally[what] = tally.get(what, 0) + 1
+
     material = classical_material(before)
     win = loss = draw = 0
     history, recorded = [], []
@@ -128,23 +134,33 @@ def replay_game(before, after_last, mover_scores, normalize, max_plies, final_is
         nxt = before[k + 1] if k + 1 < n else after_last
         # Position::isDrawn(0, keyHistory) of the new position (datagen.cpp:264-268): overrides, score 0
         halfmove = int(nxt["halfmove"])
+        why = None
         if halfmove >= 100:   # the 50-move branch returns before anything else is looked at: a draw unless checkmate
             assert k + 1 == n, "a game went on after its halfmove clock reached 100"
-            drawn = not final_is_mate
-        else:
-            drawn = is_drawn_by_repetition(identity(nxt), history, halfmove) or insufficient_material(nxt)
-        drawn = drawn or k + 1 >= max_plies   # the driver's own ply cap
-        if drawn:
+            why = None if final_is_mate else "fifty-move rule"
+            if final_is_mate:
+                count("checkmate on the 100th half-move (not a draw)")
+        elif is_drawn_by_repetition(identity(nxt), history, halfmove):
+            why = "threefold repetition"
+        elif insufficient_material(nxt):
+            why = "insufficient material"
+        if why is None and k + 1 >= max_plies:   # the driver's own ply cap
+            why = "ply cap"
+        if why is not None:
+            count("draw: " + why + (" (overriding an adjudication)" if outcome is not None else ""))
             recorded.append(0)
             return DRAW, k + 1, recorded
         recorded.append(0 if abs(white_score) <= 2 else white_score)
         if outcome is not None:
+            count("adjudicated " + ("white loss", "draw", "white win")[outcome])
             return outcome, k + 1, recorded
     # the loop went on: the position after the last recorded move must be terminal (datagen.cpp:213-221)
     assert not final_has_moves, "the recorded game stops although the reference's loop would have played on"
     last_white_to_move = not (int(after_last["stm_ep"]) & 0x80)
     if final_is_mate:
+        count("checkmate")
         return (LOSS if last_white_to_move else WIN), n, recorded
+    count("stalemate")
     return DRAW, n, recorded
 
 
@@ -164,7 +180,7 @@ def parse_games(blob):
     return games
 
 
-def verify_selfplay_file(sp, st, oracle, blob, max_plies, oracle_sample=4096, seed=0):
+def verify_selfplay_file(sp, st, oracle, blob, max_plies, oracle_sample=4096, seed=0, tally=None):
     """Everything a recorded self-play file must satisfy:
     * every move legal (host expander) and the device expander identical to it;
     * the GPU's from-scratch evals of a sample of >= `oracle_sample` recorded positions equal the CPU oracle's;
@@ -228,7 +244,7 @@ def verify_selfplay_file(sp, st, oracle, blob, max_plies, oracle_sample=4096, se
         norm_best = normalize(best if white else -best, int(classical_material(before[:1])[0]))
         assert abs(norm_best) <= VERIFICATION_SCORE_LIMIT, (gi, norm_best)
         want_outcome, stop, recorded = replay_game(before, finals[gi], mover, normalize, max_plies,
-                                                   final_is_mate[gi], final_has_moves[gi])
+                                                   final_is_mate[gi], final_has_moves[gi], tally)
         assert (want_outcome, stop) == (outcome, n), (gi, want_outcome, outcome, stop, n)
         assert recorded == [int(s) for s in scores], gi
         checked += n

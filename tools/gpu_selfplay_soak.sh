@@ -16,8 +16,10 @@ net = sp.synthetic_net_bytes(preset)
 oracle = Oracle(); oracle.use(net, preset)
 st = sp.NnueState(sp.Network(net), device=0, max_batch=1 << 20)
 t0 = time.time()
-checked = verify_selfplay_file(sp, st, oracle, blob, max_plies=300, oracle_sample=65536)
+tally = {}
+checked = verify_selfplay_file(sp, st, oracle, blob, max_plies=300, oracle_sample=65536, tally=tally)
 print("soak (net preset %s): %d plies of %d bytes verified in %.0f s: legal moves, device replay identical, 65 536 positions vs the oracle, "
       "verification filter, end ply / outcome byte / scores of every game per the restated datagen rules" % (preset, checked, len(blob), time.time() - t0))
+print("how the games ended: " + "; ".join("%s %d" % kv for kv in sorted(tally.items(), key=lambda kv: -kv[1])))
 PY
 rm -f gpurun_out/soak.0.vf
