@@ -1132,11 +1132,71 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     const size_t nUpdates = n_nodes - 1;
     std::vector<uint32_t> hParents(nUpdates), hChildren(nUpdates), cursor(levelStart.begin(), levelStart.end() - 1);
     std::vector<spx_packed_pos> hRecords(nUpdates);
-    for (size_t k = 1; k < n_nodes; ++k) {
-        const uint32_t at = cursor[depth[k]]++;  // levelStart[1] == 0: depth-1 nodes come first
-        hParents[at] = parents[k];
-        hChildren[at] = uint32_t(k);
-        hRecords[at] = positions[k];
+    // DEEP, NARROW trees (the reference's own alpha-beta search on a noisy net dives 249 plies with a few hundred nodes per
+    // level) are bound by one dependent launch per level (~15 us each). They are walked by PATHS instead: the tree is cut into
+    // heavy paths (every node continues into its largest subtree; the other children start paths of their own), a path is one
+    // wavefront pair of spx_update_chain_kernel - the accumulator stays in registers from ply to ply, ~5.5 us per ply - and all
+    // paths whose head's parent exists form one launch: 8 launches instead of 249 for that trace. Shallow wide trees (a
+    // depth-first walk to depth 12) keep the level batches, whose big launches run at the update kernel's full rate.
+    // SPX_REPLAY_PATHS=0 / 1 forces the choice.
+    bool byPaths = maxDepth >= 32 && nUpdates / std::max<uint32_t>(1, maxDepth) <= 4096;
+    if (const char* env = std::getenv("SPX_REPLAY_PATHS")) byPaths = env[0] == '1';
+    std::vector<uint32_t> hChainFirst, hChainCount, roundStart;  // paths mode: chains grouped by round; hParents = per chain
+    if (!byPaths) {
+        for (size_t k = 1; k < n_nodes; ++k) {
+            const uint32_t at = cursor[depth[k]]++;  // levelStart[1] == 0: depth-1 nodes come first
+            hParents[at] = parents[k];
+            hChildren[at] = uint32_t(k);
+            hRecords[at] = positions[k];
+        }
+    } else {
+        std::vector<uint32_t> size(n_nodes, 1), heavy(n_nodes, 0), chainOf(n_nodes, 0), roundOf(n_nodes, 0);
+        for (size_t k = n_nodes - 1; k >= 1; --k) size[parents[k]] += size[k];
+        for (size_t k = 1; k < n_nodes; ++k) {  // heavy[p] = the first child with the largest subtree
+            const uint32_t p = parents[k];
+            if (heavy[p] == 0 || size[k] > size[heavy[p]]) heavy[p] = uint32_t(k);
+        }
+        std::vector<uint32_t> chainHead, chainLen, chainRound;
+        uint32_t maxRound = 0;
+        for (size_t k = 1; k < n_nodes; ++k) {
+            const uint32_t p = parents[k];
+            if (p != 0 && heavy[p] == k) {  // continues its parent's path
+                chainOf[k] = chainOf[p];
+                roundOf[k] = roundOf[p];
+                ++chainLen[chainOf[k]];
+            } else {                        // heads a path of its own, one round after the path its parent is on
+                chainOf[k] = uint32_t(chainHead.size());
+                roundOf[k] = roundOf[p] + 1;
+                chainHead.push_back(uint32_t(k));
+                chainLen.push_back(1);
+                chainRound.push_back(roundOf[k]);
+                maxRound = std::max(maxRound, roundOf[k]);
+            }
+        }
+        const size_t nChains = chainHead.size();
+        roundStart.assign(maxRound + 2, 0);  // rounds are 1-based: roundStart[r] = first chain of round r
+        for (size_t c = 0; c < nChains; ++c) ++roundStart[chainRound[c] + 1];
+        for (uint32_t r = 1; r <= maxRound + 1; ++r) roundStart[r] += roundStart[r - 1];
+        std::vector<uint32_t> place(nChains), next(roundStart.begin(), roundStart.end() - 1);
+        for (size_t c = 0; c < nChains; ++c) place[c] = next[chainRound[c]]++;
+        hChainFirst.assign(nChains, 0);
+        hChainCount.assign(nChains, 0);
+        hParents.assign(nChains, 0);  // (per chain here: the slot the path starts from)
+        {
+            std::vector<uint32_t> lenAt(nChains);
+            for (size_t c = 0; c < nChains; ++c) lenAt[place[c]] = chainLen[c];
+            uint32_t at = 0;
+            for (size_t j = 0; j < nChains; ++j) {
+                hChainFirst[j] = at;
+                at += lenAt[j];
+            }
+        }
+        for (size_t c = 0; c < nChains; ++c) hParents[place[c]] = parents[chainHead[c]];
+        for (size_t k = 1; k < n_nodes; ++k) {  // visiting order = increasing depth along every path
+            const uint32_t j = place[chainOf[k]], at = hChainFirst[j] + hChainCount[j]++;
+            hChildren[at] = uint32_t(k);
+            hRecords[at] = positions[k];
+        }
     }
     int rc = spx_acc_reserve(ctx, n_nodes);
     if (rc != SPX_OK) return rc;
@@ -1159,6 +1219,9 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     SPX_HIP(alloc(nUpdates * sizeof(spx_packed_pos), &dRecords));
     SPX_HIP(alloc(nUpdates * 4, &dParents));
     SPX_HIP(alloc(nUpdates * 4, &dChildren));
+    void *dChainFirst = nullptr, *dChainCount = nullptr;
+    SPX_HIP(alloc(hChainFirst.size() * 4, &dChainFirst));
+    SPX_HIP(alloc(hChainCount.size() * 4, &dChainCount));
     SPX_HIP(alloc(n_evals * 4, &dEvalNodes));
     SPX_HIP(alloc(n_evals * 4, &dOut));
     SPX_HIP(alloc(sizeof(spx_packed_pos) + 4, &dRoot));
@@ -1168,8 +1231,12 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     SPX_HIP(hipMemcpyAsync(static_cast<char*>(dRoot) + sizeof(spx_packed_pos), &rootSlot, 4, hipMemcpyHostToDevice, s));
     if (nUpdates) {
         SPX_HIP(hipMemcpyAsync(dRecords, hRecords.data(), nUpdates * sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
-        SPX_HIP(hipMemcpyAsync(dParents, hParents.data(), nUpdates * 4, hipMemcpyHostToDevice, s));
+        SPX_HIP(hipMemcpyAsync(dParents, hParents.data(), hParents.size() * 4, hipMemcpyHostToDevice, s));
         SPX_HIP(hipMemcpyAsync(dChildren, hChildren.data(), nUpdates * 4, hipMemcpyHostToDevice, s));
+        if (byPaths) {
+            SPX_HIP(hipMemcpyAsync(dChainFirst, hChainFirst.data(), hChainFirst.size() * 4, hipMemcpyHostToDevice, s));
+            SPX_HIP(hipMemcpyAsync(dChainCount, hChainCount.data(), hChainCount.size() * 4, hipMemcpyHostToDevice, s));
+        }
     }
     if (n_evals) SPX_HIP(hipMemcpyAsync(dEvalNodes, eval_nodes, n_evals * 4, hipMemcpyHostToDevice, s));
     SPX_HIP(hipEventCreate(&temp.e0));
@@ -1177,7 +1244,24 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     SPX_HIP(hipEventRecord(temp.e0, s));
     rc = spx_acc_refresh_device(ctx, dRoot, static_cast<char*>(dRoot) + sizeof(spx_packed_pos), 1, s);
     if (rc != SPX_OK) return rc;
-    for (uint32_t d = 1; d <= maxDepth; ++d) {  // one update batch per level (chunked by the context's capacity); no host sync
+    if (byPaths) {  // one chain launch per round: every path whose head's parent has been materialised
+        for (size_t r = 1; r + 1 < roundStart.size(); ++r) {
+            const uint32_t lo = roundStart[r], hi = roundStart[r + 1];
+            if (hi == lo) continue;
+            ChainParams cp{};
+            cp.nChains = hi - lo;
+            cp.parentSlots = static_cast<const uint32_t*>(dParents) + lo;
+            cp.first = static_cast<const uint32_t*>(dChainFirst) + lo;
+            cp.count = static_cast<const uint32_t*>(dChainCount) + lo;
+            cp.childSlots = static_cast<const uint32_t*>(dChildren);
+            cp.childPositions = dRecords;
+            cp.t = tablesOf(ctx);
+            cp.arena = ctx->dArena;
+            cp.slotRecords = ctx->dSlotRecords;
+            SPX_HIP(launchUpdateChain(cp, s));
+        }
+    }
+    for (uint32_t d = 1; d <= maxDepth && !byPaths; ++d) {  // one update batch per level (chunked by the context's capacity); no host sync
         for (size_t lo = levelStart[d]; lo < levelStart[d + 1]; lo += ctx->maxBatch) {
             const size_t m = std::min<size_t>(ctx->maxBatch, levelStart[d + 1] - lo);
             rc = spx_acc_update_device(ctx, static_cast<char*>(dParents) + lo * 4, static_cast<char*>(dChildren) + lo * 4,

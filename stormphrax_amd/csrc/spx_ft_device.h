@@ -101,12 +101,17 @@ struct LaneBoard {
     int stm;                                  // side to move, 1 = white
 };
 
-__device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
+// the record as decodeBoard wants it: lane l holds dword l & 7 (one coalesced load; a caller that walks a chain of records
+// asks for the next one a ply ahead)
+__device__ __forceinline__ uint32_t loadRecordWord(const uint8_t* rec, uint32_t lane) {
+    return reinterpret_cast<const uint32_t*>(rec)[lane & 7];
+}
+
+__device__ __forceinline__ LaneBoard decodeBoardWord(uint32_t w, uint32_t lane) {
     LaneBoard b;
     // ONE coalesced load for the whole 32-byte record (lane l fetches dword l & 7); the wave-uniform fields come out of
     // v_readlane into SGPRs - so every mask derived from the occupancy is scalar arithmetic - and a lane's nibble comes
     // from the lane that holds its dword (ds_bpermute) instead of a second, dependent global load
-    const uint32_t w = reinterpret_cast<const uint32_t*>(rec)[lane & 7];
     b.occ = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(w), 1))) << 32) | uint32_t(__builtin_amdgcn_readlane(int(w), 0));
     b.stm = (uint32_t(__builtin_amdgcn_readlane(int(w), 6)) & 0x80u) ? 0 : 1;
     const bool occupied = (b.occ >> lane) & 1;
@@ -121,6 +126,10 @@ __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t la
     // pawn-pair features (kPpMasks is empty for those squares anyway, threats.h:109)
     b.pawnsBb = __ballot(type == 0) & 0x00FFFFFFFFFFFF00ull;
     return b;
+}
+
+__device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
+    return decodeBoardWord(loadRecordWord(rec, lane), lane);
 }
 
 // Appends one threat row per set bit of this lane's `targets` (victims popped one per wave iteration):

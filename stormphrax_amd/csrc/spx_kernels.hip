@@ -347,104 +347,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVE
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// A whole pending PATH per wavefront pair: NnueState::ensureUpToDate (nnue_state.cpp:636-697) walks forward from the last
-// clean ancestor and applies one ply after the other; here one wavefront per (path, perspective) does the same inside ONE
-// launch, the accumulator staying in registers from ply to ply (updatePsq :34-87, applyThreatUpdates :356-394, rebuilds
-// :458-536 inline) and every ply's accumulator written to its slot on the way, as the reference leaves every stack entry on
-// the path clean. The drop-in stack (include/spx_nnue.hpp) used to pay one ~29 us synchronous call per pending ply.
-// Delta derivation as in spx_update_kernel_v1 (two attack generations per ply: this path is latency-, not
-// throughput-bound).
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_chain_kernel(ChainParams p) {
-    __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
-    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
-    __shared__ uint32_t sSub[kWavesPerBlock][kU8Cap];
-    __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
-    __syncthreads();
-    const uint32_t lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
-    if (item >= 2 * p.nChains) return;
-    const uint32_t chain = item >> 1;
-    const int c = int(item & 1);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(p.first[chain]);
-    const uint32_t n = __builtin_amdgcn_readfirstlane(p.count[chain]);
-    const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[chain]);
-    uint32_t acc[8];
-    loadAcc(p.arena, parentSlot, c, lane, acc);
-    LaneBoard pb = decodeBoard(p.slotRecords + size_t(parentSlot) * 32, lane);
-    int childStm = pb.stm;
-#pragma unroll 1
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(first + k) * 32;
-        const LaneBoard cb = decodeBoard(childRec, lane);
-        childStm = cb.stm;
-        const bool changedSq = pb.piece != cb.piece;
-        const uint64_t changed = __ballot(changedSq);
-        const uint64_t kingMaskP = __ballot(pb.piece == (10 | c)), kingMaskC = __ballot(cb.piece == (10 | c));
-        const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
-        const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
-        const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) ||
-                             popc64(changed) > 4;
-        if (refresh) {
-            uint32_t nPsq, nThr;
-            buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
-            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
-        } else {
-            uint64_t tP = 0, tC = 0;
-            if (pb.piece != kNoPiece && (pb.piece >> 1) != 5) tP = pieceAttacks(pb.piece, int(lane), pb.occ) & pb.occ & ~pb.kingsBb;
-            if (cb.piece != kNoPiece && (cb.piece >> 1) != 5) tC = pieceAttacks(cb.piece, int(lane), cb.occ) & cb.occ & ~cb.kingsBb;
-            const uint64_t keep = changedSq ? 0 : (tP & tC & ~changed);
-            const int x = perspXor(c, kingC);
-            const int flipColour = (c == 0) ? 1 : 0;
-            uint32_t nPsqSub, nPsqAdd;
-            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
-            uint32_t* subList = sSub[wave];
-            uint32_t* addList = sThr[wave];
-            const uint32_t nSubCompact = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC) : 0u, sLut,
-                                                          sPsqDelta[wave][0], subList, nPsqSub);
-            const uint32_t nAddCompact = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC) : 0u, sLut,
-                                                          sPsqDelta[wave][1], addList, nPsqAdd);
-            subList += nSubCompact;
-            addList += nAddCompact;
-            uint32_t nSub = emitThreatRows(subList, 0, tP & ~keep, pb.piece, lane, x, flipColour, sLut);
-            uint32_t nAdd = emitThreatRows(addList, 0, tC & ~keep, cb.piece, lane, x, flipColour, sLut);
-            {
-                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
-                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
-                const bool pawnP = (pb.piece >> 1) == 0, pawnC = (cb.piece >> 1) == 0;
-                const bool ownSideP = pawnP && (pb.piece & 1) == c, ownSideC = pawnC && (cb.piece & 1) == c;
-                const uint64_t partP = pawnPartners(pawnP, ownSideP, lane, ownP, theirP);
-                const uint64_t partC = pawnPartners(pawnC, ownSideC, lane, ownC, theirC);
-                const uint64_t unchangedPawns = pb.pawnsBb & cb.pawnsBb & ~changed;
-                const uint64_t kept = (pawnP && pawnC && !changedSq) ? (partP & partC & unchangedPawns) : 0;
-                nSub = emitPawnPairRows(subList, nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
-                nAdd = emitPawnPairRows(addList, nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
-            }
-            __builtin_amdgcn_wave_barrier();
-            applyDeltaRows(p.t, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1], nPsqAdd, sThr[wave], nAdd + nAddCompact,
-                           sSub[wave], nSub + nSubCompact, acc);
-        }
-        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[first + k]);
-        storeAcc(p.arena, childSlot, c, lane, acc);
-        if (lane < 8 && c == 0) {
-            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = reinterpret_cast<const uint32_t*>(childRec)[lane];
-        }
-        __builtin_amdgcn_wave_barrier();  // this ply's lists are dead before the next ply's are written
-        pb = cb;
-    }
-    if (p.ftOut && n) {
-        const uint32_t half = (c == childStm) ? 0u : 1u;
-        *reinterpret_cast<u32x2*>(p.ftOut + size_t(chain) * kL1 + half * kPairs + 8 * lane) = activate(acc);
-        if (lane < 8 && c == 0) {
-            const uint8_t* last = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(first + n - 1) * 32;
-            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(chain) * 32)[lane] = reinterpret_cast<const uint32_t*>(last)[lane];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Incremental update kernel, second generation (round 2): same contract as spx_update_kernel_v1 above - child
@@ -735,6 +637,136 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_upd
             const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
             if (p.childSlots) reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
             if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A whole pending PATH per wavefront pair: NnueState::ensureUpToDate (nnue_state.cpp:636-697) walks forward from the last
+// clean ancestor and applies one ply after the other; here one wavefront per (path, perspective) does the same inside ONE
+// launch, the accumulator staying in registers from ply to ply (updatePsq :34-87, applyThreatUpdates :356-394, rebuilds
+// :458-536 inline) and every ply's accumulator written to its slot on the way, as the reference leaves every stack entry on
+// the path clean. The drop-in stack (include/spx_nnue.hpp) used to pay one ~29 us synchronous call per pending ply.
+// Delta derivation as in spx_update_kernel (ray walks around the changed squares), for the one perspective of the wave:
+// round 3 replaced the two full attack generations of the round-1 kernel here - a path is one wave pair deep, so every
+// instruction and every LDS round trip of the derivation is latency (6.1 -> see DESIGN.md 4.8 us per ply).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, 3) void spx_update_chain_kernel(ChainParams p) {  // (4 waves/SIMD: 128 VGPRs spill 52 B; the kernel runs paths a wave pair deep)
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint64_t sTab[kDeltaTabWords];               // ray / knight masks + pseudo-attack sets (11 KiB)
+    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];       // rebuilds: the full row lists
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint32_t sAdd[kWavesPerBlock][kDeltaCap];    // deltas: u8 rows to add (compact piece-square rows first) ...
+    __shared__ uint32_t sSub[kWavesPerBlock][kDeltaCap];    // ... and to subtract
+    __shared__ uint32_t sWide[kWavesPerBlock][2][8];        // wide piece-square rows to subtract / add
+    __shared__ uint8_t sMail[kWavesPerBlock][2][64];        // piece per square of the parent / child board
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
+    for (int i = threadIdx.x; i < kDeltaTabWords; i += blockDim.x) sTab[i] = p.t.deltaTab[i];
+    __syncthreads();
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
+    if (item >= 2 * p.nChains) return;
+    const uint32_t chain = item >> 1;
+    const int c = int(item & 1);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(p.first[chain]);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(p.count[chain]);
+    const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[chain]);
+    uint32_t acc[8];
+    loadAcc(p.arena, parentSlot, c, lane, acc);
+    LaneBoard pb = decodeBoard(p.slotRecords + size_t(parentSlot) * 32, lane);
+    int childStm = pb.stm;
+    const uint8_t* records = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(first) * 32;
+    uint32_t nextWord = n ? loadRecordWord(records, lane) : 0u;  // a ply's record is requested one ply ahead (long paths of a
+                                                                 // tree replay run one wave pair deep: every round trip shows)
+    const int flipColour = (c == 0) ? 1 : 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint8_t* childRec = records + size_t(k) * 32;
+        const uint32_t word = nextWord;  // (lane l < 8 holds dword l of the record: what the slot's record copy needs)
+        const LaneBoard cb = decodeBoardWord(word, lane);
+        if (k + 1 < n) nextWord = loadRecordWord(childRec + 32, lane);
+        childStm = cb.stm;
+        sMail[wave][0][lane] = uint8_t(pb.piece);
+        sMail[wave][1][lane] = uint8_t(cb.piece);
+        const bool changedSq = pb.piece != cb.piece;
+        const uint64_t changed = __ballot(changedSq);
+        const uint32_t nChanged = uint32_t(popc64(changed));
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t kingMaskP = pb.kingsBb & (c ? pb.whiteBb : ~pb.whiteBb), kingMaskC = cb.kingsBb & (c ? cb.whiteBb : ~cb.whiteBb);
+        const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
+        const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
+        // as in spx_update_kernel: rebuilt when the king changed bucket or mirror half, or the boards are not one move apart
+        bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) || nChanged > 4;
+        uint32_t nAdd = 0, nSub = 0, nWideSub = 0, nWideAdd = 0;
+        if (!refresh) {
+            // the delta of ONE perspective, derived like spx_update_kernel does it for two (ray walks around the changed squares:
+            // a fifth of the instructions of two full attack generations - on a path one wave deep every instruction is latency)
+            const int x = perspXor(c, kingC);
+            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
+            nSub = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC) : 0u, sLut, sWide[wave][0], sSub[wave],
+                                    nWideSub);
+            nAdd = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC) : 0u, sLut, sWide[wave][1], sAdd[wave],
+                                    nWideAdd);
+            {
+                uint64_t m = changed;
+                const int b = int(lane >> 5);  // lanes 0..31 walk the parent board, 32..63 the child board
+                const uint64_t occB = b ? cb.occ : pb.occ;
+#pragma unroll 1
+                while (m) {
+                    const int fA = ctz64(m);
+                    m &= m - 1;
+                    const int fB = m ? ctz64(m) : -1;
+                    m &= m - 1;
+                    const int f = (lane & 16) ? fB : fA;
+                    uint32_t desc[2];
+                    deltaCandidates(sTab, sMail[wave][b], occB, changed, max(f, 0), int(lane & 15), desc[0], desc[1]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool have = f >= 0 && desc[j] != kNoDesc;
+                        const int32_t row = descRow(sLut, sTab, have ? desc[j] : 0u, x, flipColour);
+                        const uint64_t valid = __ballot(have && row >= 0);
+                        const uint32_t lo = uint32_t(valid), hi = uint32_t(valid >> 32);
+                        const uint32_t slot = lane < 32 ? nSub + __builtin_amdgcn_mbcnt_lo(lo, 0u) : nAdd + __builtin_amdgcn_mbcnt_hi(hi, 0u);
+                        if (((valid >> lane) & 1) && slot < uint32_t(kDeltaCap)) {
+                            (lane < 32 ? sSub[wave] : sAdd[wave])[slot] = uint32_t(row) * kL1;
+                        }
+                        nSub += uint32_t(__builtin_popcount(lo));
+                        nAdd += uint32_t(__builtin_popcount(hi));
+                    }
+                }
+            }
+            {
+                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
+                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
+                nSub = emitPawnPairDelta(sSub[wave], nSub, (ownP & ~ownC) | (theirP & ~theirC), pb.pawnsBb, ownP, lane, x);
+                nAdd = emitPawnPairDelta(sAdd[wave], nAdd, (ownC & ~ownP) | (theirC & ~theirP), cb.pawnsBb, ownC, lane, x);
+            }
+            if (nSub > uint32_t(kDeltaCap) || nAdd > uint32_t(kDeltaCap)) refresh = true;  // (never in legal play)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (refresh) {
+            uint32_t nPsq, nThr;
+            buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sTab + kDeltaRayWords);
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
+        } else {
+            applyWidePsqDelta(p.t, lane, sWide[wave][0], nWideSub, sWide[wave][1], nWideAdd, acc);
+            applyU8Delta(p.t, lane, sAdd[wave], nAdd, sSub[wave], nSub, acc);
+        }
+        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[first + k]);
+        storeAcc(p.arena, childSlot, c, lane, acc);
+        if (lane < 8 && c == 0) {
+            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+        }
+        __builtin_amdgcn_wave_barrier();  // this ply's lists are dead before the next ply's are written
+        pb = cb;
+    }
+    if (p.ftOut && n) {
+        const uint32_t half = (c == childStm) ? 0u : 1u;
+        *reinterpret_cast<u32x2*>(p.ftOut + size_t(chain) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+        if (lane < 8 && c == 0) {
+            const uint8_t* last = records + size_t(n - 1) * 32;
+            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(chain) * 32)[lane] = reinterpret_cast<const uint32_t*>(last)[lane];
         }
     }
 }

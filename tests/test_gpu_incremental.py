@@ -408,23 +408,32 @@ def test_native_tree_replay_of_the_config3_trace(sp, net_blob):
         st.close()
 
 
-def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob):
+def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob, monkeypatch):
     """BASELINE config 3 as the north star words it: the make/unmake trace of the reference's own ALPHA-BETA search (depth <= 12
     from the start position: 84 066 moves, 65 536 evaluates, lines down to ply 249 with the random-weight net) through
-    spx_acc_replay_tree - every EVAL equals the reference's lazily updated NnueState::evaluate."""
+    spx_acc_replay_tree - every EVAL equals the reference's lazily updated NnueState::evaluate. A tree this deep and narrow
+    is walked by heavy PATHS (one chain-kernel launch per round of paths) instead of level batches; both walks, forced through
+    SPX_REPLAY_PATHS, must give the reference's values - on this trace and on the shallow, wide depth-first one."""
     from stormphrax_amd.trace import Trace, replay_native
 
-    path = os.path.join(GOLDEN, "trace_search_startpos_tame_64k.txt.gz")
-    trace = Trace(path)
     st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=65536)
     try:
-        pos = trace.positions()
-        got, want, ms = replay_native(st, trace, pos)
-        assert len(want) == 65536 and np.array_equal(got, want)
-        got2, _, ms2 = replay_native(st, trace, pos)
-        assert np.array_equal(got2, want)
-        print(f"alpha-beta trace: {trace.n_nodes - 1} updates + {len(want)} evals over {max(trace.depth)} levels in "
-              f"{min(ms, ms2):.2f} ms on the device")
+        for name in ("trace_search_startpos_tame_64k.txt.gz", "trace_startpos_tame_64k.txt.gz"):
+            trace = Trace(os.path.join(GOLDEN, name))
+            pos = trace.positions()
+            times = {}
+            for mode in ("default", "1", "0"):
+                if mode == "default":
+                    monkeypatch.delenv("SPX_REPLAY_PATHS", raising=False)
+                else:
+                    monkeypatch.setenv("SPX_REPLAY_PATHS", mode)
+                got, want, ms = replay_native(st, trace, pos)
+                assert len(want) == 65536 and np.array_equal(got, want), (name, mode)
+                got2, _, ms2 = replay_native(st, trace, pos)
+                assert np.array_equal(got2, want), (name, mode)
+                times[mode] = min(ms, ms2)
+            print(f"{name}: {trace.n_nodes - 1} updates + {len(want)} evals over {max(trace.depth)} levels: default "
+                  f"{times['default']:.2f} ms, by paths {times['1']:.2f} ms, by levels {times['0']:.2f} ms on the device")
     finally:
         st.close()
 
