@@ -194,8 +194,10 @@ int spx_acc_update_chain_eval(spx_ctx* ctx, uint32_t parent_slot, const uint32_t
 /* A recorded make/unmake TREE (BASELINE config 3: the PUSH / POP / EVAL stream of a search, src/thread.cpp:46-67,
  * src/thread.h:116-122) replayed natively: node 0 is the root (NnueState::reset), node k > 0 was reached from node
  * parents[k] < k by one move and positions[k] is its record. Every node gets arena slot k (the arena is grown to n_nodes
- * slots); the tree is processed LEVEL BY LEVEL - all updates of one depth are one batch of independent records - on
- * buffers uploaded once, with no host synchronisation between the levels; then the n_evals nodes of eval_nodes are
+ * slots); the tree is processed LEVEL BY LEVEL - all updates of one depth are one batch of independent records - or, when
+ * it is deep and narrow (depth >= 32, on average <= 4 096 nodes per level: a real alpha-beta search), by HEAVY PATHS - every
+ * path one wavefront pair that carries the accumulator from ply to ply, all paths whose head's parent exists one launch -
+ * on buffers uploaded once, with no host synchronisation in between; then the n_evals nodes of eval_nodes are
  * evaluated (NnueState::evaluate at those nodes) into out[]. *gpu_ms (optional) = device time from the root refresh to the
  * last evaluation. The reference walks the same tree depth-first with one lazily updated accumulator stack
  * (nnue_state.cpp:636-697); the values are identical. */
