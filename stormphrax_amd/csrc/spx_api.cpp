@@ -114,6 +114,7 @@ struct spx_ctx {
     bool updateLegacy = false;     // the round-1 update kernel (two full attack generations, rebuilds inline: ONE launch) serves
     bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
+    bool smallUpdateV1 = false;    // SPX_SMALL_UPDATE_V1=1: batches <= tinyBatchMax on the round-1 kernel instead of the chain kernel
     size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = automatic)
     size_t teamMaxPersp = 512;     // SPX_FT_TEAM_MAX: full refreshes of at most this many perspectives run one workgroup per
                                    // perspective (spx_ft_team_kernel): evaluate_once of 64 / 256 positions 30.8 -> 27.5 / 33.6 -> 28.8 us,
@@ -567,6 +568,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     ctx->updateSplitMaxV2 = 16384;
     if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
     if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
+    if (const char* env = std::getenv("SPX_SMALL_UPDATE_V1")) ctx->smallUpdateV1 = env[0] == '1';
     if (const char* env = std::getenv("SPX_FT_TEAM_MAX")) ctx->teamMaxPersp = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
@@ -1014,6 +1016,25 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     up.refreshCount = counters + ctx->refreshCur;
     // streaming (non-temporal) arena accesses only where accumulators are written: eval-only children keep cached parents
     const bool streamAcc = n >= ctx->streamAccMin && up.childSlots != nullptr;
+    if (legacy && !ctx->updateLegacyForced && !ctx->smallUpdateV1 && n <= 1024) {
+        // the smallest batches: the chain kernel on unit paths - one wave per (record, perspective) with inline rebuilds like
+        // the round-1 kernel, but with the ray-walk delta derivation: a synchronous update + eval of 1 / 1 024 records 30.5 ->
+        // 28.7 / 41.0 -> 39.7 us, the depth-first tree replay 0.523 -> 0.513 ms. From 2 048 records on its 163 VGPRs (3 waves per
+        // SIMD) lose to the round-1 kernel's 128 (53.5 vs 51 us; self-play at 16 384 seats -2 %), which keeps those
+        // (profiles/r03_ab_small_update_chain_kernel.txt; SPX_SMALL_UPDATE_V1=1: the round-1 kernel for all of them)
+        ChainParams cp{};
+        cp.nChains = uint32_t(n);
+        cp.parentSlots = up.parentSlots;
+        cp.childSlots = up.childSlots;
+        cp.childPositions = up.childPositions;
+        cp.t = up.t;
+        cp.arena = up.arena;
+        cp.slotRecords = up.slotRecords;
+        cp.ftOut = up.ftOut;
+        cp.stagedRecords = up.stagedRecords;
+        SPX_HIP(launchUpdateChain(cp, s));
+        return SPX_OK;
+    }
     SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, legacy, s));
     if (legacy) return SPX_OK;
     FtParams fp{};

@@ -59,9 +59,9 @@ struct UpdateParams {
 struct ChainParams {               // spx_update_chain_kernel: whole pending PATHS (NnueState::ensureUpToDate) in one launch
     uint32_t nChains;
     const uint32_t* parentSlots;   // [nChains] the materialised slot each path starts from
-    const uint32_t* first;         // [nChains] index of the path's first ply in the arrays below
-    const uint32_t* count;         // [nChains] plies of the path (>= 1): ply k's parent is ply k - 1
-    const uint32_t* childSlots;    // [total plies] slot every ply's accumulators are written to
+    const uint32_t* first;         // [nChains] index of the path's first ply in the arrays below; nullptr = unit paths (path i = ply i)
+    const uint32_t* count;         // [nChains] plies of the path (>= 1): ply k's parent is ply k - 1 (unused for unit paths)
+    const uint32_t* childSlots;    // [total plies] slot every ply's accumulators are written to; nullptr = eval-only
     const void* childPositions;    // spx_packed_pos[total plies]
     FtTables t;
     uint8_t* arena;

@@ -669,8 +669,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void spx_update_chain_kerne
     if (item >= 2 * p.nChains) return;
     const uint32_t chain = item >> 1;
     const int c = int(item & 1);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(p.first[chain]);
-    const uint32_t n = __builtin_amdgcn_readfirstlane(p.count[chain]);
+    // (first == nullptr: UNIT paths - path i is record i alone: a batch of independent one-ply updates, what the small-batch
+    // entry points launch)
+    const uint32_t first = p.first ? __builtin_amdgcn_readfirstlane(p.first[chain]) : chain;
+    const uint32_t n = p.first ? __builtin_amdgcn_readfirstlane(p.count[chain]) : 1u;
     const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[chain]);
     uint32_t acc[8];
     loadAcc(p.arena, parentSlot, c, lane, acc);
@@ -753,10 +755,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void spx_update_chain_kerne
             applyWidePsqDelta(p.t, lane, sWide[wave][0], nWideSub, sWide[wave][1], nWideAdd, acc);
             applyU8Delta(p.t, lane, sAdd[wave], nAdd, sSub[wave], nSub, acc);
         }
-        const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[first + k]);
-        storeAcc(p.arena, childSlot, c, lane, acc);
-        if (lane < 8 && c == 0) {
-            reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+        if (p.childSlots) {  // (nullptr: eval-only - the activations below are all that leaves)
+            const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[first + k]);
+            storeAcc(p.arena, childSlot, c, lane, acc);
+            if (lane < 8 && c == 0) {
+                reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            }
         }
         __builtin_amdgcn_wave_barrier();  // this ply's lists are dead before the next ply's are written
         pb = cb;
