@@ -515,6 +515,23 @@ def config3_leg(sp, net, device, name="trace_startpos_tame_64k.txt.gz",
         st.close()
 
 
+def selfplay_leg(sp, net, device, seats=4096, games=32768):
+    """secondary.config4_selfplay (BASELINE configs[3] shape on one GPU): `seats` concurrent games living on the device, every
+    legal move of every game evaluated per ply (eval-only children), the reference's datagen rules in the step kernel; games
+    are discarded (out_path None). The verification of such files - every game replayed through the restated rules, samples
+    against the oracle - is tests/ and tools/gpu_selfplay_soak.sh, not this leg."""
+    st = sp.NnueState(net, device=device, max_batch=seats * 64)
+    try:
+        stats = st.selfplay(n_games=seats, target_games=games, out_path=None, max_plies=300, dfrc=True, temperature_cp=30, seed=1)
+        return {"value": stats["evals"] / stats["seconds"], "unit": "leaf evals/s", "concurrent_games": seats,
+                "games": stats["games"], "positions": stats["positions"], "seconds": stats["seconds"],
+                "gpu_call_fraction": stats["gpu_seconds"] / stats["seconds"], "outcomes_white_loss_draw_win": stats["outcomes"],
+                "policy": "depth-1: score(move) = -NNUE(child), uniform among the moves within 30 cp of the best; openings, "
+                          "verification filter, adjudication, Position::isDrawn, viriformat records as src/datagen/datagen.cpp"}
+    finally:
+        st.close()
+
+
 def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelined, device):
     """Outside the headline's timed region, single-GPU runs only: puts the other configurations on the driver's clock
     (VERDICT r2 item 6). A leg that fails reports its error instead of taking the headline down."""
@@ -537,6 +554,7 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
         run("config3_alpha_beta_replay", lambda: config3_leg(
             sp, net, device, "trace_search_startpos_tame_64k.txt.gz",
             "the reference's own alpha-beta search, depth <= 12 from the start position, recorded through link-time interposition"))
+    run("config4_selfplay", lambda: selfplay_leg(sp, net, device))
     return out
 
 
@@ -572,7 +590,7 @@ def main():
                     help="N > 1: all_gather the per-rank scores of the last step (RCCL) and check the gathered array "
                          "against each rank's own shard checksum (SURVEY 8e's optional result gather; outside the timed region)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary legs (incremental ply, config-3 replay, realistic-weights net, gather ceiling) that "
+                    help="skip the secondary legs (incremental ply, config-3 replays, self-play, realistic-weights net, gather ceiling) that "
                          "the single-GPU run appends to the JSON line after the headline's timed region")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
