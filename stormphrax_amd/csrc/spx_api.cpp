@@ -1179,9 +1179,14 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
         }
         std::vector<uint32_t> chainHead, chainLen, chainRound;
         uint32_t maxRound = 0;
+        // Long paths are cut into SEGMENTS of `segment` plies, each a path of its own one round after the previous one: the
+        // paths hanging off the first plies of a 249-ply spine then start after the spine's first segment instead of after
+        // its last ply (a launch lasts as long as its longest path).
+        uint32_t segment = 32;
+        if (const char* env = std::getenv("SPX_REPLAY_SEGMENT")) segment = uint32_t(std::max(1, std::atoi(env)));
         for (size_t k = 1; k < n_nodes; ++k) {
             const uint32_t p = parents[k];
-            if (p != 0 && heavy[p] == k) {  // continues its parent's path
+            if (p != 0 && heavy[p] == k && chainLen[chainOf[p]] < segment) {  // continues its parent's path
                 chainOf[k] = chainOf[p];
                 roundOf[k] = roundOf[p];
                 ++chainLen[chainOf[k]];
