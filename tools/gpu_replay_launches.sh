@@ -23,13 +23,17 @@ import glob, sqlite3
 for f in glob.glob("$OUT/trace/*.db"):
     c = sqlite3.connect(f).cursor()
     rows = [r for r in c.execute("select name, start, end, grid_x from kernels order by start") if "spx" in r[0]]
-    # last replay: the last 8 chain launches
-    chains = [r for r in rows if "chain" in r[0]][-8:]
+    # the last replay's chain launches: the last run of chain launches without a gap of more than 1 ms
+    allc = [r for r in rows if "chain" in r[0]]
+    chains = [allc[-1]]
+    for r in reversed(allc[:-1]):
+        if chains[0][1] - r[2] > 1e6: break
+        chains.insert(0, r)
     for n, s, e, g in chains:
         print("chain launch grid %8d  %8.1f us" % (g, (e - s) / 1e3))
     t0 = chains[0][1]; tail = [r for r in rows if r[1] >= t0]
     print("from the first chain launch to the last kernel of the replay: %.1f us; kernels after the chains:" % ((tail[-1][2] - t0) / 1e3))
-    for n, s, e, g in tail[8:]:
+    for n, s, e, g in tail[len(chains):]:
         print("   %-40s %8.1f us (starts at +%.1f)" % (n.replace("spx::", "")[:40], (e - s) / 1e3, (s - t0) / 1e3))
 PY
 rm -rf $OUT/trace
