@@ -738,9 +738,14 @@ def main():
         }
         if kp and "TCC_REQ_sum" in kp["counters"]:
             c = kp["counters"]
-            roofline["l2_pmc"] = {"tcc_req_bytes_per_launch": c["TCC_REQ_sum"] * 128,
+            req_bytes, miss_bytes = c["TCC_REQ_sum"] * 128, c.get("TCC_MISS_sum", 0) * 128
+            roofline["l2_pmc"] = {"tcc_req_bytes_per_launch": req_bytes,
                                   "hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)),
-                                  "kernel_us_under_rocprofv3": kp.get("avg_us")}
+                                  "kernel_us_under_rocprofv3": kp.get("avg_us"),
+                                  # a line that misses passes through the L2 arrays twice (the fill, then the read): what the
+                                  # L2 itself moves per launch, against the same 34.5 TB/s
+                                  "bytes_incl_fills_per_launch": req_bytes + miss_bytes,
+                                  "frac_of_l2_peak_incl_fills": (req_bytes + miss_bytes) / ft_avg_s / 1e9 / L2_PEAK_GBS}
         if pmc:
             roofline["valu"] = valu_block(kp, pmc.get("valu_cycles_per_wave_instr", 4))
         line = {
