@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--wide", action="store_true", help="context with SPX_CTX_WIDE_PSQ_ROWS")
+    ap.add_argument("--variants", default=None, help="comma-separated variant ids (-1 = the product kernel); default all")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -32,6 +33,10 @@ def main():
     wide_rows, compact_rows, thr_rows = st.count_rows(pos)
     requested = 2048 * wide_rows + 1024 * (compact_rows + thr_rows)
     variants = [-1] + list(range(st.gather_probe_variants()))
+    if args.variants:
+        variants = [int(v) for v in args.variants.split(",")]
+        if -1 not in variants:
+            variants = [-1] + variants
     times = {v: [] for v in variants}
     names, sinks = {}, {}
     for _ in range(args.rounds):
@@ -44,7 +49,7 @@ def main():
     for v in variants:
         us = float(np.median(times[v])) * 1e3
         rows.append({"variant": v, "name": names[v], "us_per_launch": us, "min_us": min(times[v]) * 1e3,
-                     "max_us": max(times[v]) * 1e3, "requested_gbs": requested / us / 1e3,
+                     "max_us": max(times[v]) * 1e3, "sink_checksum": sinks[v], "requested_gbs": requested / us / 1e3,
                      "ft_kernel_over_this": ft_us / us})
     probe_sinks = {sinks[v] for v in variants if v >= 0}
     best = min((r for r in rows if r["variant"] >= 0), key=lambda r: r["us_per_launch"])
