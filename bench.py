@@ -515,21 +515,78 @@ def config3_leg(sp, net, device, name="trace_startpos_tame_64k.txt.gz",
         st.close()
 
 
-def selfplay_leg(sp, net, device, seats=4096, games=32768):
+def selfplay_leg(sp, net, device, seats=4096, games=32768, seed=1):
     """secondary.config4_selfplay (BASELINE configs[3] shape on one GPU): `seats` concurrent games living on the device, every
     legal move of every game evaluated per ply (eval-only children), the reference's datagen rules in the step kernel; games
     are discarded (out_path None). The verification of such files - every game replayed through the restated rules, samples
     against the oracle - is tests/ and tools/gpu_selfplay_soak.sh, not this leg."""
     st = sp.NnueState(net, device=device, max_batch=seats * 64)
     try:
-        stats = st.selfplay(n_games=seats, target_games=games, out_path=None, max_plies=300, dfrc=True, temperature_cp=30, seed=1)
-        return {"value": stats["evals"] / stats["seconds"], "unit": "leaf evals/s", "concurrent_games": seats,
+        stats = st.selfplay(n_games=seats, target_games=games, out_path=None, max_plies=300, dfrc=True, temperature_cp=30, seed=seed)
+        return {"value": stats["evals"] / stats["seconds"], "unit": "leaf evals/s", "concurrent_games": seats, "evals": stats["evals"],
                 "games": stats["games"], "positions": stats["positions"], "seconds": stats["seconds"],
                 "gpu_call_fraction": stats["gpu_seconds"] / stats["seconds"], "outcomes_white_loss_draw_win": stats["outcomes"],
                 "policy": "depth-1: score(move) = -NNUE(child), uniform among the moves within 30 cp of the best; openings, "
                           "verification filter, adjudication, Position::isDrawn, viriformat records as src/datagen/datagen.cpp"}
     finally:
         st.close()
+
+
+def secondary_legs_multi(sp, torch, group, net, device, rank, world, preset):
+    """N > 1: BASELINE configs[3] as it is worded - 4 096 concurrent self-play games SHARDED over the GPUs (rank r plays
+    its share of the seats and of the target with its own seed: game_id mod N), no collective in the game loop -
+    plus the same with 4 096 games PER GPU (weak scaling) and the incremental leg on every rank. Every rank runs every leg
+    behind a barrier; rank 0 reports SUM of the work over MAX of the time, and every rank's own figure. Outside the headline's
+    timed region. A leg that fails on any rank reports the error instead of taking the line down; the collectives below are
+    called by every rank whatever happened."""
+    out = {}
+
+    def run(name, fn, reduce):
+        group.barrier()
+        t0 = time.perf_counter()
+        err, mine = "", None
+        try:
+            mine = fn()
+        except Exception as exc:  # noqa: BLE001 - reported, not swallowed
+            err = f"rank {rank}: {type(exc).__name__}: {exc}"
+        failed = group.sum_int(1 if err else 0)
+        seconds = group.max_float(time.perf_counter() - t0)
+        if failed:
+            out[name] = {"error": err or f"{failed} other rank(s) failed", "ranks_failed": failed}
+        else:
+            out[name] = reduce(mine)
+        out[name]["leg_seconds"] = seconds
+        out[name]["n_gpus"] = world
+
+    def reduce_selfplay(m):
+        evals = group.sum_int(m["evals"])
+        secs = group.all_floats(m["seconds"])
+        rates = group.all_floats(m["value"])
+        frac = group.all_floats(m["gpu_call_fraction"])
+        games = group.sum_int(m["games"])
+        positions = group.sum_int(m["positions"])
+        return {"value": evals / max(secs), "unit": "leaf evals/s (all GPUs: evals of every rank / the slowest rank's seconds)",
+                "concurrent_games_per_gpu": m["concurrent_games"], "concurrent_games": m["concurrent_games"] * world,
+                "games": games, "positions": positions, "seconds_per_rank": secs, "leaf_evals_per_sec_per_rank": rates,
+                "gpu_call_fraction_per_rank": frac, "sharding": "rank r plays seats and target share r with seed 1 + r; no collective in the game loop",
+                "policy": m["policy"]}
+
+    def reduce_incremental(m):
+        rates = group.all_floats(m["value"])
+        exact = group.sum_int(int(bool(m["bit_exact_vs_full_refresh"]))) == world
+        upd = group.all_floats(m["update_kernel_ms"])
+        return {"value": float(sum(rates)), "unit": "updates+evals/s (sum of the ranks' rates over the same window)",
+                "games_per_gpu": m["games"], "updates_plus_evals_per_sec_per_rank": rates, "update_kernel_ms_per_rank": upd,
+                "bit_exact_vs_full_refresh": bool(exact)}
+
+    seats = max(256, 4096 // world)
+    run("config4_selfplay", lambda: selfplay_leg(sp, net, device, seats=seats, games=max(2048, 32768 // world), seed=1 + rank),
+        reduce_selfplay)
+    run("config4_selfplay_4096_games_per_gpu", lambda: selfplay_leg(sp, net, device, seats=4096, games=32768, seed=1 + rank),
+        reduce_selfplay)
+    if preset == "tame":
+        run("incremental", lambda: incremental_leg(sp, torch, net, device), reduce_incremental)
+    return out
 
 
 def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelined, device):
@@ -697,6 +754,9 @@ def main():
     secondary = None
     if world == 1 and not args.no_secondary and not args.net:
         secondary = secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelined, local_rank)
+    elif world > 1 and not args.no_secondary and not args.net:
+        # BASELINE configs[3] (self-play sharded over the GPUs) and the incremental leg on the N > 1 line
+        secondary = secondary_legs_multi(sp, torch, group, net, local_rank, rank, world, args.preset)
 
     if rank == 0:
         wide_rows, compact_rows, thr_rows = state.count_rows(distinct)  # host-side count; tiled batches scale the distinct block

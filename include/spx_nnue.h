@@ -310,6 +310,11 @@ int spx_pos_to_mailbox(const spx_packed_pos* pos, uint8_t mailbox[64], int* stm)
 /* Position::applyMove for a move in UCI notation (castling as king-takes-rook, e.g. e1h1, or standard e1g1);
  * legality is checked against the generated legal moves (src/position.cpp:109-197, Position::moveFromUci). */
 int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos* out);
+/* The record of every node of a recorded tree - or FOREST - of moves (trace replays): node k is a root when its move is
+ * empty (it takes the next record of `roots`), otherwise positions[parents[k]] (parents[k] < k) after `moves + 6 k`
+ * (UCI text, NUL padded to 6 bytes; "0000" = a null move: same board, other side to move, no en-passant square). */
+int spx_tree_expand_uci(const spx_packed_pos* roots, size_t n_roots, const uint32_t* parents, const char* moves, size_t n,
+                        spx_packed_pos* out);
 /* Position::applyMove WITH the reference's observer: besides the successor record, the UpdateContext the BoardObserver
  * would have captured (src/eval/nnue_state.h:28-31,118-186; src/eval/nnue.cpp:490-599): piece-square subs/adds in event
  * order, threat descriptors added/removed (x-ray extensions/retractions included, cancelling pairs kept exactly as the
@@ -370,7 +375,11 @@ int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t c
  *   spx_viri_to_marlinformat: the unfiltered positions as PackedBoard records with eval = the recorded score and wdl = the
  *     game's outcome, back to back (Marlinformat::push / writeAllWithOutcome, marlinformat.cpp:32-57);
  *   spx_viri_to_fen: one text line per unfiltered position, "<fen> | <score> | <0.0 / 0.5 / 1.0>" + '\n' (fen.cpp:32-66).
- * out = NULL counts only (*n_records / *n_bytes); SPX_ERR_CAPACITY when `capacity` (records / bytes) is too small. */
+ * out = NULL counts only (*n_records / *n_bytes); SPX_ERR_CAPACITY when `capacity` (records / bytes) is too small.
+ * One known difference (viriformat does not record it): the reference marks the move that ends a game through
+ * Position::isDrawn or a tablebase probe as filtered whatever the move (datagen.cpp:264-281), so for a game that ended that
+ * way with a quiet, non-checking last move these converters keep one position - that move's, with score 0 - the reference's
+ * writers would have dropped; the per-position filter (in check / noisy move, datagen.cpp:254) is applied exactly. */
 int spx_viri_to_marlinformat(const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity, size_t* n_records,
                              size_t* n_games);
 int spx_viri_to_fen(const void* data, size_t nbytes, char* out, size_t capacity, size_t* n_bytes, size_t* n_games);

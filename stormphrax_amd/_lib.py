@@ -137,6 +137,7 @@ SYMBOLS = {
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
     "spx_pos_apply_uci": (ctypes.c_int, [_P, ctypes.c_char_p, _P]),
+    "spx_tree_expand_uci": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P, ctypes.c_size_t, _P]),
     "spx_pos_apply_uci_observed": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _P]),
     "spx_acc_update_observed": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "spx_acc_update_observed_device": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, _P, _P]),

@@ -17,6 +17,7 @@
 #include "spx_device_math.h"
 #include "spx_internal.h"
 #include "spx_kernels.h"
+#include "spx_ftx.h"
 #include "spx_probe.h"
 
 namespace spx {
@@ -47,6 +48,20 @@ struct spx_net {
 
 constexpr size_t kProfEventsPerCall = 5;
 
+// scratch of the column-sliced full refresh (spx_ftx.hip): one set per context and per lane, allocated on first use
+struct FtxScratch {
+    uint32_t *lists = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr, *order = nullptr,
+             *groups = nullptr, *plan = nullptr;
+    size_t capacity = 0;  // positions per pass
+    bool preparedOnce = false;  // (SPX_FTX_DEBUG_REUSE=1, measurements only: later calls reuse the first call's lists)
+    void release() {
+        for (uint32_t* q : {lists, keys, ranks, hist, binStart, order, groups, plan}) {
+            if (q) (void)hipFree(q);
+        }
+        *this = FtxScratch{};
+    }
+};
+
 struct spx_ctx {
     int device = 0;
     size_t maxBatch = 0;       // scratch capacity: positions one launch sequence can hold intermediates for
@@ -56,6 +71,28 @@ struct spx_ctx {
     // weights
     int16_t* dPsqW = nullptr;
     uint8_t* dThrW = nullptr;
+    int8_t* dRowI8 = nullptr;   // the matrix-pipe gather's row table (plain i8, natural column order; FtTables::rowI8)
+    int8_t* dPsqHi = nullptr;   // high-byte planes of the piece-square rows (FtTables::psqHi)
+    bool mfmaGather = false;    // SPX_FT_MFMA_GATHER=1: spx_ft_kernel's gather on the matrix pipe (same speed, half the VALU work)
+    uint8_t* dRowS = nullptr;   // the column-sliced row table of spx_ftx.hip (built on first use)
+    FtxScratch ftx;             // its scratch (the lanes hold their own)
+    bool ftxEnabled = false;    // SPX_FTX=1 / SPX_CTX_SLICED_FT: big full refreshes take the column-sliced pipeline (spx_ftx.hip)
+    size_t ftxMin = kFtxMinPositions;  // SPX_FTX_MIN: smallest batch that takes the sliced pipeline
+    bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
+    // spx_eval_full_device_async: the pipeline's preparation (extraction, sort, plan, pack - everything before the gather)
+    // runs on its own streams, up to kFtxRing batches ahead of the gathers, each with its own scratch set: it needs the
+    // positions only, so it is issued at call time and is never on a lane's critical path
+    static constexpr int kFtxRing = 3;
+    struct FtxSlot {
+        FtxScratch scratch;
+        hipStream_t stream = nullptr;
+        hipEvent_t prepared = nullptr, gathered = nullptr;  // preparation done / the gather that read the scratch done
+        bool used = false;
+    } ftxRing[kFtxRing];
+    unsigned ftxNext = 0;
+    FtxSlot* ftxSlot = nullptr;   // set around a lane's call: the slot whose scratch this call uses (nullptr: ctx->ftx, in-stream)
+    bool ftxRingUnavailable = false;
+    bool ftxDebugReuse = false;   // SPX_FTX_DEBUG_REUSE=1: measurement aid (what would the pipeline cost without its preparation?)
     int16_t* dFtBias = nullptr;
     int8_t* dL1W = nullptr;
     int32_t *dL1B = nullptr, *dL2W = nullptr, *dL2B = nullptr, *dL3W = nullptr, *dL3B = nullptr;
@@ -100,6 +137,7 @@ struct spx_ctx {
         // staging of the chunked host-buffer call (allocated on its first use): device in/out + page-locked mirrors
         void *dIn = nullptr, *hIn = nullptr;
         int32_t *dOutStage = nullptr, *hOut = nullptr;
+        FtxScratch ftx;
     } lanes[2];
     bool lanesReady = false;
     bool lanesUnavailable = false;   // the lanes did not fit into the device memory: async calls run stream-ordered
@@ -279,6 +317,9 @@ FtTables tablesOf(const spx_ctx* ctx) {
     t.lut = ctx->dLut;
     t.deltaTab = ctx->dDeltaTab;
     t.outlierTab = ctx->dOutlierTab;
+    t.rowI8 = ctx->dRowI8;
+    t.psqHi = ctx->dPsqHi;
+    t.mfmaGather = ctx->mfmaGather;
     return t;
 }
 
@@ -508,6 +549,31 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
             return rc;
         }
         if ((rc = uploadArray(ctx->dThrW, thr.data(), thr.size(), ctx->stream)) != SPX_OK) return rc;
+        if (const char* env = std::getenv("SPX_FT_MFMA_GATHER")) ctx->mfmaGather = env[0] == '1';
+        if (ctx->mfmaGather) {
+            // the matrix-pipe gather's tables (gatherFullMfma, spx_ft_device.h): plain i8 in the file's column order. Threat rows
+            // as they are; a piece-square row's slot holds the row itself (compact), its clamped copy (near-compact: remainders in
+            // the outlier table, as for the u8 copy) or its low-byte plane l = int8(v) (wide), whose high-byte plane
+            // h = int8((v - l) >> 8) goes to the second table: v = 256 h + l mod 2^16. One all-zero row ends either table (the
+            // lists are padded to multiples of four rows with it).
+            std::vector<int8_t> rows((size_t(kThreatRows) + kPsqRows + 1) * kL1, 0), hi((size_t(kPsqRows) + 1) * kL1, 0);
+            std::memcpy(rows.data(), net->threatW(), kThreatWBytes);
+            for (uint32_t r = 0; r < kPsqRows; ++r) {
+                const int16_t* row = psq + size_t(r) * kL1;
+                int8_t* lo = rows.data() + (size_t(kThreatRows) + r) * kL1;
+                const bool narrow = ((compactBits[r >> 5] | nearBits[r >> 5]) >> (r & 31)) & 1u;
+                for (uint32_t j = 0; j < kL1; ++j) {
+                    if (narrow) {
+                        lo[j] = int8_t(std::max(-128, std::min(127, int(row[j]))));
+                    } else {
+                        lo[j] = int8_t(uint8_t(uint16_t(row[j]) & 0xFFu));
+                        hi[size_t(r) * kL1 + j] = int8_t(uint8_t(uint16_t(int(row[j]) - int(lo[j])) >> 8));
+                    }
+                }
+            }
+            if ((rc = uploadArray(ctx->dRowI8, rows.data(), rows.size(), ctx->stream)) != SPX_OK) return rc;
+            if ((rc = uploadArray(ctx->dPsqHi, hi.data(), hi.size(), ctx->stream)) != SPX_OK) return rc;
+        }
     }
     if ((rc = uploadArray(ctx->dFtBias, b + kOffFtBias, kFtBiasBytes, ctx->stream)) != SPX_OK) return rc;
     {
@@ -549,6 +615,9 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
+    if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
+    if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
+    if (const char* env = std::getenv("SPX_FTX_MIN")) ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
@@ -599,13 +668,22 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
 void spx_ctx_destroy(spx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
+    void* ptrs[] = {ctx->dRowI8, ctx->dPsqHi, ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dOutlierTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
                     ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder, ctx->dRefreshList,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
+    ctx->ftx.release();
+    for (auto& slot : ctx->ftxRing) {
+        if (slot.stream) (void)hipStreamSynchronize(slot.stream);
+        slot.scratch.release();
+        if (slot.prepared) (void)hipEventDestroy(slot.prepared);
+        if (slot.gathered) (void)hipEventDestroy(slot.gathered);
+        if (slot.stream) (void)hipStreamDestroy(slot.stream);
+    }
+    if (ctx->dRowS) (void)hipFree(ctx->dRowS);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
     if (ctx->fallbackDone) (void)hipEventDestroy(ctx->fallbackDone);
@@ -618,6 +696,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
+        lane.ftx.release();
         if (lane.ftDone) (void)hipEventDestroy(lane.ftDone);
         if (lane.done) (void)hipEventDestroy(lane.done);
         if (lane.stream) (void)hipStreamDestroy(lane.stream);
@@ -699,6 +778,36 @@ static int runTinyMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out
     return SPX_OK;
 }
 
+// the column-sliced pipeline's table (per context) and scratch (per lane; `ctx->ftx` is the set swapped in): allocated on
+// first use; a context sized to fill the HBM that has no room for them keeps the one-kernel path (false)
+static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStream_t s) {
+    if (!ctx->ftxEnabled || ctx->ftxUnavailable) return false;
+    auto fail = [&]() {
+        (void)hipGetLastError();
+        x.release();
+        ctx->ftxUnavailable = true;
+        return false;
+    };
+    if (!ctx->dRowS) {
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->dRowS), kFtxTableBytes) != hipSuccess) return fail();
+        if (launchFtxBuildTable(ctx->dThrW, ctx->dPsqW, ctx->dLut, ctx->dRowS, s) != hipSuccess) return fail();
+        // (other streams may use the table next: the lanes' streams do not wait for this one)
+        if (hipStreamSynchronize(s) != hipSuccess) return fail();
+    }
+    if (x.capacity >= passPositions) return true;
+    x.release();
+    const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
+    auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
+    if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.keys, 2 * cap * 4) || !alloc(x.ranks, 2 * cap * 4) ||
+        !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) || !alloc(x.order, (2 * cap + 128) * 4) ||
+        !alloc(x.groups, ftxGroupBytes(cap)) || !alloc(x.plan, kFtxPlanWords * 4)) {
+        return fail();
+    }
+    if (hipMemsetAsync(x.hist, 0, kFtxBins * 4, s) != hipSuccess) return fail();
+    x.capacity = cap;
+    return true;
+}
+
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream) {
     if (!ctx || (n && (!d_positions || !d_out))) {
         setError("spx_eval_full_device: null argument");
@@ -728,18 +837,74 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         SPX_HIP(hipEventRecord(ev[0], s));
     }
     const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
-    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false);
+    // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
+    // output-bucket order is sorted here
+    // (a pipelined call of a single pass prepares on a ring slot's own stream, ahead of the lanes: ctx->ftxSlot)
+    spx_ctx::FtxSlot* slot = (ctx->ftxSlot && n <= std::min(ctx->maxBatch, kFtxMaxPositions)) ? ctx->ftxSlot : nullptr;
+    FtxScratch& scratch = slot ? slot->scratch : ctx->ftx;
+    const bool sliced = !tiny && n >= ctx->ftxMin && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), slot ? slot->stream : s);
+    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, sliced);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
-    if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
-    if (ev) SPX_HIP(hipEventRecord(ev[4], s));  // after the wait: the FT interval is the kernel alone
-    FtParams fp{};
-    fp.positions = d_positions;
-    fp.nPositions = uint32_t(n);
-    fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
-    fp.t = tablesOf(ctx);
-    fp.ftOut = ctx->dFtOut;
-    SPX_HIP(launchFullFt(ctx, fp, 2 * n, s));
+    if (sliced) {
+        // passes of at most the scratch's capacity; a pass's preparation (extraction, sort, plan, pack) comes before the
+        // pipelined calls' gate, so that it runs beside another batch's gather
+        for (size_t lo = 0; lo < n; lo += scratch.capacity) {
+            const size_t m = std::min(scratch.capacity, n - lo);
+            FtxParams xp{};
+            xp.positions = static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos);
+            xp.nPositions = uint32_t(m);
+            xp.t = tablesOf(ctx);
+            xp.rowS = ctx->dRowS;
+            xp.lists = scratch.lists;
+            xp.keys = scratch.keys;
+            xp.ranks = scratch.ranks;
+            xp.hist = scratch.hist;
+            xp.binStart = scratch.binStart;
+            xp.order = scratch.order;
+            xp.groups = scratch.groups;
+            xp.plan = scratch.plan;
+            xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
+            if (slot) {
+                // the slot's stream: after the gather that last read this scratch - and behind nothing else
+                if (slot->used) SPX_HIP(hipStreamWaitEvent(slot->stream, slot->gathered, 0));
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, slot->stream));
+                scratch.preparedOnce = true;
+                SPX_HIP(hipEventRecord(slot->prepared, slot->stream));
+                // (the gathers on one stream of their own at the highest priority, everything else below it: measured, worse -
+                // every co-running kernel is starved and the gather still slows down)
+                SPX_HIP(hipStreamWaitEvent(s, slot->prepared, 0));
+                if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
+                if (ev) SPX_HIP(hipEventRecord(ev[4], s));
+                SPX_HIP(launchFtxGather(xp, s));
+                SPX_HIP(hipEventRecord(slot->gathered, s));
+                slot->used = true;
+                continue;
+            } else {
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
+                scratch.preparedOnce = true;
+            }
+            if (lo == 0) {
+                if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
+                if (ev) SPX_HIP(hipEventRecord(ev[4], s));
+            }
+            SPX_HIP(launchFtxGather(xp, s));
+            if (slot) {
+                SPX_HIP(hipEventRecord(slot->gathered, s));
+                slot->used = true;
+            }
+        }
+    } else {
+        if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
+        if (ev) SPX_HIP(hipEventRecord(ev[4], s));  // after the wait: the FT interval is the kernel alone
+        FtParams fp{};
+        fp.positions = d_positions;
+        fp.nPositions = uint32_t(n);
+        fp.order = (ctx->kingSortEnabled && !tiny) ? ctx->dPerspOrder : nullptr;
+        fp.t = tablesOf(ctx);
+        fp.ftOut = ctx->dFtOut;
+        SPX_HIP(launchFullFt(ctx, fp, 2 * n, s));
+    }
     if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
     if (ev) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
@@ -761,6 +926,7 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
     std::swap(ctx->histUsed, lane.histUsed);
     std::swap(ctx->histCur, lane.histCur);
     std::swap(ctx->refreshCur, lane.refreshCur);
+    std::swap(ctx->ftx, lane.ftx);
 }
 
 static int ensureLanes(spx_ctx* ctx) {
@@ -798,6 +964,7 @@ static void releaseLanes(spx_ctx* ctx) {
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
+        lane.ftx.release();
         if (lane.hIn) (void)hipHostFree(lane.hIn);
         if (lane.hOut) (void)hipHostFree(lane.hOut);
         if (lane.ftDone) (void)hipEventDestroy(lane.ftDone);
@@ -806,6 +973,21 @@ static void releaseLanes(spx_ctx* ctx) {
         lane = spx_ctx::EvalLane{};
     }
     ctx->lanesReady = false;
+}
+
+static bool ensureFtxRing(spx_ctx* ctx) {
+    if (!ctx->ftxEnabled || ctx->ftxUnavailable || ctx->ftxRingUnavailable) return false;
+    if (ctx->ftxRing[0].stream) return true;
+    for (auto& slot : ctx->ftxRing) {
+        if (hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&slot.prepared, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&slot.gathered, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->ftxRingUnavailable = true;
+            return false;
+        }
+    }
+    return true;
 }
 
 int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event) {
@@ -844,8 +1026,10 @@ int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, 
         swapLane(ctx, lane);
         ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
         ctx->ftGateRecord = lane.ftDone;
+        ctx->ftxSlot = ensureFtxRing(ctx) ? &ctx->ftxRing[ctx->ftxNext++ % spx_ctx::kFtxRing] : nullptr;
         rc = spx_eval_full_device(ctx, static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos), m,
                                   static_cast<int32_t*>(d_out) + lo, lane.stream);
+        ctx->ftxSlot = nullptr;
         ctx->ftGateWait = ctx->ftGateRecord = nullptr;
         swapLane(ctx, lane);
         if (rc != SPX_OK) return rc;
@@ -868,6 +1052,9 @@ int spx_ctx_synchronize(spx_ctx* ctx) {
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->lanesReady) {
         for (auto& lane : ctx->lanes) SPX_HIP(hipStreamSynchronize(lane.stream));
+    }
+    for (auto& slot : ctx->ftxRing) {
+        if (slot.stream) SPX_HIP(hipStreamSynchronize(slot.stream));
     }
     return SPX_OK;
 }
@@ -2102,6 +2289,42 @@ int spx_pos_apply_uci(const spx_packed_pos* pos, const char* uci, spx_packed_pos
     }
     makeMove(b, m);
     packBoard(b, *out);
+    return SPX_OK;
+}
+
+// a recorded tree (or forest) of moves -> the record of every node, in one native call (trace replays: hundreds of
+// thousands of nodes; one Python round trip per node would dominate)
+int spx_tree_expand_uci(const spx_packed_pos* roots, size_t n_roots, const uint32_t* parents, const char* moves, size_t n,
+                        spx_packed_pos* out) {
+    if (!parents || !moves || !out || (n_roots && !roots)) {
+        setError("spx_tree_expand_uci: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    size_t nextRoot = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const char* uci = moves + 6 * k;  // 6 bytes per node, NUL padded: "" = a root (the next of `roots`), "0000" = a null move
+        if (uci[0] == 0) {
+            if (nextRoot >= n_roots) {
+                setError("spx_tree_expand_uci: more root nodes than roots");
+                return SPX_ERR_INVALID_ARG;
+            }
+            out[k] = roots[nextRoot++];
+            continue;
+        }
+        if (parents[k] >= k) {
+            setError("spx_tree_expand_uci: node " + std::to_string(k) + " does not follow its parent");
+            return SPX_ERR_INVALID_ARG;
+        }
+        if (std::memcmp(uci, "0000", 4) == 0) {  // Position::applyNullMove: same board, other side to move, no en-passant square
+            out[k] = out[parents[k]];
+            out[k].stm_ep = uint8_t(((out[k].stm_ep & 0x80u) ^ 0x80u) | 64u);
+            continue;
+        }
+        char text[7] = {};
+        std::memcpy(text, uci, 6);
+        const int rc = spx_pos_apply_uci(&out[parents[k]], text, &out[k]);
+        if (rc != SPX_OK) return rc;
+    }
     return SPX_OK;
 }
 

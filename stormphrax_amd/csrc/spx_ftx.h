@@ -1,0 +1,80 @@
+// Column-sliced full refresh (spx_ftx.hip): parameter block, buffer sizes and launch wrappers. Device pointers only.
+//
+// The big-batch full refresh (NnueState::evaluateOnce for >= kFtxMinPositions positions) as a pipeline of small kernels
+// around one gather kernel - see spx_ftx.hip for the design and the measurements that led to it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "spx_arch.h"
+#include "spx_kernels.h"
+
+namespace spx {
+
+// ---- sliced row table: [8 slices][kFtxRows][128 B] ----
+// slice x of row r = the 128 columns {64 x .. 64 x + 63} U {512 + 64 x ..} of the row, as 8 chunks of 16 bytes; byte m of
+// chunk t is column 64 x + 8 t + 2 (m >> 2) + (m & 1) (+ 512 if m & 2): a lane of the gather that ends up with D register
+// pairs (0, 1) / (2, 3) of chunk t holds columns (c, c + 1) and their pairwise partners (c + 512, c + 513).
+// rows: [0, 64368) threat / pawn-pair rows (i8 as in the net file); [64368, +11264) piece-square rows, LOW-byte plane
+// l = int8(w) (the row itself when it fits i8); [75632, +11264) piece-square rows, HIGH-byte plane h = int8((w - l) >> 8)
+// (all zero for a row that fits i8); 86896: an all-zero row (list padding).
+constexpr uint32_t kFtxPsqLoBase = kThreatRows;
+constexpr uint32_t kFtxPsqHiBase = kThreatRows + kPsqRows;
+constexpr uint32_t kFtxZeroRow = kThreatRows + 2 * kPsqRows;
+constexpr uint32_t kFtxRows = kFtxZeroRow + 1;
+constexpr uint32_t kFtxSliceStride = kFtxRows * 128u;
+constexpr size_t kFtxTableBytes = size_t(8) * kFtxSliceStride;
+constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket: 88 KiB per slice, LDS resident in the gather
+
+// ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
+// [0] nHi [1] nPsq [2] nThr [3] 2 * position + (0 = side-to-move half, 1 = other half)
+// [4, 36) piece-square rows as slab offsets ((row - 704 bucket) * 128); [36, 68) high-byte planes of the wide ones and
+// [68, 324) threat / pawn-pair rows as slice offsets (row index * 128)
+constexpr uint32_t kFtxListStride = 328, kFtxListPsq = 4, kFtxListHi = 36, kFtxListThr = 68;
+// sort key of a perspective: king bucket * 80 + (row quartets - 1): groups of 8 neighbours in this order share a bucket
+// (one LDS slab) and have almost equal list lengths (one wave walks the 8 lists in lockstep)
+constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins;
+
+// ---- per-group lists read by the gather: [group][kFtxGroupWords] words ----
+// [0] nHiQ [1] nPsqQ [2] nThrQ (row quartets per section: the longest of the 8 lists) [3] king bucket
+// [8 + 4 u + p] output slot (word [3] of the list) of perspective 2 p + u, ~0 = hole
+// from word 32: step j (the sections one after the other), lane class e = 2 kb + u, pair p: [j][e][p] = offset of row
+// 4 jj + kb of perspective 2 p + u in section jj's table (zero rows pad short lists)
+constexpr uint32_t kFtxMaxSteps = 8 + 8 + 64, kFtxGroupWords = 32 + (kFtxMaxSteps + 8) * 32;
+
+// ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
+// {bucket, first group, end group} per segment ----
+constexpr uint32_t kFtxPlanWords = 64 + 3 * 64;
+
+constexpr size_t kFtxMinPositions = 8192;     // smaller full refreshes keep the one-kernel path
+constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~5.3 KB each); larger batches walk in passes
+
+struct FtxParams {
+    const void* positions;   // spx_packed_pos[nPositions]
+    uint32_t nPositions;
+    FtTables t;              // lut, deltaTab (pseudo-attack sets), ftBias
+    const uint8_t* rowS;     // the sliced row table
+    uint32_t* lists;         // [2 n][kFtxListStride]
+    uint32_t* keys;          // [2 n] sort keys
+    uint32_t* ranks;         // [2 n] rank inside the key's bin
+    uint32_t* hist;          // [kFtxBins] counts per key; zero on entry of the rank kernel, zeroed again by the plan kernel
+    uint32_t* binStart;      // [kFtxBins + 17] first sorted position of each bin; then bucketStart[17]
+    uint32_t* order;         // [2 n + 128] perspective at each sorted position (~0 = hole)
+    uint32_t* groups;        // [nGroupsMax][kFtxGroupWords]
+    uint32_t* plan;          // [kFtxPlanWords]
+    uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
+};
+
+inline uint32_t ftxMaxGroups(size_t nPositions) { return uint32_t((2 * nPositions + 16 * 7 + 7) / 8); }
+inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
+inline size_t ftxGroupBytes(size_t n) { return size_t(ftxMaxGroups(n)) * kFtxGroupWords * 4; }
+
+hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
+// everything before the gather (extract, rank, plan, scatter, pack): may overlap another batch's gather
+hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);
+hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream);
+
+}  // namespace spx

@@ -1,0 +1,498 @@
+// Column-sliced full refresh for gfx950 (round 4): the feature-transformer pass of NnueState::evaluateOnce for big batches.
+//
+// What the round-3 kernel (spx_ft_kernel: one wave per perspective, whole 1 KiB rows) left on the table, measured with the
+// load-only probes of spx_probe.hip on the bench batch (profiles/r04_sliced_probe_*):
+//   * all eight XCDs fetch whole rows, so the eight private 4 MiB L2s cache eight copies of the same hot rows: L2 hit rate
+//     74 %, 2.2 GB per launch over the fabric, 367 us for the loads alone;
+//   * giving XCD x only the 128-byte slice x of every row lifts the hit rate to 88 % and cuts the fabric bytes to a third,
+//     but the loads then run into the CU's texture-address path (16 cycles per wave load): 342 us;
+//   * a slice of the 704 piece-square rows of ONE king bucket is 88 KiB - it fits the CU's LDS. With the perspectives
+//     ordered by king bucket and that slab in LDS, 37 % of the row fetches never touch the texture path: 269 us;
+//   * and the VALU work of the old gather (12 instructions per row to zero-extend and add u8 columns, 850 of the kernel's
+//     1 407 instructions per perspective) disappears onto the matrix pipe: ONE v_mfma_i32_16x16x64_i8 with a constant
+//     selection matrix widens AND adds up four gathered i8 rows (tools/probes/mfma_rowsum_probe.hip).
+//
+// Pipeline (all on one stream; everything but the gather may overlap the previous batch's gather):
+//   spx_ftx_extract_kernel  one wave per POSITION: board decode and attack sets once, row lists of both perspectives
+//                           (nnue_state.cpp:309-354, 440-449) to HBM, a sort key (king bucket, list length) per perspective
+//   spx_ftx_rank_kernel     counting sort, part 1: rank of every perspective inside its key's bin
+//   spx_ftx_plan_kernel     bin starts (each bucket padded to whole groups of 8), and the PLAN: the groups cut into 32
+//                           contiguous, equally heavy ranges - one per CU of an XCD -, each a list of one-bucket segments
+//   spx_ftx_scatter_kernel  counting sort, part 2: perspective at every sorted position
+//   spx_ftx_pack_kernel     one wave per group of 8 neighbours: their lists interleaved in the gather's lane order
+//   spx_ftx_gather_kernel   256 workgroups of 16 waves (workgroup b on XCD b % 8 = slice b % 8, CU slot b / 8): per segment
+//                           the bucket's piece-square slab slice into LDS, then one wave per group: 2 perspectives x 4
+//                           rows x 128 B per wave load / LDS read, one MFMA each, pairwise activation (multilayer.h:92-152)
+//                           from the i32 sums, 2 output bytes per lane.
+// Results are bit-identical to spx_ft_kernel (sums of rows mod 2^16; tests/test_gpu_parity.py runs both).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+
+#include "spx_ft_device.h"
+#include "spx_ftx.h"
+
+namespace spx {
+
+namespace {
+
+#ifndef SPX_FTX_STATIC_LDS
+#define SPX_FTX_STATIC_LDS 0
+#endif
+#ifndef SPX_FTX_GATHER_WAVES
+#define SPX_FTX_GATHER_WAVES 16
+#endif
+constexpr uint32_t kGatherWaves = SPX_FTX_GATHER_WAVES;
+constexpr uint32_t kGatherSlabBytes = (kFtxSlabRows + 1) * 128;
+constexpr uint32_t kGatherLdsBytes = kGatherSlabBytes + kGatherWaves * 2 * 256 * 4;
+
+// column of byte m of chunk t of slice x (see spx_ftx.h)
+__device__ __forceinline__ uint32_t sliceColumn(uint32_t x, uint32_t t, uint32_t m) {
+    return 64 * x + 8 * t + 2 * (m >> 2) + (m & 1u) + ((m & 2u) ? 512u : 0u);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sliced row table from the tables the context already holds: the u8 row table (threat rows: value + 128, columns
+// interleaved per lane - relayoutThreatRow in spx_api.cpp) and the i16 piece-square table. One thread per 16-byte chunk.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void spx_ftx_build_table_kernel(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kFtxRows * 64u) return;
+    const uint32_t r = idx >> 6, x = (idx >> 3) & 7u, t = idx & 7u;
+    uint8_t out[16];
+#pragma unroll
+    for (uint32_t m = 0; m < 16; ++m) {
+        const uint32_t c = sliceColumn(x, t, m);
+        int v = 0;
+        if (r < kThreatRows) {
+            // inverse of relayoutThreatRow: column c sits in lane l = (c & 511) >> 3 at byte k(j) (+ 8 for the upper half)
+            const uint32_t l = (c & 511u) >> 3, j = c & 7u, k = (j & 4u) | ((j & 1u) << 1) | ((j & 2u) >> 1);
+            v = int(thrU8[size_t(r) * kL1 + 16 * l + (c >= 512 ? 8 : 0) + k] ^ 0x80u);
+        } else if (r < kFtxZeroRow) {
+            const uint32_t row = (r - kThreatRows) % kPsqRows;
+            const int w = psqW[size_t(row) * kL1 + c];
+            const bool fits = (lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u;  // (then l = w, h = 0)
+            const int lo = int(int8_t(uint8_t(w & 0xFF)));
+            v = r < kFtxPsqHiBase ? lo : (fits ? 0 : (w - lo) >> 8);
+        }
+        out[m] = uint8_t(v);
+    }
+    *reinterpret_cast<u32x4*>(rowS + (size_t(x) * kFtxRows + r) * 128 + 16 * t) = *reinterpret_cast<const u32x4*>(out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Extraction: one wave per position, lane = square. The record decode and the attack sets are perspective independent and
+// done once; each perspective then builds its lists in LDS and the wave copies them out.
+// ---------------------------------------------------------------------------------------------------------------------
+// (<= 64 VGPRs: two of its waves per SIMD fit beside the gather's four - the two kernels are meant to share the CUs)
+__global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel(FtxParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint64_t sPseudo[kDeltaPseudoWords];
+    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];
+    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
+    __shared__ uint32_t sHi[kWavesPerBlock][kPsqCap];
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
+    for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    __syncthreads();
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    for (uint32_t pos = blockIdx.x * kWavesPerBlock + wave; pos < p.nPositions; pos += gridDim.x * kWavesPerBlock) {
+        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(pos) * 32;
+        const LaneBoard b = decodeBoard(rec, lane);
+        const uint64_t targets = laneTargets(b, lane);
+        const int piece = b.piece;
+        const bool occupied = piece != kNoPiece;
+        const bool isPawn = (piece >> 1) == 0;
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const uint64_t ownKing = __ballot(piece == (10 | c));
+            const int kingSq = ownKing ? ctz64(ownKing) : 0;  // a record without that king is malformed: stay in bounds
+            const uint64_t ownPawns = b.pawnsBb & (c ? b.whiteBb : ~b.whiteBb);
+            const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
+            const int x = perspXor(c, kingSq);
+            const int flipColour = (c == 0) ? 1 : 0;
+            const uint32_t bucket = uint32_t(kingBucket(c == 0 ? (kingSq ^ 56) : kingSq));
+            // piece-square rows (resetPsqAccumulator, nnue_state.cpp:440-449): every one from the bucket's LDS slab; a row
+            // with weights outside i8 also has a high-byte plane to fetch
+            uint32_t row = 0;
+            bool wide = false;
+            if (occupied) {
+                row = psqRow(c, piece, int(lane), kingSq);
+                wide = !((sLut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
+            }
+            const uint64_t wideMask = __ballot(wide);
+            const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
+            if (occupied && slot < kPsqCap) {
+                sPsq[wave][slot] = (row - bucket * kFtxSlabRows) * 128u;
+                if (wide && wideSlot < kPsqCap) sHi[wave][wideSlot] = (kFtxPsqHiBase + row) * 128u;
+            }
+            const uint32_t nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
+            const uint32_t nHi = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
+            // threat rows (addThreatFeatures, nnue_state.cpp:309-328), then pawn pairs (:330-351)
+            uint32_t nThr = emitThreatRows(sThr[wave], 0, targets, piece, lane, x, flipColour, sLut, sPseudo);
+            const bool own = isPawn && (piece & 1) == c;
+            nThr = emitPawnPairRows(sThr[wave], nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
+                                    ppId(int(lane) ^ x, !own), ownPawns, x);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t q = 2 * pos + uint32_t(c);
+            uint32_t* out = p.lists + size_t(q) * kFtxListStride;
+            if (lane == 0) {
+                u32x4 hdr;
+                hdr[0] = nHi;
+                hdr[1] = nPsq;
+                hdr[2] = nThr;
+                hdr[3] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
+                __builtin_nontemporal_store(hdr, reinterpret_cast<u32x4*>(out));
+                const uint32_t quartets = (nHi + 3) / 4 + (nPsq + 3) / 4 + (nThr + 3) / 4;
+                p.keys[q] = bucket * kFtxQuartetBins + min(max(quartets, 1u), kFtxQuartetBins) - 1;
+            }
+            // (streaming stores: the lists are read once, by the pack kernel - they should not push weight rows out of the L2s)
+            if (lane < nPsq) __builtin_nontemporal_store(sPsq[wave][lane], out + kFtxListPsq + lane);
+            if (lane < nHi) __builtin_nontemporal_store(sHi[wave][lane], out + kFtxListHi + lane);
+            for (uint32_t i = lane; i < nThr; i += 64) __builtin_nontemporal_store(sThr[wave][i] >> 3, out + kFtxListThr + i);  // (row * 1024 -> row * 128)
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Counting sort by key, part 1: block-local ranks through an LDS histogram, one global atomic per block and non-empty bin.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
+    __shared__ uint32_t sCount[kFtxBins], sBase[kFtxBins];
+    for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) sCount[k] = 0;
+    __syncthreads();
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, nPersp = 2 * p.nPositions;
+    uint32_t key = 0, local = 0;
+    if (q < nPersp) {
+        key = p.keys[q];
+        local = atomicAdd(&sCount[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) {
+        if (sCount[k]) sBase[k] = atomicAdd(&p.hist[k], sCount[k]);
+    }
+    __syncthreads();
+    if (q < nPersp) p.ranks[q] = sBase[key] + local;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bin starts and the plan. One workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
+    __shared__ uint32_t sBin[kFtxBins];        // counts, then starts
+    __shared__ uint32_t sBucketStart[17], sBucketCount[16];
+    __shared__ uint32_t sScan[1024];
+    __shared__ uint32_t sCut[33];
+    __shared__ uint8_t sCost[(2 * kFtxMaxPositions + 16 * 7 + 7) / 8 + 8];  // per group
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
+        sBin[k] = p.hist[k];
+        p.hist[k] = 0;  // ready for the next batch's rank kernel
+    }
+    __syncthreads();
+    if (tid < 16) {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < kFtxQuartetBins; ++k) n += sBin[tid * kFtxQuartetBins + k];
+        sBucketCount[tid] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (uint32_t b = 0; b < 16; ++b) {
+            sBucketStart[b] = at;
+            at = (at + sBucketCount[b] + 7u) & ~7u;  // every bucket starts a new group of 8
+        }
+        sBucketStart[16] = at;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        uint32_t at = sBucketStart[tid];
+        for (uint32_t k = 0; k < kFtxQuartetBins; ++k) {
+            const uint32_t n = sBin[tid * kFtxQuartetBins + k];
+            sBin[tid * kFtxQuartetBins + k] = at;
+            at += n;
+        }
+        for (; at < sBucketStart[tid + 1]; ++at) p.order[at] = 0xFFFFFFFFu;  // holes that pad the bucket to whole groups
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) p.binStart[k] = sBin[k];
+    if (tid < 17) p.binStart[kFtxBins + tid] = sBucketStart[tid];
+
+    // cost of a group = the quartets of its longest list (its last valid perspective: bins ascend inside a bucket) + a
+    // constant for the group's fixed work; computed once per group (a bisection over the bucket's bins), kept in LDS
+    const uint32_t nGroups = sBucketStart[16] / 8;
+    for (uint32_t G = tid; G < nGroups; G += blockDim.x) {
+        uint32_t b = 0;  // the bucket whose (padded) range holds position 8 G: the last one that starts at or before it
+#pragma unroll
+        for (uint32_t step = 8; step; step >>= 1) {
+            if (sBucketStart[b + step] <= 8 * G) b += step;
+        }
+        const uint32_t last = min(8 * G + 7, sBucketStart[b] + sBucketCount[b] - 1);
+        uint32_t lo = 0, hi = kFtxQuartetBins - 1;  // the last bin of bucket b that starts at or before `last`
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) / 2;
+            if (sBin[b * kFtxQuartetBins + mid] <= last) lo = mid; else hi = mid - 1;
+        }
+        sCost[G] = uint8_t(lo + 1 + 3);
+    }
+    __syncthreads();
+    const uint32_t per = (nGroups + blockDim.x - 1) / blockDim.x;
+    const uint32_t g0 = min(tid * per, nGroups), g1 = min(g0 + per, nGroups);
+    uint32_t mine = 0;
+    for (uint32_t G = g0; G < g1; ++G) mine += sCost[G];
+    sScan[tid] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // inclusive scan
+        const uint32_t v = tid >= d ? sScan[tid - d] : 0u;
+        __syncthreads();
+        sScan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = sScan[blockDim.x - 1];
+    if (tid <= 32) sCut[tid] = tid == 32 ? nGroups : 0u;
+    __syncthreads();
+    {
+        // CU slot c ends where the running cost passes total * (c + 1) / 32
+        uint64_t before = sScan[tid] - mine;
+        uint32_t c = total ? uint32_t(before * 32 / total) : 0u;  // first slot whose end lies beyond `before`
+        for (uint32_t G = g0; G < g1 && c < 31; ++G) {
+            before += sCost[G];
+            while (c < 31 && before * 32 >= uint64_t(total) * (c + 1)) {
+                sCut[c + 1] = G + 1;
+                ++c;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t c = 1; c < 32; ++c) {  // slots nobody closed (tiny batches) take nothing
+            if (sCut[c] < sCut[c - 1]) sCut[c] = sCut[c - 1];
+        }
+        uint32_t nSeg = 0, b = 0;  // (the cuts ascend, so does the bucket)
+        for (uint32_t c = 0; c < 32; ++c) {
+            p.plan[c] = nSeg;
+            uint32_t G = sCut[c];
+            const uint32_t end = max(sCut[c + 1], G);
+            while (G < end) {
+                while (b < 15 && G >= sBucketStart[b + 1] / 8) ++b;
+                const uint32_t e = min(end, b < 15 ? max(sBucketStart[b + 1] / 8, G + 1) : end);
+                p.plan[64 + 3 * nSeg] = b;
+                p.plan[64 + 3 * nSeg + 1] = G;
+                p.plan[64 + 3 * nSeg + 2] = e;
+                ++nSeg;
+                G = e;
+            }
+        }
+        p.plan[32] = nSeg;
+        p.plan[33] = nGroups;
+    }
+}
+
+__global__ void spx_ftx_scatter_kernel(FtxParams p) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < 2 * p.nPositions) p.order[p.binStart[p.keys[q]] + p.ranks[q]] = q;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pack: one wave per group of 8 neighbours of the sorted order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spx_ftx_pack_kernel(FtxParams p) {
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    const uint32_t G = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (G >= p.plan[33]) return;
+    uint32_t* out = p.groups + size_t(G) * kFtxGroupWords;
+    // lanes 0..7 hold the header of perspective g = lane
+    uint32_t q = 0xFFFFFFFFu;
+    u32x4 hdr = {0, 0, 0, 0xFFFFFFFFu};
+    if (lane < 8) {
+        q = p.order[8 * G + lane];
+        if (q != 0xFFFFFFFFu) hdr = *reinterpret_cast<const u32x4*>(p.lists + size_t(q) * kFtxListStride);
+    }
+    uint32_t nHiQ = (hdr[0] + 3) / 4, nPsqQ = (hdr[1] + 3) / 4, nThrQ = (hdr[2] + 3) / 4;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {  // maxima over the 8 perspectives (lanes 8.. carry zeros)
+        nHiQ = max(nHiQ, uint32_t(__shfl_xor(int(nHiQ), d, 64)));
+        nPsqQ = max(nPsqQ, uint32_t(__shfl_xor(int(nPsqQ), d, 64)));
+        nThrQ = max(nThrQ, uint32_t(__shfl_xor(int(nThrQ), d, 64)));
+    }
+    nHiQ = __builtin_amdgcn_readfirstlane(nHiQ);
+    nPsqQ = __builtin_amdgcn_readfirstlane(nPsqQ);
+    nThrQ = __builtin_amdgcn_readfirstlane(nThrQ);
+    const uint32_t firstQ = __builtin_amdgcn_readfirstlane(q);  // (position 8 G of a group is never a hole)
+    if (lane == 0) {
+        u32x4 h;
+        h[0] = nHiQ;
+        h[1] = nPsqQ;
+        h[2] = nThrQ;
+        h[3] = p.keys[firstQ] / kFtxQuartetBins;
+        *reinterpret_cast<u32x4*>(out) = h;
+    }
+    if (lane < 8) out[8 + 4 * (lane & 1u) + (lane >> 1)] = hdr[3];  // perspective g = 2 p + u -> word 8 + 4 u + p
+    // a lane's class is fixed - word 32 j + (lane & 31) of step j is class e = (lane >> 2) & 7, pair lane & 3 -, so it reads
+    // ONE perspective's list; lanes 0..31 take the even steps, 32..63 the odd ones: independent loads, no shuffles in the loop
+    const uint32_t e = (lane >> 2) & 7u, pr = lane & 3u, kb = e >> 1, g = 2 * pr + (e & 1u);
+    const uint32_t gq = uint32_t(__shfl(int(q), int(g), 64));
+    const uint32_t gHi = uint32_t(__shfl(int(hdr[0]), int(g), 64)), gPsq = uint32_t(__shfl(int(hdr[1]), int(g), 64)),
+                   gThr = uint32_t(__shfl(int(hdr[2]), int(g), 64));
+    const uint32_t* mine = p.lists + size_t(gq == 0xFFFFFFFFu ? 0u : gq) * kFtxListStride;  // (a hole's counts are zero)
+    const uint32_t nSteps = nHiQ + nPsqQ + nThrQ, jEnd = (nSteps + 7u) & ~7u;
+#pragma unroll 4
+    for (uint32_t j = lane >> 5; j < jEnd; j += 2) {
+        uint32_t v;
+        if (j < nHiQ) {
+            const uint32_t i = 4 * j + kb;
+            v = i < gHi ? __builtin_nontemporal_load(mine + kFtxListHi + i) : kFtxZeroRow * 128u;
+        } else if (j < nHiQ + nPsqQ) {
+            const uint32_t i = 4 * (j - nHiQ) + kb;
+            v = i < gPsq ? __builtin_nontemporal_load(mine + kFtxListPsq + i) : kFtxSlabRows * 128u;  // the slab's zero row
+        } else {
+            const uint32_t i = 4 * (j - nHiQ - nPsqQ) + kb;
+            v = i < gThr ? __builtin_nontemporal_load(mine + kFtxListThr + i) : kFtxZeroRow * 128u;
+        }
+        __builtin_nontemporal_store(v, out + 32 + 32 * j + (lane & 31u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gather.
+// ---------------------------------------------------------------------------------------------------------------------
+// (<= 96 VGPRs, the budget of five waves per SIMD, though a workgroup brings four: the rest is the extraction's room)
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(4, 8))) void spx_ftx_gather_kernel(FtxParams p) {
+    // LDS is DYNAMIC on purpose: with a static 120 KiB the compiler knows that only four waves per SIMD can be resident and
+    // pads the kernel's register count up to that occupancy's floor (97 -> 104 allocated); at 84 registers a workgroup leaves
+    // room for two of the extraction kernel's waves per SIMD beside it
+#if SPX_FTX_STATIC_LDS
+    __shared__ __align__(16) uint8_t sDyn[kGatherLdsBytes];
+#else
+    extern __shared__ __align__(16) uint8_t sDyn[];
+#endif
+    uint8_t* const sSlab = sDyn;                                                             // the bucket's slab slice + an all-zero row
+    uint32_t (*const sEnt)[2][256] = reinterpret_cast<uint32_t (*)[2][256]>(sDyn + kGatherSlabBytes);  // per wave: two stages of 8 steps of entries
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
+    const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
+    const uint8_t* slice = p.rowS + size_t(xcd) * kFtxSliceStride;
+    const uint32_t laneOff = 16 * t;
+    const i32x4 sel = mfmaSelector(lane);
+    // this lane's output columns: D registers (0, 1) = columns (c, c + 1), (2, 3) = their partners (c + 512, c + 513)
+    const uint32_t col = 64 * xcd + 8 * t + 2 * kb;
+    const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
+    const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
+    for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
+    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket:
+    // its slab slice goes to LDS once). A version that handed out chunks of 16-64 groups, one workgroup each, through the
+    // hardware's dispatcher ran 18-34 % slower alone (a slab reload per chunk) and overlapped no better.
+    const uint32_t segFirst = p.plan[cu], segEnd = p.plan[cu + 1];
+    for (uint32_t seg = segFirst; seg < segEnd; ++seg) {
+        const uint32_t bucket = p.plan[64 + 3 * seg], gFirst = p.plan[64 + 3 * seg + 1], gEnd = p.plan[64 + 3 * seg + 2];
+        __syncthreads();  // the previous segment's readers are done with the slab
+        {
+            const u32x4* src = reinterpret_cast<const u32x4*>(slice + size_t(kFtxPsqLoBase + bucket * kFtxSlabRows) * 128);
+            for (uint32_t i = threadIdx.x; i < kFtxSlabRows * 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab)[i] = src[i];
+        }
+        __syncthreads();
+        for (uint32_t G = gFirst + wave; G < gEnd; G += kGatherWaves) {
+            const uint32_t* in = p.groups + size_t(G) * kFtxGroupWords;
+            const u32x4 hdr = *reinterpret_cast<const u32x4*>(in);
+            const uint32_t nHiQ = __builtin_amdgcn_readfirstlane(hdr[0]), nPsqQ = __builtin_amdgcn_readfirstlane(hdr[1]);
+            const uint32_t nSteps = nHiQ + nPsqQ + __builtin_amdgcn_readfirstlane(hdr[2]);
+            const u32x4* ent = reinterpret_cast<const u32x4*>(in + 32);
+            i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            uint32_t j = 0;
+            while (j < nSteps) {
+                uint32_t* stage = sEnt[wave][(j >> 3) & 1];
+                if ((j & 7u) == 0) {  // a new stage of 8 steps of entries: 1 KiB, every lane a different 16 bytes
+                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = ent[8 * j + lane];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // a burst = two steps (8 loads in flight) unless the stage, the list or the high-byte section ends in between
+                const uint32_t k = j & 7u;
+                const bool two = k < 7 && j + 1 < nSteps && j + 1 != nHiQ;
+                const u32x4 e0 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e));
+                const u32x4 e1 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
+                i32x4 w[8];
+                if (j >= nHiQ && j < nHiQ + nPsqQ) {
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(sSlab + e0[pr] + laneOff);
+                } else {
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e0[pr] + laneOff));
+                }
+                if (two) {
+                    if (j + 1 >= nHiQ && j + 1 < nHiQ + nPsqQ) {
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(sSlab + e1[pr] + laneOff);
+                    } else {
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e1[pr] + laneOff));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // every load of the burst is requested before the first MFMA waits
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[pr], d[pr], 0, 0, 0);
+                if (two) {
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[4 + pr], d[pr], 0, 0, 0);
+                }
+                j += two ? 2u : 1u;
+                if (j == nHiQ) {  // the high-byte planes' sums count 256-fold
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
+                }
+            }
+            // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 p + u
+            const u32x4 dst = *reinterpret_cast<const u32x4*>(in + 8 + 4 * u);  // their output slots (asked for here: 4 registers less in the loop)
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const uint32_t a = pkAdd16(biasA, __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
+                const uint32_t b = pkAdd16(biasB, __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
+                const i16x2 zero = {0, 0}, top = {255, 255};
+                const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
+                const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero), top));
+                const uint32_t o = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));
+                if (dst[pr] != 0xFFFFFFFFu) {
+                    *reinterpret_cast<uint16_t*>(p.ftOut + size_t(dst[pr]) * kPairs + 64 * xcd + 8 * t + 2 * kb) =
+                        uint16_t((o & 0xFFu) | ((o >> 8) & 0xFF00u));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_ftx_build_table_kernel, dim3((kFtxRows * 64u + 255) / 256), dim3(256), 0, stream, thrU8, psqW, lut, rowS);
+    return hipGetLastError();
+}
+
+hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
+    const uint32_t nPersp = 2 * p.nPositions;
+    const uint32_t extractBlocks = min((p.nPositions + kWavesPerBlock - 1) / kWavesPerBlock, 256u * 16u);
+    hipLaunchKernelGGL(spx_ftx_extract_kernel, dim3(extractBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_rank_kernel, dim3((nPersp + 1023) / 1024), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_scatter_kernel, dim3((nPersp + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_pack_kernel, dim3((ftxMaxGroups(p.nPositions) + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream) {
+    const uint32_t gridBlocks = 256;
+    // more than 64 KiB of dynamic LDS has to be allowed once per device
+    static std::atomic<uint64_t> allowed{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return hipGetLastError();
+    if (!SPX_FTX_STATIC_LDS && !(allowed.load() >> (device & 63) & 1u)) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_ftx_gather_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kGatherLdsBytes));
+        if (attr != hipSuccess) return attr;
+        allowed.fetch_or(uint64_t(1) << (device & 63));
+    }
+    hipLaunchKernelGGL(spx_ftx_gather_kernel, dim3(gridBlocks), dim3(64 * kGatherWaves), SPX_FTX_STATIC_LDS ? 0 : kGatherLdsBytes, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace spx

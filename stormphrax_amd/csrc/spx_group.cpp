@@ -152,8 +152,14 @@ int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, 
     const int rc = forEachShard(group, params->n_games, "spx_group_selfplay_run", [&](size_t r, size_t lo, size_t hi) {
         spx_selfplay_params mine = *params;
         mine.n_games = uint32_t(hi - lo);
+        // the target itself is shared out: with fewer games wanted than members have seats, the members whose share
+        // is empty sit the run out instead of playing one game each beyond the target
         size_t tLo, tHi;
-        shardBounds(std::max<size_t>(params->target_games, active), r, active, tLo, tHi);
+        shardBounds(params->target_games, r, active, tLo, tHi);
+        if (tHi == tLo) {
+            part[r] = spx_selfplay_stats{};
+            return int(SPX_OK);
+        }
         mine.target_games = uint32_t(tHi - tLo);
         mine.seed = params->seed + r;
         const std::string path = (out_path && out_path[0]) ? std::string(out_path) + "." + std::to_string(r) + ".vf" : std::string();

@@ -23,6 +23,11 @@ struct FtTables {
     const uint32_t* lut;     // kLutWords threat LUT
     const uint64_t* deltaTab;  // kDeltaTabWords ray / knight masks + pseudo-attack sets (threat-delta derivation)
     const uint32_t* outlierTab;  // [kPsqRows][kOutlierCap] remainders of the near-compact rows, or nullptr (net has none)
+    // the matrix-pipe gather's tables (gatherFullMfma): plain i8, natural column order
+    const int8_t* rowI8;     // [64368 + 11264 + 1][1024]: threat rows; per piece-square row its i8 copy (compact), clamped copy
+                             // (near-compact) or low-byte plane (wide); one all-zero row
+    const int8_t* psqHi;     // [11264 + 1][1024]: high-byte planes of the piece-square rows (zero for compact rows); a zero row
+    bool mfmaGather;         // full refreshes gather on the matrix pipe (SPX_FT_MFMA_GATHER=1; rowI8 / psqHi are set then)
 };
 
 struct FtParams {
@@ -127,15 +132,14 @@ struct SeatState {          // one per seat
     uint32_t reserved;      // ... in which case the result adjudicated with that move (+ 1; 0 = none) stands
 };
 
-struct SelfplayCounters {   // one per run, device memory; a copy travels to the host after every ply
-    unsigned long long streamWords;  // 4-byte words of viriformat output written so far (ring position = mod ringWords)
+struct SelfplayCounters {   // one per run, device memory, shared by the halves; a copy travels to the host after every ply
     unsigned long long games, positions, outcomes[3], discarded;
     uint32_t started;       // games counted towards the target (begun and not discarded by the verification filter)
     uint32_t poolCursor;    // openings taken from the pool so far
     uint32_t poolSize;      // openings the host has published so far (ring: entry i lives at i % poolCap)
     uint32_t reserved;
 };
-static_assert(sizeof(SelfplayCounters) % 4 == 0 && sizeof(SelfplayCounters) / 4 < 63, "spx_game_status_kernel copies it word by word");
+static_assert(sizeof(SelfplayCounters) % 8 == 0 && sizeof(SelfplayCounters) / 8 < 62, "spx_game_status_kernel copies it in 64-bit words");
 
 struct GameStepParams {
     uint32_t nSeats;                // seats of this half; every pointer below is already offset to its first seat
@@ -160,8 +164,12 @@ struct GameStepParams {
     const uint64_t* poolSeeds;      // [poolCap]
     uint32_t poolCap;
     SelfplayCounters* counters;
+    // The output ring and its write position belong to THIS HALF alone: the halves run concurrently on two streams,
+    // and a position shared between them let one half's status kernel publish words the other half had reserved but not yet
+    // written. A half's status kernel runs behind its own step kernel, so every word below its snapshot of `streamWords` is there.
     uint32_t* ring;                 // [ringWords] viriformat output (page-locked host memory mapped into the device)
     uint32_t ringWords;
+    unsigned long long* streamWords;  // 4-byte words this half has written so far (ring position = mod ringWords)
     uint32_t* updParents;           // [nSeats] the half's materialising update, one record per seat: parent slot (the null
     uint32_t* updChildren;          //          slot for a new game or an idle seat), child slot (the seat's other slot) ...
     uint64_t* updPositions;         // [nSeats] ... and the seat's new current record (empty for an idle seat)
@@ -221,8 +229,9 @@ hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream);
-// hostStatus: device view of page-locked host memory laid out as { SelfplayCounters, uint32_t total }
-hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, void* hostStatus, hipStream_t stream);
+// hostStatus: device view of page-locked host memory laid out as { SelfplayCounters, u64 streamWords of the half, u64 total }
+hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, const unsigned long long* streamWords,
+                            void* hostStatus, hipStream_t stream);
 hipError_t launchAdjust(const AdjustParams& p, hipStream_t stream);
 hipError_t launchSlotAct(const SlotActParams& p, uint32_t gridBlocks, hipStream_t stream);
 uint32_t ftWavesPerBlock();

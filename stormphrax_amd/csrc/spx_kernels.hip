@@ -35,8 +35,16 @@ namespace spx {
 // kNear: the net has near-compact piece-square rows (FtTables::outlierTab): they take the 1 KiB path, their wide weights'
 //        remainders are summed through 4 KiB of LDS per wave (buildFullLists). Nets without such rows run the kNear = false
 //        instantiation - the same code as before the feature existed.
-template <bool kNear>
-__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
+// kMfma: the gather runs on the matrix pipe (gatherFullMfma: one v_mfma_i32_16x16x64_i8 widens and adds up four gathered rows;
+//        plain-i8 row table, lane owns columns 256 q + 16 (lane & 15) + 4 (lane >> 4) + r). Round 4, opt-in (SPX_FT_MFMA_GATHER=1):
+//        VALU instructions per perspective 1 407 -> ~750, kernel time unchanged (0.419 vs 0.421 ms at 6 waves/SIMD x 4 loads; 5 x 8:
+//        0.472 with spills, 4 x 8: 0.436, 4 x 16: 0.502, 3 x 16: 0.460; profiles/r04_ab_ft_mfma_gather.txt) - this kernel waits for
+//        its row loads, not for the VALU. The column-sliced pipeline (spx_ftx.hip) is where the idea pays.
+#ifndef SPX_FT_MFMA_WAVES_PER_SIMD
+#define SPX_FT_MFMA_WAVES_PER_SIMD 6
+#endif
+template <bool kNear, bool kMfma>
+__global__ __launch_bounds__(64 * kWavesPerBlock, kMfma ? (kNear ? 4 : SPX_FT_MFMA_WAVES_PER_SIMD) : SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ __align__(16) int32_t sNear[kNear ? kWavesPerBlock : 1][kNear ? int(kL1) : 4];  // per-column remainder sums
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
@@ -85,14 +93,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        const bool hasNear = buildFullLists<kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
-                                                   p.t.outlierTab, sNear[kNear ? wave : 0]);
+        const bool hasNear = buildFullLists<kNear, kMfma>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
+                                                          p.t.outlierTab, sNear[kNear ? wave : 0]);
         uint32_t acc[8];
-        gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
+        if constexpr (kMfma) {
+            gatherFullMfma(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
+        } else {
+            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
+        }
 
         if (p.accOut) {
             const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
-            storeAcc(p.accOut, slot, c, lane, acc);
+            if constexpr (kMfma) {
+                storeAccMfma(p.accOut, slot, c, lane, acc);
+            } else {
+                storeAcc(p.accOut, slot, c, lane, acc);
+            }
             if (c == 0 && lane < 8) {  // the record travels with the slot (parent of later incremental updates)
                 reinterpret_cast<uint32_t*>(p.slotRecords + size_t(slot) * 32)[lane] =
                     reinterpret_cast<const uint32_t*>(rec)[lane];
@@ -100,7 +116,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void sp
         }
         if (p.ftOut) {
             const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
-            *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            if constexpr (kMfma) {
+                storeActivationsMfma(p.ftOut + size_t(posIdx) * kL1 + half * kPairs, lane, acc);
+            } else {
+                *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
+            }
         }
     }
 }
@@ -1324,10 +1344,17 @@ hipError_t launchFtTeam(const FtParams& p, uint32_t gridBlocks, hipStream_t stre
 }
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
-    if (p.t.outlierTab) {
-        hipLaunchKernelGGL((spx_ft_kernel<true>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    const dim3 grid(gridBlocks), block(64 * kWavesPerBlock);
+    if (!p.t.mfmaGather) {
+        if (p.t.outlierTab) {
+            hipLaunchKernelGGL((spx_ft_kernel<true, false>), grid, block, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((spx_ft_kernel<false, false>), grid, block, 0, stream, p);
+        }
+    } else if (p.t.outlierTab) {  // SPX_FT_MFMA_GATHER=1
+        hipLaunchKernelGGL((spx_ft_kernel<true, true>), grid, block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((spx_ft_kernel<false>), dim3(gridBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((spx_ft_kernel<false, true>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }

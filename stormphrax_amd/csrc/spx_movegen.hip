@@ -421,7 +421,7 @@ __device__ void writeGame(const GameStepParams& p, uint32_t g, uint32_t lane, co
     unsigned long long base = 0;
     if (lane == 0) {
         SelfplayCounters* c = p.counters;
-        base = atomicAdd(&c->streamWords, static_cast<unsigned long long>(8u + nWords + 1u));
+        base = atomicAdd(p.streamWords, static_cast<unsigned long long>(8u + nWords + 1u));
         atomicAdd(&c->games, 1ull);
         atomicAdd(&c->positions, static_cast<unsigned long long>(nWords));
         atomicAdd(&c->outcomes[outcome], 1ull);
@@ -573,7 +573,10 @@ __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
         if (lane == 0) {
             SelfplayCounters* c = p.counters;
             if (discard) atomicAdd(&c->discarded, 1ull);
-            const bool ticket = discard || atomicAdd(&c->started, 1u) < p.targetGames;
+            // (a plain look first: once the target is reached the drained seats stop adding to the counter every ply - it could
+            // wrap on a very long tail - and stop queueing on one global atomic)
+            const bool ticket = discard || (*reinterpret_cast<volatile uint32_t*>(&c->started) < p.targetGames &&
+                                            atomicAdd(&c->started, 1u) < p.targetGames);
             if (ticket) {
                 const uint32_t k = atomicAdd(&c->poolCursor, 1u);
                 if (k < *reinterpret_cast<volatile uint32_t*>(&c->poolSize)) claim = k;
@@ -709,18 +712,26 @@ hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream) {
 
 // End of a half's ply: the run-wide counters and this ply's child count go to the host (page-locked memory mapped into the
 // device: no blit kernels on the stream) and the child cursor is zeroed for the half's next move generation.
-__global__ __launch_bounds__(64) void spx_game_status_kernel(const SelfplayCounters* counters, uint32_t* total, uint32_t* hostStatus) {
-    constexpr uint32_t kWords = sizeof(SelfplayCounters) / 4;
+// The shared counters are copied in 64-bit words with 64-bit atomic loads (the other half's step kernel may be adding to
+// them: a word-by-word copy could tear a counter whose low word wraps); they only grow, the host takes the element-wise maximum.
+__global__ __launch_bounds__(64) void spx_game_status_kernel(const SelfplayCounters* counters, uint32_t* total,
+                                                             const unsigned long long* streamWords, unsigned long long* hostStatus) {
+    constexpr uint32_t kWords = sizeof(SelfplayCounters) / 8;
     const uint32_t t = threadIdx.x;
-    if (t < kWords) hostStatus[t] = reinterpret_cast<const uint32_t*>(counters)[t];
-    if (t == kWords) {
-        hostStatus[kWords] = *total;
+    if (t < kWords) {
+        hostStatus[t] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(counters) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == kWords) hostStatus[kWords] = *streamWords;  // this half's own: its step kernel is done (same stream)
+    if (t == kWords + 1) {
+        hostStatus[kWords + 1] = *total;
         *total = 0;
     }
 }
 
-hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, void* hostStatus, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_game_status_kernel, dim3(1), dim3(64), 0, stream, counters, total, static_cast<uint32_t*>(hostStatus));
+hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, const unsigned long long* streamWords,
+                            void* hostStatus, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_game_status_kernel, dim3(1), dim3(64), 0, stream, counters, total, streamWords,
+                       static_cast<unsigned long long*>(hostStatus));
     return hipGetLastError();
 }
 

@@ -801,9 +801,10 @@ namespace {
 
 // One half of the seats: its own child buffers, update list and status mirror. The two halves run on the context's two
 // lanes and are both kept in flight: the small kernels of one half's ply overlap the other half's update kernel.
-struct HalfStatus {              // what the host reads back per ply (page-locked)
+struct HalfStatus {              // what the host reads back per ply (page-locked); 64-bit words, as spx_game_status_kernel writes them
     SelfplayCounters counters;   // run-wide counters as of the end of this half's step kernel
-    uint32_t total;              // children generated this ply (must fit `cap`)
+    unsigned long long streamWords;  // words this half has written to ITS ring so far
+    unsigned long long total;    // children generated this ply (must fit `cap`)
 };
 
 constexpr uint32_t kPliesInFlight = 2;  // direct launches, per half: the host enqueues this far ahead of the results it has seen
@@ -828,6 +829,11 @@ struct DeviceHalf {
     uint64_t enqueued = 0, acked = 0;  // plies enqueued / plies whose results the host has read
     hipGraphExec_t graph[kGraphsInFlight] = {};  // graph mode: kGraphPlies consecutive plies of this half each, captured once
     uint32_t index = 0;              // which lane of the context this half runs on
+    // this half's output ring (page-locked host memory the step kernel writes through its device mapping) and position
+    uint32_t *hRing = nullptr, *dRing = nullptr;
+    uint32_t ringWords = 0;
+    unsigned long long* dStreamWords = nullptr;
+    uint64_t streamWords = 0, consumedWords = 0;  // newest snapshot seen / words already written to the file
 };
 
 // The games live on the device: per ply and half the host enqueues one fixed chain of launches and, kPliesInFlight plies
@@ -898,20 +904,17 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     auto* hPoolRecords = pinned.get<spx_packed_pos>(16384);
     auto* hPoolSeeds = pinned.get<uint64_t>(16384);
     auto* hPoolSize = pinned.get<uint32_t>(1);
-    // the output ring: page-locked host memory the step kernel writes through its device mapping
-    uint32_t* hRing = nullptr;
-    uint32_t* dRing = nullptr;
-    struct RingCloser {
-        uint32_t*& r;
-        ~RingCloser() {
-            if (r) (void)hipHostFree(r);
-        }
-    } ringCloser{hRing};
-    bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dState && dInitial && dGameMoves && dKeys &&
-              dPoolRecords && dPoolSeeds && dCounters && hPoolRecords && hPoolSeeds && hPoolSize &&
-              hipHostMalloc(reinterpret_cast<void**>(&hRing), size_t(ringWords) * 4, hipHostMallocMapped) == hipSuccess &&
-              hipHostGetDevicePointer(reinterpret_cast<void**>(&dRing), hRing, 0) == hipSuccess;
     std::vector<DeviceHalf> halves(nHalves);
+    struct RingCloser {  // the halves' output rings
+        std::vector<DeviceHalf>& h;
+        ~RingCloser() {
+            for (DeviceHalf& hf : h) {
+                if (hf.hRing) (void)hipHostFree(hf.hRing);
+            }
+        }
+    } ringCloser{halves};
+    bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dState && dInitial && dGameMoves && dKeys &&
+              dPoolRecords && dPoolSeeds && dCounters && hPoolRecords && hPoolSeeds && hPoolSize;
     for (uint32_t h = 0; h < nHalves && ok; ++h) {
         DeviceHalf& hf = halves[h];
         hf.index = h;
@@ -928,7 +931,12 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         hf.dUpdChildren = dev.get<uint32_t>(seats);
         hf.dUpdPositions = dev.get<uint64_t>(size_t(seats) * 4);
         hf.hStatus = pinned.getMapped<HalfStatus>(kStatusSlots, &hf.dStatus);
-        ok = hf.hStatus && hf.dStatus && hf.dTotal && hipMemset(hf.dTotal, 0, 4) == hipSuccess;
+        hf.ringWords = ringWords;
+        hf.dStreamWords = dev.get<unsigned long long>(1);
+        ok = hf.hStatus && hf.dStatus && hf.dTotal && hf.dStreamWords && hipMemset(hf.dTotal, 0, 4) == hipSuccess &&
+             hipMemset(hf.dStreamWords, 0, 8) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&hf.hRing), size_t(ringWords) * 4, hipHostMallocMapped) == hipSuccess &&
+             hipHostGetDevicePointer(reinterpret_cast<void**>(&hf.dRing), hf.hRing, 0) == hipSuccess;
         ok = ok && hf.dChildren && hf.dMoves && hf.dParents && hf.dEvals && hf.dTotal && hf.dUpdParents && hf.dUpdChildren &&
              hf.dUpdPositions && hf.hStatus && seats <= ctxMaxBatch(ctx);
     }
@@ -977,7 +985,6 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     const auto t0 = std::chrono::steady_clock::now();
     double gpuWait = 0.0, enqueueSeconds = 0.0;
     SelfplayCounters latest{};       // newest counters seen
-    uint64_t consumedWords = 0;      // ring words already written to the file
     uint32_t published = 0;          // openings handed to the device so far
     uint64_t evals = 0, steps = 0;
 
@@ -1058,8 +1065,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         gp.poolSeeds = dPoolSeeds;
         gp.poolCap = poolCap;
         gp.counters = dCounters;
-        gp.ring = dRing;
-        gp.ringWords = ringWords;
+        gp.ring = hf.dRing;
+        gp.ringWords = hf.ringWords;
+        gp.streamWords = hf.dStreamWords;
         gp.updParents = hf.dUpdParents;
         gp.updChildren = hf.dUpdChildren;
         gp.updPositions = hf.dUpdPositions;
@@ -1068,7 +1076,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         // the new game's opening (null slot -> rebuilt from scratch by the update kernel)
         r = spx_acc_update_device(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, seats, s);
         if (r != SPX_OK) return r;
-        SPX_SP_HIP(launchGameStatus(dCounters, hf.dTotal, hf.dStatus + statusSlot, s));
+        SPX_SP_HIP(launchGameStatus(dCounters, hf.dTotal, hf.dStreamWords, hf.dStatus + statusSlot, s));
         return SPX_OK;
     };
     // The per-ply chain is a fixed sequence of ~9 launches with fixed arguments: a launch-bound inner loop at small seat
@@ -1149,7 +1157,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
             evals += st.total;
             // every counter only grows: the newest view is the element-wise maximum of the halves' snapshots
             const SelfplayCounters& c = st.counters;
-            latest.streamWords = std::max(latest.streamWords, c.streamWords);
+            hf.streamWords = std::max<uint64_t>(hf.streamWords, st.streamWords);
             latest.games = std::max(latest.games, c.games);
             latest.positions = std::max(latest.positions, c.positions);
             for (int o = 0; o < 3; ++o) latest.outcomes[o] = std::max(latest.outcomes[o], c.outcomes[o]);
@@ -1161,18 +1169,20 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
             setError("spx_selfplay_run: the opening pool ran dry (internal: the publishing margin was too small)");
             return SPX_ERR_CAPACITY;
         }
-        if (latest.streamWords - consumedWords > ringWords) {
+        // only THIS half's ring, up to the position its own status kernel reported behind its own step kernel (the event waited
+        // for above): every word below it has been written. (Games of the two halves interleave in the file in any order.)
+        if (hf.streamWords - hf.consumedWords > hf.ringWords) {
             setError("spx_selfplay_run: the output ring overflowed");
             return SPX_ERR_CAPACITY;
         }
-        while (consumedWords < latest.streamWords) {
-            const uint32_t at = uint32_t(consumedWords % ringWords);
-            const uint64_t m = std::min<uint64_t>(latest.streamWords - consumedWords, ringWords - at);
-            if (out && std::fwrite(hRing + at, 4, size_t(m), out) != size_t(m)) {
+        while (hf.consumedWords < hf.streamWords) {
+            const uint32_t at = uint32_t(hf.consumedWords % hf.ringWords);
+            const uint64_t m = std::min<uint64_t>(hf.streamWords - hf.consumedWords, hf.ringWords - at);
+            if (out && std::fwrite(hf.hRing + at, 4, size_t(m), out) != size_t(m)) {
                 setError("spx_selfplay_run: short write to the output file");
                 return SPX_ERR_INVALID_ARG;
             }
-            consumedWords += m;
+            hf.consumedWords += m;
         }
         return SPX_OK;
     };

@@ -22,7 +22,8 @@ from . import nnue
 
 
 class Trace:
-    def __init__(self, path):
+    def __init__(self, path=None, lines=None):
+        """`path`: a trace file (plain or .gz); or `lines`: the trace as an iterable of text lines."""
         self.root_fen = None
         self.parent = [-1]          # node -> parent node (node 0 = root)
         self.depth = [0]
@@ -54,7 +55,11 @@ class Trace:
                     enter_null()
                 assert stm[stack[-1]] == side, "trace: side to move does not fit the stack"
 
-        with (gzip.open(path, "rt") if str(path).endswith(".gz") else open(path)) as f:
+        import contextlib
+
+        source = (contextlib.nullcontext(lines) if lines is not None
+                  else gzip.open(path, "rt") if str(path).endswith(".gz") else open(path))
+        with source as f:
             for line in f:
                 t = line.split()
                 if not t or t[0].startswith("#"):
@@ -126,3 +131,59 @@ def replay_native(state, trace, positions=None):
     nodes = np.array([e[0] for e in trace.evals], dtype=np.uint32)
     got, ms = state.replay_tree(pos, parents.astype(np.uint32), nodes)
     return got, np.array([e[1] for e in trace.evals], dtype=np.int32), ms
+
+
+class Forest:
+    """Many recorded search trees as ONE tree under a virtual root, for spx_acc_replay_tree (BASELINE config 3 in the shape
+    that thousands of concurrent searches give: VERDICT r3 item 4). Node 0 is the virtual root (the first tree's root
+    position; never evaluated); tree t's root is a child of node 0 whose board has nothing to do with its parent's - the
+    update kernels rebuild such a child from scratch, exactly what NnueState::reset does. Stored as a compressed .npz of flat
+    arrays (tests/golden/forest_search_*.npz, written by tests/golden/make_golden.py `forest`): `parent` (node -> parent),
+    `move` (6-byte UCI text per node: empty = a tree's root, "0000" = a null move), `root_fen`, `eval_node` / `eval_value`
+    (the reference's NnueState::evaluate at those nodes)."""
+
+    def __init__(self, path):
+        z = np.load(path, allow_pickle=False)
+        self.parent = z["parent"].astype(np.uint32)
+        self.move = np.ascontiguousarray(z["move"])
+        self.root_fens = [str(f) for f in z["root_fen"]]
+        self.eval_node = z["eval_node"].astype(np.uint32)
+        self.eval_value = z["eval_value"].astype(np.int32)
+        self.depth = z["depth"].astype(np.int32)
+        self.n_nodes = len(self.parent)
+        self.n_trees = len(self.root_fens)
+
+    @staticmethod
+    def build(traces):
+        """Flat arrays of a list of Trace objects (the recording side)."""
+        parent, move, depth, eval_node, eval_value, fens = [0], [b""], [0], [], [], []
+        for tr in traces:
+            base = len(parent)
+            fens.append(tr.root_fen)
+            for k in range(tr.n_nodes):
+                parent.append(0 if k == 0 else base + tr.parent[k])
+                move.append(b"" if k == 0 else b"0000" if tr.null[k] else tr.moves[k].encode())
+                depth.append(1 + tr.depth[k])
+            eval_node += [base + e[0] for e in tr.evals]
+            eval_value += [e[1] for e in tr.evals]
+        return {"parent": np.asarray(parent, dtype=np.uint32), "move": np.asarray(move, dtype="S6"),
+                "depth": np.asarray(depth, dtype=np.int16), "root_fen": np.asarray(fens),
+                "eval_node": np.asarray(eval_node, dtype=np.uint32), "eval_value": np.asarray(eval_value, dtype=np.int32)}
+
+    def positions(self):
+        """Packed record of every node: one native call (spx_tree_expand_uci)."""
+        from . import _lib
+
+        roots = nnue.positions_from_fens(self.root_fens)
+        all_roots = np.concatenate([roots[:1], roots])  # node 0, the virtual root, borrows the first tree's position
+        out = np.zeros(self.n_nodes, dtype=nnue.PACKED_DTYPE)
+        _lib.check(_lib.load().spx_tree_expand_uci(all_roots.ctypes.data, len(all_roots), self.parent.ctypes.data,
+                                                    self.move.ctypes.data, self.n_nodes, out.ctypes.data))
+        return out
+
+
+def replay_forest(state, forest, positions=None):
+    """Every tree of `forest` at once through ONE spx_acc_replay_tree call. -> (gpu values, reference values, device ms)"""
+    pos = forest.positions() if positions is None else positions
+    got, ms = state.replay_tree(pos, forest.parent, forest.eval_node)
+    return got, forest.eval_value, ms

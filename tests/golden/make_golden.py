@@ -130,6 +130,34 @@ def make_search_trace():
           sum(1 for ln in out if ln.startswith("PUSH")), "moves")
 
 
+def make_forest(n_trees=256, evals_per_tree=1024):
+    """BASELINE config 3 in the shape concurrent searches give: the reference's own alpha-beta search
+    (`searchtrace`, depth <= 12) recorded from `n_trees` different roots - random playouts of 6-60 plies, every second one
+    double Chess960 -, the first `evals_per_tree` NnueState::evaluate calls of each with every applyMove / pop in between,
+    stored as ONE forest of flat arrays (stormphrax_amd.trace.Forest)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import stormphrax_amd as sp
+    from stormphrax_amd.trace import Forest, Trace
+
+    roots = sp.random_positions(n_trees, seed=777, min_ply=6, max_ply=60, dfrc_every=2)
+    probe = Probe(PROBES["tame"])
+    traces = []
+    for i in range(n_trees):
+        fen = sp.position_to_fen(roots[i])
+        out = probe.cmd(f"searchtrace {evals_per_tree} 12 60000 {fen}")
+        tr = Trace(lines=out)
+        assert tr.root_fen and len(tr.evals) > 0, (i, fen, out[:3])
+        traces.append(tr)
+    probe.close()
+    arrays = Forest.build(traces)
+    path = os.path.join(HERE, f"forest_search_{n_trees}x{evals_per_tree}_tame.npz")
+    np.savez_compressed(path, **arrays)
+    print("forest written:", path, os.path.getsize(path), "bytes;", len(arrays["parent"]), "nodes,", len(arrays["eval_node"]), "evals,",
+          "deepest node", int(arrays["depth"].max()))
+
+
 def make_wire():
     """Wire-format and WDL goldens: bytes written by the reference's own marlinformat / viriformat code."""
     import random
@@ -260,6 +288,8 @@ def main():
         return make_big_trace()
     if sys.argv[1:] == ["searchtrace"]:
         return make_search_trace()
+    if sys.argv[1:] == ["forest"]:
+        return make_forest()
     probes = {k: Probe(v) for k, v in PROBES.items()}
     fens = [(STARTPOS, "startpos")]
     fens += [(f.strip(), "bench") for f in open(os.path.join(HERE, "bench_fens.txt")) if f.strip()]

@@ -90,6 +90,14 @@ def test_two_rank_control_flow_on_one_gpu(script, tmp_path):
     if script == "bench":
         assert line["bit_exact_sample"] is True and line["config"]["gathered_scores_ok"] is True
         assert line["value"] > 1e6 and "cpu_baseline" not in line
+        # the N > 1 line carries BASELINE configs[3] (self-play sharded over the ranks) and the incremental leg
+        sec = line["secondary"]
+        c4 = sec["config4_selfplay"]
+        assert c4["n_gpus"] == 2 and c4["value"] > 1e6 and c4["concurrent_games"] == 4096 and c4["concurrent_games_per_gpu"] == 2048
+        assert len(c4["leaf_evals_per_sec_per_rank"]) == 2 and c4["games"] >= 32768
+        assert sec["config4_selfplay_4096_games_per_gpu"]["concurrent_games"] == 8192
+        inc = sec["incremental"]
+        assert inc["n_gpus"] == 2 and inc["bit_exact_vs_full_refresh"] is True and len(inc["updates_plus_evals_per_sec_per_rank"]) == 2
     else:
         assert line["games"] == 1400 and sum(line["outcomes_white_loss_draw_win"]) == 1400
         assert os.path.getsize(tmp_path / "sp.0.vf") > 0 and os.path.getsize(tmp_path / "sp.1.vf") > 0

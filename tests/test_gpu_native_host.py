@@ -82,3 +82,56 @@ def test_apply_immediately_keeps_the_datagen_invariant(preset, seed, fen):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "1500 moves" in out.stdout and " 0 mismatches" in out.stdout
     print(out.stdout.strip())
+
+
+# ---- the reference ENGINE on the GPU evaluator (oracle/ref_gpu.cpp) ----
+REF_GPU = os.path.join(ROOT, "oracle", "_ref", "sp_ref_gpu_tame")
+needs_ref_gpu = pytest.mark.skipif(not os.path.exists(REF_GPU), reason="oracle/_ref/sp_ref_gpu_tame is built by `make -C oracle refgpu` "
+                                   "where /root/reference exists and travels to the GPU box in oracle/_ref/")
+
+
+def _ref_gpu(*args, stdin=None, timeout=900):
+    out = subprocess.run([REF_GPU, *args], input=stdin, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout
+
+
+def _bench_nodes(text):
+    line = [ln for ln in text.splitlines() if ln.endswith(" nps") and " nodes " in ln and not ln.startswith("info")][-1]
+    return int(line.split()[0])
+
+
+@needs_ref_gpu
+def test_reference_search_counts_the_same_nodes_on_gpu_evaluations():
+    """Stormphrax's own objects (search, move ordering, TT, everything) linked against libspx_nnue.so, eval::NnueState's
+    entry points forwarded to include/spx_nnue.hpp by link-time interposition - no reference source touched. The
+    reference's only functional test is the node count of `bench` (src/bench.cpp:95-150: fixed-depth searches of 52
+    positions): a search is deterministic in its evaluations, so the count with every evaluation made on the GPU (lazy
+    accumulator stack: push / pop / evaluate with pending plies, null moves) must equal the CPU build's; in `both` mode every
+    GPU value is also compared with the reference's own NnueState::evaluate on the spot."""
+    both = _ref_gpu("bench", "4", "both")
+    assert _bench_nodes(both) == _bench_nodes(_ref_gpu("bench", "4", "cpu")) == 129771
+    report = [ln for ln in both.splitlines() if ln.startswith("# bench:")][-1]
+    print(report)
+    assert "checked against the CPU value: 0 mismatches" in report and "libspx_nnue (GPU)" in report
+    assert int(report.split()[2]) > 50000  # evaluations
+    gpu6, cpu6 = _ref_gpu("bench", "6", "gpu"), _ref_gpu("bench", "6", "cpu")
+    assert _bench_nodes(gpu6) == _bench_nodes(cpu6) == 469287
+    print([ln for ln in gpu6.splitlines() if ln.startswith("# bench:")][-1])
+
+
+@needs_ref_gpu
+def test_reference_raweval_and_datagen_invariant_on_the_gpu_state():
+    """`raweval` (src/uci.cpp:797-800: eval::staticEvalOnce) of the golden FENs through the reference binary with the GPU
+    evaluator behind it = the CPU build's output = the goldens; and datagen's step (src/datagen/datagen.cpp:257-262):
+    NnueState::applyImmediately fed with the REFERENCE'S OWN UpdateContext (converted field by field to spx_move_delta,
+    applied by spx_acc_update_observed) keeps staticEvalOnce(pos) == staticEval(pos, nnueState) over 1 500 plies of
+    standard and double-Chess960 games."""
+    recs = [json.loads(line) for line in open(os.path.join(GOLDEN, "evals.jsonl"))][:600]
+    fens = "".join(r["fen"] + "\n" for r in recs)
+    gpu = [int(v) for v in _ref_gpu("raweval", "gpu", stdin=fens).splitlines() if not v.startswith("#")]
+    cpu = [int(v) for v in _ref_gpu("raweval", "cpu", stdin=fens).splitlines() if not v.startswith("#")]
+    assert gpu == cpu == [max(-24999, min(24999, r["tame"])) for r in recs]
+    out = _ref_gpu("game", "1500", "11")
+    print(out.splitlines()[0])
+    assert "broken 0 times on the GPU state; GPU value != CPU value 0 times" in out and "1500 plies" in out

@@ -333,3 +333,98 @@ def test_pipelined_async_calls_equal_the_synchronous_path(sp, oracle, net_blob):
         st.close()
         for q in ptrs:
             lib.spx_host_free(q)
+
+
+def _state_with_env(sp, blob, env, **kw):
+    """A context created under extra environment switches (the library reads them in spx_ctx_create)."""
+    import os
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return sp.NnueState(sp.Network(blob), device=0, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("preset", ["tame", "extreme", "mixed", "near", "realistic"])
+def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net_blob, preset):
+    """SPX_FTX=1: big full refreshes take the column-sliced pipeline of spx_ftx.hip (extraction pass, counting sort by
+    (king bucket, list length), plan, pack, gather on the matrix pipe with the bucket's piece-square slab in LDS). Same sums
+    mod 2^16, so the evaluations must equal spx_ft_kernel's and the oracle's bit for bit: batches at the pipeline's threshold,
+    ragged ones, more than one pass (> 65 536 positions), nets with wide rows (low / high byte planes) and near-compact rows
+    (taken as wide rows here), synchronous and pipelined calls."""
+    blob = net_blob(preset)
+    pos = sp.random_positions(70001, seed=909, min_ply=0, max_ply=160, dfrc_every=3)
+    with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 17) as plain, \
+            _state_with_env(sp, blob, {"SPX_FTX": "1"}, max_batch=1 << 17) as sliced:
+        want = plain.evaluate_once(pos)
+        oracle.use(blob, preset)
+        mail, stm = sp.positions_to_mailboxes(pos[:3000])
+        assert np.array_equal(want[:3000], oracle.eval_mailboxes(mail, stm))
+        for n in (70001, 8192, 20001, 65536, 65537, 100):  # (100: below the threshold, the one-kernel path of the same context)
+            got = sliced.evaluate_once(pos[:n])
+            bad = np.nonzero(got != want[:n])[0]
+            assert bad.size == 0, f"n={n}: {bad.size} mismatches, first at {bad[0]}: {sp.position_to_fen(pos[bad[0]])}"
+        # activations, byte for byte
+        sliced.evaluate_once(pos[:9000])
+        a = sliced.debug_ft(9000)
+        plain.evaluate_once(pos[:9000])
+        assert np.array_equal(a, plain.debug_ft(9000))
+        # pipelined calls: preparation on the ring's streams, several batches in flight (inputs / outputs in page-locked host
+        # memory the device addresses directly, as in test_pipelined_async_calls_equal_the_synchronous_path)
+        import ctypes
+
+        from stormphrax_amd import _lib
+
+        lib = _lib.load()
+        sizes, offs = (30000, 9000, 40000, 12345, 30000), (0, 1000, 2000, 3000, 4000)
+        pin = lib.spx_host_alloc(len(pos) * 32)
+        pouts = [lib.spx_host_alloc(n * 4) for n in sizes]
+        assert pin and all(pouts)
+        try:
+            np.ctypeslib.as_array((ctypes.c_uint8 * (len(pos) * 32)).from_address(pin))[:] = pos.view(np.uint8).reshape(-1)
+            outs = [np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(q)) for n, q in zip(sizes, pouts)]
+            for rep in range(2):
+                for o in outs:
+                    o[:] = -1
+                for o, off in zip(outs, offs):
+                    assert sliced.evaluate_once_device_async(pin + 32 * off, len(o), o.ctypes.data)
+                sliced.synchronize()
+                for o, off in zip(outs, offs):
+                    assert np.array_equal(o, want[off:off + len(o)]), (rep, off)
+        finally:
+            for q in [pin] + pouts:
+                lib.spx_host_free(q)
+
+
+@pytest.mark.parametrize("preset", ["tame", "extreme", "near", "realistic"])
+def test_matrix_pipe_gather_of_the_one_kernel_path(sp, oracle, net_blob, preset):
+    """SPX_FT_MFMA_GATHER=1: spx_ft_kernel adds its rows up on the matrix pipe (one v_mfma_i32_16x16x64_i8 per four gathered
+    rows x 256 columns, plain-i8 row table, high-byte planes for wide piece-square rows) - evaluations, activations and the
+    accumulators it leaves in the arena equal the VALU gather's and the oracle's."""
+    blob = net_blob(preset)
+    pos = sp.random_positions(6000, seed=910, min_ply=0, max_ply=160, dfrc_every=3)
+    oracle.use(blob, preset)
+    mail, stm = sp.positions_to_mailboxes(pos)
+    want = oracle.eval_mailboxes(mail, stm)
+    with _state_with_env(sp, blob, {"SPX_FT_MFMA_GATHER": "1"}, max_batch=8192) as st, \
+            sp.NnueState(sp.Network(blob), device=0, max_batch=8192) as plain:
+        for n in (6000, 513, 1500):
+            assert np.array_equal(st.evaluate_once(pos[:n]), want[:n]), n
+        st.evaluate_once(pos)
+        plain.evaluate_once(pos)
+        assert np.array_equal(st.debug_ft(6000), plain.debug_ft(6000))
+        slots = np.arange(6000, dtype=np.uint32)
+        st.reserve_slots(12000)
+        st.reset(pos, slots)
+        assert np.array_equal(st.evaluate(slots), want)
+        nxt, moved = sp.random_successors(pos, seed=6)  # incremental updates on top of the accumulators it wrote
+        idx = np.nonzero(moved)[0]
+        got = st.update_evaluate(slots[idx], slots[idx] + 6000, nxt[idx])
+        m2, s2 = sp.positions_to_mailboxes(nxt[idx])
+        assert np.array_equal(got, oracle.eval_mailboxes(m2, s2))
