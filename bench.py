@@ -515,6 +515,30 @@ def config3_leg(sp, net, device, name="trace_startpos_tame_64k.txt.gz",
         st.close()
 
 
+def forest_leg(sp, net, device, name="forest_search_256x1024_tame.npz"):
+    """secondary.config3_alpha_beta_replay_x256: 256 alpha-beta search trees of the reference (its own
+    search recorded from 256 different roots, tests/golden/make_golden.py `forest`) in flight AT ONCE through ONE
+    spx_acc_replay_tree call - the shape thousands of concurrent searches give the evaluator, where the single tree of
+    config3_alpha_beta_replay is a latency figure. Every EVAL must equal what the reference's NnueState::evaluate recorded."""
+    from stormphrax_amd.trace import Forest, replay_forest
+
+    forest = Forest(os.path.join(ROOT, "tests", "golden", name))
+    st = sp.NnueState(net, device=device, max_batch=1 << 17)
+    try:
+        pos = forest.positions()
+        runs = [replay_forest(st, forest, pos) for _ in range(3)]
+        ms = min(r[2] for r in runs)
+        ok = all(bool(np.array_equal(r[0], forest.eval_value)) for r in runs)
+        work = forest.n_nodes - 1 + len(forest.eval_node)
+        return {"value": work / (ms / 1e3), "unit": "updates+evals/s", "device_ms": ms, "trees": forest.n_trees,
+                "updates": forest.n_nodes - 1, "evals": len(forest.eval_node), "tree_levels": int(forest.depth.max()),
+                "every_eval_equals_the_reference": ok,
+                "trace": f"tests/golden/{name} (the reference's own alpha-beta search, depth <= 12, from {forest.n_trees} roots: "
+                         "random playouts of 6-60 plies, every second one double Chess960)"}
+    finally:
+        st.close()
+
+
 def selfplay_leg(sp, net, device, seats=4096, games=32768, seed=1):
     """secondary.config4_selfplay (BASELINE configs[3] shape on one GPU): `seats` concurrent games living on the device, every
     legal move of every game evaluated per ply (eval-only children), the reference's datagen rules in the step kernel; games
@@ -611,6 +635,7 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
         run("config3_alpha_beta_replay", lambda: config3_leg(
             sp, net, device, "trace_search_startpos_tame_64k.txt.gz",
             "the reference's own alpha-beta search, depth <= 12 from the start position, recorded through link-time interposition"))
+        run("config3_alpha_beta_replay_x256", lambda: forest_leg(sp, net, device))
     run("config4_selfplay", lambda: selfplay_leg(sp, net, device))
     return out
 

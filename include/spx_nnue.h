@@ -74,13 +74,6 @@ uint64_t spx_net_digest(const spx_net* net);
  * the rest (2 KiB i16 rows). See spx_ctx_compact_psq_rows / spx_ctx_near_psq_rows for what a given context actually did. */
 int spx_net_psq_row_classes(const spx_net* net, uint32_t* fit_i8, uint32_t* near_compact, uint32_t* wide);
 
-/* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
- * 2 extreme (i16 accumulator wraps too) - uniform random weights; 3 realistic: the weight SHAPE of a trained QA = 255 net
- * (src/eval/arch.h:36-50) - heavy-tailed piece-square rows of which about 40 % fit i8, 40 % have a handful of weights
- * beyond it and 20 % are densely wide, Laplace-like i8 threat and L1 weights - so that the measured rate does not rest on
- * every piece-square row being compact. Writes spx_synth_net_bytes() bytes. */
-size_t spx_synth_net_bytes(void);
-int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
 uint64_t spx_fnv1a64(const void* data, size_t nbytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -232,7 +225,11 @@ enum {
     /* datagen's view of a score (Searcher::runDatagenSearch, src/search.cpp:237-238), applied after the stages above:
      * WHITE_POV negates the evals of positions with black to move; WDL maps the score through wdl::normalizeScore
      * (src/wdl.cpp:28-79: f64 cubic in Position::classicalMaterial of the record, std::round; zero and decisive scores
-     * pass through) - the value the reference's adjudication counters compare (src/datagen/datagen.cpp:224-252). */
+     * pass through) - the value the reference's adjudication counters compare (src/datagen/datagen.cpp:224-252).
+     * Parity target of the f64 part: the cubic is evaluated with FUSED multiply-adds, as the reference's clang x86-64 release
+     * builds contract it (-ffp-contract=on is that compiler's default); the CPU oracle is built with -ffp-contract=off. The
+     * two flavours were scanned over every material value x every score in +-26 000 (4.16 M pairs): the rounded integers
+     * never differ, so a GCC / MSVC build of the reference that does not contract is the same parity target (tolerance: none). */
     SPX_ADJUST_WHITE_POV = 4,
     SPX_ADJUST_WDL = 8
 };
@@ -284,22 +281,6 @@ uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx);
  * the incremental kernels read such a row from the i16 table. 0 with SPX_NO_COMPACT=1 or SPX_NO_NEAR=1. */
 uint32_t spx_ctx_near_psq_rows(const spx_ctx* ctx);
 
-/* Device-side intermediates of the last spx_eval_full* call on this context, for tests and profiling:
- * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
-int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
-
-/* Gather-ceiling probe (measurement infrastructure; stormphrax_amd/csrc/spx_probe.hip): replays the row fetches of a
- * full refresh of `d_positions` (device pointer, n <= spx_ctx_scratch_batch) - same king-bucket order, same grid and XCD
- * traversal, same rows - with LOADS ONLY (one xor per loaded dword), `iters` launches timed with HIP events on the
- * context's stream. variant 0 .. spx_debug_gather_probe_variants() - 1 selects the memory path / occupancy
- * (spx_debug_gather_probe_name); variant -1 times the product feature-transformer kernel in the same way.
- * `sink_checksum` (optional) receives a checksum of what the loads xor-ed to: equal for every variant >= 0.
- * No reference counterpart: it measures what bounds nnue_state.cpp:89-145 / input.h:283-293 style row gathers on gfx950. */
-int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
-                           uint64_t* sink_checksum);
-int spx_debug_gather_probe_variants(void);
-const char* spx_debug_gather_probe_name(int variant);
-
 /* ------------------------------------------------------------------------------------------------------------------
  * Host helpers (position plumbing for harnesses; counterparts: src/position.cpp FEN parsing, marlinformat pack,
  * src/datagen/datagen.cpp:146-171 random openings).
@@ -344,22 +325,12 @@ int spx_acc_update_observed(spx_ctx* ctx, const uint32_t* parent_slots, const ui
 int spx_acc_update_observed_device(spx_ctx* ctx, const void* d_parent_slots, const void* d_child_slots,
                                    const void* d_child_positions, const void* d_deltas, size_t n, void* d_out,
                                    void* stream);
-int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
-/* The same kind of batch generated ON THE DEVICE (move generation + uniform move choice kernels, no evaluations) straight
- * into d_out (count records of device memory): game i plays min_ply + (draw mod range) random plies from the standard start
- * or, every dfrc_every-th game, a double-Chess960 start; a game that runs out of moves keeps its final position. Seeded and
- * reproducible, but a different stream of positions than spx_random_positions. The host only places the start pieces. */
-int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, void* d_out);
-/* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
- * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */
-int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);
 /* viriformat game streams (src/datagen/viriformat.cpp:28-63: PackedBoard + {u16 move, i16 score}* + 4 zero bytes per
  * game) -> one record per played move (the position BEFORE the move, `eval` = the recorded score, `wdl` = the game's
  * outcome). `unfiltered` (optional, one byte per record) tells which of them the reference's marlinformat output keeps:
  * Marlinformat::push drops a position when the side to move is in check or the played move is noisy - a capture, an
  * en passant or a queen promotion (datagen.cpp:254, position.cpp:683-689, marlinformat.cpp:31-36): 1 = stored, 0 =
- * filtered. Pass out = NULL to count only. spx_viri_random_game writes one random game (test / demo input; scores are
- * random). */
+ * filtered. Pass out = NULL to count only. */
 int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, uint8_t* unfiltered,
                     size_t capacity, size_t* n_positions, size_t* n_games);
 /* The same expansion on the device (one thread per game replays the moves on the packed records): byte-identical output
@@ -369,7 +340,6 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
  * last position). `bad_games` may be NULL. */
 int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packed_pos* out, uint8_t* unfiltered,
                         size_t capacity, size_t* n_positions, size_t* n_games, size_t* bad_games);
-int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
 /* datagen's two other output formats (datagen.cpp:340-346), converted from a viriformat stream - what the reference would
  * have written for the same games had it been started with "marlinformat" / "fen":
  *   spx_viri_to_marlinformat: the unfiltered positions as PackedBoard records with eval = the recorded score and wdl = the
@@ -383,7 +353,6 @@ int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t c
 int spx_viri_to_marlinformat(const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity, size_t* n_records,
                              size_t* n_games);
 int spx_viri_to_fen(const void* data, size_t nbytes, char* out, size_t capacity, size_t* n_bytes, size_t* n_games);
-uint64_t spx_perft(const char* fen, int depth);
 
 /* ---- legal move generation + make-move on the device (takes the host out of the self-play loop) ----
  * For each of the n records: every legal move (viriformat move word, src/datagen/viriformat.cpp:37-52; castling as
@@ -451,31 +420,6 @@ int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* params, const char
  * no exchange step; stats are summed (seconds: the slowest member). Members need spx_selfplay_run's context capacity for
  * their share. */
 int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, const char* out_path, spx_selfplay_stats* stats);
-
-/* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):
- * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */
-int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows, int* n_psq, uint32_t* threat_rows,
-                       int* n_threat);
-
-/* Host emulation of the update kernel's DELTA derivation (same SPX_HD code, lane by lane): the rows perspective `colour`
- * loses (sub) and gains (add) between two boards one move apart - piece-square rows (capacity 8 each) and threat /
- * pawn-pair rows (capacity 288 each). *refresh = 1 (and empty lists) when the perspective is rebuilt instead: its king
- * changed bucket or mirror half (psq.h:264-283, nnue_state.h:118-128) or more than four squares differ. Test-only. */
-int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, int colour, uint32_t* psq_sub,
-                    int* n_psq_sub, uint32_t* psq_add, int* n_psq_add, uint32_t* threat_sub, int* n_threat_sub,
-                    uint32_t* threat_add, int* n_threat_add, int* refresh);
-
-/* Host evaluation of what SPX_ADJUST_WDL computes per position (same source as the kernel): Position::classicalMaterial
- * (src/position.h:515-521) of the record and wdl::normalizeScore (src/wdl.cpp:28-79) of `score` at it. Test-only. */
-int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, int32_t* normalized);
-
-/* Host evaluation of the datagen bookkeeping the device step kernel and the host self-play path share (same source):
- * counters[3] = the game's win / loss / draw ply counters (src/datagen/datagen.cpp:197-199), advanced by one searched move
- * with normalised white-point-of-view score `norm_score` at Position::plyFromStartpos `ply` (datagen.cpp:224-252);
- * *outcome = 0 / 1 / 2 (white loss / draw / win) or 255 = the game goes on. *insufficient = the material part of
- * Position::isDrawn for `pos` (src/position.cpp:639-666). Either output group may be skipped with NULL. Test-only. */
-int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
-                            const spx_packed_pos* pos, int* insufficient);
 
 #ifdef __cplusplus
 }

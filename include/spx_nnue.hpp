@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "spx_nnue.h"
+#include "spx_nnue_dev.h"  // (Network::synthetic only: the repo's synthetic presets, for tools and tests)
 
 namespace spx_nnue {
 

@@ -1,0 +1,88 @@
+/* spx_nnue_dev.h - development / test / measurement entry points of libspx_nnue.so.
+ *
+ * NOT part of the drop-in boundary (include/spx_nnue.h is): nothing here replaces a call of Stormphrax's src/eval. These are
+ * the synthetic network presets every golden of this repository is pinned on (the reference's default net cannot be
+ * fetched offline), generators of random legal positions and games for the harnesses, host emulations of the kernels'
+ * per-lane code that let the CPU test suite check device logic without a GPU, the activations of the last call, and the
+ * load-only gather probe behind bench.py's roofline ceiling. They live in the same shared library so that tests and
+ * bench.py exercise exactly the code the product runs. */
+#ifndef SPX_NNUE_DEV_H
+#define SPX_NNUE_DEV_H
+
+#include "spx_nnue.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Repo-owned synthetic network (the default net cannot be fetched offline). preset: 0 tame, 1 wild (i32 wraps),
+ * 2 extreme (i16 accumulator wraps too) - uniform random weights; 3 realistic: the weight SHAPE of a trained QA = 255 net
+ * (src/eval/arch.h:36-50) - heavy-tailed piece-square rows of which about 40 % fit i8, 40 % have a handful of weights
+ * beyond it and 20 % are densely wide, Laplace-like i8 threat and L1 weights - so that the measured rate does not rest on
+ * every piece-square row being compact. Writes spx_synth_net_bytes() bytes. */
+size_t spx_synth_net_bytes(void);
+int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
+
+/* Device-side intermediates of the last spx_eval_full* call on this context, for tests and profiling:
+ * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
+int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
+
+/* Gather-ceiling probe (measurement infrastructure; stormphrax_amd/csrc/spx_probe.hip): replays the row fetches of a
+ * full refresh of `d_positions` (device pointer, n <= spx_ctx_scratch_batch) - same king-bucket order, same grid and XCD
+ * traversal, same rows - with LOADS ONLY (one xor per loaded dword), `iters` launches timed with HIP events on the
+ * context's stream. variant 0 .. spx_debug_gather_probe_variants() - 1 selects the memory path / occupancy
+ * (spx_debug_gather_probe_name); variant -1 times the product feature-transformer kernel in the same way.
+ * `sink_checksum` (optional) receives a checksum of what the loads xor-ed to: equal for every variant >= 0.
+ * No reference counterpart: it measures what bounds nnue_state.cpp:89-145 / input.h:283-293 style row gathers on gfx950. */
+int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
+                           uint64_t* sink_checksum);
+int spx_debug_gather_probe_variants(void);
+const char* spx_debug_gather_probe_name(int variant);
+
+/* `count` random legal positions (host chess core): game i plays min_ply .. max_ply uniformly random plies from the standard
+ * start or, every dfrc_every-th game (0 = never), from a double-Chess960 start. Seeded and reproducible. */
+int spx_random_positions(uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, spx_packed_pos* out);
+/* The same kind of batch generated ON THE DEVICE (move generation + uniform move choice kernels, no evaluations) straight
+ * into d_out (count records of device memory): game i plays min_ply + (draw mod range) random plies from the standard start
+ * or, every dfrc_every-th game, a double-Chess960 start; a game that runs out of moves keeps its final position. Seeded and
+ * reproducible, but a different stream of positions than spx_random_positions. The host only places the start pieces. */
+int spx_random_positions_gpu(spx_ctx* ctx, uint64_t seed, size_t count, int min_ply, int max_ply, int dfrc_every, void* d_out);
+/* One uniformly random legal move per record (datagen-style playouts in bulk): out[i] = positions[i] after the move,
+ * moved[i] = 0 when the side to move has no legal move (out[i] = positions[i]). `moved` may be NULL. */
+int spx_random_successors(uint64_t seed, const spx_packed_pos* positions, size_t n, spx_packed_pos* out, uint8_t* moved);
+
+/* One random game as a viriformat stream (test / demo input; the scores are random). */
+int spx_viri_random_game(uint64_t seed, int plies, int dfrc, void* buf, size_t capacity, size_t* nbytes);
+
+/* perft of the host chess core (legal move generation check against published counts). */
+uint64_t spx_perft(const char* fen, int depth);
+
+/* Host emulation of the kernels' per-lane feature extraction (same SPX_HD code, run lane by lane on the CPU):
+ * row ids of one perspective `colour` of `pos`. psq_rows capacity 32, threat_rows capacity 256. Test-only. */
+int spx_debug_features(const spx_packed_pos* pos, int colour, uint32_t* psq_rows, int* n_psq, uint32_t* threat_rows,
+                       int* n_threat);
+
+/* Host emulation of the update kernel's DELTA derivation (same SPX_HD code, lane by lane): the rows perspective `colour`
+ * loses (sub) and gains (add) between two boards one move apart - piece-square rows (capacity 8 each) and threat /
+ * pawn-pair rows (capacity 288 each). *refresh = 1 (and empty lists) when the perspective is rebuilt instead: its king
+ * changed bucket or mirror half (psq.h:264-283, nnue_state.h:118-128) or more than four squares differ. Test-only. */
+int spx_debug_delta(const spx_packed_pos* parent, const spx_packed_pos* child, int colour, uint32_t* psq_sub,
+                    int* n_psq_sub, uint32_t* psq_add, int* n_psq_add, uint32_t* threat_sub, int* n_threat_sub,
+                    uint32_t* threat_add, int* n_threat_add, int* refresh);
+
+/* Host evaluation of what SPX_ADJUST_WDL computes per position (same source as the kernel): Position::classicalMaterial
+ * (src/position.h:515-521) of the record and wdl::normalizeScore (src/wdl.cpp:28-79) of `score` at it. Test-only. */
+int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, int32_t* normalized);
+
+/* Host evaluation of the datagen bookkeeping the device step kernel and the host self-play path share (same source):
+ * counters[3] = the game's win / loss / draw ply counters (src/datagen/datagen.cpp:197-199), advanced by one searched move
+ * with normalised white-point-of-view score `norm_score` at Position::plyFromStartpos `ply` (datagen.cpp:224-252);
+ * *outcome = 0 / 1 / 2 (white loss / draw / win) or 255 = the game goes on. *insufficient = the material part of
+ * Position::isDrawn for `pos` (src/position.cpp:639-666). Either output group may be skipped with NULL. Test-only. */
+int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
+                            const spx_packed_pos* pos, int* insufficient);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_NNUE_DEV_H */

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/spx_nnue.h"
+#include "../../include/spx_nnue_dev.h"
 #include "spx_chess.h"
 #include "spx_device_math.h"
 #include "spx_internal.h"

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../include/spx_nnue.h"
+#include "../../include/spx_nnue_dev.h"
 #include "spx_device_math.h"
 
 namespace spx {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/spx_nnue.h"
+#include "../../include/spx_nnue_dev.h"
 #include "spx_internal.h"
 
 struct spx_group {

@@ -258,7 +258,9 @@ struct ItemWalk {
 };
 
 template <bool kSplit, bool kStream>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 4) void spx_update_kernel_v1(UpdateParams p) {  // ~120 VGPRs: two boards live
+// (one wave per record, both perspectives - the A/B-only shape of this kernel - needs ~135 VGPRs: 3 waves/SIMD, no spills;
+// round 3 shipped it at 4 waves with 8 VGPRs and 30 SGPRs spilled)
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 3) void spx_update_kernel_v1(UpdateParams p) {  // ~120 VGPRs: two boards live
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
@@ -498,7 +500,8 @@ __device__ __forceinline__ uint32_t emitPawnPairDelta(uint32_t* list, uint32_t n
 // handled here: their ids (2 * record + colour) are appended to p.refreshList and the feature-transformer kernel,
 // launched right behind this one on the same stream, rebuilds exactly those (3-4 % of the perspectives in play).
 template <bool kSplit, bool kStream>
-__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_UPDATE_WAVES) void spx_update_kernel(UpdateParams p) {
+// (kSplit = small batches, bound by one record's latency: 4 waves/SIMD leave it the registers it spilled at 5)
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4 ? 4 : SPX_UPDATE_WAVES) : SPX_UPDATE_WAVES) void spx_update_kernel(UpdateParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint64_t sTab[kDeltaTabWords];                  // ray / knight masks + pseudo-attack sets (11 KiB)
     __shared__ uint32_t sAdd[kWavesPerBlock][2][kDeltaCap];    // per perspective: u8 rows to add ...
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void spx_update_chain_kerne
 constexpr uint32_t kDeltaBytes = 1080;
 
 // One wavefront per (record, perspective): twice the waves, half the serial latency, no spills (as in spx_update_kernel).
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_update_observed_kernel(UpdateParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, 3) void spx_update_observed_kernel(UpdateParams p) {  // (4 waves/SIMD: 4 VGPRs spilled)
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];
     __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/spx_nnue.h declares (no compute calls without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/spx_nnue.h (the drop-in boundary) and include/spx_nnue_dev.h (test /
+measurement entry points of the same library) declare (no compute calls without a GPU)."""
 import ctypes
 import os
 import re
@@ -8,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "spx_nnue.h")).read()
+def declared_symbols(header="spx_nnue.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(spx_[a-z0-9_]+)\s*\(", text)))
 
@@ -18,11 +19,13 @@ def test_header_and_library_agree(sp):
     from stormphrax_amd import _lib
 
     lib = _lib.load()
-    names = declared_symbols()
-    assert len(names) >= 18
-    for name in names:
-        assert hasattr(lib, name), f"{name} is declared in include/spx_nnue.h but not exported"
-    assert sorted(_lib.SYMBOLS) == names, "ctypes prototypes drifted from the header"
+    names, dev = declared_symbols(), declared_symbols("spx_nnue_dev.h")
+    assert len(names) >= 18 and len(dev) >= 12 and not set(names) & set(dev)
+    # the boundary header carries no test scaffolding
+    assert not [n for n in names if "debug" in n or "synth" in n or "random" in n or "perft" in n]
+    for name in names + dev:
+        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+    assert sorted(_lib.SYMBOLS) == sorted(names + dev), "ctypes prototypes drifted from the headers"
     assert ctypes.sizeof(_lib.PackedPos) == 32 and sp.PACKED_DTYPE.itemsize == 32
 
 

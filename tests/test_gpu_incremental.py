@@ -485,3 +485,35 @@ def test_selfplay_edge_sizes(sp, net_blob, oracle, tmp_path, n_games, target):
         assert stats["games"] == target and sum(stats["outcomes"]) == target
         oracle.use(net_blob("tame"), "tame")
         assert verify_selfplay_file(sp, st, oracle, open(path, "rb").read(), max_plies=80, oracle_sample=256) == stats["positions"]
+
+
+def test_native_replay_of_256_alpha_beta_search_trees_at_once(sp, net_blob):
+    """tests/golden/forest_search_256x1024_tame.npz: the reference's own alpha-beta search recorded from 256 roots (standard
+    and double-Chess960 midgames), 365 000 nodes and 257 400 NnueState::evaluate values, replayed as ONE forest through one
+    spx_acc_replay_tree call - by levels (the library's choice at this width) and by heavy paths (forced) - every value equal
+    to the reference's; the trees' roots hang off a virtual root and are rebuilt from scratch by the update kernels."""
+    import os
+
+    from stormphrax_amd.trace import Forest, replay_forest
+
+    forest = Forest(os.path.join(os.path.dirname(__file__), "golden", "forest_search_256x1024_tame.npz"))
+    assert forest.n_trees == 256 and forest.n_nodes == 365000 and len(forest.eval_node) == 257400
+    pos = forest.positions()
+    assert len({bytes(pos[i]) for i in np.nonzero(forest.parent[1:] == 0)[0] + 1}) > 200  # the roots differ
+    for paths in ("0", "1", None):
+        old = os.environ.get("SPX_REPLAY_PATHS")
+        if paths is None:
+            os.environ.pop("SPX_REPLAY_PATHS", None)
+        else:
+            os.environ["SPX_REPLAY_PATHS"] = paths
+        try:
+            with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=1 << 17) as st:
+                got, want, ms = replay_forest(st, forest, pos)
+        finally:
+            if old is None:
+                os.environ.pop("SPX_REPLAY_PATHS", None)
+            else:
+                os.environ["SPX_REPLAY_PATHS"] = old
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (paths, bad.size, int(bad[0]))
+        print(f"SPX_REPLAY_PATHS={paths}: {ms:.3f} ms on the device, {(forest.n_nodes - 1 + len(want)) / (ms / 1e3):.3e} updates+evals/s")
