@@ -420,6 +420,47 @@ def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
         st.close()
 
 
+def sliced_leg(args, sp, torch, group, net, blob, d_pos, positions):
+    """secondary.sliced_pipeline (built): the same batch through the column-sliced full-refresh pipeline
+    (SPX_CTX_SLICED_FT; stormphrax_amd/csrc/spx_ftx.hip) - stream-ordered and pipelined rates, the gather kernel's own time
+    next to spx_ft_kernel's, what everything before the gather costs, and the rate the same calls reach when the lists are
+    NOT rebuilt every step (SPX_FTX_DEBUG_REUSE: the bound a free preparation would give). Scores checked against the
+    headline context's and the CPU oracle's on a sample. Not the default path: see `note`."""
+    import copy
+
+    out = {}
+    for mode, reuse in (("stream_ordered", False), ("pipelined", False), ("stream_ordered_lists_reused", True)):
+        if reuse:
+            os.environ["SPX_FTX_DEBUG_REUSE"] = "1"
+        try:
+            st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch, sliced_ft=True)
+        finally:
+            os.environ.pop("SPX_FTX_DEBUG_REUSE", None)
+        try:
+            a = copy.copy(args)
+            a.steps, a.warmup = min(args.steps, 100), min(args.warmup, 10)
+            elapsed, (sort_ms, ft_ms, mlp_ms, calls), _, last = timed_full_run(a, torch, group, st, d_pos, mode == "pipelined",
+                                                                              settle_seconds=0.3)
+            calls = max(calls, 1)
+            step_ms = elapsed / a.steps * 1e3
+            rec = {"value": args.batch * a.steps / elapsed, "unit": "evals/s", "ms_per_step": step_ms,
+                   "gather_kernel_ms": ft_ms / calls, "sort_ms": sort_ms / calls, "mlp_ms": mlp_ms / calls}
+            if mode == "stream_ordered":
+                rec["preparation_ms"] = step_ms - (sort_ms + ft_ms + mlp_ms) / calls  # extraction, sort, plan, scatter, pack (+ launch gaps)
+                n_sample = min(2048, len(positions))
+                rec["bit_exact_sample"] = bool(oracle_sample_check(sp, blob, positions[:n_sample], last[:n_sample].cpu().numpy()))
+                rec["checksum"] = int(last.sum(dtype=torch.int64).item())
+            out[mode] = rec
+        finally:
+            st.close()
+    out["note"] = ("XCD x reads the 128-byte slice x of every row (L2 hit rate 74 -> 87 %, fabric bytes / 2.5), the king bucket's "
+                   "piece-square slab lives in LDS, four gathered i8 rows are widened and added by ONE v_mfma_i32_16x16x64_i8: the "
+                   "gather alone takes 0.66 x spx_ft_kernel's time. But the row lists must cross XCDs, i.e. be produced by a pass of "
+                   "their own, and that pass (VALU-bound extraction + sort + pack) costs more than the gather saves and does not "
+                   "overlap with it: one persistent workgroup per CU leaves no room for co-running kernels (DESIGN.md 4.9)")
+    return out
+
+
 def incremental_leg(sp, torch, net, device, games=65536, chain=6, seconds=0.6):
     """secondary.incremental (BASELINE configs[2] shape): `games` concurrent games, one fused update + eval batch per ply,
     pipelined plies. Boards are generated on the device: spx_random_positions_gpu is deterministic per seed, so the same
@@ -629,6 +670,8 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
     if args.batch <= state.scratch_batch:
         run("gather_ceiling", lambda: gather_ceiling(state, d_pos, args.batch))
     run("realistic_rows", lambda: realistic_leg(args, sp, torch, group, d_pos, positions, pipelined))
+    if args.batch <= state.scratch_batch and args.batch >= 8192 and not args.net:
+        run("sliced_pipeline", lambda: sliced_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
     if args.preset == "tame":  # (the trace was recorded on the tame net)
         run("incremental", lambda: incremental_leg(sp, torch, net, device))
         run("config3_replay", lambda: config3_leg(sp, net, device))

@@ -86,7 +86,12 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
 /* As spx_ctx_create, with option flags. SPX_CTX_WIDE_PSQ_ROWS: every piece-square row is gathered from the 2 KiB i16
  * table, i.e. the lossless "compact row" optimisation (1 KiB u8 copies of rows whose weights all fit i8) is off - what a
  * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
-enum { SPX_CTX_WIDE_PSQ_ROWS = 1 };
+/* SPX_CTX_SLICED_FT (round 4, experimental; also SPX_FTX=1 in the environment): full refreshes of 8 192 positions and more
+ * take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction pass writes every perspective's row lists,
+ * a counting sort groups them by king bucket and length, and the gather - XCD x reads slice x of every row, the bucket's
+ * piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.66 x the one-kernel path's time); results
+ * are bit-identical. Off by default: the lists cost more to produce than the gather saves. */
+enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
 /* Positions the context keeps intermediates for at once: min(max_batch, SPX_SCRATCH_CAP = 4 Mi by default). The
  * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an

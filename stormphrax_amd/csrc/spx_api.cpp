@@ -470,7 +470,7 @@ struct CtxDeleter {  // a context that fails half-way through its creation relea
 }  // namespace
 
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out) {
-    if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS))) {
+    if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS | SPX_CTX_SLICED_FT))) {
         setError("spx_ctx_create: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -616,6 +616,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
+    ctx->ftxEnabled = (flags & SPX_CTX_SLICED_FT) != 0;
     if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_MIN")) ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));

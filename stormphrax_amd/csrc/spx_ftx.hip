@@ -371,6 +371,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
 #endif
     uint8_t* const sSlab = sDyn;                                                             // the bucket's slab slice + an all-zero row
     uint32_t (*const sEnt)[2][256] = reinterpret_cast<uint32_t (*)[2][256]>(sDyn + kGatherSlabBytes);  // per wave: two stages of 8 steps of entries
+    // (s_setprio 3 for this kernel's waves - so that a co-running extraction only fills the issue slots it leaves - changed
+    // nothing: 0.459 vs 0.460 ms per pipelined step; a start gate - the next batch's preparation held back with
+    // hipStreamWaitValue64 until every workgroup of this launch had counted itself in - halved the rate: the waiting stream
+    // blocks a hardware queue others share. Both removed; profiles/r04_sliced_pipeline_overlap_attempts.txt)
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
     const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;

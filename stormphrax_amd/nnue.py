@@ -40,6 +40,7 @@ def synthetic_net_bytes(preset="tame", seed=DEFAULT_SEED):
 
 ADJUST_STATIC, ADJUST_EVAL, ADJUST_WHITE_POV, ADJUST_WDL = 1, 2, 4, 8
 CTX_WIDE_PSQ_ROWS = 1  # spx_ctx_create_ex flag: no compact (u8) copies of piece-square rows
+CTX_SLICED_FT = 2       # spx_ctx_create_ex flag: big full refreshes through the column-sliced pipeline (spx_ftx.hip; experimental)
 
 
 def adjust_params(contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL):
@@ -95,10 +96,10 @@ class Network:
 class NnueState:
     """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
 
-    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False):
+    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=False):
         lib = _lib.load()
         handle = ctypes.c_void_p()
-        flags = CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0
+        flags = (CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0) | (CTX_SLICED_FT if sliced_ft else 0)
         check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
         self._h = handle
         self._net = network

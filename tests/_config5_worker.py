@@ -29,9 +29,14 @@ def main():
     d_out = torch.empty(n, dtype=torch.int32, device="cuda")
     st = sp.NnueState(sp.Network(blob), device=0, max_batch=n)
     assert st.scratch_batch < n
+    import time
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     st.evaluate_once_device_async(d_pos.data_ptr(), n, d_out.data_ptr())
     st.synchronize()
     torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0  # ONE call over the whole resident batch (first call: includes the lanes' allocation)
     in_use = total - torch.cuda.mem_get_info(0)[0]
     tiles = d_out.view(n // distinct, distinct)
     same = True
@@ -42,8 +47,14 @@ def main():
     oracle.use(blob, "tame")
     mail, stm = sp.positions_to_mailboxes(base[sample])
     exact = bool(np.array_equal(tiles[0].cpu().numpy()[sample], oracle.eval_mailboxes(mail, stm)))
-    print(json.dumps({"positions": n, "chunks": -(-n // st.scratch_batch), "in_use_gb": in_use / 1e9, "total_gb": total / 1e9,
-                      "tiles_identical": same, "oracle_sample_exact": exact}))
+    line = {"config": "BASELINE configs[4]: the largest position batch that fits the HBM, one spx_eval_full_device_async call",
+            "positions": n, "chunks": -(-n // st.scratch_batch), "in_use_gb": in_use / 1e9, "total_gb": total / 1e9,
+            "seconds": seconds, "evals_per_sec": n / seconds, "tiles_identical": same, "oracle_sample_exact": exact}
+    print(json.dumps(line))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):  # (the GPU box: kept as a profile of the round)
+        with open(os.path.join(out_dir, "config5_hbm_filling.json"), "w") as f:
+            f.write(json.dumps(line, indent=1) + "\n")
     st.close()
 
 
