@@ -45,8 +45,8 @@ L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggre
 N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
 # committed rocprofv3 PMC passes of this command, newest round first (tools/gpu_final.sh puts this round's in place before the
 # bench lines are taken; the kernels these counters describe did not change in round 3)
-PMC_FILES = {"full": ["r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
-             "incremental": ["r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
+PMC_FILES = {"full": ["r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
+             "incremental": ["r04_pmc_incremental.json", "r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
 
 
 def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):

@@ -1,6 +1,6 @@
 # Round-end measurement set (GPU box): bench lines, secondary measurements, rocprofv3 stats + counters.
 # usage: bash tools/gpu_final.sh <tag>   -> gpurun_out/final_<tag>/   (copy what is quoted into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -16,7 +16,7 @@ cp $REPO/gpurun_out/pmc_inc_$TAG/pmc.json $OUT/pmc_incremental.json
 rm -rf $REPO/gpurun_out/prof_$TAG $REPO/gpurun_out/pmc_inc_$TAG
 [ -s $OUT/pmc_full_refresh.json ] && cp $OUT/pmc_full_refresh.json $REPO/profiles/${TAG}_pmc_full_refresh.json
 [ -s $OUT/pmc_incremental.json ] && cp $OUT/pmc_incremental.json $REPO/profiles/${TAG}_pmc_incremental.json
-python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+( time python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err ) 2> $OUT/bench_n1_wall_time.txt
 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1_driver_args.json 2> $OUT/bench_driver.err
 python bench.py --no-pipeline --no-cpu-baseline > $OUT/bench_n1_strict_stream_order.json 2> $OUT/bench_strict.err
 python bench.py --device-positions --no-cpu-baseline --no-wide > $OUT/bench_n1_device_positions.json 2> $OUT/bench_devpos.err
@@ -57,6 +57,15 @@ for f in sorted(glob.glob("$OUT/sp_pmc_*/*.db")):
         print("   %-44s %-18s mean/dispatch %16.1f  dispatches %d" % (r[0].replace("spx::", "")[:44], r[1], r[2], r[3]))
 PY
 rm -rf $OUT/sp_pmc_*
+# round 4: the N > 1 line's new legs (two ranks sharing this GPU over gloo: control flow, not a scaling number), BASELINE configs[4],
+# the column-sliced pipeline's kernels, the reference engine on the GPU evaluator
+SPX_BENCH_SHARE_GPU=1 SPX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-wide > $OUT/bench_n2_two_ranks_sharing_one_gpu.json 2> $OUT/bench_n2.err
+python tests/_config5_worker.py > $OUT/config5.log 2>&1 && cp $REPO/gpurun_out/config5_hbm_filling.json $OUT/bench_n1_config5_hbm_filling.json
+SPX_FTX=1 bash tools/gpu_kstats.sh sliced_$TAG --no-pipeline > $OUT/kstats_sliced_pipeline_stream_ordered.txt 2>&1
+bash tools/gpu_pmc_ftx.sh $TAG > /dev/null 2>&1; cp $REPO/gpurun_out/pmc_ftx_$TAG.txt $OUT/pmc_sliced_pipeline.txt
+( for mode in cpu gpu; do $REPO/oracle/_ref/sp_ref_gpu_tame bench 6 $mode | grep -v "^info\|^fen:\|^bestmove\|^$"; done
+  $REPO/oracle/_ref/sp_ref_gpu_tame bench 4 both | grep -v "^info\|^fen:\|^bestmove\|^$"
+  $REPO/oracle/_ref/sp_ref_gpu_tame game 3000 5 ) > $OUT/reference_engine_on_gpu_evaluator.txt 2>&1
 bash tools/gpu_stats.sh default_$TAG > $OUT/rocprofv3_kernel_stats_default_cmd.txt 2>&1
 bash tools/gpu_stats.sh headline_$TAG --no-secondary --no-wide > $OUT/rocprofv3_kernel_stats_headline_only.txt 2>&1
 bash tools/gpu_stats.sh inc_$TAG --mode incremental > $OUT/rocprofv3_incremental_kernel_stats.txt 2>&1

@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/stats_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o t -- python $REPO/bench.py --no-cpu-baseline "$@" > $OUT/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o t -- python $REPO/bench.py --no-cpu-baseline "$@" > $OUT/run.log 2>&1
 python3 - "$@" <<PY
 import glob, sqlite3, sys
 print("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline " + " ".join(sys.argv[1:]))

@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"final_{TAG}")
 DST = os.path.join(ROOT, "profiles")
@@ -41,10 +41,18 @@ names = {
     "pmc_selfplay_4096_seats.txt": "pmc_selfplay_4096_seats.txt",
     "gather_ceiling.json": "gather_ceiling.json", "gather_ceiling_wide_psq_rows.json": "gather_ceiling_wide_psq_rows.json",
     "raweval_walk.txt": "raweval_walk_evaluate_by_pending_plies.txt", "selfplay_gpu_busy.txt": "selfplay_gpu_busy_4096_seats.txt",
+    "bench_n2_two_ranks_sharing_one_gpu.json": "bench_n2_two_ranks_sharing_one_gpu.json",
+    "bench_n1_config5_hbm_filling.json": "bench_n1_config5_hbm_filling.json",
+    "kstats_sliced_pipeline_stream_ordered.txt": "kstats_sliced_pipeline_stream_ordered_final_binary.txt",
+    "pmc_sliced_pipeline.txt": "pmc_sliced_pipeline.txt",
+    "reference_engine_on_gpu_evaluator.txt": "reference_engine_on_gpu_evaluator.txt",
 }
 for src, dst in names.items():
     target = os.path.join(DST, f"{TAG}_{dst}")
-    if src.startswith("bench") and src.endswith(".json"):
+    if not os.path.exists(os.path.join(SRC, src)):
+        print("missing:", src)
+        continue
+    if src.startswith("bench") and src.endswith(".json") and "config5" not in src:
         open(target, "w").write(open(os.path.join(SRC, src)).read().strip().splitlines()[-1] + "\n")
     else:
         shutil.copy(os.path.join(SRC, src), target)
