@@ -37,6 +37,9 @@ int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
 int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
                            uint64_t* sink_checksum);
 int spx_debug_gather_probe_variants(void);
+/* Diagnostics of the column-sliced pipeline (SPX_CTX_SLICED_FT): start / end of each of the 256 workgroups of the last gather that
+ * used scratch set `slot` (-1: the context's own, 0 .. 2: the pipelined calls' ring), device clock ticks of 10 ns; out[512]. */
+int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out);
 const char* spx_debug_gather_probe_name(int variant);
 
 /* `count` random legal positions (host chess core): game i plays min_ply .. max_ply uniformly random plies from the standard

@@ -872,7 +872,11 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             if (slot) {
                 // the slot's stream: after the gather that last read this scratch - and behind nothing else
                 if (slot->used) SPX_HIP(hipStreamWaitEvent(slot->stream, slot->gathered, 0));
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, slot->stream));
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) {
+                    SPX_HIP(launchFtxPrepare(xp, slot->stream));
+                } else {
+                    SPX_HIP(launchFtxResetQueues(xp, slot->stream));
+                }
                 scratch.preparedOnce = true;
                 SPX_HIP(hipEventRecord(slot->prepared, slot->stream));
                 // (the gathers on one stream of their own at the highest priority, everything else below it: measured, worse -
@@ -885,7 +889,11 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
                 slot->used = true;
                 continue;
             } else {
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) {
+                    SPX_HIP(launchFtxPrepare(xp, s));
+                } else {
+                    SPX_HIP(launchFtxResetQueues(xp, s));
+                }
                 scratch.preparedOnce = true;
             }
             if (lo == 0) {
@@ -2232,6 +2240,24 @@ int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int 
         for (size_t i = 0; i < host.size(); ++i) sum += host[i] * (2 * i + 1);
         *sink_checksum = sum;
     }
+    return SPX_OK;
+}
+
+// start / end of every workgroup of the LAST column-sliced gather that used the given scratch set (slot -1: the context's own,
+// 0 .. 2: the pipelined calls' ring), on the device's constant 100 MHz clock: out[2 b] = start, out[2 b + 1] = end of workgroup b
+int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
+    if (!ctx || !out || slot < -1 || slot >= spx_ctx::kFtxRing) {
+        setError("spx_debug_ftx_block_times: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->ftxRing[slot].scratch;
+    if (!x.plan) {
+        setError("spx_debug_ftx_block_times: that scratch set was never used");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipDeviceSynchronize());
+    SPX_HIP(hipMemcpy(out, x.plan + kFtxPlanTimes, 512 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SPX_OK;
 }
 

@@ -47,7 +47,9 @@ constexpr uint32_t kFtxMaxSteps = 8 + 8 + 64, kFtxGroupWords = 32 + (kFtxMaxStep
 
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
-constexpr uint32_t kFtxPlanWords = 64 + 3 * 64;
+constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
+constexpr uint32_t kFtxPlanQueues = kFtxPlanTimes + 4 * 256;  // [8 XCDs][64] next unclaimed group of every segment (the gather's work queues)
+constexpr uint32_t kFtxPlanWords = kFtxPlanQueues + 8 * 64;
 
 constexpr size_t kFtxMinPositions = 8192;     // smaller full refreshes keep the one-kernel path
 constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~5.3 KB each); larger batches walk in passes
@@ -76,5 +78,6 @@ hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const 
 // everything before the gather (extract, rank, plan, scatter, pack): may overlap another batch's gather
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);
 hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream);
+hipError_t launchFtxResetQueues(const FtxParams& p, hipStream_t stream);  // (SPX_FTX_DEBUG_REUSE: before a gather without a preparation)
 
 }  // namespace spx

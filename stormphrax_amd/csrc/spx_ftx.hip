@@ -45,7 +45,7 @@ namespace {
 #endif
 constexpr uint32_t kGatherWaves = SPX_FTX_GATHER_WAVES;
 constexpr uint32_t kGatherSlabBytes = (kFtxSlabRows + 1) * 128;
-constexpr uint32_t kGatherLdsBytes = kGatherSlabBytes + kGatherWaves * 2 * 256 * 4;
+constexpr uint32_t kGatherLdsBytes = kGatherSlabBytes + kGatherWaves * 2 * 256 * 4;  // (+ 16 bytes behind it: the helping phase's choice)
 
 // column of byte m of chunk t of slice x (see spx_ftx.h)
 __device__ __forceinline__ uint32_t sliceColumn(uint32_t x, uint32_t t, uint32_t m) {
@@ -288,7 +288,16 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         }
         p.plan[32] = nSeg;
         p.plan[33] = nGroups;
+        for (uint32_t x = 0; x < 8; ++x) {  // every XCD walks every segment (its slice of it): one queue head per (XCD, segment)
+            for (uint32_t k = 0; k < nSeg; ++k) p.plan[kFtxPlanQueues + 64 * x + k] = p.plan[64 + 3 * k + 1];
+        }
     }
+}
+
+// (SPX_FTX_DEBUG_REUSE only: the gather's work queues back to the segments' first groups, the lists being kept)
+__global__ void spx_ftx_reset_queues_kernel(FtxParams p) {
+    const uint32_t x = threadIdx.x >> 6, k = threadIdx.x & 63u;
+    if (k < p.plan[32]) p.plan[kFtxPlanQueues + 64 * x + k] = p.plan[64 + 3 * k + 1];
 }
 
 __global__ void spx_ftx_scatter_kernel(FtxParams p) {
@@ -365,7 +374,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     // pads the kernel's register count up to that occupancy's floor (97 -> 104 allocated); at 84 registers a workgroup leaves
     // room for two of the extraction kernel's waves per SIMD beside it
 #if SPX_FTX_STATIC_LDS
-    __shared__ __align__(16) uint8_t sDyn[kGatherLdsBytes];
+    __shared__ __align__(16) uint8_t sDyn[kGatherLdsBytes + 16];
 #else
     extern __shared__ __align__(16) uint8_t sDyn[];
 #endif
@@ -378,6 +387,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
     const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
+    // diagnostics (spx_debug_ftx_block_times): when did this workgroup start and end (constant 100 MHz clock)
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x] = wall_clock64();
     const uint8_t* slice = p.rowS + size_t(xcd) * kFtxSliceStride;
     const uint32_t laneOff = 16 * t;
     const i32x4 sel = mfmaSelector(lane);
@@ -386,19 +397,58 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
     const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
     for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
-    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket:
-    // its slab slice goes to LDS once). A version that handed out chunks of 16-64 groups, one workgroup each, through the
-    // hardware's dispatcher ran 18-34 % slower alone (a slab reload per chunk) and overlapped no better.
-    const uint32_t segFirst = p.plan[cu], segEnd = p.plan[cu + 1];
-    for (uint32_t seg = segFirst; seg < segEnd; ++seg) {
-        const uint32_t bucket = p.plan[64 + 3 * seg], gFirst = p.plan[64 + 3 * seg + 1], gEnd = p.plan[64 + 3 * seg + 2];
-        __syncthreads();  // the previous segment's readers are done with the slab
-        {
+    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` starts on its planned share, segment by segment (a segment = one bucket:
+    // its slab slice goes to LDS once). The groups of a segment are CLAIMED from a queue head in memory (one atomic per group, asked
+    // for one group ahead), not strided statically, and a workgroup that has finished its own segments HELPS: it picks the segment of
+    // its XCD with the most groups left, loads that bucket's slab and claims from the same queue. A workgroup that starts late or runs
+    // slowly - because another kernel shares its CU - then simply ends up with fewer groups, instead of being the kernel's tail.
+    // (A version that handed out chunks of 16-64 groups, one workgroup each, through the hardware's dispatcher ran 18-34 % slower
+    // alone: a slab reload per chunk.)
+    uint32_t* const queues = p.plan + kFtxPlanQueues + 64 * xcd;
+    uint32_t* const sVictim = reinterpret_cast<uint32_t*>(sDyn + kGatherLdsBytes);
+    const uint32_t nSeg = p.plan[32];
+    auto claim = [&](uint32_t seg) -> uint32_t {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(&queues[seg], 1u);
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    uint32_t loaded = 0xFFFFFFFFu;
+    uint32_t seg = p.plan[cu];
+    const uint32_t ownEnd = p.plan[cu + 1];
+    bool helping = false;
+    for (;;) {
+        if (seg >= ownEnd || helping) {  // own share done: help where most is left
+            helping = true;
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t left = 0;
+                if (lane < nSeg) {
+                    // (an atomic load: the other workgroups' claims live in the XCD's L2, a plain load may be served from this CU's L1)
+                    const uint32_t head = __hip_atomic_load(&queues[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t end = p.plan[64 + 3 * lane + 2];
+                    left = end > head ? end - head : 0u;
+                }
+                uint32_t best = (left << 6) | lane;  // most groups left; ties by index
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) best = max(best, uint32_t(__shfl_xor(int(best), dlt, 64)));
+                if (lane == 0) *sVictim = (best >> 6) ? (best & 63u) : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            seg = *sVictim;
+            if (seg == 0xFFFFFFFFu) break;
+        }
+        const uint32_t bucket = p.plan[64 + 3 * seg], gEnd = p.plan[64 + 3 * seg + 2];
+        if (bucket != loaded) {
+            __syncthreads();  // the previous segment's readers are done with the slab
             const u32x4* src = reinterpret_cast<const u32x4*>(slice + size_t(kFtxPsqLoBase + bucket * kFtxSlabRows) * 128);
             for (uint32_t i = threadIdx.x; i < kFtxSlabRows * 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab)[i] = src[i];
+            __syncthreads();
+            loaded = bucket;
         }
-        __syncthreads();
-        for (uint32_t G = gFirst + wave; G < gEnd; G += kGatherWaves) {
+        uint32_t nextG = claim(seg);
+        while (nextG < gEnd) {
+            const uint32_t G = nextG;
+            nextG = claim(seg);  // (travels while this group is gathered)
             const uint32_t* in = p.groups + size_t(G) * kFtxGroupWords;
             const u32x4 hdr = *reinterpret_cast<const u32x4*>(in);
             const uint32_t nHiQ = __builtin_amdgcn_readfirstlane(hdr[0]), nPsqQ = __builtin_amdgcn_readfirstlane(hdr[1]);
@@ -464,7 +514,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (!helping) ++seg;
     }
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream) {
@@ -483,6 +535,11 @@ hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launchFtxResetQueues(const FtxParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_ftx_reset_queues_kernel, dim3(1), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream) {
     const uint32_t gridBlocks = 256;
     // more than 64 KiB of dynamic LDS has to be allowed once per device
@@ -491,11 +548,11 @@ hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream) {
     if (hipGetDevice(&device) != hipSuccess) return hipGetLastError();
     if (!SPX_FTX_STATIC_LDS && !(allowed.load() >> (device & 63) & 1u)) {
         const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_ftx_gather_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kGatherLdsBytes));
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kGatherLdsBytes + 16));
         if (attr != hipSuccess) return attr;
         allowed.fetch_or(uint64_t(1) << (device & 63));
     }
-    hipLaunchKernelGGL(spx_ftx_gather_kernel, dim3(gridBlocks), dim3(64 * kGatherWaves), SPX_FTX_STATIC_LDS ? 0 : kGatherLdsBytes, stream, p);
+    hipLaunchKernelGGL(spx_ftx_gather_kernel, dim3(gridBlocks), dim3(64 * kGatherWaves), SPX_FTX_STATIC_LDS ? 0 : kGatherLdsBytes + 16, stream, p);
     return hipGetLastError();
 }
 

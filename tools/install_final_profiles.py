@@ -57,7 +57,10 @@ for src, dst in names.items():
     else:
         shutil.copy(os.path.join(SRC, src), target)
 for f in sorted(glob.glob(os.path.join(DST, f"{TAG}_bench*.json"))):
-    j = json.loads(open(f).read().strip().splitlines()[-1])
+    try:
+        j = json.loads(open(f).read().strip().splitlines()[-1])
+    except ValueError:  # (a pretty-printed record, not a bench line)
+        continue
     r = j.get("roofline", {})
     print(os.path.basename(f), "%.4e" % j["value"], "ms/step %.4f" % j["ms_per_step"], "frac %.3f" % r.get("frac", 0),
           "wide", (j.get("wide_psq_rows") or {}).get("value"), "cpu", (j.get("cpu_baseline") or {}).get("value"),
