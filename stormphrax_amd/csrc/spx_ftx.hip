@@ -40,6 +40,9 @@ namespace {
 #ifndef SPX_FTX_STATIC_LDS
 #define SPX_FTX_STATIC_LDS 0
 #endif
+#ifndef SPX_FTX_QUEUES
+#define SPX_FTX_QUEUES 0  // 1: the gather's groups are claimed from queues and finished workgroups help (below); measured, not the default
+#endif
 #ifndef SPX_FTX_GATHER_WAVES
 #define SPX_FTX_GATHER_WAVES 16
 #endif
@@ -397,13 +400,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
     const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
     for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
-    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` starts on its planned share, segment by segment (a segment = one bucket:
-    // its slab slice goes to LDS once). The groups of a segment are CLAIMED from a queue head in memory (one atomic per group, asked
-    // for one group ahead), not strided statically, and a workgroup that has finished its own segments HELPS: it picks the segment of
-    // its XCD with the most groups left, loads that bucket's slab and claims from the same queue. A workgroup that starts late or runs
-    // slowly - because another kernel shares its CU - then simply ends up with fewer groups, instead of being the kernel's tail.
+    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket: its
+    // slab slice goes to LDS once), its 16 waves striding over the segment's groups.
+    // SPX_FTX_QUEUES=1 (built and measured, not the default): the groups of a segment are CLAIMED from a queue head in memory
+    // (one atomic per group, asked for one group ahead), and a workgroup that has finished its own segments HELPS - it picks the
+    // segment of its XCD with the most groups left, loads that bucket's slab and claims from the same queue -, so that a workgroup
+    // that starts late or runs slowly is not the kernel's tail. Alone 301 us instead of 283 (the claims); pipelined 0.457 ms per
+    // step - exactly what the fixed shares give: the per-workgroup timestamps (spx_debug_ftx_block_times) show every workgroup
+    // starting within 3 us and all of them slowed alike when other kernels share the CUs. There is no tail to balance.
     // (A version that handed out chunks of 16-64 groups, one workgroup each, through the hardware's dispatcher ran 18-34 % slower
     // alone: a slab reload per chunk.)
+    constexpr bool kQueues = SPX_FTX_QUEUES != 0;
     uint32_t* const queues = p.plan + kFtxPlanQueues + 64 * xcd;
     uint32_t* const sVictim = reinterpret_cast<uint32_t*>(sDyn + kGatherLdsBytes);
     const uint32_t nSeg = p.plan[32];
@@ -418,6 +425,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     bool helping = false;
     for (;;) {
         if (seg >= ownEnd || helping) {  // own share done: help where most is left
+            if (!kQueues) break;
             helping = true;
             __syncthreads();
             if (wave == 0) {
@@ -437,7 +445,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             seg = *sVictim;
             if (seg == 0xFFFFFFFFu) break;
         }
-        const uint32_t bucket = p.plan[64 + 3 * seg], gEnd = p.plan[64 + 3 * seg + 2];
+        const uint32_t bucket = p.plan[64 + 3 * seg], gFirst = p.plan[64 + 3 * seg + 1], gEnd = p.plan[64 + 3 * seg + 2];
         if (bucket != loaded) {
             __syncthreads();  // the previous segment's readers are done with the slab
             const u32x4* src = reinterpret_cast<const u32x4*>(slice + size_t(kFtxPsqLoBase + bucket * kFtxSlabRows) * 128);
@@ -445,10 +453,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             __syncthreads();
             loaded = bucket;
         }
-        uint32_t nextG = claim(seg);
+        uint32_t nextG = kQueues ? claim(seg) : gFirst + wave;
         while (nextG < gEnd) {
             const uint32_t G = nextG;
-            nextG = claim(seg);  // (travels while this group is gathered)
+            nextG = kQueues ? claim(seg) : G + kGatherWaves;  // (a claim travels while this group is gathered)
             const uint32_t* in = p.groups + size_t(G) * kFtxGroupWords;
             const u32x4 hdr = *reinterpret_cast<const u32x4*>(in);
             const uint32_t nHiQ = __builtin_amdgcn_readfirstlane(hdr[0]), nPsqQ = __builtin_amdgcn_readfirstlane(hdr[1]);
