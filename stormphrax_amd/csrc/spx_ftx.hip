@@ -185,21 +185,34 @@ __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
 // Bin starts and the plan. One workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
-    __shared__ uint32_t sBin[kFtxBins];        // counts, then starts
+    __shared__ uint32_t sBin[kFtxBins + 1];    // counts, then starts
     __shared__ uint32_t sBucketStart[17], sBucketCount[16];
+    __shared__ uint32_t sGroups[kFtxBins];     // per bin: groups whose longest list ends in it; then the index of the first of them
+    __shared__ uint32_t sCost[kFtxBins];       // per bin: their cost; then the exclusive prefix of it
     __shared__ uint32_t sScan[1024];
     __shared__ uint32_t sCut[33];
-    __shared__ uint8_t sCost[(2 * kFtxMaxPositions + 16 * 7 + 7) / 8 + 8];  // per group
+    __shared__ uint32_t sSegs;
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
         sBin[k] = p.hist[k];
         p.hist[k] = 0;  // ready for the next batch's rank kernel
     }
     __syncthreads();
-    if (tid < 16) {
-        uint32_t n = 0;
-        for (uint32_t k = 0; k < kFtxQuartetBins; ++k) n += sBin[tid * kFtxQuartetBins + k];
-        sBucketCount[tid] = n;
+    // bucket totals and bin starts: one wave per bucket, 80 bins = two per lane (lanes 0 .. 39), a wave scan
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t c0 = 0, c1 = 0, mineIncl = 0;
+    {
+        if (lane < kFtxQuartetBins / 2) {
+            c0 = sBin[wave * kFtxQuartetBins + 2 * lane];
+            c1 = sBin[wave * kFtxQuartetBins + 2 * lane + 1];
+        }
+        mineIncl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = uint32_t(__shfl_up(int(mineIncl), d, 64));
+            if (lane >= uint32_t(d)) mineIncl += v;
+        }
+        if (lane == 63) sBucketCount[wave] = mineIncl;
     }
     __syncthreads();
     if (tid == 0) {
@@ -211,69 +224,92 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         sBucketStart[16] = at;
     }
     __syncthreads();
-    if (tid < 16) {
-        uint32_t at = sBucketStart[tid];
-        for (uint32_t k = 0; k < kFtxQuartetBins; ++k) {
-            const uint32_t n = sBin[tid * kFtxQuartetBins + k];
-            sBin[tid * kFtxQuartetBins + k] = at;
-            at += n;
+    {
+        const uint32_t base = sBucketStart[wave];
+        if (lane < kFtxQuartetBins / 2) {
+            sBin[wave * kFtxQuartetBins + 2 * lane] = base + mineIncl - c0 - c1;
+            sBin[wave * kFtxQuartetBins + 2 * lane + 1] = base + mineIncl - c1;
         }
-        for (; at < sBucketStart[tid + 1]; ++at) p.order[at] = 0xFFFFFFFFu;  // holes that pad the bucket to whole groups
+        const uint32_t end = base + sBucketCount[wave];
+        if (lane < 8 && end + lane < sBucketStart[wave + 1]) p.order[end + lane] = 0xFFFFFFFFu;  // holes that pad the bucket to whole groups
     }
     __syncthreads();
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) p.binStart[k] = sBin[k];
     if (tid < 17) p.binStart[kFtxBins + tid] = sBucketStart[tid];
 
-    // cost of a group = the quartets of its longest list (its last valid perspective: bins ascend inside a bucket) + a
-    // constant for the group's fixed work; computed once per group (a bisection over the bucket's bins), kept in LDS
+    // Cost of a group = the quartets of its longest list (its last valid perspective: bins ascend inside a bucket) + a constant
+    // for the group's fixed work - piecewise constant over the BINS, so everything below runs over 1 280 bins, not 16 K groups.
+    // Inside bucket b (relative positions, groups of 8 from its start) the groups whose last member lies in [s, e) are
+    // G' = s / 8 .. e / 8 - 1, plus the bucket's final partial group, whose last member is the bucket's last perspective.
     const uint32_t nGroups = sBucketStart[16] / 8;
-    for (uint32_t G = tid; G < nGroups; G += blockDim.x) {
-        uint32_t b = 0;  // the bucket whose (padded) range holds position 8 G: the last one that starts at or before it
-#pragma unroll
-        for (uint32_t step = 8; step; step >>= 1) {
-            if (sBucketStart[b + step] <= 8 * G) b += step;
-        }
-        const uint32_t last = min(8 * G + 7, sBucketStart[b] + sBucketCount[b] - 1);
-        uint32_t lo = 0, hi = kFtxQuartetBins - 1;  // the last bin of bucket b that starts at or before `last`
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) / 2;
-            if (sBin[b * kFtxQuartetBins + mid] <= last) lo = mid; else hi = mid - 1;
-        }
-        sCost[G] = uint8_t(lo + 1 + 3);
+    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
+        const uint32_t b = k / kFtxQuartetBins, kk = k % kFtxQuartetBins, base = sBucketStart[b], count = sBucketCount[b];
+        const uint32_t s0 = sBin[k] - base, e0 = (kk + 1 < kFtxQuartetBins ? sBin[k + 1] : base + count) - base;
+        uint32_t ng = e0 / 8 - s0 / 8;
+        if (e0 > s0 && e0 == count && (count & 7u)) ++ng;  // (the partial group: the last one of the bucket's last bin)
+        sGroups[k] = ng;
+        sCost[k] = ng * (kk + 1 + 3);
     }
     __syncthreads();
-    const uint32_t per = (nGroups + blockDim.x - 1) / blockDim.x;
-    const uint32_t g0 = min(tid * per, nGroups), g1 = min(g0 + per, nGroups);
-    uint32_t mine = 0;
-    for (uint32_t G = g0; G < g1; ++G) mine += sCost[G];
-    sScan[tid] = mine;
+    uint32_t g2[2] = {0, 0}, w2[2] = {0, 0};
+    if (tid < kFtxBins / 2) {
+        g2[0] = sGroups[2 * tid], g2[1] = sGroups[2 * tid + 1];
+        w2[0] = sCost[2 * tid], w2[1] = sCost[2 * tid + 1];
+    }
+    sScan[tid] = w2[0] + w2[1];
     __syncthreads();
-    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // inclusive scan
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // inclusive scan of the costs
         const uint32_t v = tid >= d ? sScan[tid - d] : 0u;
         __syncthreads();
         sScan[tid] += v;
         __syncthreads();
     }
     const uint32_t total = sScan[blockDim.x - 1];
-    if (tid <= 32) sCut[tid] = tid == 32 ? nGroups : 0u;
+    const uint32_t costBefore = sScan[tid] - (w2[0] + w2[1]);
     __syncthreads();
-    {
-        // CU slot c ends where the running cost passes total * (c + 1) / 32
-        uint64_t before = sScan[tid] - mine;
-        uint32_t c = total ? uint32_t(before * 32 / total) : 0u;  // first slot whose end lies beyond `before`
-        for (uint32_t G = g0; G < g1 && c < 31; ++G) {
-            before += sCost[G];
-            while (c < 31 && before * 32 >= uint64_t(total) * (c + 1)) {
-                sCut[c + 1] = G + 1;
-                ++c;
+    if (tid < kFtxBins / 2) {
+        sCost[2 * tid] = costBefore;
+        sCost[2 * tid + 1] = costBefore + w2[0];
+    }
+    sScan[tid] = g2[0] + g2[1];
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // ... and of the group counts: first group of every bin
+        const uint32_t v = tid >= d ? sScan[tid - d] : 0u;
+        __syncthreads();
+        sScan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t groupsBefore = sScan[tid] - (g2[0] + g2[1]);
+    __syncthreads();
+    if (tid < kFtxBins / 2) {
+        sGroups[2 * tid] = groupsBefore;  // (bins follow the sorted order, so the running count IS the group index)
+        sGroups[2 * tid + 1] = groupsBefore + g2[0];
+    }
+    __syncthreads();
+    // CU slot c - 1 ends with the group at which the running cost reaches total * c / 32: bisect the bins' cost prefix
+    if (tid <= 32) {
+        uint32_t cut = tid == 32 ? nGroups : 0u;
+        if (tid >= 1 && tid < 32 && total) {
+            const uint64_t target32 = uint64_t(total) * tid;  // compare 32 * cost with it
+            uint32_t lo = 0, hi = kFtxBins - 1;             // the last bin whose prefix is below the target
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) / 2;
+                if (uint64_t(sCost[mid]) * 32 < target32) lo = mid; else hi = mid - 1;
             }
+            const uint32_t w = lo % kFtxQuartetBins + 1 + 3;
+            const uint64_t need = target32 - uint64_t(sCost[lo]) * 32;  // > 0
+            const uint32_t within = uint32_t((need + 32ull * w - 1) / (32ull * w));  // groups of this bin up to and including the one that reaches it
+            const uint32_t binGroups = (lo + 1 < kFtxBins ? sGroups[lo + 1] : nGroups) - sGroups[lo];
+            cut = sGroups[lo] + min(within, binGroups);
         }
+        sCut[tid] = cut;
     }
     __syncthreads();
     if (tid == 0) {
-        for (uint32_t c = 1; c < 32; ++c) {  // slots nobody closed (tiny batches) take nothing
+        for (uint32_t c = 1; c <= 32; ++c) {  // (monotone whatever the rounding did)
             if (sCut[c] < sCut[c - 1]) sCut[c] = sCut[c - 1];
         }
+        sCut[32] = nGroups;
         uint32_t nSeg = 0, b = 0;  // (the cuts ascend, so does the bucket)
         for (uint32_t c = 0; c < 32; ++c) {
             p.plan[c] = nSeg;
@@ -291,9 +327,11 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         }
         p.plan[32] = nSeg;
         p.plan[33] = nGroups;
-        for (uint32_t x = 0; x < 8; ++x) {  // every XCD walks every segment (its slice of it): one queue head per (XCD, segment)
-            for (uint32_t k = 0; k < nSeg; ++k) p.plan[kFtxPlanQueues + 64 * x + k] = p.plan[64 + 3 * k + 1];
-        }
+        sSegs = nSeg;
+    }
+    __syncthreads();
+    if (tid < 512 && (tid & 63u) < sSegs) {  // one queue head per (XCD, segment) (SPX_FTX_QUEUES)
+        p.plan[kFtxPlanQueues + 64 * (tid >> 6) + (tid & 63u)] = p.plan[64 + 3 * (tid & 63u) + 1];
     }
 }
 
