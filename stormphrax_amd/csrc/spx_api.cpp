@@ -51,12 +51,12 @@ constexpr size_t kProfEventsPerCall = 5;
 
 // scratch of the column-sliced full refresh (spx_ftx.hip): one set per context and per lane, allocated on first use
 struct FtxScratch {
-    uint32_t *lists = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr, *order = nullptr,
-             *groups = nullptr, *plan = nullptr;
+    uint32_t *lists = nullptr, *heads = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
+             *sorted = nullptr, *plan = nullptr;
     size_t capacity = 0;  // positions per pass
     bool preparedOnce = false;  // (SPX_FTX_DEBUG_REUSE=1, measurements only: later calls reuse the first call's lists)
     void release() {
-        for (uint32_t* q : {lists, keys, ranks, hist, binStart, order, groups, plan}) {
+        for (uint32_t* q : {lists, heads, keys, ranks, hist, binStart, sorted, plan}) {
             if (q) (void)hipFree(q);
         }
         *this = FtxScratch{};
@@ -800,9 +800,9 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     x.release();
     const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
-    if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.keys, 2 * cap * 4) || !alloc(x.ranks, 2 * cap * 4) ||
-        !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) || !alloc(x.order, (2 * cap + 128) * 4) ||
-        !alloc(x.groups, ftxGroupBytes(cap)) || !alloc(x.plan, kFtxPlanWords * 4)) {
+    if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 8) || !alloc(x.keys, 2 * cap * 4) ||
+        !alloc(x.ranks, 2 * cap * 4) || !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) ||
+        !alloc(x.sorted, (2 * cap + 128) * 16) || !alloc(x.plan, kFtxPlanWords * 4)) {
         return fail();
     }
     if (hipMemsetAsync(x.hist, 0, kFtxBins * 4, s) != hipSuccess) return fail();
@@ -851,7 +851,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     if (sliced) {
-        // passes of at most the scratch's capacity; a pass's preparation (extraction, sort, plan, pack) comes before the
+        // passes of at most the scratch's capacity; a pass's preparation (extraction, sort, plan) comes before the
         // pipelined calls' gate, so that it runs beside another batch's gather
         for (size_t lo = 0; lo < n; lo += scratch.capacity) {
             const size_t m = std::min(scratch.capacity, n - lo);
@@ -861,22 +861,18 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.t = tablesOf(ctx);
             xp.rowS = ctx->dRowS;
             xp.lists = scratch.lists;
+            xp.heads = scratch.heads;
             xp.keys = scratch.keys;
             xp.ranks = scratch.ranks;
             xp.hist = scratch.hist;
             xp.binStart = scratch.binStart;
-            xp.order = scratch.order;
-            xp.groups = scratch.groups;
+            xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
             if (slot) {
                 // the slot's stream: after the gather that last read this scratch - and behind nothing else
                 if (slot->used) SPX_HIP(hipStreamWaitEvent(slot->stream, slot->gathered, 0));
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) {
-                    SPX_HIP(launchFtxPrepare(xp, slot->stream));
-                } else {
-                    SPX_HIP(launchFtxResetQueues(xp, slot->stream));
-                }
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, slot->stream));
                 scratch.preparedOnce = true;
                 SPX_HIP(hipEventRecord(slot->prepared, slot->stream));
                 // (the gathers on one stream of their own at the highest priority, everything else below it: measured, worse -
@@ -889,11 +885,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
                 slot->used = true;
                 continue;
             } else {
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) {
-                    SPX_HIP(launchFtxPrepare(xp, s));
-                } else {
-                    SPX_HIP(launchFtxResetQueues(xp, s));
-                }
+                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
                 scratch.preparedOnce = true;
             }
             if (lo == 0) {

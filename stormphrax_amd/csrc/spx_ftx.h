@@ -30,29 +30,24 @@ constexpr size_t kFtxTableBytes = size_t(8) * kFtxSliceStride;
 constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket: 88 KiB per slice, LDS resident in the gather
 
 // ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
-// [0] nHi [1] nPsq [2] nThr [3] 2 * position + (0 = side-to-move half, 1 = other half)
-// [4, 36) piece-square rows as slab offsets ((row - 704 bucket) * 128); [36, 68) high-byte planes of the wide ones and
-// [68, 324) threat / pawn-pair rows as slice offsets (row index * 128)
-constexpr uint32_t kFtxListStride = 328, kFtxListPsq = 4, kFtxListHi = 36, kFtxListThr = 68;
+// [0, 32) piece-square rows as slab offsets ((row - 704 bucket) * 128); [32, 64) high-byte planes of the wide ones and
+// [64, 320) threat / pawn-pair rows as slice offsets (row index * 128). Words behind a section's count are undefined.
+// heads[perspective] = {nHi | nPsq << 8 | nThr << 16, 2 * position + (0 = side-to-move half, 1 = other half)}
+constexpr uint32_t kFtxListStride = 320, kFtxListPsq = 0, kFtxListHi = 32, kFtxListThr = 64;
 // sort key of a perspective: king bucket * 80 + (row quartets - 1): groups of 8 neighbours in this order share a bucket
 // (one LDS slab) and have almost equal list lengths (one wave walks the 8 lists in lockstep)
 constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins;
 
-// ---- per-group lists read by the gather: [group][kFtxGroupWords] words ----
-// [0] nHiQ [1] nPsqQ [2] nThrQ (row quartets per section: the longest of the 8 lists) [3] king bucket
-// [8 + 4 u + p] output slot (word [3] of the list) of perspective 2 p + u, ~0 = hole
-// from word 32: step j (the sections one after the other), lane class e = 2 kb + u, pair p: [j][e][p] = offset of row
-// 4 jj + kb of perspective 2 p + u in section jj's table (zero rows pad short lists)
-constexpr uint32_t kFtxMaxSteps = 8 + 8 + 64, kFtxGroupWords = 32 + (kFtxMaxSteps + 8) * 32;
+// ---- sorted[position in the sorted order] = {head word 0, output slot (~0 = hole), list offset in bytes, -} ----
+// the gather's wave reads the 8 entries of its group and then the 8 lists themselves, a stage of 8 steps at a time
 
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
-constexpr uint32_t kFtxPlanQueues = kFtxPlanTimes + 4 * 256;  // [8 XCDs][64] next unclaimed group of every segment (the gather's work queues)
-constexpr uint32_t kFtxPlanWords = kFtxPlanQueues + 8 * 64;
+constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
 
 constexpr size_t kFtxMinPositions = 8192;     // smaller full refreshes keep the one-kernel path
-constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~5.3 KB each); larger batches walk in passes
+constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~2.6 KB each); larger batches walk in passes
 
 struct FtxParams {
     const void* positions;   // spx_packed_pos[nPositions]
@@ -60,24 +55,21 @@ struct FtxParams {
     FtTables t;              // lut, deltaTab (pseudo-attack sets), ftBias
     const uint8_t* rowS;     // the sliced row table
     uint32_t* lists;         // [2 n][kFtxListStride]
+    uint32_t* heads;         // [2 n][2]
     uint32_t* keys;          // [2 n] sort keys
     uint32_t* ranks;         // [2 n] rank inside the key's bin
     uint32_t* hist;          // [kFtxBins] counts per key; zero on entry of the rank kernel, zeroed again by the plan kernel
     uint32_t* binStart;      // [kFtxBins + 17] first sorted position of each bin; then bucketStart[17]
-    uint32_t* order;         // [2 n + 128] perspective at each sorted position (~0 = hole)
-    uint32_t* groups;        // [nGroupsMax][kFtxGroupWords]
+    uint32_t* sorted;        // [2 n + 128][4]
     uint32_t* plan;          // [kFtxPlanWords]
     uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
 };
 
-inline uint32_t ftxMaxGroups(size_t nPositions) { return uint32_t((2 * nPositions + 16 * 7 + 7) / 8); }
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
-inline size_t ftxGroupBytes(size_t n) { return size_t(ftxMaxGroups(n)) * kFtxGroupWords * 4; }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
-// everything before the gather (extract, rank, plan, scatter, pack): may overlap another batch's gather
+// everything before the gather (extract, rank, plan, scatter): may overlap another batch's gather
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);
 hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream);
-hipError_t launchFtxResetQueues(const FtxParams& p, hipStream_t stream);  // (SPX_FTX_DEBUG_REUSE: before a gather without a preparation)
 
 }  // namespace spx

@@ -46,6 +46,9 @@ namespace {
 #ifndef SPX_FTX_GATHER_WAVES
 #define SPX_FTX_GATHER_WAVES 16
 #endif
+#ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
+#define SPX_FTX_GATHER_WAVES_PER_SIMD 4  // register budget: 512 / this
+#endif
 constexpr uint32_t kGatherWaves = SPX_FTX_GATHER_WAVES;
 constexpr uint32_t kGatherSlabBytes = (kFtxSlabRows + 1) * 128;
 constexpr uint32_t kGatherLdsBytes = kGatherSlabBytes + kGatherWaves * 2 * 256 * 4;  // (+ 16 bytes behind it: the helping phase's choice)
@@ -87,36 +90,62 @@ __global__ void spx_ftx_build_table_kernel(const uint8_t* thrU8, const int16_t* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Extraction: one wave per position, lane = square. The record decode and the attack sets are perspective independent and
-// done once; each perspective then builds its lists in LDS and the wave copies them out.
+// Extraction: one wave per position, lane = square. Everything that does not depend on the perspective is done once (VERDICT
+// r3 item 5): the record decode, the attack sets, and the ENUMERATION of the feature candidates - every (attacker, victim)
+// pair and every pawn pair becomes one item of a flat list in LDS (the serial part: one item per lane and round, as many rounds
+// as the busiest square has targets). Each perspective then turns the items into rows 64 at a time - one or two rounds
+// instead of one per target of the busiest square - and writes them straight to its list.
 // ---------------------------------------------------------------------------------------------------------------------
-// (<= 64 VGPRs: two of its waves per SIMD fit beside the gather's four - the two kernels are meant to share the CUs)
+constexpr uint32_t kItemCap = 512;  // <= 30 attackers x 8 targets + the pawn pairs; malformed records are cut off here
+// items: from | to << 6 | kind << 12; kind 0 = threat pair, 1 = two pawns of one colour (from < to), 2 = pawns of different
+// colours (a feature of the perspective that owns `from`, whose mask it is: nnue_state.cpp:330-351)
+
 __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel(FtxParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kThreatCap];
-    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];
-    __shared__ uint32_t sHi[kWavesPerBlock][kPsqCap];
+    __shared__ uint16_t sItems[kWavesPerBlock][kItemCap];
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
     __syncthreads();
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    uint16_t* const items = sItems[wave];
     for (uint32_t pos = blockIdx.x * kWavesPerBlock + wave; pos < p.nPositions; pos += gridDim.x * kWavesPerBlock) {
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(pos) * 32;
         const LaneBoard b = decodeBoard(rec, lane);
-        const uint64_t targets = laneTargets(b, lane);
         const int piece = b.piece;
         const bool occupied = piece != kNoPiece;
-        const bool isPawn = (piece >> 1) == 0;
+        uint32_t nItems = 0;
+        {
+            uint64_t todo = laneTargets(b, lane);  // kind 0: the occupied non-king squares this lane's piece attacks
+            uint32_t tag = 0;
+            const bool pawnHere = (b.pawnsBb >> lane) & 1;
+            const uint64_t mine = b.pawnsBb & ((piece & 1) ? b.whiteBb : ~b.whiteBb);
+            uint64_t same = 0;
+            for (int round = 0; round < 2; ++round) {
+                while (__ballot(todo != 0)) {
+                    const bool active = todo != 0;
+                    const uint32_t to = active ? uint32_t(ctz64(todo)) : 0u;
+                    todo &= todo - 1;
+                    const uint32_t slot = nItems + prefixCount(__ballot(active));
+                    if (active && slot < kItemCap) items[slot] = uint16_t(lane | (to << 6) | (round ? (((same >> to) & 1) ? 1u : 2u) << 12 : tag));
+                    nItems = min(nItems + uint32_t(popc64(__ballot(active))), kItemCap);
+                }
+                if (round == 0 && pawnHere) {  // then the pawn pairs of this lane's pawn
+                    same = mine & ~((2ull << lane) - 1);
+                    todo = (same | (b.pawnsBb & ~mine)) & ppMask(int(lane));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
             const uint64_t ownKing = __ballot(piece == (10 | c));
             const int kingSq = ownKing ? ctz64(ownKing) : 0;  // a record without that king is malformed: stay in bounds
-            const uint64_t ownPawns = b.pawnsBb & (c ? b.whiteBb : ~b.whiteBb);
-            const uint64_t theirPawns = b.pawnsBb & ~ownPawns;
             const int x = perspXor(c, kingSq);
             const int flipColour = (c == 0) ? 1 : 0;
             const uint32_t bucket = uint32_t(kingBucket(c == 0 ? (kingSq ^ 56) : kingSq));
+            const uint32_t q = 2 * pos + uint32_t(c);
+            uint32_t* out = p.lists + size_t(q) * kFtxListStride;
             // piece-square rows (resetPsqAccumulator, nnue_state.cpp:440-449): every one from the bucket's LDS slab; a row
             // with weights outside i8 also has a high-byte plane to fetch
             uint32_t row = 0;
@@ -128,35 +157,45 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             const uint64_t wideMask = __ballot(wide);
             const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
             if (occupied && slot < kPsqCap) {
-                sPsq[wave][slot] = (row - bucket * kFtxSlabRows) * 128u;
-                if (wide && wideSlot < kPsqCap) sHi[wave][wideSlot] = (kFtxPsqHiBase + row) * 128u;
+                out[kFtxListPsq + slot] = (row - bucket * kFtxSlabRows) * 128u;
+                if (wide && wideSlot < kPsqCap) out[kFtxListHi + wideSlot] = (kFtxPsqHiBase + row) * 128u;
             }
             const uint32_t nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
             const uint32_t nHi = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-            // threat rows (addThreatFeatures, nnue_state.cpp:309-328), then pawn pairs (:330-351)
-            uint32_t nThr = emitThreatRows(sThr[wave], 0, targets, piece, lane, x, flipColour, sLut, sPseudo);
-            const bool own = isPawn && (piece & 1) == c;
-            nThr = emitPawnPairRows(sThr[wave], nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
-                                    ppId(int(lane) ^ x, !own), ownPawns, x);
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t q = 2 * pos + uint32_t(c);
-            uint32_t* out = p.lists + size_t(q) * kFtxListStride;
+            // threat rows (addThreatFeatures, nnue_state.cpp:309-328) and pawn pairs (:330-351)
+            uint32_t nThr = 0;
+            for (uint32_t base = 0; base < nItems; base += 64) {
+                const bool active = base + lane < nItems;
+                const uint32_t item = active ? items[base + lane] : 0u;
+                const int from = item & 63u, to = (item >> 6) & 63u;
+                const uint32_t kind = item >> 12;
+                const int pf = __shfl(piece, from, 64), pt = __shfl(piece, to, 64);
+                int32_t r = -1;
+                if (active) {
+                    if (kind == 0) {
+                        const int pieceRel = pf ^ flipColour, sqRel = from ^ x;
+                        const uint64_t pseudoRel = sPseudo[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
+                        r = threatRow(sLut, pieceRel, sqRel, pseudoRel, pt ^ flipColour, to ^ x);
+                    } else {
+                        const bool own = (pf & 1) == c;
+                        if (kind == 1 || own) r = int32_t(ppRow(ppId(from ^ x, !own), ppId(to ^ x, kind == 1 ? !own : true)));
+                    }
+                }
+                const uint64_t valid = __ballot(r >= 0);
+                const uint32_t at = nThr + prefixCount(valid);
+                if (r >= 0 && at < kThreatCap) out[kFtxListThr + at] = uint32_t(r) * 128u;
+                nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+            }
             if (lane == 0) {
-                u32x4 hdr;
-                hdr[0] = nHi;
-                hdr[1] = nPsq;
-                hdr[2] = nThr;
-                hdr[3] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
-                __builtin_nontemporal_store(hdr, reinterpret_cast<u32x4*>(out));
+                u32x2 head;
+                head[0] = nHi | (nPsq << 8) | (nThr << 16);
+                head[1] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
+                *reinterpret_cast<u32x2*>(p.heads + 2 * size_t(q)) = head;
                 const uint32_t quartets = (nHi + 3) / 4 + (nPsq + 3) / 4 + (nThr + 3) / 4;
                 p.keys[q] = bucket * kFtxQuartetBins + min(max(quartets, 1u), kFtxQuartetBins) - 1;
             }
-            // (streaming stores: the lists are read once, by the pack kernel - they should not push weight rows out of the L2s)
-            if (lane < nPsq) __builtin_nontemporal_store(sPsq[wave][lane], out + kFtxListPsq + lane);
-            if (lane < nHi) __builtin_nontemporal_store(sHi[wave][lane], out + kFtxListHi + lane);
-            for (uint32_t i = lane; i < nThr; i += 64) __builtin_nontemporal_store(sThr[wave][i] >> 3, out + kFtxListThr + i);  // (row * 1024 -> row * 128)
-            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();  // (the next position's items overwrite these)
     }
 }
 
@@ -191,7 +230,6 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
     __shared__ uint32_t sCost[kFtxBins];       // per bin: their cost; then the exclusive prefix of it
     __shared__ uint32_t sScan[1024];
     __shared__ uint32_t sCut[33];
-    __shared__ uint32_t sSegs;
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
         sBin[k] = p.hist[k];
@@ -231,7 +269,9 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
             sBin[wave * kFtxQuartetBins + 2 * lane + 1] = base + mineIncl - c1;
         }
         const uint32_t end = base + sBucketCount[wave];
-        if (lane < 8 && end + lane < sBucketStart[wave + 1]) p.order[end + lane] = 0xFFFFFFFFu;  // holes that pad the bucket to whole groups
+        if (lane < 8 && end + lane < sBucketStart[wave + 1]) {  // holes that pad the bucket to whole groups
+            reinterpret_cast<u32x4*>(p.sorted)[end + lane] = u32x4{0u, 0xFFFFFFFFu, 0u, 0u};
+        }
     }
     __syncthreads();
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) p.binStart[k] = sBin[k];
@@ -327,93 +367,34 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         }
         p.plan[32] = nSeg;
         p.plan[33] = nGroups;
-        sSegs = nSeg;
-    }
-    __syncthreads();
-    if (tid < 512 && (tid & 63u) < sSegs) {  // one queue head per (XCD, segment) (SPX_FTX_QUEUES)
-        p.plan[kFtxPlanQueues + 64 * (tid >> 6) + (tid & 63u)] = p.plan[64 + 3 * (tid & 63u) + 1];
     }
 }
 
-// (SPX_FTX_DEBUG_REUSE only: the gather's work queues back to the segments' first groups, the lists being kept)
-__global__ void spx_ftx_reset_queues_kernel(FtxParams p) {
-    const uint32_t x = threadIdx.x >> 6, k = threadIdx.x & 63u;
-    if (k < p.plan[32]) p.plan[kFtxPlanQueues + 64 * x + k] = p.plan[64 + 3 * k + 1];
-}
-
+// counting sort, part 2: the perspective's head and list at its place in the sorted order
 __global__ void spx_ftx_scatter_kernel(FtxParams p) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < 2 * p.nPositions) p.order[p.binStart[p.keys[q]] + p.ranks[q]] = q;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Pack: one wave per group of 8 neighbours of the sorted order.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spx_ftx_pack_kernel(FtxParams p) {
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
-    const uint32_t G = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (G >= p.plan[33]) return;
-    uint32_t* out = p.groups + size_t(G) * kFtxGroupWords;
-    // lanes 0..7 hold the header of perspective g = lane
-    uint32_t q = 0xFFFFFFFFu;
-    u32x4 hdr = {0, 0, 0, 0xFFFFFFFFu};
-    if (lane < 8) {
-        q = p.order[8 * G + lane];
-        if (q != 0xFFFFFFFFu) hdr = *reinterpret_cast<const u32x4*>(p.lists + size_t(q) * kFtxListStride);
-    }
-    uint32_t nHiQ = (hdr[0] + 3) / 4, nPsqQ = (hdr[1] + 3) / 4, nThrQ = (hdr[2] + 3) / 4;
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {  // maxima over the 8 perspectives (lanes 8.. carry zeros)
-        nHiQ = max(nHiQ, uint32_t(__shfl_xor(int(nHiQ), d, 64)));
-        nPsqQ = max(nPsqQ, uint32_t(__shfl_xor(int(nPsqQ), d, 64)));
-        nThrQ = max(nThrQ, uint32_t(__shfl_xor(int(nThrQ), d, 64)));
-    }
-    nHiQ = __builtin_amdgcn_readfirstlane(nHiQ);
-    nPsqQ = __builtin_amdgcn_readfirstlane(nPsqQ);
-    nThrQ = __builtin_amdgcn_readfirstlane(nThrQ);
-    const uint32_t firstQ = __builtin_amdgcn_readfirstlane(q);  // (position 8 G of a group is never a hole)
-    if (lane == 0) {
-        u32x4 h;
-        h[0] = nHiQ;
-        h[1] = nPsqQ;
-        h[2] = nThrQ;
-        h[3] = p.keys[firstQ] / kFtxQuartetBins;
-        *reinterpret_cast<u32x4*>(out) = h;
-    }
-    if (lane < 8) out[8 + 4 * (lane & 1u) + (lane >> 1)] = hdr[3];  // perspective g = 2 p + u -> word 8 + 4 u + p
-    // a lane's class is fixed - word 32 j + (lane & 31) of step j is class e = (lane >> 2) & 7, pair lane & 3 -, so it reads
-    // ONE perspective's list; lanes 0..31 take the even steps, 32..63 the odd ones: independent loads, no shuffles in the loop
-    const uint32_t e = (lane >> 2) & 7u, pr = lane & 3u, kb = e >> 1, g = 2 * pr + (e & 1u);
-    const uint32_t gq = uint32_t(__shfl(int(q), int(g), 64));
-    const uint32_t gHi = uint32_t(__shfl(int(hdr[0]), int(g), 64)), gPsq = uint32_t(__shfl(int(hdr[1]), int(g), 64)),
-                   gThr = uint32_t(__shfl(int(hdr[2]), int(g), 64));
-    const uint32_t* mine = p.lists + size_t(gq == 0xFFFFFFFFu ? 0u : gq) * kFtxListStride;  // (a hole's counts are zero)
-    const uint32_t nSteps = nHiQ + nPsqQ + nThrQ, jEnd = (nSteps + 7u) & ~7u;
-#pragma unroll 4
-    for (uint32_t j = lane >> 5; j < jEnd; j += 2) {
-        uint32_t v;
-        if (j < nHiQ) {
-            const uint32_t i = 4 * j + kb;
-            v = i < gHi ? __builtin_nontemporal_load(mine + kFtxListHi + i) : kFtxZeroRow * 128u;
-        } else if (j < nHiQ + nPsqQ) {
-            const uint32_t i = 4 * (j - nHiQ) + kb;
-            v = i < gPsq ? __builtin_nontemporal_load(mine + kFtxListPsq + i) : kFtxSlabRows * 128u;  // the slab's zero row
-        } else {
-            const uint32_t i = 4 * (j - nHiQ - nPsqQ) + kb;
-            v = i < gThr ? __builtin_nontemporal_load(mine + kFtxListThr + i) : kFtxZeroRow * 128u;
-        }
-        __builtin_nontemporal_store(v, out + 32 + 32 * j + (lane & 31u));
-    }
+    if (q >= 2 * p.nPositions) return;
+    const u32x2 head = *reinterpret_cast<const u32x2*>(p.heads + 2 * size_t(q));
+    reinterpret_cast<u32x4*>(p.sorted)[p.binStart[p.keys[q]] + p.ranks[q]] = u32x4{head[0], head[1], q * (kFtxListStride * 4u), 0u};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Gather.
 // ---------------------------------------------------------------------------------------------------------------------
-// (<= 96 VGPRs, the budget of five waves per SIMD, though a workgroup brings four: the rest is the extraction's room)
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(4, 8))) void spx_ftx_gather_kernel(FtxParams p) {
+// 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket:
+// its slab slice goes to LDS once), its 16 waves striding over the segment's groups. A wave reads its group's 8 lists
+// itself, a STAGE of 8 steps at a time: lane (g = lane & 7, ks = lane >> 3) fetches the four rows of step ks of perspective
+// g (16 bytes of its list; rows past the list's end become the all-zero row) and puts them where the burst's lanes expect them -
+// word 32 k + 4 e + pr of the stage = row 4 j + kb of perspective 2 pr + u, e = 2 kb + u. The next stage's 16 bytes and the
+// next group's 8 heads are asked for a stage / a group ahead.
+// (Rounds of measurements that shaped it, profiles/r04_sliced_pipeline_overlap_attempts.txt: a separate pack kernel writing
+// the interleaved stages to memory first - 36 us per 64 Ki positions for what the gather's idle VALU does here; groups claimed
+// from work queues with finished workgroups helping - 301 us instead of 283 alone and no gain when other kernels share the
+// CUs, every workgroup slows down alike, there is no tail; chunks of groups through the hardware dispatcher - a slab reload
+// per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse.)
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(SPX_FTX_GATHER_WAVES_PER_SIMD, 8))) void spx_ftx_gather_kernel(FtxParams p) {
     // LDS is DYNAMIC on purpose: with a static 120 KiB the compiler knows that only four waves per SIMD can be resident and
-    // pads the kernel's register count up to that occupancy's floor (97 -> 104 allocated); at 84 registers a workgroup leaves
-    // room for two of the extraction kernel's waves per SIMD beside it
+    // pads the kernel's register count up to that occupancy's floor
 #if SPX_FTX_STATIC_LDS
     __shared__ __align__(16) uint8_t sDyn[kGatherLdsBytes + 16];
 #else
@@ -421,13 +402,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
 #endif
     uint8_t* const sSlab = sDyn;                                                             // the bucket's slab slice + an all-zero row
     uint32_t (*const sEnt)[2][256] = reinterpret_cast<uint32_t (*)[2][256]>(sDyn + kGatherSlabBytes);  // per wave: two stages of 8 steps of entries
-    // (s_setprio 3 for this kernel's waves - so that a co-running extraction only fills the issue slots it leaves - changed
-    // nothing: 0.459 vs 0.460 ms per pipelined step; a start gate - the next batch's preparation held back with
-    // hipStreamWaitValue64 until every workgroup of this launch had counted itself in - halved the rate: the waiting stream
-    // blocks a hardware queue others share. Both removed; profiles/r04_sliced_pipeline_overlap_attempts.txt)
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
     const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
+    const uint32_t g = lane & 7u, ks = lane >> 3;              // the lane's part in filling a stage
+    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
     // diagnostics (spx_debug_ftx_block_times): when did this workgroup start and end (constant 100 MHz clock)
     if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x] = wall_clock64();
     const uint8_t* slice = p.rowS + size_t(xcd) * kFtxSliceStride;
@@ -438,51 +417,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
     const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
     for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
-    // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket: its
-    // slab slice goes to LDS once), its 16 waves striding over the segment's groups.
-    // SPX_FTX_QUEUES=1 (built and measured, not the default): the groups of a segment are CLAIMED from a queue head in memory
-    // (one atomic per group, asked for one group ahead), and a workgroup that has finished its own segments HELPS - it picks the
-    // segment of its XCD with the most groups left, loads that bucket's slab and claims from the same queue -, so that a workgroup
-    // that starts late or runs slowly is not the kernel's tail. Alone 301 us instead of 283 (the claims); pipelined 0.457 ms per
-    // step - exactly what the fixed shares give: the per-workgroup timestamps (spx_debug_ftx_block_times) show every workgroup
-    // starting within 3 us and all of them slowed alike when other kernels share the CUs. There is no tail to balance.
-    // (A version that handed out chunks of 16-64 groups, one workgroup each, through the hardware's dispatcher ran 18-34 % slower
-    // alone: a slab reload per chunk.)
-    constexpr bool kQueues = SPX_FTX_QUEUES != 0;
-    uint32_t* const queues = p.plan + kFtxPlanQueues + 64 * xcd;
-    uint32_t* const sVictim = reinterpret_cast<uint32_t*>(sDyn + kGatherLdsBytes);
-    const uint32_t nSeg = p.plan[32];
-    auto claim = [&](uint32_t seg) -> uint32_t {
-        uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(&queues[seg], 1u);
-        return __builtin_amdgcn_readfirstlane(g);
-    };
+    // (32-bit byte offsets from a scalar base: one address register per load instead of two)
+    auto headOf = [&](uint32_t G) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.sorted) + 16u * (8u * G + g)); };
     uint32_t loaded = 0xFFFFFFFFu;
-    uint32_t seg = p.plan[cu];
     const uint32_t ownEnd = p.plan[cu + 1];
-    bool helping = false;
-    for (;;) {
-        if (seg >= ownEnd || helping) {  // own share done: help where most is left
-            if (!kQueues) break;
-            helping = true;
-            __syncthreads();
-            if (wave == 0) {
-                uint32_t left = 0;
-                if (lane < nSeg) {
-                    // (an atomic load: the other workgroups' claims live in the XCD's L2, a plain load may be served from this CU's L1)
-                    const uint32_t head = __hip_atomic_load(&queues[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t end = p.plan[64 + 3 * lane + 2];
-                    left = end > head ? end - head : 0u;
-                }
-                uint32_t best = (left << 6) | lane;  // most groups left; ties by index
-#pragma unroll
-                for (int dlt = 1; dlt < 64; dlt <<= 1) best = max(best, uint32_t(__shfl_xor(int(best), dlt, 64)));
-                if (lane == 0) *sVictim = (best >> 6) ? (best & 63u) : 0xFFFFFFFFu;
-            }
-            __syncthreads();
-            seg = *sVictim;
-            if (seg == 0xFFFFFFFFu) break;
-        }
+    for (uint32_t seg = p.plan[cu]; seg < ownEnd; ++seg) {
         const uint32_t bucket = p.plan[64 + 3 * seg], gFirst = p.plan[64 + 3 * seg + 1], gEnd = p.plan[64 + 3 * seg + 2];
         if (bucket != loaded) {
             __syncthreads();  // the previous segment's readers are done with the slab
@@ -491,21 +430,61 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             __syncthreads();
             loaded = bucket;
         }
-        uint32_t nextG = kQueues ? claim(seg) : gFirst + wave;
-        while (nextG < gEnd) {
-            const uint32_t G = nextG;
-            nextG = kQueues ? claim(seg) : G + kGatherWaves;  // (a claim travels while this group is gathered)
-            const uint32_t* in = p.groups + size_t(G) * kFtxGroupWords;
-            const u32x4 hdr = *reinterpret_cast<const u32x4*>(in);
-            const uint32_t nHiQ = __builtin_amdgcn_readfirstlane(hdr[0]), nPsqQ = __builtin_amdgcn_readfirstlane(hdr[1]);
-            const uint32_t nSteps = nHiQ + nPsqQ + __builtin_amdgcn_readfirstlane(hdr[2]);
-            const u32x4* ent = reinterpret_cast<const u32x4*>(in + 32);
+        uint32_t G = gFirst + wave;
+        u32x4 headNext = {0, 0xFFFFFFFFu, 0, 0};
+        if (G < gEnd) headNext = headOf(G);
+        while (G < gEnd) {
+            const u32x4 head = headNext;
+            const uint32_t nextG = G + kGatherWaves;
+            if (nextG < gEnd) headNext = headOf(nextG);
+            // this lane's perspective g: its counts and its list; the group's sections are as long as its longest list
+            const uint32_t cHi = head[0] & 0xFFu, cPsq = (head[0] >> 8) & 0xFFu, cThr = head[0] >> 16;
+            const uint32_t mine = head[2];  // (its byte offset)
+            uint32_t qA = ((cHi + 3) >> 2) | (((cPsq + 3) >> 2) << 16), qB = (cThr + 3) >> 2;
+#pragma unroll
+            for (int dlt = 1; dlt < 8; dlt <<= 1) {
+                qA = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qA),
+                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qA), dlt, 64)))));
+                qB = max(qB, uint32_t(__shfl_xor(int(qB), dlt, 64)));
+            }
+            qA = __builtin_amdgcn_readfirstlane(qA);
+            const uint32_t nHiQ = qA & 0xFFFFu, nPsqQ = qA >> 16, nHiPsqQ = nHiQ + nPsqQ;
+            const uint32_t nSteps = nHiPsqQ + __builtin_amdgcn_readfirstlane(qB);
+            // step j0 + ks of this lane's list: which section, which quartet of it, how many rows the list has there
+            auto place = [&](uint32_t j0, uint32_t& at, uint32_t& left, uint32_t& zero) {
+                const uint32_t j = j0 + ks;
+                uint32_t base, count, first;
+                if (j < nHiQ) {
+                    base = kFtxListHi, count = cHi, first = 4 * j, zero = kFtxZeroRow * 128u;
+                } else if (j < nHiPsqQ) {
+                    base = kFtxListPsq, count = cPsq, first = 4 * (j - nHiQ), zero = kFtxSlabRows * 128u;  // (the slab's zero row)
+                } else {
+                    base = kFtxListThr, count = cThr, first = 4 * (j - nHiPsqQ), zero = kFtxZeroRow * 128u;
+                }
+                at = base + first;
+                left = count > first ? count - first : 0u;  // (0 too for the steps behind the group's last one)
+            };
+            auto fetch = [&](uint32_t j0) -> u32x4 {
+                uint32_t at, left, zero;
+                place(j0, at, left, zero);
+                u32x4 v = {0, 0, 0, 0};
+                if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.lists) + (mine + 4 * at));
+                return v;
+            };
+            auto put = [&](uint32_t j0, const u32x4& v, uint32_t* stage) {
+                uint32_t at, left, zero;
+                place(j0, at, left, zero);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) stage[fillAt + 8 * i] = i < left ? v[i] : zero;
+            };
+            u32x4 ahead = fetch(0);
             i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
             uint32_t j = 0;
             while (j < nSteps) {
                 uint32_t* stage = sEnt[wave][(j >> 3) & 1];
-                if ((j & 7u) == 0) {  // a new stage of 8 steps of entries: 1 KiB, every lane a different 16 bytes
-                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = ent[8 * j + lane];
+                if ((j & 7u) == 0) {  // a new stage of 8 steps
+                    put(j, ahead, stage);
+                    if (j + 8 < nSteps) ahead = fetch(j + 8);
                     __builtin_amdgcn_wave_barrier();
                 }
                 // a burst = two steps (8 loads in flight) unless the stage, the list or the high-byte section ends in between
@@ -514,7 +493,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                 const u32x4 e0 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e));
                 const u32x4 e1 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
                 i32x4 w[8];
-                if (j >= nHiQ && j < nHiQ + nPsqQ) {
+                if (j >= nHiQ && j < nHiPsqQ) {
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(sSlab + e0[pr] + laneOff);
                 } else {
@@ -522,7 +501,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                     for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e0[pr] + laneOff));
                 }
                 if (two) {
-                    if (j + 1 >= nHiQ && j + 1 < nHiQ + nPsqQ) {
+                    if (j + 1 >= nHiQ && j + 1 < nHiPsqQ) {
 #pragma unroll
                         for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(sSlab + e1[pr] + laneOff);
                     } else {
@@ -543,24 +522,24 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                     for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
                 }
             }
-            // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 p + u
-            const u32x4 dst = *reinterpret_cast<const u32x4*>(in + 8 + 4 * u);  // their output slots (asked for here: 4 registers less in the loop)
+            // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
+                const uint32_t dst = uint32_t(__shfl(int(head[1]), 2 * pr + int(u), 64));  // (lanes 0 .. 7 hold perspectives 0 .. 7)
                 const uint32_t a = pkAdd16(biasA, __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
                 const uint32_t b = pkAdd16(biasB, __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
                 const i16x2 zero = {0, 0}, top = {255, 255};
                 const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
                 const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero), top));
                 const uint32_t o = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));
-                if (dst[pr] != 0xFFFFFFFFu) {
-                    *reinterpret_cast<uint16_t*>(p.ftOut + size_t(dst[pr]) * kPairs + 64 * xcd + 8 * t + 2 * kb) =
+                if (dst != 0xFFFFFFFFu) {
+                    *reinterpret_cast<uint16_t*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * t + 2 * kb) =
                         uint16_t((o & 0xFFu) | ((o >> 8) & 0xFF00u));
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            G = nextG;
         }
-        if (!helping) ++seg;
     }
     if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x + 1] = wall_clock64();
 }
@@ -577,12 +556,6 @@ hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_ftx_rank_kernel, dim3((nPersp + 1023) / 1024), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_scatter_kernel, dim3((nPersp + 255) / 256), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(spx_ftx_pack_kernel, dim3((ftxMaxGroups(p.nPositions) + 3) / 4), dim3(256), 0, stream, p);
-    return hipGetLastError();
-}
-
-hipError_t launchFtxResetQueues(const FtxParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_ftx_reset_queues_kernel, dim3(1), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
