@@ -11,14 +11,15 @@ no data-path collective), weak scaling; value = all ranks' positions / max-over-
         bench.py --gpus 8 --steps 200 --warmup 20
 
 Rank 0 prints ONE JSON line. Extra objects:
-  `roofline`      the feature-transformer kernel against the roof that BINDS it. The 100 MB of weight rows are resident in
-                  L2 / Infinity Cache, so the gather is bound by the L2 -> CU path and VALU issue, not by HBM: `bound` =
-                  "l2", `achieved` = bytes the kernel's loads request per launch / its HIP-event duration, `peak` = the
-                  34.5 TB/s aggregate L2 bandwidth. The SURVEY 8(d) algorithmic-bytes figure and the measured HBM/fabric
-                  traffic (rocprofv3 PMC pass committed under profiles/) are reported beside it under `hbm`, the VALU issue
+  `roofline`      the dominant kernel - the column-sliced pipeline's gather (spx_ftx_gather_kernel; batches below 24 576
+                  positions: spx_ft_kernel) - against the roof that BINDS it. The 100 MB of weight rows are resident in L2 /
+                  Infinity Cache, so the gather is bound by the L2 -> CU path, not by HBM: `bound` = "l2", `achieved` = bytes
+                  the kernel's row loads request from the L2s per launch / its HIP-event duration, `peak` = the 34.5 TB/s
+                  aggregate L2 bandwidth. The SURVEY 8(d) algorithmic-bytes figure and the measured HBM/fabric traffic
+                  (rocprofv3 PMC pass committed under profiles/) are reported beside it under `hbm`, the VALU issue
                   utilisation from the same PMC passes under `valu`. Every `frac` is <= 1 and recomputable from profiles/.
-  `wide_psq_rows` the same timed run on a context with SPX_CTX_WIDE_PSQ_ROWS (no 1 KiB u8 copies of piece-square rows):
-                  the figure a net whose piece-square weights do not fit i8 would get.
+  `wide_psq_rows` the same timed run on a context with SPX_CTX_WIDE_PSQ_ROWS (the one-kernel path, no 1 KiB u8 copies of
+                  piece-square rows): every piece-square row fetched as its 2 KiB i16 row.
   `cpu_baseline`  the compiled reference (`oracle/_ref/sp_ref_probe_tame[_avx512]`) timed on a bounded sample of the same
                   batch on this box's host cores. Its absence is an error (--allow-port-baseline times the scalar C
                   restatement instead).
@@ -352,8 +353,13 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2, settle
     sync()
     group.barrier()
     sync()
-    chunks = -(-args.batch // state.scratch_batch)  # calls above the scratch capacity run as several launch sequences
-    state.profile_begin(args.steps * chunks)
+    # calls above the scratch capacity run as several launch sequences; pipelined calls above one pass of the column-sliced
+    # pipeline (65 536 positions) too, one per pass
+    per_call = state.scratch_batch
+    if pipelined and state.takes_sliced_pipeline(args.batch):
+        per_call = min(per_call, 65536)
+    chunks = -(-args.batch // per_call)
+    state.profile_begin(min(args.steps * chunks, 1 << 16))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -362,6 +368,7 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2, settle
     sync()
     elapsed = time.perf_counter() - t0
     sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
+    timed_full_run.prepare_ms = state.profile_prepare_ms() / max(calls / chunks, 1)  # per step; see spx_profile_last_prepare_ms
     prof = (sort_ms, ft_ms, mlp_ms, calls / chunks)  # per-kernel times per STEP (= per batch), as the byte counts are
     # per-rank view for the report (rank order): each rank's FT-kernel time is its own, free of the barrier wait
     timed_full_run.per_rank_ft_ms = group.all_floats(ft_ms / max(calls / chunks, 1))
@@ -420,20 +427,22 @@ def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
         st.close()
 
 
-def sliced_leg(args, sp, torch, group, net, blob, d_pos, positions):
-    """secondary.sliced_pipeline (built): the same batch through the column-sliced full-refresh pipeline
-    (SPX_CTX_SLICED_FT; stormphrax_amd/csrc/spx_ftx.hip) - stream-ordered and pipelined rates, the gather kernel's own time
-    next to spx_ft_kernel's, what everything before the gather costs, and the rate the same calls reach when the lists are
-    NOT rebuilt every step (SPX_FTX_DEBUG_REUSE: the bound a free preparation would give). Scores checked against the
-    headline context's and the CPU oracle's on a sample. Not the default path: see `note`."""
+def paths_leg(args, sp, torch, group, net, blob, d_pos, positions):
+    """secondary.full_refresh_paths: the headline batch through BOTH full-refresh implementations - the column-sliced pipeline
+    (stormphrax_amd/csrc/spx_ftx.hip; the default from 24 576 positions up) and the one-kernel path (spx_ft_kernel:
+    SPX_CTX_ONE_KERNEL_FT) - stream-ordered and pipelined, with the main kernel's own time and what runs before it; and the rate
+    the pipeline's calls reach when the lists are NOT rebuilt every step (SPX_FTX_DEBUG_REUSE: the bound a free preparation would
+    give). Scores checked against the CPU oracle on a sample; checksums must agree between the paths."""
     import copy
 
     out = {}
-    for mode, reuse in (("stream_ordered", False), ("pipelined", False), ("stream_ordered_lists_reused", True)):
+    for path, mode, reuse in (("sliced_pipeline", "stream_ordered", False), ("sliced_pipeline", "pipelined", False),
+                              ("sliced_pipeline", "stream_ordered_lists_reused", True),
+                              ("one_kernel", "stream_ordered", False), ("one_kernel", "pipelined", False)):
         if reuse:
             os.environ["SPX_FTX_DEBUG_REUSE"] = "1"
         try:
-            st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch, sliced_ft=True)
+            st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch, sliced_ft=path == "sliced_pipeline")
         finally:
             os.environ.pop("SPX_FTX_DEBUG_REUSE", None)
         try:
@@ -442,22 +451,24 @@ def sliced_leg(args, sp, torch, group, net, blob, d_pos, positions):
             elapsed, (sort_ms, ft_ms, mlp_ms, calls), _, last = timed_full_run(a, torch, group, st, d_pos, mode == "pipelined",
                                                                               settle_seconds=0.3)
             calls = max(calls, 1)
-            step_ms = elapsed / a.steps * 1e3
-            rec = {"value": args.batch * a.steps / elapsed, "unit": "evals/s", "ms_per_step": step_ms,
-                   "gather_kernel_ms": ft_ms / calls, "sort_ms": sort_ms / calls, "mlp_ms": mlp_ms / calls}
+            rec = {"value": args.batch * a.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / a.steps * 1e3,
+                   "main_kernel": "spx_ftx_gather_kernel" if path == "sliced_pipeline" else "spx_ft_kernel",
+                   "main_kernel_ms": ft_ms / calls, "sort_ms": sort_ms / calls, "mlp_ms": mlp_ms / calls}
             if mode == "stream_ordered":
-                rec["preparation_ms"] = step_ms - (sort_ms + ft_ms + mlp_ms) / calls  # extraction, sort, plan, scatter, pack (+ launch gaps)
+                rec["before_main_kernel_ms"] = timed_full_run.prepare_ms  # the pipeline's extraction, counting sort, plan
                 n_sample = min(2048, len(positions))
                 rec["bit_exact_sample"] = bool(oracle_sample_check(sp, blob, positions[:n_sample], last[:n_sample].cpu().numpy()))
                 rec["checksum"] = int(last.sum(dtype=torch.int64).item())
-            out[mode] = rec
+            out.setdefault(path, {})[mode] = rec
         finally:
             st.close()
-    out["note"] = ("XCD x reads the 128-byte slice x of every row (L2 hit rate 74 -> 87 %, fabric bytes / 2.5), the king bucket's "
-                   "piece-square slab lives in LDS, four gathered i8 rows are widened and added by ONE v_mfma_i32_16x16x64_i8: the "
-                   "gather alone takes 0.66 x spx_ft_kernel's time. But the row lists must cross XCDs, i.e. be produced by a pass of "
-                   "their own, and that pass (VALU-bound extraction + sort + pack) costs more than the gather saves and does not "
-                   "overlap with it: one persistent workgroup per CU leaves no room for co-running kernels (DESIGN.md 4.9)")
+    out["checksums_agree"] = out["sliced_pipeline"]["stream_ordered"]["checksum"] == out["one_kernel"]["stream_ordered"]["checksum"]
+    out["note"] = ("sliced pipeline: XCD x reads the 128-byte slice x of every row (L2 hit rate 76 -> 83-89 %, fabric bytes / 3), "
+                   "the king bucket's piece-square slab lives in LDS, four gathered i8 rows are widened and added by ONE "
+                   "v_mfma_i32_16x16x64_i8: the gather takes 0.7 x spx_ft_kernel's time. The row lists must cross XCDs, i.e. be "
+                   "produced by a pass of their own (one extraction per position, a counting sort by (king bucket, list length), a "
+                   "plan); kernels sharing the CUs slow each other down by what they would take alone, so the step costs the sum "
+                   "(DESIGN.md 4.9)")
     return out
 
 
@@ -670,8 +681,8 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
     if args.batch <= state.scratch_batch:
         run("gather_ceiling", lambda: gather_ceiling(state, d_pos, args.batch))
     run("realistic_rows", lambda: realistic_leg(args, sp, torch, group, d_pos, positions, pipelined))
-    if args.batch <= state.scratch_batch and args.batch >= 8192 and not args.net:
-        run("sliced_pipeline", lambda: sliced_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
+    if args.batch <= state.scratch_batch and args.batch >= 24576 and not args.net:
+        run("full_refresh_paths", lambda: paths_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
     if args.preset == "tame":  # (the trace was recorded on the tame net)
         run("incremental", lambda: incremental_leg(sp, torch, net, device))
         run("config3_replay", lambda: config3_leg(sp, net, device))
@@ -789,6 +800,7 @@ def main():
 
     elapsed, (sort_ms, ft_ms, mlp_ms, calls), settle_steps, d_last = timed_full_run(args, torch, group, state, d_pos, pipelined)
     rank_ft_ms = timed_full_run.per_rank_ft_ms
+    timed_prepare_ms = timed_full_run.prepare_ms
     # checksum of checksums over all shards (summed in slabs: no 8-byte copy of an HBM-filling score array)
     checksum = group.sum_int(sum(int(d_last[lo:lo + (1 << 26)].sum(dtype=torch.int64).item())
                                  for lo in range(0, args.batch, 1 << 26)))
@@ -836,7 +848,8 @@ def main():
         ft_avg_s = ft_ms / max(calls, 1) / 1e3
         value = world * args.batch * args.steps / elapsed
         pmc = load_pmc("full", batch=args.batch, preset=args.preset, net=args.net) if n_distinct == args.batch else None
-        kp = kernel_pmc(pmc, "spx_ft_kernel")
+        sliced = state.takes_sliced_pipeline(min(args.batch, state.scratch_batch))
+        kp = kernel_pmc(pmc, "spx_ftx_gather_kernel" if sliced else "spx_ft_kernel")
         hbm = {
             "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_position": algo_bytes / args.batch,
             "algorithmic_gbs": algo_bytes / ft_avg_s / 1e9, "peak": HBM_PEAK_GBS,
@@ -852,18 +865,39 @@ def main():
             tb = (2 * kp["counters"]["FETCH_SIZE"] + kp["counters"]["WRITE_SIZE"]) * 1024
             hbm.update(traffic_bytes_per_launch=tb, traffic_gbs=tb / ft_avg_s / 1e9, frac=tb / ft_avg_s / 1e9 / HBM_PEAK_GBS,
                        frac_of_achievable=tb / ft_avg_s / 1e9 / HBM_ACHIEVABLE_GBS)
+        main_kernel = "spx_ftx_gather_kernel" if sliced else "spx_ft_kernel"
+        if sliced:
+            # the pipeline's gather asks the L2 for the threat / pawn-pair rows and the high-byte planes of the wide piece-square
+            # rows (128 B per row and XCD = 1 KiB per row); the piece-square rows' low-byte planes come from the LDS slab
+            requested = 1024 * (thr_rows + wide_rows) + 36 * args.batch
+            lds_served = 1024 * psq_rows
         l2_gbs = requested / ft_avg_s / 1e9
         roofline = {
-            "kernel": "spx_ft_kernel", "bound": "l2", "achieved": l2_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s",
+            "kernel": main_kernel, "bound": "l2", "achieved": l2_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s",
             "frac": l2_gbs / L2_PEAK_GBS, "traffic": hbm["traffic_bytes_per_launch"],
             "requested_bytes_per_launch": requested, "ft_kernel_ms": ft_avg_s * 1e3,
             "rows_per_launch": {"psq_wide_2KiB": wide_rows, "psq_compact_1KiB": compact_rows, "threat_1KiB": thr_rows},
-            "note": "achieved = bytes requested by the kernel's row loads (2 KiB per wide piece-square row, 1 KiB per "
-                    "compact piece-square / threat / pawn-pair row, + record and score) / the FT kernel's HIP-event "
-                    "duration, against the aggregate L2 bandwidth; the committed PMC pass counts the same bytes as "
-                    "TCC_REQ x 128 B (l2_pmc)",
+            "note": ("achieved = bytes the gather's row loads ask the L2s for (1 KiB per threat / pawn-pair row and per high-byte "
+                     "plane of a wide piece-square row, summed over the 8 column slices; + record and score) / the gather "
+                     "kernel's HIP-event duration, against the aggregate L2 bandwidth. The piece-square rows (lds_served_bytes) "
+                     "come from the king bucket's slab in LDS and are NOT in `achieved`; rows_incl_lds_gbs counts them too, for "
+                     "comparison with the one-kernel path's figure (secondary.full_refresh_paths). The committed PMC pass counts "
+                     "what the kernel really asked for - padding rows, row lists and slab fills included - as TCC_REQ x 128 B "
+                     "(l2_pmc)") if sliced else
+                    ("achieved = bytes requested by the kernel's row loads (2 KiB per wide piece-square row, 1 KiB per "
+                     "compact piece-square / threat / pawn-pair row, + record and score) / the FT kernel's HIP-event "
+                     "duration, against the aggregate L2 bandwidth; the committed PMC pass counts the same bytes as "
+                     "TCC_REQ x 128 B (l2_pmc)"),
             "l2_pmc": None, "hbm": hbm, "valu": None,
         }
+        if sliced:
+            roofline["lds_served_bytes_per_launch"] = lds_served
+            roofline["rows_incl_lds_gbs"] = (requested + lds_served) / ft_avg_s / 1e9
+            roofline["before_gather_ms"] = timed_prepare_ms
+            roofline["pipeline"] = ("spx_ftx_extract_kernel -> spx_ftx_rank_kernel -> spx_ftx_plan_kernel -> spx_ftx_scatter_kernel "
+                                    "-> spx_ftx_gather_kernel; before_gather_ms = HIP-event time between the sorts and the gather "
+                                    "(stream-ordered steps: the four preparation kernels; pipelined steps: they run on a stream "
+                                    "of their own beside the previous batch's gather, this is what is left of the wait)")
         if kp and "TCC_REQ_sum" in kp["counters"]:
             c = kp["counters"]
             req_bytes, miss_bytes = c["TCC_REQ_sum"] * 128, c.get("TCC_MISS_sum", 0) * 128
@@ -921,7 +955,10 @@ def main():
                                     "(oracle/spx_oracle.c) after the timed region",
                 "gathered_scores_ok": gathered_ok,
                 "checksum": checksum,
-                "kernel_ms": {"sort": sort_ms / max(calls, 1), "ft": ft_ms / max(calls, 1), "mlp": mlp_ms / max(calls, 1)},
+                "kernel_ms": {"sort": sort_ms / max(calls, 1), "before_ft": timed_prepare_ms, "ft": ft_ms / max(calls, 1),
+                              "mlp": mlp_ms / max(calls, 1)},
+                "full_refresh_path": ("column-sliced pipeline (spx_ftx.hip): extraction, counting sort, plan, gather" if sliced
+                                      else "one kernel (spx_ft_kernel)"),
             },
             "roofline": roofline,
         }

@@ -86,13 +86,19 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
 /* As spx_ctx_create, with option flags. SPX_CTX_WIDE_PSQ_ROWS: every piece-square row is gathered from the 2 KiB i16
  * table, i.e. the lossless "compact row" optimisation (1 KiB u8 copies of rows whose weights all fit i8) is off - what a
  * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
-/* SPX_CTX_SLICED_FT (round 4, experimental; also SPX_FTX=1 in the environment): full refreshes of 8 192 positions and more
- * take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction pass writes every perspective's row lists,
- * a counting sort groups them by king bucket and length, and the gather - XCD x reads slice x of every row, the bucket's
- * piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.66 x the one-kernel path's time); results
- * are bit-identical. Off by default: the lists cost more to produce than the gather saves. */
-enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2 };
+/* Full refreshes of 24 576 positions and more take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction
+ * pass writes every perspective's row lists, a counting sort groups them by king bucket and length, and the gather - XCD x
+ * reads slice x of every row, the bucket's piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.7 x
+ * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's
+ * tables and scratch (89 MB + 2.6 KB per position of a 65 536-position pass, four passes' worth for pipelined calls) are
+ * allocated on the first such batch; if that fails the one-kernel path serves it.
+ * SPX_CTX_ONE_KERNEL_FT (or SPX_FTX=0 in the environment): never take the pipeline. SPX_CTX_SLICED_FT (or SPX_FTX=1): take it
+ * (the default; kept from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
+enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2, SPX_CTX_ONE_KERNEL_FT = 4 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
+/* 1 if a full refresh of n positions takes the column-sliced pipeline on this context as things stand (enabled, n at or above
+ * the threshold, no failed allocation of its tables so far), 0 if the one-kernel path. */
+int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n);
 /* Positions the context keeps intermediates for at once: min(max_batch, SPX_SCRATCH_CAP = 4 Mi by default). The
  * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an
  * HBM-filling batch costs 36 bytes per resident position: record in, score out); the arena entry points (spx_acc_*) and
@@ -266,6 +272,10 @@ int spx_acc_update_eval_device_counted(spx_ctx* ctx, const void* d_parent_slots,
  * sort kernels, the feature-transformer kernel and the MLP kernel in milliseconds. Used by bench.py's roofline line. */
 int spx_profile_begin(spx_ctx* ctx, size_t max_calls);
 int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms, size_t* calls);
+/* ... and, of the calls the last spx_profile_end summed up, the time between the sorts and the feature-transformer stage's main
+ * kernel (ft_ms: spx_ft_kernel, or the column-sliced pipeline's gather): on stream-ordered calls the pipeline's preparation
+ * kernels (extraction, counting sort, plan); on pipelined calls what was left of the wait for the other lane's stage. */
+int spx_profile_last_prepare_ms(const spx_ctx* ctx, double* prepare_ms);
 
 /* Active feature rows of a batch, both perspectives summed (what a full refresh gathers): algorithmic bytes =
  * 2048 * psq_rows + 1024 * threat_rows (+ 36 B per position of record and score). Host-side count. */

@@ -38,7 +38,7 @@ int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int 
                            uint64_t* sink_checksum);
 int spx_debug_gather_probe_variants(void);
 /* Diagnostics of the column-sliced pipeline (SPX_CTX_SLICED_FT): start / end of each of the 256 workgroups of the last gather that
- * used scratch set `slot` (-1: the context's own, 0 .. 2: the pipelined calls' ring), device clock ticks of 10 ns; out[512]. */
+ * used scratch set `slot` (-1: the context's own, 0 / 1: the pipelined calls' lanes), device clock ticks of 10 ns; out[512]. */
 int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out);
 const char* spx_debug_gather_probe_name(int variant);
 

@@ -96,7 +96,9 @@ SYMBOLS = {
     "spx_ctx_destroy": (None, [_P]),
     "spx_eval_full": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
     "spx_eval_full_device": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
+    "spx_ctx_sliced_ft": (ctypes.c_int, [_P, ctypes.c_size_t]),
     "spx_profile_begin": (ctypes.c_int, [_P, ctypes.c_size_t]),
+    "spx_profile_last_prepare_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
     "spx_profile_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_size_t)]),
     "spx_acc_reserve": (ctypes.c_int, [_P, ctypes.c_size_t]),
     "spx_acc_refresh": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t]),

@@ -77,22 +77,13 @@ struct spx_ctx {
     bool mfmaGather = false;    // SPX_FT_MFMA_GATHER=1: spx_ft_kernel's gather on the matrix pipe (same speed, half the VALU work)
     uint8_t* dRowS = nullptr;   // the column-sliced row table of spx_ftx.hip (built on first use)
     FtxScratch ftx;             // its scratch (the lanes hold their own)
-    bool ftxEnabled = false;    // SPX_FTX=1 / SPX_CTX_SLICED_FT: big full refreshes take the column-sliced pipeline (spx_ftx.hip)
+    bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); SPX_FTX=0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // SPX_FTX_MIN: smallest batch that takes the sliced pipeline
+    bool ftxMinForced = false;    // (SPX_FTX_MIN given: the same threshold for stream-ordered and pipelined calls)
     bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
-    // spx_eval_full_device_async: the pipeline's preparation (extraction, sort, plan, pack - everything before the gather)
-    // runs on its own streams, up to kFtxRing batches ahead of the gathers, each with its own scratch set: it needs the
-    // positions only, so it is issued at call time and is never on a lane's critical path
-    static constexpr int kFtxRing = 3;
-    struct FtxSlot {
-        FtxScratch scratch;
-        hipStream_t stream = nullptr;
-        hipEvent_t prepared = nullptr, gathered = nullptr;  // preparation done / the gather that read the scratch done
-        bool used = false;
-    } ftxRing[kFtxRing];
-    unsigned ftxNext = 0;
-    FtxSlot* ftxSlot = nullptr;   // set around a lane's call: the slot whose scratch this call uses (nullptr: ctx->ftx, in-stream)
-    bool ftxRingUnavailable = false;
+    // (spx_eval_full_device_async: each lane has its own scratch set - swapLane -, so one lane's preparation runs beside the
+    // other lane's gather. A ring of extra streams that prepared up to three batches ahead cost 12 %: 1.60 against 1.81e8
+    // evals/s - more streams than hardware queues serialise; profiles/r04_sliced_pipeline_overlap_attempts.txt)
     bool ftxDebugReuse = false;   // SPX_FTX_DEBUG_REUSE=1: measurement aid (what would the pipeline cost without its preparation?)
     int16_t* dFtBias = nullptr;
     int8_t* dL1W = nullptr;
@@ -165,6 +156,7 @@ struct spx_ctx {
     uint32_t ftGridCap = 0;
     uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
+    double profLastPrepareMs = 0.0;
     std::vector<hipEvent_t> profEvents;  // kProfEventsPerCall per recorded call: [0] start, [1] after the sorts, [4] before
                                          // the FT kernel (after a pipelined call's wait), [2] after it, [3] after the MLP
     size_t profUsed = 0;
@@ -470,7 +462,7 @@ struct CtxDeleter {  // a context that fails half-way through its creation relea
 }  // namespace
 
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out) {
-    if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS | SPX_CTX_SLICED_FT))) {
+    if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS | SPX_CTX_SLICED_FT | SPX_CTX_ONE_KERNEL_FT))) {
         setError("spx_ctx_create: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -616,10 +608,13 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
     if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
-    ctx->ftxEnabled = (flags & SPX_CTX_SLICED_FT) != 0;
+    ctx->ftxEnabled = !(flags & (SPX_CTX_ONE_KERNEL_FT | SPX_CTX_WIDE_PSQ_ROWS)) || (flags & SPX_CTX_SLICED_FT);
     if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
-    if (const char* env = std::getenv("SPX_FTX_MIN")) ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
+    if (const char* env = std::getenv("SPX_FTX_MIN")) {
+        ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
+        ctx->ftxMinForced = true;
+    }
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
@@ -678,13 +673,6 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         if (p) (void)hipFree(p);
     }
     ctx->ftx.release();
-    for (auto& slot : ctx->ftxRing) {
-        if (slot.stream) (void)hipStreamSynchronize(slot.stream);
-        slot.scratch.release();
-        if (slot.prepared) (void)hipEventDestroy(slot.prepared);
-        if (slot.gathered) (void)hipEventDestroy(slot.gathered);
-        if (slot.stream) (void)hipStreamDestroy(slot.stream);
-    }
     if (ctx->dRowS) (void)hipFree(ctx->dRowS);
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
@@ -841,12 +829,11 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
     // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
     // output-bucket order is sorted here
-    // (a pipelined call of a single pass prepares on a ring slot's own stream, ahead of the lanes: ctx->ftxSlot)
-    spx_ctx::FtxSlot* slot = (ctx->ftxSlot && n <= std::min(ctx->maxBatch, kFtxMaxPositions)) ? ctx->ftxSlot : nullptr;
-    FtxScratch& scratch = slot ? slot->scratch : ctx->ftx;
-    const bool sliced = !tiny && n >= ctx->ftxMin && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), slot ? slot->stream : s);
-    // (Keeping everything else - this batch's sort and preparation, the other lane's MLP - strictly BETWEEN two gathers instead of
-    // beside one was measured too: 0.551 ms per step against 0.459 - the cross-stream event chain costs more than the co-runners.)
+    FtxScratch& scratch = ctx->ftx;
+    // (pipelined calls - a lane's gate is set - gain from 12 Ki positions on, stream-ordered ones from 24 Ki:
+    // profiles/r04_sliced_pipeline_crossover.txt)
+    const size_t sliceFrom = (ctx->ftGateRecord && !ctx->ftxMinForced) ? std::min(ctx->ftxMin, kFtxMinPositionsPipelined) : ctx->ftxMin;
+    const bool sliced = !tiny && n >= sliceFrom && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), s);
     int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, sliced);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
@@ -869,34 +856,16 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
-            if (slot) {
-                // the slot's stream: after the gather that last read this scratch - and behind nothing else
-                if (slot->used) SPX_HIP(hipStreamWaitEvent(slot->stream, slot->gathered, 0));
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, slot->stream));
-                scratch.preparedOnce = true;
-                SPX_HIP(hipEventRecord(slot->prepared, slot->stream));
-                // (the gathers on one stream of their own at the highest priority, everything else below it: measured, worse -
-                // every co-running kernel is starved and the gather still slows down)
-                SPX_HIP(hipStreamWaitEvent(s, slot->prepared, 0));
-                if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
-                if (ev) SPX_HIP(hipEventRecord(ev[4], s));
-                SPX_HIP(launchFtxGather(xp, s));
-                SPX_HIP(hipEventRecord(slot->gathered, s));
-                slot->used = true;
-                continue;
-            } else {
-                if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
-                scratch.preparedOnce = true;
-            }
+            // a pipelined call: the preparation is not gated - it runs beside the other lane's gather and MLP -, the gather is
+            // (the two lanes' gathers are chained). Gating the preparation too: 1.58 instead of 1.81e8 evals/s; no gate at all: 1.83e8,
+            // but then the gather's event interval includes its wait for free CUs
+            if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
+            scratch.preparedOnce = true;
             if (lo == 0) {
                 if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
                 if (ev) SPX_HIP(hipEventRecord(ev[4], s));
             }
             SPX_HIP(launchFtxGather(xp, s));
-            if (slot) {
-                SPX_HIP(hipEventRecord(slot->gathered, s));
-                slot->used = true;
-            }
         }
     } else {
         if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
@@ -979,21 +948,6 @@ static void releaseLanes(spx_ctx* ctx) {
     ctx->lanesReady = false;
 }
 
-static bool ensureFtxRing(spx_ctx* ctx) {
-    if (!ctx->ftxEnabled || ctx->ftxUnavailable || ctx->ftxRingUnavailable) return false;
-    if (ctx->ftxRing[0].stream) return true;
-    for (auto& slot : ctx->ftxRing) {
-        if (hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&slot.prepared, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&slot.gathered, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->ftxRingUnavailable = true;
-            return false;
-        }
-    }
-    return true;
-}
-
 int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event) {
     if (!ctx) {
         setError("spx_eval_full_device_async: null context");
@@ -1020,20 +974,22 @@ int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, 
         setError("batch of " + std::to_string(n) + " exceeds context capacity " + std::to_string(ctx->callLimit));
         return SPX_ERR_CAPACITY;
     }
-    // chunks of the scratch capacity alternate between the two lanes (one chunk for an ordinary batch)
+    // chunks of the scratch capacity alternate between the two lanes (one chunk for an ordinary batch); where the column-sliced
+    // pipeline runs, chunks of one of ITS passes: a lane walks the passes of its chunk one after the other, two lanes overlap
+    // them (131 072 positions per call: 1.73 -> 1.8e8 evals/s)
+    const size_t chunk = (ctx->ftxEnabled && !ctx->ftxUnavailable && n > kFtxMaxPositions) ? std::min(ctx->maxBatch, kFtxMaxPositions)
+                                                                                            : ctx->maxBatch;
     spx_ctx::EvalLane* last = nullptr;
-    for (size_t lo = 0; lo < n || lo == 0; lo += ctx->maxBatch) {
-        const size_t m = std::min(ctx->maxBatch, n - lo);
+    for (size_t lo = 0; lo < n || lo == 0; lo += chunk) {
+        const size_t m = std::min(chunk, n - lo);
         spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
         spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
         ++ctx->laneNext;
         swapLane(ctx, lane);
         ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
         ctx->ftGateRecord = lane.ftDone;
-        ctx->ftxSlot = ensureFtxRing(ctx) ? &ctx->ftxRing[ctx->ftxNext++ % spx_ctx::kFtxRing] : nullptr;
         rc = spx_eval_full_device(ctx, static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos), m,
                                   static_cast<int32_t*>(d_out) + lo, lane.stream);
-        ctx->ftxSlot = nullptr;
         ctx->ftGateWait = ctx->ftGateRecord = nullptr;
         swapLane(ctx, lane);
         if (rc != SPX_OK) return rc;
@@ -1056,9 +1012,6 @@ int spx_ctx_synchronize(spx_ctx* ctx) {
     SPX_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->lanesReady) {
         for (auto& lane : ctx->lanes) SPX_HIP(hipStreamSynchronize(lane.stream));
-    }
-    for (auto& slot : ctx->ftxRing) {
-        if (slot.stream) SPX_HIP(hipStreamSynchronize(slot.stream));
     }
     return SPX_OK;
 }
@@ -1804,6 +1757,10 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
     return SPX_OK;
 }
 
+int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n) {
+    return ctx && ctx->ftxEnabled && !ctx->ftxUnavailable && n >= ctx->ftxMin && n > ctx->tinyBatchMax ? 1 : 0;
+}
+
 size_t spx_ctx_scratch_batch(const spx_ctx* ctx) {
     return ctx ? ctx->maxBatch : 0;
 }
@@ -1823,6 +1780,7 @@ int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms
     }
     SPX_HIP(hipSetDevice(ctx->device));
     *sort_ms = *ft_ms = *mlp_ms = 0.0;
+    double prepare = 0.0;
     *calls = ctx->profUsed / kProfEventsPerCall;
     for (size_t i = 0; i + kProfEventsPerCall - 1 < ctx->profUsed; i += kProfEventsPerCall) {
         float a = 0.f, b = 0.f, c = 0.f;
@@ -1833,8 +1791,20 @@ int spx_profile_end(spx_ctx* ctx, double* sort_ms, double* ft_ms, double* mlp_ms
         *sort_ms += a;
         *ft_ms += b;
         *mlp_ms += c;
+        SPX_HIP(hipEventElapsedTime(&a, ctx->profEvents[i + 1], ctx->profEvents[i + 4]));
+        prepare += a;
     }
+    ctx->profLastPrepareMs = prepare;
     ctx->profUsed = ctx->profEvents.size();  // stop recording until the next spx_profile_begin
+    return SPX_OK;
+}
+
+int spx_profile_last_prepare_ms(const spx_ctx* ctx, double* prepare_ms) {
+    if (!ctx || !prepare_ms) {
+        setError("spx_profile_last_prepare_ms: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    *prepare_ms = ctx->profLastPrepareMs;
     return SPX_OK;
 }
 
@@ -2236,13 +2206,13 @@ int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int 
 }
 
 // start / end of every workgroup of the LAST column-sliced gather that used the given scratch set (slot -1: the context's own,
-// 0 .. 2: the pipelined calls' ring), on the device's constant 100 MHz clock: out[2 b] = start, out[2 b + 1] = end of workgroup b
+// 0 / 1: the pipelined calls' lanes), on the device's constant 100 MHz clock: out[2 b] = start, out[2 b + 1] = end of workgroup b
 int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
-    if (!ctx || !out || slot < -1 || slot >= spx_ctx::kFtxRing) {
+    if (!ctx || !out || slot < -1 || slot > 1) {
         setError("spx_debug_ftx_block_times: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
-    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->ftxRing[slot].scratch;
+    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->lanes[slot].ftx;
     if (!x.plan) {
         setError("spx_debug_ftx_block_times: that scratch set was never used");
         return SPX_ERR_INVALID_ARG;

@@ -49,6 +49,17 @@ __device__ __forceinline__ uint32_t laneId() {
 __device__ __forceinline__ uint32_t prefixCount(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
+// inclusive prefix sum over the wave's 64 lanes, on the DPP cross-lane path (no LDS): row_shr 1, 2, 4, 8 scan every row of
+// 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals on (rows 1 and 3, then rows 2 and 3)
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));
+    return v;
+}
 __device__ __forceinline__ uint32_t pkAdd16(uint32_t a, uint32_t b) {
     // two independent wrapping 16-bit adds (v_pk_add_u16): exactly the reference's add_epi16 semantics
     const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);

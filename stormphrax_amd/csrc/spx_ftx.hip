@@ -92,47 +92,58 @@ __global__ void spx_ftx_build_table_kernel(const uint8_t* thrU8, const int16_t* 
 // ---------------------------------------------------------------------------------------------------------------------
 // Extraction: one wave per position, lane = square. Everything that does not depend on the perspective is done once (VERDICT
 // r3 item 5): the record decode, the attack sets, and the ENUMERATION of the feature candidates - every (attacker, victim)
-// pair and every pawn pair becomes one item of a flat list in LDS (the serial part: one item per lane and round, as many rounds
-// as the busiest square has targets). Each perspective then turns the items into rows 64 at a time - one or two rounds
-// instead of one per target of the busiest square - and writes them straight to its list.
+// pair and every pawn pair becomes one item of a flat list in LDS (a wave scan of the lanes' counts places them; each lane then
+// writes its own, as many rounds as the busiest square has targets). Each perspective then turns the items into rows 64 at a
+// time - typically one round per kind instead of one per target of the busiest square - and writes them straight to its list.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kItemCap = 512;  // <= 30 attackers x 8 targets + the pawn pairs; malformed records are cut off here
-// items: from | to << 6 | kind << 12; kind 0 = threat pair, 1 = two pawns of one colour (from < to), 2 = pawns of different
-// colours (a feature of the perspective that owns `from`, whose mask it is: nnue_state.cpp:330-351)
+constexpr uint32_t kItemCap = 256;  // per kind: <= 30 attackers x 8 targets; malformed records are cut off here
+// threat items: attacker square | victim square << 6; pawn items: from | to << 6 | (1 = same colour (from < to), 0 = different
+// colours: a feature of the perspective that owns `from`, whose mask it is - nnue_state.cpp:330-351) << 12
 
 __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel(FtxParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];
-    __shared__ uint16_t sItems[kWavesPerBlock][kItemCap];
+    __shared__ uint16_t sItems[kWavesPerBlock][2][kItemCap];
     for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
     __syncthreads();
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
-    uint16_t* const items = sItems[wave];
+    uint16_t* const threatItems = sItems[wave][0];
+    uint16_t* const pawnItems = sItems[wave][1];
     for (uint32_t pos = blockIdx.x * kWavesPerBlock + wave; pos < p.nPositions; pos += gridDim.x * kWavesPerBlock) {
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(pos) * 32;
         const LaneBoard b = decodeBoard(rec, lane);
         const int piece = b.piece;
         const bool occupied = piece != kNoPiece;
-        uint32_t nItems = 0;
+        uint32_t nThreatItems, nPawnItems;
         {
-            uint64_t todo = laneTargets(b, lane);  // kind 0: the occupied non-king squares this lane's piece attacks
-            uint32_t tag = 0;
-            const bool pawnHere = (b.pawnsBb >> lane) & 1;
-            const uint64_t mine = b.pawnsBb & ((piece & 1) ? b.whiteBb : ~b.whiteBb);
-            uint64_t same = 0;
-            for (int round = 0; round < 2; ++round) {
-                while (__ballot(todo != 0)) {
-                    const bool active = todo != 0;
-                    const uint32_t to = active ? uint32_t(ctz64(todo)) : 0u;
-                    todo &= todo - 1;
-                    const uint32_t slot = nItems + prefixCount(__ballot(active));
-                    if (active && slot < kItemCap) items[slot] = uint16_t(lane | (to << 6) | (round ? (((same >> to) & 1) ? 1u : 2u) << 12 : tag));
-                    nItems = min(nItems + uint32_t(popc64(__ballot(active))), kItemCap);
+            uint64_t targets = laneTargets(b, lane);  // the occupied non-king squares this lane's piece attacks
+            uint64_t partners = 0, same = 0;
+            if ((b.pawnsBb >> lane) & 1) {
+                const uint64_t mine = b.pawnsBb & ((piece & 1) ? b.whiteBb : ~b.whiteBb);
+                same = mine & ~((2ull << lane) - 1);
+                partners = (same | (b.pawnsBb & ~mine)) & ppMask(int(lane));
+                same &= partners;
+            }
+            // every lane's items go behind those of the lanes below it: one scan for both kinds, then no lane waits for another
+            const uint32_t mineCount = uint32_t(popc64(targets)) | (uint32_t(popc64(partners)) << 16);
+            const uint32_t incl = waveInclusiveScan(mineCount);
+            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            nThreatItems = min(total & 0xFFFFu, kItemCap);
+            nPawnItems = min(total >> 16, kItemCap);
+            uint32_t atThreat = (incl - mineCount) & 0xFFFFu, atPawn = (incl - mineCount) >> 16;
+            while (targets | partners) {
+                if (targets) {
+                    const uint32_t to = uint32_t(ctz64(targets));
+                    targets &= targets - 1;
+                    if (atThreat < kItemCap) threatItems[atThreat] = uint16_t(lane | (to << 6));
+                    ++atThreat;
                 }
-                if (round == 0 && pawnHere) {  // then the pawn pairs of this lane's pawn
-                    same = mine & ~((2ull << lane) - 1);
-                    todo = (same | (b.pawnsBb & ~mine)) & ppMask(int(lane));
+                if (partners) {
+                    const uint32_t to = uint32_t(ctz64(partners));
+                    partners &= partners - 1;
+                    if (atPawn < kItemCap) pawnItems[atPawn] = uint16_t(lane | (to << 6) | (uint32_t((same >> to) & 1) << 12));
+                    ++atPawn;
                 }
             }
         }
@@ -162,29 +173,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             }
             const uint32_t nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
             const uint32_t nHi = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-            // threat rows (addThreatFeatures, nnue_state.cpp:309-328) and pawn pairs (:330-351)
             uint32_t nThr = 0;
-            for (uint32_t base = 0; base < nItems; base += 64) {
-                const bool active = base + lane < nItems;
-                const uint32_t item = active ? items[base + lane] : 0u;
-                const int from = item & 63u, to = (item >> 6) & 63u;
-                const uint32_t kind = item >> 12;
-                const int pf = __shfl(piece, from, 64), pt = __shfl(piece, to, 64);
-                int32_t r = -1;
-                if (active) {
-                    if (kind == 0) {
-                        const int pieceRel = pf ^ flipColour, sqRel = from ^ x;
-                        const uint64_t pseudoRel = sPseudo[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
-                        r = threatRow(sLut, pieceRel, sqRel, pseudoRel, pt ^ flipColour, to ^ x);
-                    } else {
-                        const bool own = (pf & 1) == c;
-                        if (kind == 1 || own) r = int32_t(ppRow(ppId(from ^ x, !own), ppId(to ^ x, kind == 1 ? !own : true)));
-                    }
-                }
+            auto emit = [&](int32_t r) {
                 const uint64_t valid = __ballot(r >= 0);
                 const uint32_t at = nThr + prefixCount(valid);
                 if (r >= 0 && at < kThreatCap) out[kFtxListThr + at] = uint32_t(r) * 128u;
                 nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
+            };
+            // threat rows (addThreatFeatures, nnue_state.cpp:309-328): the reference drops the pairs whose index is negative
+            for (uint32_t base = 0; base < nThreatItems; base += 64) {
+                const bool active = base + lane < nThreatItems;
+                const uint32_t item = active ? threatItems[base + lane] : 0u;
+                const int from = item & 63u, to = item >> 6;
+                const int pieceRel = __shfl(piece, from, 64) ^ flipColour, victimRel = __shfl(piece, to, 64) ^ flipColour;
+                int32_t r = -1;
+                if (active) {
+                    const int sqRel = from ^ x;
+                    const uint64_t pseudoRel = sPseudo[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
+                    r = threatRow(sLut, pieceRel, sqRel, pseudoRel, victimRel, to ^ x);
+                }
+                emit(r);
+            }
+            // pawn pairs (:330-351)
+            for (uint32_t base = 0; base < nPawnItems; base += 64) {
+                const bool active = base + lane < nPawnItems;
+                const uint32_t item = active ? pawnItems[base + lane] : 0u;
+                const int from = item & 63u, to = (item >> 6) & 63u;
+                const bool sameColour = item >> 12;
+                const bool own = (__shfl(piece, from, 64) & 1) == c;
+                int32_t r = -1;
+                if (active && (sameColour || own)) r = int32_t(ppRow(ppId(from ^ x, !own), ppId(to ^ x, sameColour ? !own : true)));
+                emit(r);
             }
             if (lane == 0) {
                 u32x2 head;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
     __shared__ uint32_t sBucketStart[17], sBucketCount[16];
     __shared__ uint32_t sGroups[kFtxBins];     // per bin: groups whose longest list ends in it; then the index of the first of them
     __shared__ uint32_t sCost[kFtxBins];       // per bin: their cost; then the exclusive prefix of it
-    __shared__ uint32_t sScan[1024];
+    __shared__ uint32_t sWaveSum[32];
     __shared__ uint32_t sCut[33];
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
@@ -244,22 +263,15 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
             c0 = sBin[wave * kFtxQuartetBins + 2 * lane];
             c1 = sBin[wave * kFtxQuartetBins + 2 * lane + 1];
         }
-        mineIncl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = uint32_t(__shfl_up(int(mineIncl), d, 64));
-            if (lane >= uint32_t(d)) mineIncl += v;
-        }
+        mineIncl = waveInclusiveScan(c0 + c1);
         if (lane == 63) sBucketCount[wave] = mineIncl;
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t at = 0;
-        for (uint32_t b = 0; b < 16; ++b) {
-            sBucketStart[b] = at;
-            at = (at + sBucketCount[b] + 7u) & ~7u;  // every bucket starts a new group of 8
-        }
-        sBucketStart[16] = at;
+    if (wave == 0) {
+        const uint32_t padded = lane < 16 ? (sBucketCount[lane] + 7u) & ~7u : 0u;  // every bucket starts a new group of 8
+        const uint32_t incl = waveInclusiveScan(padded);
+        if (lane < 16) sBucketStart[lane] = incl - padded;
+        if (lane == 16) sBucketStart[16] = incl;
     }
     __syncthreads();
     {
@@ -296,32 +308,20 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         g2[0] = sGroups[2 * tid], g2[1] = sGroups[2 * tid + 1];
         w2[0] = sCost[2 * tid], w2[1] = sCost[2 * tid + 1];
     }
-    sScan[tid] = w2[0] + w2[1];
+    // exclusive prefixes of the costs and of the group counts over the bins (two per thread): wave scans + the 16 wave totals
+    const uint32_t wIncl = waveInclusiveScan(w2[0] + w2[1]), gIncl = waveInclusiveScan(g2[0] + g2[1]);
+    if (lane == 63) sWaveSum[wave] = wIncl, sWaveSum[16 + wave] = gIncl;
     __syncthreads();
-    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // inclusive scan of the costs
-        const uint32_t v = tid >= d ? sScan[tid - d] : 0u;
-        __syncthreads();
-        sScan[tid] += v;
-        __syncthreads();
+    uint32_t wBase = 0, gBase = 0, total = 0;
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t w = sWaveSum[i], g = sWaveSum[16 + i];
+        total += w;
+        if (i < wave) wBase += w, gBase += g;
     }
-    const uint32_t total = sScan[blockDim.x - 1];
-    const uint32_t costBefore = sScan[tid] - (w2[0] + w2[1]);
-    __syncthreads();
     if (tid < kFtxBins / 2) {
+        const uint32_t costBefore = wBase + wIncl - (w2[0] + w2[1]), groupsBefore = gBase + gIncl - (g2[0] + g2[1]);
         sCost[2 * tid] = costBefore;
         sCost[2 * tid + 1] = costBefore + w2[0];
-    }
-    sScan[tid] = g2[0] + g2[1];
-    __syncthreads();
-    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {  // ... and of the group counts: first group of every bin
-        const uint32_t v = tid >= d ? sScan[tid - d] : 0u;
-        __syncthreads();
-        sScan[tid] += v;
-        __syncthreads();
-    }
-    const uint32_t groupsBefore = sScan[tid] - (g2[0] + g2[1]);
-    __syncthreads();
-    if (tid < kFtxBins / 2) {
         sGroups[2 * tid] = groupsBefore;  // (bins follow the sorted order, so the running count IS the group index)
         sGroups[2 * tid + 1] = groupsBefore + g2[0];
     }
@@ -342,31 +342,41 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
             const uint32_t binGroups = (lo + 1 < kFtxBins ? sGroups[lo + 1] : nGroups) - sGroups[lo];
             cut = sGroups[lo] + min(within, binGroups);
         }
-        sCut[tid] = cut;
+        sCut[tid] = cut;  // (ascending: the targets ascend)
     }
     __syncthreads();
-    if (tid == 0) {
-        for (uint32_t c = 1; c <= 32; ++c) {  // (monotone whatever the rounding did)
-            if (sCut[c] < sCut[c - 1]) sCut[c] = sCut[c - 1];
+    // segments: CU slot c's range [cut c, cut c + 1) cut again where the bucket changes - one thread per slot
+    if (wave == 0) {
+        uint32_t start = 0, end = 0, mine = 0;
+        if (lane < 32) {
+            start = sCut[lane], end = max(sCut[lane + 1], start);
+            if (end > start) {
+                mine = 1;
+                for (uint32_t bb = 1; bb < 16; ++bb) {  // bucket starts strictly inside (an empty bucket's start is its successor's)
+                    const uint32_t at = sBucketStart[bb] / 8;
+                    if (at > start && at < end && at != sBucketStart[bb + 1] / 8) ++mine;
+                }
+            }
         }
-        sCut[32] = nGroups;
-        uint32_t nSeg = 0, b = 0;  // (the cuts ascend, so does the bucket)
-        for (uint32_t c = 0; c < 32; ++c) {
-            p.plan[c] = nSeg;
-            uint32_t G = sCut[c];
-            const uint32_t end = max(sCut[c + 1], G);
+        const uint32_t incl = waveInclusiveScan(mine);
+        uint32_t k = incl - mine;
+        if (lane < 32) {
+            p.plan[lane] = k;
+            uint32_t G = start, bb = 0;
             while (G < end) {
-                while (b < 15 && G >= sBucketStart[b + 1] / 8) ++b;
-                const uint32_t e = min(end, b < 15 ? max(sBucketStart[b + 1] / 8, G + 1) : end);
-                p.plan[64 + 3 * nSeg] = b;
-                p.plan[64 + 3 * nSeg + 1] = G;
-                p.plan[64 + 3 * nSeg + 2] = e;
-                ++nSeg;
+                while (bb < 15 && G >= sBucketStart[bb + 1] / 8) ++bb;  // the bucket of group G
+                const uint32_t e = min(end, bb < 15 ? sBucketStart[bb + 1] / 8 : end);
+                p.plan[64 + 3 * k] = bb;
+                p.plan[64 + 3 * k + 1] = G;
+                p.plan[64 + 3 * k + 2] = e;
+                ++k;
                 G = e;
             }
         }
-        p.plan[32] = nSeg;
-        p.plan[33] = nGroups;
+        if (lane == 63) {
+            p.plan[32] = incl;
+            p.plan[33] = nGroups;
+        }
     }
 }
 

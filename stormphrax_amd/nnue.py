@@ -40,7 +40,8 @@ def synthetic_net_bytes(preset="tame", seed=DEFAULT_SEED):
 
 ADJUST_STATIC, ADJUST_EVAL, ADJUST_WHITE_POV, ADJUST_WDL = 1, 2, 4, 8
 CTX_WIDE_PSQ_ROWS = 1  # spx_ctx_create_ex flag: no compact (u8) copies of piece-square rows
-CTX_SLICED_FT = 2       # spx_ctx_create_ex flag: big full refreshes through the column-sliced pipeline (spx_ftx.hip; experimental)
+CTX_SLICED_FT = 2       # spx_ctx_create_ex flag: big full refreshes through the column-sliced pipeline (spx_ftx.hip; the default)
+CTX_ONE_KERNEL_FT = 4   # ... never: every full refresh through spx_ft_kernel
 
 
 def adjust_params(contempt=(0, 0), optimism=(0, 0), stages=ADJUST_STATIC | ADJUST_EVAL):
@@ -96,10 +97,10 @@ class Network:
 class NnueState:
     """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
 
-    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=False):
+    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=None):
         lib = _lib.load()
         handle = ctypes.c_void_p()
-        flags = (CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0) | (CTX_SLICED_FT if sliced_ft else 0)
+        flags = (CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0) | (0 if sliced_ft is None else CTX_SLICED_FT if sliced_ft else CTX_ONE_KERNEL_FT)
         check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
         self._h = handle
         self._net = network
@@ -207,6 +208,10 @@ class NnueState:
     def synchronize(self):
         check(_lib.load().spx_ctx_synchronize(self._h))
 
+    def takes_sliced_pipeline(self, n):
+        """Does a full refresh of n positions take the column-sliced pipeline (spx_ftx.hip) on this context?"""
+        return bool(_lib.load().spx_ctx_sliced_ft(self._h, n))
+
     def profile_begin(self, max_calls):
         check(_lib.load().spx_profile_begin(self._h, max_calls))
 
@@ -215,6 +220,13 @@ class NnueState:
         s, a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
         check(_lib.load().spx_profile_end(self._h, ctypes.byref(s), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return s.value, a.value, b.value, c.value
+
+    def profile_prepare_ms(self):
+        """Of the calls the last profile_end summed up: the time between the sorts and the FT stage's main kernel (the column-sliced
+        pipeline's preparation kernels on stream-ordered calls)."""
+        v = ctypes.c_double()
+        check(_lib.load().spx_profile_last_prepare_ms(self._h, ctypes.byref(v)))
+        return v.value
 
     # ---- incremental path: accumulator arena (mirrors NnueState::reset / push+applyMove / evaluate) ----
     def reserve_slots(self, n_slots):

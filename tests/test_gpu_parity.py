@@ -353,20 +353,22 @@ def _state_with_env(sp, blob, env, **kw):
 
 @pytest.mark.parametrize("preset", ["tame", "extreme", "mixed", "near", "realistic"])
 def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net_blob, preset):
-    """SPX_FTX=1: big full refreshes take the column-sliced pipeline of spx_ftx.hip (extraction pass, counting sort by
-    (king bucket, list length), plan, pack, gather on the matrix pipe with the bucket's piece-square slab in LDS). Same sums
-    mod 2^16, so the evaluations must equal spx_ft_kernel's and the oracle's bit for bit: batches at the pipeline's threshold,
+    """Big full refreshes take the column-sliced pipeline of spx_ftx.hip (extraction pass, counting sort by (king bucket, list
+    length), plan, gather on the matrix pipe with the bucket's piece-square slab in LDS; the default from 24 576 positions up,
+    here from 8 192: SPX_FTX_MIN). Same sums mod 2^16, so the evaluations must equal those of spx_ft_kernel (a context created
+    with sliced_ft=False: SPX_CTX_ONE_KERNEL_FT) and the oracle's bit for bit: batches at the pipeline's threshold,
     ragged ones, more than one pass (> 65 536 positions), nets with wide rows (low / high byte planes) and near-compact rows
     (taken as wide rows here), synchronous and pipelined calls."""
     blob = net_blob(preset)
     pos = sp.random_positions(70001, seed=909, min_ply=0, max_ply=160, dfrc_every=3)
-    with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 17) as plain, \
-            _state_with_env(sp, blob, {"SPX_FTX": "1"}, max_batch=1 << 17) as sliced:
+    with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 17, sliced_ft=False) as plain, \
+            _state_with_env(sp, blob, {"SPX_FTX_MIN": "8200"}, max_batch=1 << 17) as sliced:
+        assert not plain.takes_sliced_pipeline(70001) and sliced.takes_sliced_pipeline(8200) and not sliced.takes_sliced_pipeline(8199)
         want = plain.evaluate_once(pos)
         oracle.use(blob, preset)
         mail, stm = sp.positions_to_mailboxes(pos[:3000])
         assert np.array_equal(want[:3000], oracle.eval_mailboxes(mail, stm))
-        for n in (70001, 8192, 20001, 65536, 65537, 100):  # (100: below the threshold, the one-kernel path of the same context)
+        for n in (70001, 8200, 20001, 65536, 65537, 100):  # (100: below the threshold, the one-kernel path of the same context)
             got = sliced.evaluate_once(pos[:n])
             bad = np.nonzero(got != want[:n])[0]
             assert bad.size == 0, f"n={n}: {bad.size} mismatches, first at {bad[0]}: {sp.position_to_fen(pos[bad[0]])}"
