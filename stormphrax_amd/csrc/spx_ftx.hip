@@ -47,7 +47,7 @@ namespace {
 #define SPX_FTX_GATHER_WAVES 16
 #endif
 #ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
-#define SPX_FTX_GATHER_WAVES_PER_SIMD 4  // register budget: 512 / this
+#define SPX_FTX_GATHER_WAVES_PER_SIMD 5  // register budget: 512 / this = 96 (a workgroup brings 4 waves per SIMD: the rest is room for two of the extraction's)
 #endif
 constexpr uint32_t kGatherWaves = SPX_FTX_GATHER_WAVES;
 constexpr uint32_t kGatherSlabBytes = (kFtxSlabRows + 1) * 128;
