@@ -393,15 +393,24 @@ def self_launch(n):
 
 
 def gather_ceiling(state, d_pos, n, iters=30):
-    """roofline.ceiling: the load-only replay of this batch's row fetches (spx_probe.hip; the product kernel's own lists, grid
-    and traversal, global_load_dwordx4 at 5 waves/SIMD - the fastest of the probe's variants, profiles/r03_gather_ceiling.json)
-    next to the product kernel timed the same way (alone, stream-ordered)."""
+    """roofline.ceiling: load-only replays of this batch's row fetches (spx_probe.hip) next to the kernels they bound, all timed
+    the same way (alone, stream-ordered): whole 1 KiB rows with the one-kernel path's own lists, grid and traversal
+    (global_load_dwordx4 at 5 waves/SIMD - the fastest whole-row variant) against spx_ft_kernel; and the column-sliced form - slice x
+    of every row on XCD x, the king bucket's piece-square slab in LDS - which the pipeline's gather kernel implements (its own
+    time: secondary.full_refresh_paths.sliced_pipeline.stream_ordered.main_kernel_ms)."""
     name, probe_ms, _ = state.gather_probe(d_pos.data_ptr(), n, 0, iters)
     _, ft_ms, _ = state.gather_probe(d_pos.data_ptr(), n, -1, iters)
-    return {"probe": name, "probe_us": probe_ms * 1e3, "ft_kernel_alone_us": ft_ms * 1e3, "frac_of_probe": probe_ms / ft_ms,
-            "note": "frac_of_probe = load-only replay time / feature-transformer kernel time, both alone on the stream: what the "
-                    "kernel reaches of the rate this chip sustains for the same row fetches with no extraction, no widening, "
-                    "no activation (a measured ceiling for this access pattern, unlike the guide's streaming L2 figure)"}
+    out = {"probe": name, "probe_us": probe_ms * 1e3, "ft_kernel_alone_us": ft_ms * 1e3, "frac_of_probe": probe_ms / ft_ms,
+           "note": "frac_of_probe = load-only replay time / spx_ft_kernel (the one-kernel path) time, both alone on the stream: what "
+                   "that kernel reaches of the rate this chip sustains for the same row fetches with no extraction, no widening, "
+                   "no activation (a measured ceiling for this access pattern, unlike the guide's streaming L2 figure)"}
+    for v in range(state.gather_probe_variants() - 1, -1, -1):
+        if "slab in LDS" in state.gather_probe_name(v):
+            sname, sliced_ms, _ = state.gather_probe(d_pos.data_ptr(), n, v, iters)
+            out["sliced_probe"] = sname
+            out["sliced_probe_us"] = sliced_ms * 1e3
+            break
+    return out
 
 
 def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
@@ -827,8 +836,10 @@ def main():
         wide = {"value": world * args.batch * args.steps / w_elapsed, "unit": "evals/s",
                 "ms_per_step": w_elapsed / args.steps * 1e3, "ft_kernel_ms": w_ft / max(w_calls, 1),
                 "identical_scores": bool(w_same),
-                "note": "same timed run on a context created with SPX_CTX_WIDE_PSQ_ROWS: every piece-square row fetched "
-                        "as its 2 KiB i16 row (what a net whose piece-square weights do not fit i8 gets)"}
+                "note": "same timed run on a context created with SPX_CTX_WIDE_PSQ_ROWS: the ONE-KERNEL path (spx_ft_kernel) with every "
+                        "piece-square row fetched as its 2 KiB i16 row - the round-1..3 worst case, kept for comparison. What nets "
+                        "with wide piece-square rows get on the default path (high-byte planes beside the LDS slab) is the "
+                        "`realistic_rows` line"}
         wstate.close()
 
     secondary = None

@@ -316,6 +316,10 @@ class NnueState:
     def gather_probe_variants():
         return int(_lib.load().spx_debug_gather_probe_variants())
 
+    @staticmethod
+    def gather_probe_name(variant):
+        return _lib.load().spx_debug_gather_probe_name(variant).decode()
+
     def __enter__(self):
         return self
 

@@ -45,6 +45,10 @@ names = {
     "bench_n1_config5_hbm_filling.json": "bench_n1_config5_hbm_filling.json",
     "kstats_sliced_pipeline_stream_ordered.txt": "kstats_sliced_pipeline_stream_ordered_final_binary.txt",
     "pmc_sliced_pipeline.txt": "pmc_sliced_pipeline.txt",
+    "kstats_one_kernel_path_stream_ordered.txt": "kstats_one_kernel_path_stream_ordered.txt",
+    "timeline_pipelined_steps.txt": "timeline_pipelined_steps.txt",
+    "sliced_pipeline_crossover.txt": "sliced_pipeline_crossover.txt",
+    "reference_differential_one_kernel_path.json": "reference_differential_one_kernel_path.json",
     "reference_engine_on_gpu_evaluator.txt": "reference_engine_on_gpu_evaluator.txt",
 }
 for src, dst in names.items():
