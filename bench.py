@@ -921,6 +921,15 @@ def main():
                                   "frac_of_l2_peak_incl_fills": (req_bytes + miss_bytes) / ft_avg_s / 1e9 / L2_PEAK_GBS}
         if pmc:
             roofline["valu"] = valu_block(kp, pmc.get("valu_cycles_per_wave_instr", 4))
+        if kp and "TCP_TOTAL_CACHE_ACCESSES_sum" in kp["counters"] and "GRBM_GUI_ACTIVE" in kp["counters"]:
+            # the unit the counters show busiest: the CU's texture / L1 path takes one 64-byte access per cycle, a 16-byte-per-lane
+            # wave load is 16 of them whatever it coalesces to (MI355X_MICROARCH.md: 64 B/clk/CU)
+            acc, cyc = kp["counters"]["TCP_TOTAL_CACHE_ACCESSES_sum"], kp["counters"]["GRBM_GUI_ACTIVE"] / 8.0
+            roofline["l1_path"] = {"accesses_per_launch": acc, "bytes_per_access": 64, "kernel_cycles": cyc,
+                                   "busy_frac": acc / (N_SIMDS / 4 * cyc),
+                                   "mfma_busy_frac": kp["counters"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (N_SIMDS * cyc),
+                                   "note": "TCP_TOTAL_CACHE_ACCESSES / (256 CUs x kernel cycles) from the committed PMC passes (the "
+                                           "kernel alone: rocprofv3 serialises the dispatches it counts)"}
         line = {
             "metric": "nnue_position_evals_per_sec",
             "value": value,
