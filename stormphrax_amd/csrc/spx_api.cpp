@@ -79,6 +79,7 @@ struct spx_ctx {
     FtxScratch ftx;             // its scratch (the lanes hold their own)
     bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); SPX_FTX=0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // SPX_FTX_MIN: smallest batch that takes the sliced pipeline
+    int ftxFailAfter = -1, ftxScratchSets = 0;  // (SPX_FTX_FAIL_AFTER: simulated allocation failure)
     bool ftxMinForced = false;    // (SPX_FTX_MIN given: the same threshold for stream-ordered and pipelined calls)
     bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
     // (spx_eval_full_device_async: each lane has its own scratch set - swapLane -, so one lane's preparation runs beside the
@@ -611,6 +612,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     ctx->ftxEnabled = !(flags & (SPX_CTX_ONE_KERNEL_FT | SPX_CTX_WIDE_PSQ_ROWS)) || (flags & SPX_CTX_SLICED_FT);
     if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
+    if (const char* env = std::getenv("SPX_FTX_FAIL_AFTER")) ctx->ftxFailAfter = std::atoi(env);
     if (const char* env = std::getenv("SPX_FTX_MIN")) {
         ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
         ctx->ftxMinForced = true;
@@ -786,6 +788,8 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     }
     if (x.capacity >= passPositions) return true;
     x.release();
+    // (SPX_FTX_FAIL_AFTER=k, tests only: the k-th scratch set "does not fit" - what a context sized to fill the HBM runs into)
+    if (ctx->ftxFailAfter >= 0 && ctx->ftxScratchSets++ >= ctx->ftxFailAfter) return fail();
     const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
     if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 8) || !alloc(x.keys, 2 * cap * 4) ||

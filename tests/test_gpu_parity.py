@@ -399,9 +399,55 @@ def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net
                 sliced.synchronize()
                 for o, off in zip(outs, offs):
                     assert np.array_equal(o, want[off:off + len(o)]), (rep, off)
+            # one pipelined call above a pass of the pipeline (65 536 positions): cut into passes that alternate between the lanes
+            big = lib.spx_host_alloc(len(pos) * 4)
+            assert big
+            pouts.append(big)
+            o = np.ctypeslib.as_array((ctypes.c_int32 * len(pos)).from_address(big))
+            o[:] = -1
+            assert sliced.evaluate_once_device_async(pin, len(pos), o.ctypes.data)
+            sliced.synchronize()
+            assert np.array_equal(o, want)
         finally:
             for q in [pin] + pouts:
                 lib.spx_host_free(q)
+
+
+def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_blob):
+    """The column-sliced pipeline allocates its table and scratch sets on first use; when one does not fit (a context sized to
+    fill the HBM: simulated with SPX_FTX_FAIL_AFTER) that call and all later ones take spx_ft_kernel - another GPU path, same
+    results - while a gather already issued on the other lane finishes on the scratch set it has."""
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    blob = net_blob("tame")
+    n = 40000
+    pos = sp.random_positions(n, seed=911, min_ply=0, max_ply=160, dfrc_every=3)
+    with sp.NnueState(sp.Network(blob), device=0, max_batch=65536, sliced_ft=False) as plain:
+        want = plain.evaluate_once(pos)
+    pin = lib.spx_host_alloc(n * 32)
+    pouts = [lib.spx_host_alloc(n * 4) for _ in range(4)]
+    assert pin and all(pouts)
+    try:
+        np.ctypeslib.as_array((ctypes.c_uint8 * (n * 32)).from_address(pin))[:] = pos.view(np.uint8).reshape(-1)
+        outs = [np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(q)) for q in pouts]
+        for fail_after in (0, 1):  # (0: the first scratch set already; 1: the second lane's)
+            with _state_with_env(sp, blob, {"SPX_FTX_FAIL_AFTER": str(fail_after)}, max_batch=65536) as st:
+                assert st.takes_sliced_pipeline(n)
+                for o in outs:
+                    o[:] = -1
+                for o in outs:
+                    assert st.evaluate_once_device_async(pin, n, o.ctypes.data)
+                st.synchronize()
+                for o in outs:
+                    assert np.array_equal(o, want), fail_after
+                assert not st.takes_sliced_pipeline(n)
+                assert np.array_equal(st.evaluate_once(pos), want)
+    finally:
+        for q in [pin] + pouts:
+            lib.spx_host_free(q)
 
 
 @pytest.mark.parametrize("preset", ["tame", "extreme", "near", "realistic"])
