@@ -79,6 +79,8 @@ struct spx_ctx {
     FtxScratch ftx;             // its scratch (the lanes hold their own)
     bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); SPX_FTX=0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // SPX_FTX_MIN: smallest batch that takes the sliced pipeline
+    bool ftuEnabled = false;      // SPX_FTU=1: big fused update + eval batches through the incremental pipeline (spx_ftu_*)
+    size_t ftuMin = 16384;        // SPX_FTU_MIN
     int ftxFailAfter = -1, ftxScratchSets = 0;  // (SPX_FTX_FAIL_AFTER: simulated allocation failure)
     bool ftxMinForced = false;    // (SPX_FTX_MIN given: the same threshold for stream-ordered and pipelined calls)
     bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
@@ -613,6 +615,8 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
     if (const char* env = std::getenv("SPX_FTX_FAIL_AFTER")) ctx->ftxFailAfter = std::atoi(env);
+    if (const char* env = std::getenv("SPX_FTU")) ctx->ftuEnabled = env[0] == '1';
+    if (const char* env = std::getenv("SPX_FTU_MIN")) ctx->ftuMin = std::max<size_t>(8, size_t(std::atoll(env)));
     if (const char* env = std::getenv("SPX_FTX_MIN")) {
         ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
         ctx->ftxMinForced = true;
@@ -859,6 +863,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.binStart = scratch.binStart;
             xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
+            xp.listStride = kFtxListStride;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
             // a pipelined call: the preparation is not gated - it runs beside the other lane's gather and MLP -, the gather is
             // (the two lanes' gathers are chained). Gating the preparation too: 1.58 instead of 1.81e8 evals/s; no gate at all: 1.83e8,
@@ -1183,7 +1188,45 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
         SPX_HIP(launchUpdateChain(cp, s));
         return SPX_OK;
     }
-    SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, legacy, s));
+    // SPX_FTU=1 (round 4, opt-in): the INCREMENTAL pipeline on the column-sliced row table (spx_ftx.h: FtuParams) - delta lists of
+    // every record in a pass of their own, the shared counting sort + plan, then the apply kernel, XCD x updating columns
+    // {64 x ..} U {512 + 64 x ..} of every child. Fused update + eval batches only; passes of <= 65 536 records.
+    bool slicedUpdate = false;
+    if (!legacy && ctx->ftuEnabled && !up.nRecordsPtr && up.ftOut && up.stagedRecords && n >= ctx->ftuMin &&
+        ensureFtx(ctx, ctx->ftx, std::min(n, kFtxMaxPositions), s)) {
+        slicedUpdate = true;
+        const FtxScratch& scratch = ctx->ftx;
+        for (size_t lo = 0; lo < n; lo += scratch.capacity) {
+            const size_t m = std::min(scratch.capacity, n - lo);
+            FtuParams fu{};
+            fu.x.nPositions = uint32_t(m);
+            fu.x.t = up.t;
+            fu.x.rowS = ctx->dRowS;
+            fu.x.lists = scratch.lists;
+            fu.x.heads = scratch.heads;
+            fu.x.keys = scratch.keys;
+            fu.x.ranks = scratch.ranks;
+            fu.x.hist = scratch.hist;
+            fu.x.binStart = scratch.binStart;
+            fu.x.sorted = scratch.sorted;
+            fu.x.plan = scratch.plan;
+            fu.x.ftOut = up.ftOut + lo * size_t(kL1);
+            fu.x.listStride = kFtuListStride;
+            fu.parentSlots = up.parentSlots + lo;
+            fu.childSlots = up.childSlots ? up.childSlots + lo : nullptr;
+            fu.childPositions = static_cast<const char*>(up.childPositions) + lo * sizeof(spx_packed_pos);
+            fu.arena = up.arena;
+            fu.slotRecords = up.slotRecords;
+            fu.stagedRecords = up.stagedRecords + lo * 32;
+            fu.refreshList = up.refreshList;
+            fu.refreshCount = up.refreshCount;
+            fu.firstRecord = uint32_t(lo);
+            SPX_HIP(launchFtuDerive(fu, s));
+            SPX_HIP(launchFtxSortAndPlan(fu.x, s));
+            SPX_HIP(launchFtuApply(fu, s));
+        }
+    }
+    if (!slicedUpdate) SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, legacy, s));
     if (legacy) return SPX_OK;
     FtParams fp{};
     fp.positions = up.childPositions;

@@ -21,6 +21,7 @@
 #include <cstdint>
 
 #include "spx_ft_device.h"
+#include "spx_ftx.h"
 
 namespace spx {
 
@@ -494,6 +495,115 @@ __device__ __forceinline__ uint32_t emitPawnPairDelta(uint32_t* list, uint32_t n
 #define SPX_UPDATE_WAVES 5  // 96 VGPRs: no spills (6 -> 80 VGPRs spills 14-25)
 #endif
 
+// The delta row lists of one record's perspective(s) [cFirst, cLast), into LDS (phase 1 of spx_update_kernel; also the whole of
+// spx_ftu_derive_kernel): piece-square rows of the changed squares (updatePsq, nnue_state.cpp:34-87), threat rows from ray walks
+// around them (applyThreatUpdates :356-394), pawn pairs of the pawns that left / arrived (generatePpRows :163-307). subList /
+// addList: u8-table rows (compact piece-square rows first), wideList[c][0 / 1]: wide piece-square rows to subtract / add.
+// refresh[c]: the perspective must be rebuilt instead. Returns the child's side to move.
+__device__ __forceinline__ int deriveDeltaLists(const uint8_t* parentRec, const uint8_t* childRec, uint32_t lane, int cFirst, int cLast,
+                                                const uint32_t* sLut, const uint64_t* sTab, uint8_t (*mail)[64],
+                                                uint32_t (*addList)[kDeltaCap], uint32_t (*subList)[kDeltaCap],
+                                                uint32_t (*wideList)[2][8], uint32_t (&nAdd)[2], uint32_t (&nSub)[2],
+                                                uint32_t (&nWideSub)[2], uint32_t (&nWideAdd)[2], bool (&refresh)[2]) {
+        int childStm;
+        {
+            const LaneBoard pb = decodeBoard(parentRec, lane);
+            const LaneBoard cb = decodeBoard(childRec, lane);
+            childStm = cb.stm;
+            mail[0][lane] = uint8_t(pb.piece);
+            mail[1][lane] = uint8_t(cb.piece);
+            const bool changedSq = pb.piece != cb.piece;
+            const uint64_t changed = __ballot(changedSq);
+            const uint32_t nChanged = uint32_t(popc64(changed));
+            __builtin_amdgcn_wave_barrier();
+
+            int x[2], kingC[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint64_t kingMaskP = pb.kingsBb & (c ? pb.whiteBb : ~pb.whiteBb);
+                const uint64_t kingMaskC = cb.kingsBb & (c ? cb.whiteBb : ~cb.whiteBb);
+                const int kingP = kingMaskP ? ctz64(kingMaskP) : 0;
+                kingC[c] = kingMaskC ? ctz64(kingMaskC) : 0;
+                const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC[c] ^ 56) : kingC[c];
+                // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the
+                // caller paired unrelated boards) and is rebuilt, like a king that changed bucket or mirror half
+                refresh[c] = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC[c] & 7) >= 4) ||
+                             nChanged > 4;
+                x[c] = perspXor(c, kingC[c]);  // bucket and mirror half are those of the parent too
+            }
+
+            // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
+            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c < cFirst || c >= cLast || refresh[c]) continue;
+                nSub[c] = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC[c]) : 0u, sLut,
+                                           wideList[c][0], subList[c], nWideSub[c]);
+                nAdd[c] = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC[c]) : 0u, sLut,
+                                           wideList[c][1], addList[c], nWideAdd[c]);
+            }
+
+            // ---- threat delta: ray walks around the changed squares, lane = board << 5 | square index << 4 | slot;
+            //      two changed squares per pass, so a second pass only for castling / en passant ----
+            {
+                uint64_t m = nChanged <= 4 ? changed : 0;
+                const int b = int(lane >> 5);
+                const uint64_t occB = b ? cb.occ : pb.occ;
+#pragma unroll 1
+                while (m) {
+                    const int fA = ctz64(m);
+                    m &= m - 1;
+                    const int fB = m ? ctz64(m) : -1;
+                    m &= m - 1;
+                    const int f = (lane & 16) ? fB : fA;
+                    uint32_t desc[2];
+                    deltaCandidates(sTab, mail[b], occB, changed, max(f, 0), int(lane & 15), desc[0], desc[1]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c < cFirst || c >= cLast || refresh[c]) continue;
+                        const int flipColour = (c == 0) ? 1 : 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const bool have = f >= 0 && desc[j] != kNoDesc;
+                            const int32_t row = descRow(sLut, sTab, have ? desc[j] : 0u, x[c], flipColour);
+                            const uint64_t valid = __ballot(have && row >= 0);
+                            const uint32_t lo = uint32_t(valid), hi = uint32_t(valid >> 32);
+                            // parent-board lanes (0..31) -> rows to subtract, child-board lanes (32..63) -> rows to add
+                            const uint32_t slot = lane < 32 ? nSub[c] + __builtin_amdgcn_mbcnt_lo(lo, 0u)
+                                                            : nAdd[c] + __builtin_amdgcn_mbcnt_hi(hi, 0u);
+                            if (((valid >> lane) & 1) && slot < uint32_t(kDeltaCap)) {
+                                (lane < 32 ? subList[c] : addList[c])[slot] = uint32_t(row) * kL1;
+                            }
+                            nSub[c] += uint32_t(__builtin_popcount(lo));
+                            nAdd[c] += uint32_t(__builtin_popcount(hi));
+                        }
+                    }
+                }
+            }
+
+            // ---- pawn-pair delta (generatePpRows): pairs of the pawns that left / arrived ----
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c < cFirst || c >= cLast || refresh[c]) continue;
+                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
+                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
+                nSub[c] = emitPawnPairDelta(subList[c], nSub[c], (ownP & ~ownC) | (theirP & ~theirC), pb.pawnsBb, ownP,
+                                            lane, x[c]);
+                nAdd[c] = emitPawnPairDelta(addList[c], nAdd[c], (ownC & ~ownP) | (theirC & ~theirP), cb.pawnsBb, ownC,
+                                            lane, x[c]);
+            }
+            // every emitter above has run: a list that outgrew its capacity (never in legal play) is not applied - its
+            // perspective is rebuilt instead (applyU8Delta relies on nAdd + nSub <= 2 * kDeltaCap <= 256 rows)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (nSub[c] > uint32_t(kDeltaCap) || nAdd[c] > uint32_t(kDeltaCap)) refresh[c] = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        return childStm;
+}
+
 // kSplit = false: one wavefront per record does both perspectives (board decoding and the ray walks shared);
 // kSplit = true: one wavefront per (record, perspective) - twice the waves for batches too small to fill the chip.
 // Perspectives that must be REBUILT (king changed bucket / mirror half, boards more than one move apart) are not
@@ -539,101 +649,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4
         // ================= phase 1: the delta row lists of the perspective(s), into LDS =================
         uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
         bool refresh[2] = {false, false};
-        int childStm;
-        {
-            const LaneBoard pb = decodeBoard(parentRec, lane);
-            const LaneBoard cb = decodeBoard(childRec, lane);
-            childStm = cb.stm;
-            sMail[wave][0][lane] = uint8_t(pb.piece);
-            sMail[wave][1][lane] = uint8_t(cb.piece);
-            const bool changedSq = pb.piece != cb.piece;
-            const uint64_t changed = __ballot(changedSq);
-            const uint32_t nChanged = uint32_t(popc64(changed));
-            __builtin_amdgcn_wave_barrier();
-
-            int x[2], kingC[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint64_t kingMaskP = pb.kingsBb & (c ? pb.whiteBb : ~pb.whiteBb);
-                const uint64_t kingMaskC = cb.kingsBb & (c ? cb.whiteBb : ~cb.whiteBb);
-                const int kingP = kingMaskP ? ctz64(kingMaskP) : 0;
-                kingC[c] = kingMaskC ? ctz64(kingMaskC) : 0;
-                const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC[c] ^ 56) : kingC[c];
-                // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the
-                // caller paired unrelated boards) and is rebuilt, like a king that changed bucket or mirror half
-                refresh[c] = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC[c] & 7) >= 4) ||
-                             nChanged > 4;
-                x[c] = perspXor(c, kingC[c]);  // bucket and mirror half are those of the parent too
-            }
-
-            // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
-            const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c < cFirst || c >= cLast || refresh[c]) continue;
-                nSub[c] = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC[c]) : 0u, sLut,
-                                           sWide[wave][c][0], sSub[wave][c], nWideSub[c]);
-                nAdd[c] = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC[c]) : 0u, sLut,
-                                           sWide[wave][c][1], sAdd[wave][c], nWideAdd[c]);
-            }
-
-            // ---- threat delta: ray walks around the changed squares, lane = board << 5 | square index << 4 | slot;
-            //      two changed squares per pass, so a second pass only for castling / en passant ----
-            {
-                uint64_t m = nChanged <= 4 ? changed : 0;
-                const int b = int(lane >> 5);
-                const uint64_t occB = b ? cb.occ : pb.occ;
-#pragma unroll 1
-                while (m) {
-                    const int fA = ctz64(m);
-                    m &= m - 1;
-                    const int fB = m ? ctz64(m) : -1;
-                    m &= m - 1;
-                    const int f = (lane & 16) ? fB : fA;
-                    uint32_t desc[2];
-                    deltaCandidates(sTab, sMail[wave][b], occB, changed, max(f, 0), int(lane & 15), desc[0], desc[1]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        if (c < cFirst || c >= cLast || refresh[c]) continue;
-                        const int flipColour = (c == 0) ? 1 : 0;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const bool have = f >= 0 && desc[j] != kNoDesc;
-                            const int32_t row = descRow(sLut, sTab, have ? desc[j] : 0u, x[c], flipColour);
-                            const uint64_t valid = __ballot(have && row >= 0);
-                            const uint32_t lo = uint32_t(valid), hi = uint32_t(valid >> 32);
-                            // parent-board lanes (0..31) -> rows to subtract, child-board lanes (32..63) -> rows to add
-                            const uint32_t slot = lane < 32 ? nSub[c] + __builtin_amdgcn_mbcnt_lo(lo, 0u)
-                                                            : nAdd[c] + __builtin_amdgcn_mbcnt_hi(hi, 0u);
-                            if (((valid >> lane) & 1) && slot < uint32_t(kDeltaCap)) {
-                                (lane < 32 ? sSub[wave][c] : sAdd[wave][c])[slot] = uint32_t(row) * kL1;
-                            }
-                            nSub[c] += uint32_t(__builtin_popcount(lo));
-                            nAdd[c] += uint32_t(__builtin_popcount(hi));
-                        }
-                    }
-                }
-            }
-
-            // ---- pawn-pair delta (generatePpRows): pairs of the pawns that left / arrived ----
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c < cFirst || c >= cLast || refresh[c]) continue;
-                const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
-                const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
-                nSub[c] = emitPawnPairDelta(sSub[wave][c], nSub[c], (ownP & ~ownC) | (theirP & ~theirC), pb.pawnsBb, ownP,
-                                            lane, x[c]);
-                nAdd[c] = emitPawnPairDelta(sAdd[wave][c], nAdd[c], (ownC & ~ownP) | (theirC & ~theirP), cb.pawnsBb, ownC,
-                                            lane, x[c]);
-            }
-            // every emitter above has run: a list that outgrew its capacity (never in legal play) is not applied - its
-            // perspective is rebuilt instead (applyU8Delta relies on nAdd + nSub <= 2 * kDeltaCap <= 256 rows)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (nSub[c] > uint32_t(kDeltaCap) || nAdd[c] > uint32_t(kDeltaCap)) refresh[c] = true;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        const int childStm = deriveDeltaLists(parentRec, childRec, lane, cFirst, cLast, sLut, sTab, sMail[wave], sAdd[wave], sSub[wave],
+                                              sWide[wave], nAdd, nSub, nWideSub, nWideAdd, refresh);
 
         // ================= phase 2: child = parent - removed rows + added rows =================
 #pragma unroll 1
@@ -662,6 +679,84 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4
             if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The incremental pipeline's first pass (spx_ftx.h, FtuParams): one wavefront per record derives the delta lists of both
+// perspectives exactly as spx_update_kernel does and writes them - as offsets into the column-sliced row table - to HBM, with a
+// head and a sort key per perspective; spx_ftu_apply_kernel (spx_ftx.hip) reads them once per column slice.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_ftu_derive_kernel(FtuParams p) {
+    __shared__ uint32_t sLut[kLutWords];
+    __shared__ uint64_t sTab[kDeltaTabWords];
+    __shared__ uint32_t sAdd[kWavesPerBlock][2][kDeltaCap];
+    __shared__ uint32_t sSub[kWavesPerBlock][2][kDeltaCap];
+    __shared__ uint32_t sWide[kWavesPerBlock][2][2][8];
+    __shared__ uint8_t sMail[kWavesPerBlock][2][64];
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.x.t.lut[i];
+    for (int i = threadIdx.x; i < kDeltaTabWords; i += blockDim.x) sTab[i] = p.x.t.deltaTab[i];
+    __syncthreads();
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < p.x.nPositions; it += gridDim.x * kWavesPerBlock) {
+        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
+        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
+        const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
+        uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
+        bool refresh[2] = {false, false};
+        const int childStm = deriveDeltaLists(parentRec, childRec, lane, 0, 2, sLut, sTab, sMail[wave], sAdd[wave], sSub[wave],
+                                              sWide[wave], nAdd, nSub, nWideSub, nWideAdd, refresh);
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t q = 2 * it + uint32_t(c);
+            if (c ? refresh[1] : refresh[0]) {
+                if (lane == 0) {
+                    p.refreshList[atomicAdd(p.refreshCount, 1u)] = 2 * (p.firstRecord + it) + uint32_t(c);
+                    p.x.keys[q] = kFtuSkipKey;
+                }
+                continue;
+            }
+            const uint32_t na = c ? nAdd[1] : nAdd[0], ns = c ? nSub[1] : nSub[0];
+            const uint32_t nws = c ? nWideSub[1] : nWideSub[0], nwa = c ? nWideAdd[1] : nWideAdd[0];
+            uint32_t* out = p.x.lists + size_t(q) * kFtuListStride;
+            // u8-table offsets are row * 1024 with the piece-square slots right behind the threat rows - as in the sliced table:
+            // row * 128 there; a wide piece-square row (offset row * 2048 into the i16 table) = its low-byte plane + its high-byte plane
+            for (uint32_t i = lane; i < ns; i += 64) out[kFtuSub + i] = sSub[wave][c][i] >> 3;
+            for (uint32_t i = lane; i < na; i += 64) out[kFtuAdd + i] = sAdd[wave][c][i] >> 3;
+            if (lane < nws) {
+                const uint32_t row = sWide[wave][c][0][lane] >> 11;
+                out[kFtuSub + ns + lane] = (kFtxPsqLoBase + row) * 128u;
+                out[kFtuHiSub + lane] = (kFtxPsqHiBase + row) * 128u;
+            }
+            if (lane < nwa) {
+                const uint32_t row = sWide[wave][c][1][lane] >> 11;
+                out[kFtuAdd + na + lane] = (kFtxPsqLoBase + row) * 128u;
+                out[kFtuHiAdd + lane] = (kFtxPsqHiBase + row) * 128u;
+            }
+            if (lane == 0) {
+                u32x2 head;
+                head[0] = nws | (nwa << 8) | ((ns + nws) << 16) | ((na + nwa) << 24);
+                head[1] = 2 * it + ((c == childStm) ? 0u : 1u);  // stm half first
+                *reinterpret_cast<u32x2*>(p.x.heads + 2 * size_t(q)) = head;
+                const uint32_t quartets = (nws + 3) / 4 + (nwa + 3) / 4 + (ns + nws + 3) / 4 + (na + nwa + 3) / 4;
+                p.x.keys[q] = min(max(quartets, 1u), kFtxQuartetBins) - 1;  // (one bucket: the order is by list length alone)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // this record's lists are dead before the next record's are written
+        if (lane < 8) {
+            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
+            if (p.childSlots) {
+                const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
+                reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
+            }
+            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
+        }
+    }
+}
+
+hipError_t launchFtuDerive(const FtuParams& p, hipStream_t stream) {
+    const uint32_t blocks = min((p.x.nPositions + kWavesPerBlock - 1) / kWavesPerBlock, 256u * 16u);
+    hipLaunchKernelGGL(spx_ftu_derive_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -18,25 +18,29 @@ def preset_of(path):
         return f.readline().split()[2].rstrip(";")
 
 
-@pytest.fixture(scope="module", params=["default-kernels", "ray-walk-kernel"])
+@pytest.fixture(scope="module", params=["default-kernels", "ray-walk-kernel", "column-sliced-pipeline"])
 def states(sp, net_blob, request):
-    """Every test of this module runs twice: with the library's own choice of update kernel (batches this small take the
-    single-launch round-1 kernel) and with the second-generation kernel forced (SPX_UPDATE_V1=0, read when the context is
-    created): ray-walk threat deltas + deferred rebuild pass, what batches above 8 192 records get."""
+    """Every test of this module runs three times: with the library's own choice of update kernel (batches this small take the
+    single-launch round-1 kernel), with the second-generation kernel forced (SPX_UPDATE_V1=0, read when the context is
+    created): ray-walk threat deltas + deferred rebuild pass, what batches above 8 192 records get - and with the opt-in incremental
+    pipeline on the column-sliced row table (SPX_FTU=1: spx_ftu_derive_kernel, counting sort + plan, spx_ftu_apply_kernel; fused
+    update + eval batches of 64 records and more here)."""
     cache = {}
+    env = {"default-kernels": {}, "ray-walk-kernel": {"SPX_UPDATE_V1": "0"},
+           "column-sliced-pipeline": {"SPX_UPDATE_V1": "0", "SPX_FTU": "1", "SPX_FTU_MIN": "64"}}[request.param]
 
     def get(preset):
         if preset not in cache:
-            old = os.environ.get("SPX_UPDATE_V1")
-            if request.param == "ray-walk-kernel":
-                os.environ["SPX_UPDATE_V1"] = "0"
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
             try:
                 cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
             finally:
-                if old is None:
-                    os.environ.pop("SPX_UPDATE_V1", None)
-                else:
-                    os.environ["SPX_UPDATE_V1"] = old
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         return cache[preset]
 
     yield get
