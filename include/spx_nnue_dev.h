@@ -40,6 +40,10 @@ int spx_debug_gather_probe_variants(void);
 /* Diagnostics of the column-sliced pipeline (SPX_CTX_SLICED_FT): start / end of each of the 256 workgroups of the last gather that
  * used scratch set `slot` (-1: the context's own, 0 / 1: the pipelined calls' lanes), device clock ticks of 10 ns; out[512]. */
 int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out);
+/* ... and the plan those workgroups walked: out[0 .. 256) = plan words (CU slot c -> first segment at [c], number of segments at [32],
+ * number of groups at [33], segments {king bucket, first group, end group} from word 64), then 1 280 + 17 words: the first sorted
+ * position of every (king bucket, list length) bin and the buckets' starts. out[256 + 1 297]. */
+int spx_debug_ftx_plan(spx_ctx* ctx, int slot, uint32_t* out);
 const char* spx_debug_gather_probe_name(int variant);
 
 /* `count` random legal positions (host chess core): game i plays min_ply .. max_ply uniformly random plies from the standard

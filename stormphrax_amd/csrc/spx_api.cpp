@@ -2270,6 +2270,26 @@ int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
     return SPX_OK;
 }
 
+// the plan and the bin starts of the LAST column-sliced gather of that scratch set: out[0 .. kFtxPlanTimes) = plan words (CU slot ->
+// first segment, segments {bucket, first group, end group}), then kFtxBins + 17 words: first sorted position of every (bucket, length)
+// bin, then the buckets' starts. tools/gpu_ftx_block_times.py fits the plan's cost model against the workgroups' times with it.
+int spx_debug_ftx_plan(spx_ctx* ctx, int slot, uint32_t* out) {
+    if (!ctx || !out || slot < -1 || slot > 1) {
+        setError("spx_debug_ftx_plan: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->lanes[slot].ftx;
+    if (!x.plan) {
+        setError("spx_debug_ftx_plan: that scratch set was never used");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipDeviceSynchronize());
+    SPX_HIP(hipMemcpy(out, x.plan, kFtxPlanTimes * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpy(out + kFtxPlanTimes, x.binStart, (kFtxBins + 17) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
 int spx_debug_gather_probe_variants(void) {
     return probeVariantCount();
 }

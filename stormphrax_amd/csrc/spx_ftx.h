@@ -43,6 +43,14 @@ constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins;
 
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
+#ifndef SPX_FTX_GROUP_COST
+#define SPX_FTX_GROUP_COST 1  // (A/B over 0, 1, 3, 6, 10: 1 is best by 1 %; many of a group's steps are cheap LDS steps)
+#endif
+constexpr uint32_t kFtxGroupCost = SPX_FTX_GROUP_COST;  // plan: a group costs its steps + this
+#ifndef SPX_FTX_SEGMENT_COST
+#define SPX_FTX_SEGMENT_COST 256  // (A/B over 0 .. 1 500: flat optimum between 200 and 440, +2 % stream-ordered, +3.5 % pipelined over 0)
+#endif
+constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // plan: a slab reload inside a CU slot's range, in steps (a group costs its steps + 3)
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
 constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
 

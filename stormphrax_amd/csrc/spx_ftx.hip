@@ -246,6 +246,7 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
     __shared__ uint32_t sGroups[kFtxBins];     // per bin: groups whose longest list ends in it; then the index of the first of them
     __shared__ uint32_t sCost[kFtxBins];       // per bin: their cost; then the exclusive prefix of it
     __shared__ uint32_t sWaveSum[32];
+    __shared__ uint8_t sHead[kFtxBins];
     __shared__ uint32_t sCut[33];
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
@@ -298,7 +299,12 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         uint32_t ng = e0 / 8 - s0 / 8;
         if (e0 > s0 && e0 == count && (count & 7u)) ++ng;  // (the partial group: the last one of the bucket's last bin)
         sGroups[k] = ng;
-        sCost[k] = ng * (kk + 1 + 3);
+        // a bucket that starts INSIDE a CU slot's range costs that slot a slab reload behind a barrier - its 16 waves wait for the last
+        // group of the previous bucket (tools/gpu_ftx_block_times.py: ~15 us per extra segment; kFtxSegmentCost, in steps, from an A/B). The bin that holds the
+        // bucket's first group carries it; a cut that falls into it goes to the bucket's start (below)
+        const bool bucketHead = ng > 0 && s0 / 8 == 0 && base > 0;
+        sHead[k] = bucketHead;
+        sCost[k] = ng * (kk + 1 + kFtxGroupCost) + (bucketHead ? kFtxSegmentCost : 0u);
     }
     __syncthreads();
     uint32_t g2[2] = {0, 0}, w2[2] = {0, 0};
@@ -334,9 +340,12 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
                 const uint32_t mid = (lo + hi + 1) / 2;
                 if (uint64_t(sCost[mid]) * 32 < target32) lo = mid; else hi = mid - 1;
             }
-            const uint32_t w = lo % kFtxQuartetBins + 1 + 3;
+            const uint32_t w = lo % kFtxQuartetBins + 1 + kFtxGroupCost;
             const uint64_t need = target32 - uint64_t(sCost[lo]) * 32;  // > 0
-            const uint32_t within = uint32_t((need + 32ull * w - 1) / (32ull * w));  // groups of this bin up to and including the one that reaches it
+            const uint64_t extra = sHead[lo] ? 32ull * kFtxSegmentCost : 0ull;
+            // groups of this bin up to and including the one that reaches it; inside a bucket head's surcharge: none - the bucket
+            // starts the next slot, whose first slab load is the one every slot pays
+            const uint32_t within = need <= extra ? 0u : uint32_t((need - extra + 32ull * w - 1) / (32ull * w));
             const uint32_t binGroups = (lo + 1 < kFtxBins ? sGroups[lo + 1] : nGroups) - sGroups[lo];
             cut = sGroups[lo] + min(within, binGroups);
         }
@@ -418,7 +427,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t g = lane & 7u, ks = lane >> 3;              // the lane's part in filling a stage
     const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
     // diagnostics (spx_debug_ftx_block_times): when did this workgroup start and end (constant 100 MHz clock)
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x] = wall_clock64();
+    if (threadIdx.x == 0) {
+        reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x] = wall_clock64();
+        reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x + 1] = 0;  // (end: the LAST wave's, below)
+    }
     const uint8_t* slice = p.rowS + size_t(xcd) * kFtxSliceStride;
     const uint32_t laneOff = 16 * t;
     const i32x4 sel = mfmaSelector(lane);
@@ -551,7 +563,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             G = nextG;
         }
     }
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x + 1] = wall_clock64();
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes) + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
