@@ -12,18 +12,19 @@
 //     1 407 instructions per perspective) disappears onto the matrix pipe: ONE v_mfma_i32_16x16x64_i8 with a constant
 //     selection matrix widens AND adds up four gathered i8 rows (tools/probes/mfma_rowsum_probe.hip).
 //
-// Pipeline (all on one stream; everything but the gather may overlap the previous batch's gather):
-//   spx_ftx_extract_kernel  one wave per POSITION: board decode and attack sets once, row lists of both perspectives
-//                           (nnue_state.cpp:309-354, 440-449) to HBM, a sort key (king bucket, list length) per perspective
+// Pipeline (all on one stream; on the two lanes of the pipelined entry point a batch's preparation runs beside the other lane's gather):
+//   spx_ftx_extract_kernel  one wave per POSITION: board decode, attack sets and the feature candidates once, the row lists of both
+//                           perspectives (nnue_state.cpp:309-354, 440-449) to HBM, a head and a sort key (king bucket, list length)
 //   spx_ftx_rank_kernel     counting sort, part 1: rank of every perspective inside its key's bin
 //   spx_ftx_plan_kernel     bin starts (each bucket padded to whole groups of 8), and the PLAN: the groups cut into 32
 //                           contiguous, equally heavy ranges - one per CU of an XCD -, each a list of one-bucket segments
-//   spx_ftx_scatter_kernel  counting sort, part 2: perspective at every sorted position
-//   spx_ftx_pack_kernel     one wave per group of 8 neighbours: their lists interleaved in the gather's lane order
+//   spx_ftx_scatter_kernel  counting sort, part 2: every perspective's head and list at its place in the sorted order
 //   spx_ftx_gather_kernel   256 workgroups of 16 waves (workgroup b on XCD b % 8 = slice b % 8, CU slot b / 8): per segment
-//                           the bucket's piece-square slab slice into LDS, then one wave per group: 2 perspectives x 4
-//                           rows x 128 B per wave load / LDS read, one MFMA each, pairwise activation (multilayer.h:92-152)
-//                           from the i32 sums, 2 output bytes per lane.
+//                           the bucket's piece-square slab slice into LDS, then one wave per group of 8 perspectives: it reads the
+//                           8 lists itself, 2 perspectives x 4 rows x 128 B per wave load / LDS read, one MFMA each, pairwise
+//                           activation (multilayer.h:92-152) from the i32 sums, 2 output bytes per lane.
+// The incremental path on the same tables (opt-in): spx_ftu_derive_kernel (spx_kernels.hip) -> rank / plan / scatter ->
+// spx_ftu_apply_kernel (below).
 // Results are bit-identical to spx_ft_kernel (sums of rows mod 2^16; tests/test_gpu_parity.py runs both).
 #include <hip/hip_runtime.h>
 
