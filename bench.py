@@ -356,7 +356,7 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2, settle
     # calls above the scratch capacity run as several launch sequences; pipelined calls above one pass of the column-sliced
     # pipeline (65 536 positions) too, one per pass
     per_call = state.scratch_batch
-    if pipelined and state.takes_sliced_pipeline(args.batch):
+    if pipelined and state.takes_sliced_pipeline(args.batch, pipelined=True):
         per_call = min(per_call, 65536)
     chunks = -(-args.batch // per_call)
     state.profile_begin(min(args.steps * chunks, 1 << 16))
@@ -859,7 +859,7 @@ def main():
         ft_avg_s = ft_ms / max(calls, 1) / 1e3
         value = world * args.batch * args.steps / elapsed
         pmc = load_pmc("full", batch=args.batch, preset=args.preset, net=args.net) if n_distinct == args.batch else None
-        sliced = state.takes_sliced_pipeline(min(args.batch, state.scratch_batch))
+        sliced = state.takes_sliced_pipeline(min(args.batch, state.scratch_batch), pipelined=pipelined)
         kp = kernel_pmc(pmc, "spx_ftx_gather_kernel" if sliced else "spx_ft_kernel")
         hbm = {
             "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_position": algo_bytes / args.batch,

@@ -96,8 +96,9 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
  * (the default; kept from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
 enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2, SPX_CTX_ONE_KERNEL_FT = 4 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
-/* 1 if a full refresh of n positions takes the column-sliced pipeline on this context as things stand (enabled, n at or above
- * the threshold, no failed allocation of its tables so far), 0 if the one-kernel path. */
+/* Does a full refresh of n positions take the column-sliced pipeline on this context as things stand (enabled, n at or above the
+ * threshold, no failed allocation of its tables so far)? Bit 0: a stream-ordered call (spx_eval_full[_device]) does; bit 1: a
+ * pipelined call (spx_eval_full_device_async) does - its threshold is lower. 0 = the one-kernel path either way. */
 int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n);
 /* Positions the context keeps intermediates for at once: min(max_batch, SPX_SCRATCH_CAP = 4 Mi by default). The
  * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an

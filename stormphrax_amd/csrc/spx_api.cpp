@@ -1805,7 +1805,9 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
 }
 
 int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n) {
-    return ctx && ctx->ftxEnabled && !ctx->ftxUnavailable && n >= ctx->ftxMin && n > ctx->tinyBatchMax ? 1 : 0;
+    if (!ctx || !ctx->ftxEnabled || ctx->ftxUnavailable || n <= ctx->tinyBatchMax) return 0;
+    const size_t pipelinedFrom = ctx->ftxMinForced ? ctx->ftxMin : std::min(ctx->ftxMin, kFtxMinPositionsPipelined);
+    return (n >= ctx->ftxMin ? 1 : 0) | (n >= pipelinedFrom ? 2 : 0);
 }
 
 size_t spx_ctx_scratch_batch(const spx_ctx* ctx) {

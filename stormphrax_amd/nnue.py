@@ -208,9 +208,10 @@ class NnueState:
     def synchronize(self):
         check(_lib.load().spx_ctx_synchronize(self._h))
 
-    def takes_sliced_pipeline(self, n):
-        """Does a full refresh of n positions take the column-sliced pipeline (spx_ftx.hip) on this context?"""
-        return bool(_lib.load().spx_ctx_sliced_ft(self._h, n))
+    def takes_sliced_pipeline(self, n, pipelined=False):
+        """Does a full refresh of n positions take the column-sliced pipeline (spx_ftx.hip) on this context - as a stream-ordered
+        call, or (pipelined=True) as a call of evaluate_once_device_async, whose threshold is lower?"""
+        return bool(_lib.load().spx_ctx_sliced_ft(self._h, n) & (2 if pipelined else 1))
 
     def profile_begin(self, max_calls):
         check(_lib.load().spx_profile_begin(self._h, max_calls))

@@ -364,6 +364,7 @@ def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net
     with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 17, sliced_ft=False) as plain, \
             _state_with_env(sp, blob, {"SPX_FTX_MIN": "8200"}, max_batch=1 << 17) as sliced:
         assert not plain.takes_sliced_pipeline(70001) and sliced.takes_sliced_pipeline(8200) and not sliced.takes_sliced_pipeline(8199)
+        assert not plain.takes_sliced_pipeline(70001, pipelined=True) and sliced.takes_sliced_pipeline(8200, pipelined=True)
         want = plain.evaluate_once(pos)
         oracle.use(blob, preset)
         mail, stm = sp.positions_to_mailboxes(pos[:3000])
