@@ -131,6 +131,31 @@ def test_malformed_records_do_not_fault(sp, states):
     assert np.array_equal(st.evaluate_once(good), want)  # the context is still healthy
 
 
+def test_malformed_records_in_a_pipeline_sized_batch(sp, net_blob):
+    """The same through the column-sliced pipeline (30 000 records, every fourth one garbage - random bytes, 64 occupied squares with
+    every nibble 0xF, an empty board): its extraction caps, sort keys and lists must hold for boards no game produces, the valid
+    records around them keep their scores, and a second, clean batch comes out right."""
+    n = 30000
+    good = sp.random_positions(n, seed=13)
+    with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=n, sliced_ft=False) as plain, \
+            sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=n) as st:
+        assert st.takes_sliced_pipeline(n)
+        want = plain.evaluate_once(good)
+        bad = good.copy()
+        rng = np.random.default_rng(6)
+        raw = bad.view(np.uint8).reshape(-1, 32)
+        raw[::4] = rng.integers(0, 256, (len(raw[::4]), 32), dtype=np.uint8)
+        raw[8] = 0xFF
+        raw[12] = 0
+        raw[16, :8] = 0xFF  # 64 pieces, valid nibbles: queens and knights everywhere
+        raw[16, 8:24] = 0x49
+        got = st.evaluate_once(bad)
+        keep = np.ones(n, dtype=bool)
+        keep[::4] = False
+        assert np.array_equal(got[keep], want[keep])
+        assert np.array_equal(st.evaluate_once(good), want)
+
+
 def test_mixed_compact_and_wide_piece_square_rows(sp, oracle, net_blob, states):
     """Piece-square rows whose weights all fit i8 are served from a 1 KiB u8 copy, the others from the i16 table.
     A net with both kinds (conftest._mixed_rows_net) must still equal the oracle bit for bit; the per-row
