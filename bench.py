@@ -11,7 +11,7 @@ no data-path collective), weak scaling; value = all ranks' positions / max-over-
         bench.py --gpus 8 --steps 200 --warmup 20
 
 Rank 0 prints ONE JSON line. Extra objects:
-  `roofline`      the dominant kernel - the column-sliced pipeline's gather (spx_ftx_gather_kernel; batches below 24 576
+  `roofline`      the dominant kernel - the column-sliced pipeline's gather (spx_ftx_gather_kernel; batches below 16 384
                   positions: spx_ft_kernel) - against the roof that BINDS it. The 100 MB of weight rows are resident in L2 /
                   Infinity Cache, so the gather is bound by the L2 -> CU path, not by HBM: `bound` = "l2", `achieved` = bytes
                   the kernel's row loads request from the L2s per launch / its HIP-event duration, `peak` = the 34.5 TB/s
@@ -438,7 +438,7 @@ def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
 
 def paths_leg(args, sp, torch, group, net, blob, d_pos, positions):
     """secondary.full_refresh_paths: the headline batch through BOTH full-refresh implementations - the column-sliced pipeline
-    (stormphrax_amd/csrc/spx_ftx.hip; the default from 24 576 positions up) and the one-kernel path (spx_ft_kernel:
+    (stormphrax_amd/csrc/spx_ftx.hip; the default from 16 384 positions up) and the one-kernel path (spx_ft_kernel:
     SPX_CTX_ONE_KERNEL_FT) - stream-ordered and pipelined, with the main kernel's own time and what runs before it; and the rate
     the pipeline's calls reach when the lists are NOT rebuilt every step (SPX_FTX_DEBUG_REUSE: the bound a free preparation would
     give). Scores checked against the CPU oracle on a sample; checksums must agree between the paths."""
@@ -690,7 +690,7 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
     if args.batch <= state.scratch_batch:
         run("gather_ceiling", lambda: gather_ceiling(state, d_pos, args.batch))
     run("realistic_rows", lambda: realistic_leg(args, sp, torch, group, d_pos, positions, pipelined))
-    if args.batch <= state.scratch_batch and args.batch >= 24576 and not args.net:
+    if args.batch <= state.scratch_batch and args.batch >= 16384 and not args.net:
         run("full_refresh_paths", lambda: paths_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
     if args.preset == "tame":  # (the trace was recorded on the tame net)
         run("incremental", lambda: incremental_leg(sp, torch, net, device))

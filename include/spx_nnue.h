@@ -86,7 +86,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
 /* As spx_ctx_create, with option flags. SPX_CTX_WIDE_PSQ_ROWS: every piece-square row is gathered from the 2 KiB i16
  * table, i.e. the lossless "compact row" optimisation (1 KiB u8 copies of rows whose weights all fit i8) is off - what a
  * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
-/* Full refreshes of 24 576 positions and more take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction
+/* Full refreshes of 16 384 positions and more take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction
  * pass writes every perspective's row lists, a counting sort groups them by king bucket and length, and the gather - XCD x
  * reads slice x of every row, the bucket's piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.7 x
  * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's

@@ -838,7 +838,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
     // output-bucket order is sorted here
     FtxScratch& scratch = ctx->ftx;
-    // (pipelined calls - a lane's gate is set - gain from 12 Ki positions on, stream-ordered ones from 24 Ki:
+    // (pipelined calls - a lane's gate is set - gain from 12 Ki positions on, stream-ordered ones from 16 Ki:
     // profiles/r04_sliced_pipeline_crossover.txt)
     const size_t sliceFrom = (ctx->ftGateRecord && !ctx->ftxMinForced) ? std::min(ctx->ftxMin, kFtxMinPositionsPipelined) : ctx->ftxMin;
     const bool sliced = !tiny && n >= sliceFrom && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), s);

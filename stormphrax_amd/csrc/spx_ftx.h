@@ -54,7 +54,7 @@ constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // p
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
 constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
 
-constexpr size_t kFtxMinPositions = 24576;    // smaller full refreshes keep the one-kernel path (faster below ~24 Ki: profiles/r04_sliced_pipeline_crossover.txt)
+constexpr size_t kFtxMinPositions = 16384;    // smaller full refreshes keep the one-kernel path (the paths cross at ~14 Ki: profiles/r04_sliced_pipeline_crossover.txt)
 constexpr size_t kFtxMinPositionsPipelined = 12288;  // ... of spx_eval_full_device_async (the preparation runs beside the other lane's gather)
 constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~2.6 KB each); larger batches walk in passes
 

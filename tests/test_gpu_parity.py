@@ -379,7 +379,7 @@ def _state_with_env(sp, blob, env, **kw):
 @pytest.mark.parametrize("preset", ["tame", "extreme", "mixed", "near", "realistic"])
 def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net_blob, preset):
     """Big full refreshes take the column-sliced pipeline of spx_ftx.hip (extraction pass, counting sort by (king bucket, list
-    length), plan, gather on the matrix pipe with the bucket's piece-square slab in LDS; the default from 24 576 positions up,
+    length), plan, gather on the matrix pipe with the bucket's piece-square slab in LDS; the default from 16 384 positions up,
     here from 8 192: SPX_FTX_MIN). Same sums mod 2^16, so the evaluations must equal those of spx_ft_kernel (a context created
     with sliced_ft=False: SPX_CTX_ONE_KERNEL_FT) and the oracle's bit for bit: batches at the pipeline's threshold,
     ragged ones, more than one pass (> 65 536 positions), nets with wide rows (low / high byte planes) and near-compact rows
