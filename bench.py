@@ -439,21 +439,15 @@ def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
 def paths_leg(args, sp, torch, group, net, blob, d_pos, positions):
     """secondary.full_refresh_paths: the headline batch through BOTH full-refresh implementations - the column-sliced pipeline
     (stormphrax_amd/csrc/spx_ftx.hip; the default from 16 384 positions up) and the one-kernel path (spx_ft_kernel:
-    SPX_CTX_ONE_KERNEL_FT) - stream-ordered and pipelined, with the main kernel's own time and what runs before it; and the rate
-    the pipeline's calls reach when the lists are NOT rebuilt every step (SPX_FTX_DEBUG_REUSE: the bound a free preparation would
-    give). Scores checked against the CPU oracle on a sample; checksums must agree between the paths."""
+    SPX_CTX_ONE_KERNEL_FT) - stream-ordered and pipelined, with the main kernel's own time and what runs before it. Scores checked
+    against the CPU oracle on a sample; checksums must agree between the paths. (Round 4 also timed the pipeline with its lists NOT
+    rebuilt - the bound a free preparation would give, 1.95e8 - through a switch inside the library; the switch is gone)"""
     import copy
 
     out = {}
-    for path, mode, reuse in (("sliced_pipeline", "stream_ordered", False), ("sliced_pipeline", "pipelined", False),
-                              ("sliced_pipeline", "stream_ordered_lists_reused", True),
-                              ("one_kernel", "stream_ordered", False), ("one_kernel", "pipelined", False)):
-        if reuse:
-            os.environ["SPX_FTX_DEBUG_REUSE"] = "1"
-        try:
-            st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch, sliced_ft=path == "sliced_pipeline")
-        finally:
-            os.environ.pop("SPX_FTX_DEBUG_REUSE", None)
+    for path, mode in (("sliced_pipeline", "stream_ordered"), ("sliced_pipeline", "pipelined"),
+                       ("one_kernel", "stream_ordered"), ("one_kernel", "pipelined")):
+        st = sp.NnueState(net, device=torch.cuda.current_device(), max_batch=args.batch, sliced_ft=path == "sliced_pipeline")
         try:
             a = copy.copy(args)
             a.steps, a.warmup = min(args.steps, 100), min(args.warmup, 10)

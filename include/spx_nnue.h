@@ -92,15 +92,38 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
  * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's
  * tables and scratch (89 MB + 2.6 KB per position of a 65 536-position pass, four passes' worth for pipelined calls) are
  * allocated on the first such batch; if that fails the one-kernel path serves it.
- * SPX_CTX_ONE_KERNEL_FT (or SPX_FTX=0 in the environment): never take the pipeline. SPX_CTX_SLICED_FT (or SPX_FTX=1): take it
- * (the default; kept from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
+ * SPX_CTX_ONE_KERNEL_FT (or option ftx = 0): never take the pipeline. SPX_CTX_SLICED_FT (or ftx = 1): take it (the default; kept
+ * from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
 enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2, SPX_CTX_ONE_KERNEL_FT = 4 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
 /* Does a full refresh of n positions take the column-sliced pipeline on this context as things stand (enabled, n at or above the
  * threshold, no failed allocation of its tables so far)? Bit 0: a stream-ordered call (spx_eval_full[_device]) does; bit 1: a
  * pipelined call (spx_eval_full_device_async) does - its threshold is lower. 0 = the one-kernel path either way. */
 int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n);
-/* Positions the context keeps intermediates for at once: min(max_batch, SPX_SCRATCH_CAP = 4 Mi by default). The
+/* Tuning knobs of a context - the analogue of the reference's tunable constants (src/tunable.h:161-169) and UCI options for this
+ * path; none changes a result. spx_ctx_set_option changes one knob of one context between calls (not while a call of that context is
+ * in flight); SPX_OPTIONS="name=value,name=value" in the environment - the only environment variable the library reads besides
+ * LOCAL_WORLD_SIZE (self-play's host-thread share per rank) - applies to every context the process creates. Unknown names / malformed values: SPX_ERR_INVALID_ARG.
+ *   ftx 0|1                 big full refreshes through the column-sliced pipeline (as SPX_CTX_SLICED_FT / _ONE_KERNEL_FT)
+ *   ftx_min N               smallest batch that takes it (default 16 384; 12 288 for pipelined calls)
+ *   ftx_hot_rows N          threat / pawn-pair rows the gather keeps in LDS beside the piece-square slab (default: what fits)
+ *   tiny_batch_max N        batches up to N positions skip the sorts (default 8 192)
+ *   mlp_share_max N         positions up to which four waves share one MLP tile (default 8 192)
+ *   ft_team_max N           full refreshes of up to N perspectives run one workgroup per perspective (default 512)
+ *   update_chain_max N      fused updates of up to N records take the single-launch chain kernel (default 1 024)
+ *   update_split_max N      updates of up to N records give every perspective a wave of its own (default 16 384)
+ *   stream_acc_min N        updates from N records on access the arena non-temporally (default 32 768)
+ *   refresh_waves N         waves of the rebuild pass behind an update (default 0 = automatic)
+ *   ft_blocks_per_cu N, update_blocks_per_cu N    grid caps of the one-kernel full refresh / the update kernel (48 / 24)
+ *   king_sort 0|1           one-kernel path: perspectives in king-bucket order (default 1)
+ *   replay_paths -1|0|1, replay_segment N         spx_acc_replay_tree: by heavy paths / by levels / its own choice; plies per segment
+ *   selfplay_graph 0|1, selfplay_graph_plies N, selfplay_trace 0|1    spx_selfplay_run: plies captured into hipGraphs (default) or
+ *                           launched one by one; plies per graph (0 = automatic; even, 2..16); a timing line on stderr at the end
+ *   ftx_fail_after K        test hook: the K-th scratch set of the pipeline "does not fit" (default -1: never)
+ * SPX_OPTIONS only (they shape what a context allocates): scratch_cap N (below), compact_rows 0|1, near_rows 0|1 (A/B of the
+ * lossless 1 KiB copies of piece-square rows that fit i8 / almost fit i8). */
+int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value);
+/* Positions the context keeps intermediates for at once: min(max_batch, scratch_cap = 4 Mi by default). The
  * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an
  * HBM-filling batch costs 36 bytes per resident position: record in, score out); the arena entry points (spx_acc_*) and
  * spx_movegen take at most this many records per call. */

@@ -54,7 +54,6 @@ struct FtxScratch {
     uint32_t *lists = nullptr, *heads = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
              *sorted = nullptr, *plan = nullptr;
     size_t capacity = 0;  // positions per pass
-    bool preparedOnce = false;  // (SPX_FTX_DEBUG_REUSE=1, measurements only: later calls reuse the first call's lists)
     void release() {
         for (uint32_t* q : {lists, heads, keys, ranks, hist, binStart, sorted, plan}) {
             if (q) (void)hipFree(q);
@@ -72,22 +71,16 @@ struct spx_ctx {
     // weights
     int16_t* dPsqW = nullptr;
     uint8_t* dThrW = nullptr;
-    int8_t* dRowI8 = nullptr;   // the matrix-pipe gather's row table (plain i8, natural column order; FtTables::rowI8)
-    int8_t* dPsqHi = nullptr;   // high-byte planes of the piece-square rows (FtTables::psqHi)
-    bool mfmaGather = false;    // SPX_FT_MFMA_GATHER=1: spx_ft_kernel's gather on the matrix pipe (same speed, half the VALU work)
     uint8_t* dRowS = nullptr;   // the column-sliced row table of spx_ftx.hip (built on first use)
     FtxScratch ftx;             // its scratch (the lanes hold their own)
-    bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); SPX_FTX=0 / SPX_CTX_ONE_KERNEL_FT: never
-    size_t ftxMin = kFtxMinPositions;  // SPX_FTX_MIN: smallest batch that takes the sliced pipeline
-    bool ftuEnabled = false;      // SPX_FTU=1: big fused update + eval batches through the incremental pipeline (spx_ftu_*)
-    size_t ftuMin = 16384;        // SPX_FTU_MIN
-    int ftxFailAfter = -1, ftxScratchSets = 0;  // (SPX_FTX_FAIL_AFTER: simulated allocation failure)
-    bool ftxMinForced = false;    // (SPX_FTX_MIN given: the same threshold for stream-ordered and pipelined calls)
+    bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); option ftx = 0 / SPX_CTX_ONE_KERNEL_FT: never
+    size_t ftxMin = kFtxMinPositions;  // option ftx_min: smallest batch that takes the sliced pipeline
+    int ftxFailAfter = -1, ftxScratchSets = 0;  // (option ftx_fail_after: simulated allocation failure)
+    bool ftxMinForced = false;    // (ftx_min given: the same threshold for stream-ordered and pipelined calls)
     bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
     // (spx_eval_full_device_async: each lane has its own scratch set - swapLane -, so one lane's preparation runs beside the
     // other lane's gather. A ring of extra streams that prepared up to three batches ahead cost 12 %: 1.60 against 1.81e8
     // evals/s - more streams than hardware queues serialise; profiles/r04_sliced_pipeline_overlap_attempts.txt)
-    bool ftxDebugReuse = false;   // SPX_FTX_DEBUG_REUSE=1: measurement aid (what would the pipeline cost without its preparation?)
     int16_t* dFtBias = nullptr;
     int8_t* dL1W = nullptr;
     int32_t *dL1B = nullptr, *dL2W = nullptr, *dL2B = nullptr, *dL3W = nullptr, *dL3B = nullptr;
@@ -143,19 +136,21 @@ struct spx_ctx {
     void* hTinyIo = nullptr;       // page-locked, device-mapped staging of the tiny-batch host call: records, then scores
     size_t mlpShareMax = 0;        // spx_mlp_kernel: positions up to which four waves share one 16-position tile
     size_t streamAccMin = 0;       // spx_update_kernel: records from which the arena is accessed non-temporally
-    size_t updateSplitMax = 0;     // spx_update_kernel: records up to which the perspectives get separate waves
-    bool updateLegacy = false;     // the round-1 update kernel (two full attack generations, rebuilds inline: ONE launch) serves
-    bool updateLegacyForced = false;  // the tiny latency-bound batches; SPX_UPDATE_V1=1 / 0 forces it on / off for A/B runs
+    size_t updateChainMax = 1024;  // option update_chain_max: fused update batches up to this size take spx_update_chain_kernel on
+                                   // unit paths (one launch, rebuilds inline); larger ones spx_update_kernel + the rebuild pass
+    int64_t selfplayOptions[3] = {1, 0, 0};  // options selfplay_graph (0: direct launches), selfplay_graph_plies (0: automatic), selfplay_trace
+    int replayPaths = -1;          // option replay_paths: spx_acc_replay_tree by heavy paths (1) / by levels (0) / its own choice (-1)
+    uint32_t replaySegment = 32;   // option replay_segment: plies per path segment of the replay
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
-    bool smallUpdateV1 = false;    // SPX_SMALL_UPDATE_V1=1: batches <= tinyBatchMax on the round-1 kernel instead of the chain kernel
-    size_t refreshWaves = 0;       // SPX_REFRESH_WAVES: waves of the rebuild pass (0 = automatic)
-    size_t teamMaxPersp = 512;     // SPX_FT_TEAM_MAX: full refreshes of at most this many perspectives run one workgroup per
+    size_t refreshWaves = 0;       // option refresh_waves: waves of the rebuild pass (0 = automatic)
+    size_t teamMaxPersp = 512;     // option ft_team_max: full refreshes of at most this many perspectives run one workgroup per
                                    // perspective (spx_ft_team_kernel): evaluate_once of 64 / 256 positions 30.8 -> 27.5 / 33.6 -> 28.8 us,
                                    // 1 024 positions 43.3 -> 44.6 (profiles/r03_ab_rebuild_pass_team_kernel.txt); 0 = never
-    uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (SPX_NO_COMPACT=1: none)
+    uint32_t compactPsqRows = 0;   // piece-square rows with an i8 copy in the u8 row table (compact_rows = 0: none)
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
-    bool kingSortEnabled = true;   // SPX_NO_SORT=1 walks perspectives in input order (A/B of the L2-locality sort)
+    bool kingSortEnabled = true;   // option king_sort = 0 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
+    uint32_t computeUnits = 0;
     uint32_t ftGridCap = 0;
     uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
     // optional per-kernel timing (spx_profile_*): event triples recorded around the two kernels of each call
@@ -180,6 +175,10 @@ size_t ctxMaxBatch(const spx_ctx* ctx) {
 
 uint8_t* ctxSlotRecords(const spx_ctx* ctx) {
     return ctx->dSlotRecords;
+}
+
+int64_t ctxSelfplayOption(const spx_ctx* ctx, int which) {
+    return ctx->selfplayOptions[which];
 }
 }  // namespace spx
 
@@ -313,9 +312,6 @@ FtTables tablesOf(const spx_ctx* ctx) {
     t.lut = ctx->dLut;
     t.deltaTab = ctx->dDeltaTab;
     t.outlierTab = ctx->dOutlierTab;
-    t.rowI8 = ctx->dRowI8;
-    t.psqHi = ctx->dPsqHi;
-    t.mfmaGather = ctx->mfmaGather;
     return t;
 }
 
@@ -436,7 +432,7 @@ uint64_t spx_fnv1a64(const void* data, size_t nbytes) {
 }
 
 constexpr size_t kTinyIoRecords = 8192;
-constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible SPX_TINY_BATCH_MAX)
+constexpr size_t kTinyIoBytesPerRecord = sizeof(spx_packed_pos) + 3 * sizeof(uint32_t) + 4;  // record, score, two slot ids  // capacity of the zero-copy staging buffer (>= any sensible tiny_batch_max)
 
 int spx_device_count(int* count) {
     if (!count) {
@@ -452,6 +448,106 @@ int spx_device_count(int* count) {
     }
     *count = n;
     return SPX_OK;
+}
+
+// ---- options: the tuning knobs of a context (what the reference keeps in tunable.h / its UCI options) ----
+// SPX_OPTIONS="name=value,name=value" applies to every context the process creates (the ONE environment variable this file
+// reads); spx_ctx_set_option changes a knob of one context between calls. Unknown names and malformed values are refused.
+static int parseOptionsEnv(std::vector<std::pair<std::string, long long>>& out) {
+    const char* env = std::getenv("SPX_OPTIONS");
+    if (!env) return SPX_OK;
+    std::string text(env);
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t end = text.find(',', at);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(at, end - at);
+        at = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        char* tail = nullptr;
+        const long long v = eq == std::string::npos ? 0 : std::strtoll(item.c_str() + eq + 1, &tail, 10);
+        if (eq == std::string::npos || eq == 0 || eq + 1 == item.size() || (tail && *tail)) {
+            setError("SPX_OPTIONS: malformed item '" + item + "' (expected name=integer)");
+            return SPX_ERR_INVALID_ARG;
+        }
+        out.emplace_back(item.substr(0, eq), v);
+    }
+    return SPX_OK;
+}
+
+int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) {
+        setError("spx_ctx_set_option: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const std::string key(name);
+    auto nonNegative = [&](size_t& field) {
+        if (value < 0) {
+            setError("option " + key + " must not be negative");
+            return int(SPX_ERR_INVALID_ARG);
+        }
+        field = size_t(value);
+        return int(SPX_OK);
+    };
+    if (key == "ftx") {  // big full refreshes through the column-sliced pipeline (1) or spx_ft_kernel (0)
+        ctx->ftxEnabled = value != 0;
+        return SPX_OK;
+    }
+    if (key == "ftx_min") {  // smallest batch that takes the pipeline (the same threshold for stream-ordered and pipelined calls)
+        if (value < 8) {
+            setError("option ftx_min must be at least 8");
+            return SPX_ERR_INVALID_ARG;
+        }
+        ctx->ftxMin = size_t(value);
+        ctx->ftxMinForced = true;
+        return SPX_OK;
+    }
+    if (key == "ftx_fail_after") {  // test hook: the k-th scratch set of the pipeline "does not fit" (-1: never)
+        ctx->ftxFailAfter = int(value);
+        return SPX_OK;
+    }
+    if (key == "king_sort") {  // one-kernel path: walk the perspectives in king-bucket order (1) or as they come (0)
+        ctx->kingSortEnabled = value != 0;
+        return SPX_OK;
+    }
+    if (key == "tiny_batch_max") return nonNegative(ctx->tinyBatchMax);
+    if (key == "mlp_share_max") return nonNegative(ctx->mlpShareMax);
+    if (key == "stream_acc_min") return nonNegative(ctx->streamAccMin);
+    if (key == "update_split_max") return nonNegative(ctx->updateSplitMaxV2);
+    if (key == "update_chain_max") return nonNegative(ctx->updateChainMax);
+    if (key == "refresh_waves") return nonNegative(ctx->refreshWaves);
+    if (key == "ft_team_max") return nonNegative(ctx->teamMaxPersp);
+    if (key == "ft_blocks_per_cu" || key == "update_blocks_per_cu") {
+        if (value < 1 || value > 4096) {
+            setError("option " + key + " must be in [1, 4096]");
+            return SPX_ERR_INVALID_ARG;
+        }
+        (key[0] == 'f' ? ctx->ftGridCap : ctx->updateGridCap) = ctx->computeUnits * uint32_t(value);
+        return SPX_OK;
+    }
+    if (key == "selfplay_graph" || key == "selfplay_graph_plies" || key == "selfplay_trace") {
+        ctx->selfplayOptions[key == "selfplay_graph" ? 0 : key == "selfplay_graph_plies" ? 1 : 2] = value;
+        return SPX_OK;
+    }
+    if (key == "replay_paths") {
+        ctx->replayPaths = value < 0 ? -1 : (value != 0);
+        return SPX_OK;
+    }
+    if (key == "replay_segment") {
+        if (value < 1) {
+            setError("option replay_segment must be positive");
+            return SPX_ERR_INVALID_ARG;
+        }
+        ctx->replaySegment = uint32_t(std::min<int64_t>(value, 1 << 20));
+        return SPX_OK;
+    }
+    if (key == "scratch_cap" || key == "compact_rows" || key == "near_rows") {
+        setError("option " + key + " shapes what a context allocates: set it through SPX_OPTIONS before the context is created");
+        return SPX_ERR_INVALID_ARG;
+    }
+    setError("unknown option '" + key + "'");
+    return SPX_ERR_INVALID_ARG;
 }
 
 int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** out) {
@@ -478,26 +574,34 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipSetDevice(device));
     std::unique_ptr<spx_ctx, CtxDeleter> ctx(new spx_ctx());
     ctx->device = device;
-    // Intermediates (1 KiB of activations + sort scratch per position) are kept for at most SPX_SCRATCH_CAP positions
+    // Intermediates (1 KiB of activations + sort scratch per position) are kept for at most scratch_cap positions
     // (default 4 Mi): a context created for an HBM-filling batch (BASELINE config 5: 36 bytes per resident position -
     // record in, score out) walks it in chunks of that size instead of reserving ~1.1 KB of scratch per position
+    std::vector<std::pair<std::string, long long>> envOptions;
+    int rc = parseOptionsEnv(envOptions);
+    if (rc != SPX_OK) return rc;
     size_t scratchCap = size_t(1) << 22;
-    if (const char* env = std::getenv("SPX_SCRATCH_CAP")) {
-        // launch parameters are 32-bit (2 * n perspective ids, n * 1024 activation offsets are 64-bit): positions per chunk
-        // stay at or below 2^30; a non-positive or unparsable value is refused rather than turned into a huge size_t
-        const long long v = std::atoll(env);
-        if (v <= 0 || v > (1ll << 30)) {
-            setError("SPX_SCRATCH_CAP must be in [1, 2^30]");
-            return SPX_ERR_INVALID_ARG;
+    bool optCompactRows = true, optNearRows = true;
+    for (const auto& [name, v] : envOptions) {  // the options that shape what a context allocates: SPX_OPTIONS only
+        if (name == "scratch_cap") {
+            // launch parameters are 32-bit (2 * n perspective ids, n * 1024 activation offsets are 64-bit): positions per chunk
+            // stay at or below 2^30; a non-positive value is refused rather than turned into a huge size_t
+            if (v <= 0 || v > (1ll << 30)) {
+                setError("option scratch_cap must be in [1, 2^30]");
+                return SPX_ERR_INVALID_ARG;
+            }
+            scratchCap = std::max<size_t>(1024, size_t(v));
+        } else if (name == "compact_rows") {
+            optCompactRows = v != 0;
+        } else if (name == "near_rows") {
+            optNearRows = v != 0;
         }
-        scratchCap = std::max<size_t>(1024, size_t(v));
     }
     ctx->callLimit = max_batch;
     ctx->maxBatch = std::min(max_batch, scratchCap);
     max_batch = ctx->maxBatch;
     SPX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 
-    int rc;
     const unsigned char* b = net->blob.data();
     uint32_t compactBits[kLutCompactWords] = {}, nearBits[kLutCompactWords] = {};
     if ((rc = uploadArray(ctx->dPsqW, b + kOffPsqW, kPsqWBytes, ctx->stream)) != SPX_OK) return rc;
@@ -508,13 +612,11 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
         for (uint32_t r = 0; r < kThreatRows; ++r) {
             relayoutThreatRow(net->threatW() + size_t(r) * kL1, thr.data() + size_t(r) * kL1);
         }
-        bool useCompact = !(flags & SPX_CTX_WIDE_PSQ_ROWS);
-        if (const char* env = std::getenv("SPX_NO_COMPACT")) useCompact = useCompact && env[0] == '0';
+        const bool useCompact = !(flags & SPX_CTX_WIDE_PSQ_ROWS) && optCompactRows;
         const int16_t* psq = reinterpret_cast<const int16_t*>(b + kOffPsqW);
         // near-compact rows: all but <= kOutlierCap weights fit i8 -> the u8 copy holds them clamped, the remainders go to
-        // a side table the full-refresh kernel adds in (SPX_NO_NEAR=1: such rows stay wide)
-        bool useNear = useCompact;
-        if (const char* env = std::getenv("SPX_NO_NEAR")) useNear = useNear && env[0] == '0';
+        // a side table the full-refresh kernel adds in (option near_rows = 0: such rows stay wide)
+        const bool useNear = useCompact && optNearRows;
         std::vector<uint32_t> outliers;
         for (uint32_t r = 0; r < kPsqRows && useCompact; ++r) {
             const int16_t* row = psq + size_t(r) * kL1;
@@ -545,31 +647,6 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
             return rc;
         }
         if ((rc = uploadArray(ctx->dThrW, thr.data(), thr.size(), ctx->stream)) != SPX_OK) return rc;
-        if (const char* env = std::getenv("SPX_FT_MFMA_GATHER")) ctx->mfmaGather = env[0] == '1';
-        if (ctx->mfmaGather) {
-            // the matrix-pipe gather's tables (gatherFullMfma, spx_ft_device.h): plain i8 in the file's column order. Threat rows
-            // as they are; a piece-square row's slot holds the row itself (compact), its clamped copy (near-compact: remainders in
-            // the outlier table, as for the u8 copy) or its low-byte plane l = int8(v) (wide), whose high-byte plane
-            // h = int8((v - l) >> 8) goes to the second table: v = 256 h + l mod 2^16. One all-zero row ends either table (the
-            // lists are padded to multiples of four rows with it).
-            std::vector<int8_t> rows((size_t(kThreatRows) + kPsqRows + 1) * kL1, 0), hi((size_t(kPsqRows) + 1) * kL1, 0);
-            std::memcpy(rows.data(), net->threatW(), kThreatWBytes);
-            for (uint32_t r = 0; r < kPsqRows; ++r) {
-                const int16_t* row = psq + size_t(r) * kL1;
-                int8_t* lo = rows.data() + (size_t(kThreatRows) + r) * kL1;
-                const bool narrow = ((compactBits[r >> 5] | nearBits[r >> 5]) >> (r & 31)) & 1u;
-                for (uint32_t j = 0; j < kL1; ++j) {
-                    if (narrow) {
-                        lo[j] = int8_t(std::max(-128, std::min(127, int(row[j]))));
-                    } else {
-                        lo[j] = int8_t(uint8_t(uint16_t(row[j]) & 0xFFu));
-                        hi[size_t(r) * kL1 + j] = int8_t(uint8_t(uint16_t(int(row[j]) - int(lo[j])) >> 8));
-                    }
-                }
-            }
-            if ((rc = uploadArray(ctx->dRowI8, rows.data(), rows.size(), ctx->stream)) != SPX_OK) return rc;
-            if ((rc = uploadArray(ctx->dPsqHi, hi.data(), hi.size(), ctx->stream)) != SPX_OK) return rc;
-        }
     }
     if ((rc = uploadArray(ctx->dFtBias, b + kOffFtBias, kFtBiasBytes, ctx->stream)) != SPX_OK) return rc;
     {
@@ -610,38 +687,15 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
-    if (const char* env = std::getenv("SPX_NO_SORT")) ctx->kingSortEnabled = env[0] == '0';
     ctx->ftxEnabled = !(flags & (SPX_CTX_ONE_KERNEL_FT | SPX_CTX_WIDE_PSQ_ROWS)) || (flags & SPX_CTX_SLICED_FT);
-    if (const char* env = std::getenv("SPX_FTX")) ctx->ftxEnabled = env[0] == '1';
-    if (const char* env = std::getenv("SPX_FTX_DEBUG_REUSE")) ctx->ftxDebugReuse = env[0] == '1';
-    if (const char* env = std::getenv("SPX_FTX_FAIL_AFTER")) ctx->ftxFailAfter = std::atoi(env);
-    if (const char* env = std::getenv("SPX_FTU")) ctx->ftuEnabled = env[0] == '1';
-    if (const char* env = std::getenv("SPX_FTU_MIN")) ctx->ftuMin = std::max<size_t>(8, size_t(std::atoll(env)));
-    if (const char* env = std::getenv("SPX_FTX_MIN")) {
-        ctx->ftxMin = std::max<size_t>(8, size_t(std::atoll(env)));
-        ctx->ftxMinForced = true;
-    }
     // A/B on MI355X (tools/gpu_small_ab.sh, us per incremental ply unsplit/unshared -> split+shared): 1 024 records
     // 52.5 -> 34.0, 4 096: 60.3 -> 53.4, 8 192: 87.4 -> 81.8; split alone 32 768: 263 -> 247, 65 536: 471 -> 455,
     // 131 072: 873 -> 857, 524 288: 3276 -> 3295; sharing tiles costs throughput from 16 384 positions on
-    ctx->updateSplitMax = 262144;
     ctx->streamAccMin = 32768;
-    if (const char* env = std::getenv("SPX_STREAM_ACC_MIN")) ctx->streamAccMin = size_t(std::atoll(env));
     ctx->mlpShareMax = 8192;
     ctx->tinyBatchMax = kTinyIoRecords;  // MI355X, us per synchronous host call without -> with: 1 position 48 -> 28, 1 024: 68 -> 37, 2 048: 73 -> 47, 4 096: 93 -> 71, 8 192: 126 -> 117
-    if (const char* env = std::getenv("SPX_TINY_BATCH_MAX")) ctx->tinyBatchMax = size_t(std::atoll(env));
     SPX_HIP(hipHostMalloc(&ctx->hTinyIo, kTinyIoRecords * kTinyIoBytesPerRecord, hipHostMallocMapped));
-    if (const char* env = std::getenv("SPX_MLP_SHARE_MAX")) ctx->mlpShareMax = size_t(std::atoll(env));
-    if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX")) ctx->updateSplitMax = size_t(std::atoll(env));
-    if (const char* env = std::getenv("SPX_UPDATE_V1")) {
-        ctx->updateLegacyForced = true;
-        ctx->updateLegacy = env[0] == '1';
-    }
     ctx->updateSplitMaxV2 = 16384;
-    if (const char* env = std::getenv("SPX_UPDATE_SPLIT_MAX_V2")) ctx->updateSplitMaxV2 = size_t(std::atoll(env));
-    if (const char* env = std::getenv("SPX_REFRESH_WAVES")) ctx->refreshWaves = size_t(std::atoll(env));
-    if (const char* env = std::getenv("SPX_SMALL_UPDATE_V1")) ctx->smallUpdateV1 = env[0] == '1';
-    if (const char* env = std::getenv("SPX_FT_TEAM_MAX")) ctx->teamMaxPersp = size_t(std::atoll(env));
     {
         const int32_t* w = reinterpret_cast<const int32_t*>(b + kOffL2W);
         bool small = true;
@@ -654,16 +708,17 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     // persistent-ish grid: workgroups (4 waves) per CU, grid-stride over perspectives. A/B on MI355X: 2 -> 0.72 ms,
     // 4 -> 0.575, 8 -> 0.565, 16 -> 0.557, 64 -> 0.554 (finer-grained tail balancing)
     // round 2, with the round-robin chunk traversal (tools/gpu_r02_p.sh): 16 -> 0.4427, 32 -> 0.4204, 48 -> 0.4160, 64 -> 0.4203, 96 -> 0.4284
-    uint32_t blocksPerCu = 48;
-    if (const char* env = std::getenv("SPX_FT_BLOCKS_PER_CU")) blocksPerCu = uint32_t(std::max(1, std::atoi(env)));
-    ctx->ftGridCap = uint32_t(prop.multiProcessorCount) * blocksPerCu;
+    ctx->computeUnits = uint32_t(prop.multiProcessorCount);
+    ctx->ftGridCap = ctx->computeUnits * 48u;
     // the update kernel measured on the same sweep (tools/gpu_r02_r.sh, us per ply at 65 536 records):
     // 16 -> 318.5, 32 -> 318.2, 48 -> 325.2, 64 -> 336.0; finer, on the final build (tools/gpu_r02_ag.sh): 12 -> 317.5,
     // 16 -> 315.8, 20 -> 311.8, 24 -> 309.7, 28 -> 313.3, 32 -> 316.1 (self-play at 4 096 games: +1.6 % at 24 too)
-    uint32_t updateBlocksPerCu = 24;
-    if (const char* env = std::getenv("SPX_UPDATE_BLOCKS_PER_CU")) updateBlocksPerCu = uint32_t(std::max(1, std::atoi(env)));
-    ctx->updateGridCap = uint32_t(prop.multiProcessorCount) * updateBlocksPerCu;
+    ctx->updateGridCap = ctx->computeUnits * 24u;
     SPX_HIP(hipDeviceSynchronize());  // the hist memset ran on the null stream, the context's stream does not wait for it
+    for (const auto& [name, v] : envOptions) {
+        if (name == "scratch_cap" || name == "compact_rows" || name == "near_rows") continue;
+        if ((rc = spx_ctx_set_option(ctx.get(), name.c_str(), v)) != SPX_OK) return rc;
+    }
     *out = ctx.release();
     return SPX_OK;
 }
@@ -671,7 +726,7 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
 void spx_ctx_destroy(spx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {ctx->dRowI8, ctx->dPsqHi, ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
+    void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dOutlierTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
                     ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder, ctx->dRefreshList,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
@@ -792,7 +847,7 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     }
     if (x.capacity >= passPositions) return true;
     x.release();
-    // (SPX_FTX_FAIL_AFTER=k, tests only: the k-th scratch set "does not fit" - what a context sized to fill the HBM runs into)
+    // (option ftx_fail_after = k, tests only: the k-th scratch set "does not fit" - what a context sized to fill the HBM runs into)
     if (ctx->ftxFailAfter >= 0 && ctx->ftxScratchSets++ >= ctx->ftxFailAfter) return fail();
     const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
@@ -863,13 +918,11 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.binStart = scratch.binStart;
             xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
-            xp.listStride = kFtxListStride;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
             // a pipelined call: the preparation is not gated - it runs beside the other lane's gather and MLP -, the gather is
             // (the two lanes' gathers are chained). Gating the preparation too: 1.58 instead of 1.81e8 evals/s; no gate at all: 1.83e8,
             // but then the gather's event interval includes its wait for free CUs
-            if (!(ctx->ftxDebugReuse && scratch.preparedOnce)) SPX_HIP(launchFtxPrepare(xp, s));
-            scratch.preparedOnce = true;
+            SPX_HIP(launchFtxPrepare(xp, s));
             if (lo == 0) {
                 if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
                 if (ev) SPX_HIP(hipEventRecord(ev[4], s));
@@ -1105,7 +1158,7 @@ static int checkAcc(spx_ctx* ctx, size_t n, const char* who) {
     }
     if (n > ctx->maxBatch) {
         setError(std::string(who) + ": batch of " + std::to_string(n) + " exceeds what one arena call accepts (" +
-                 std::to_string(ctx->maxBatch) + " = min(max_batch, SPX_SCRATCH_CAP): spx_ctx_scratch_batch); only "
+                 std::to_string(ctx->maxBatch) + " = min(max_batch, scratch_cap): spx_ctx_scratch_batch); only "
                  "spx_eval_full* walk larger batches in chunks");
         return SPX_ERR_CAPACITY;
     }
@@ -1162,19 +1215,17 @@ static int updateEvalDevice(spx_ctx* ctx, const void* d_parent_slots, const void
 // the feature-transformer kernel over the refresh list (ids in the context's dRefreshList, the count in one of two alternating
 // device words behind the sort histograms; the pass clears the other one for the next update).
 static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipStream_t s) {
-    const bool legacy = ctx->updateLegacyForced ? ctx->updateLegacy : (n <= ctx->tinyBatchMax && !up.nRecordsPtr);
-    const bool split = n <= (legacy ? ctx->updateSplitMax : ctx->updateSplitMaxV2);  // one wave per (record, perspective)
+    const bool split = n <= ctx->updateSplitMaxV2;  // one wave per (record, perspective)
     uint32_t* counters = ctx->dHist + 3 * kHistWords;
     up.refreshList = ctx->dRefreshList;
     up.refreshCount = counters + ctx->refreshCur;
     // streaming (non-temporal) arena accesses only where accumulators are written: eval-only children keep cached parents
     const bool streamAcc = n >= ctx->streamAccMin && up.childSlots != nullptr;
-    if (legacy && !ctx->updateLegacyForced && !ctx->smallUpdateV1 && n <= 1024) {
-        // the smallest batches: the chain kernel on unit paths - one wave per (record, perspective) with inline rebuilds like
-        // the round-1 kernel, but with the ray-walk delta derivation: a synchronous update + eval of 1 / 1 024 records 30.5 ->
-        // 28.7 / 41.0 -> 39.7 us, the depth-first tree replay 0.523 -> 0.513 ms. From 2 048 records on its 163 VGPRs (3 waves per
-        // SIMD) lose to the round-1 kernel's 128 (53.5 vs 51 us; self-play at 16 384 seats -2 %), which keeps those
-        // (profiles/r03_ab_small_update_chain_kernel.txt; SPX_SMALL_UPDATE_V1=1: the round-1 kernel for all of them)
+    if (n <= ctx->updateChainMax && !up.nRecordsPtr) {
+        // the smallest batches: the chain kernel on unit paths - one wave per (record, perspective), rebuilds inline, ONE launch: a
+        // synchronous update + eval of 1 / 1 024 records 28.7 / 39.7 us. From 2 048 records on its 163 VGPRs (3 waves per SIMD)
+        // lose to spx_update_kernel + the rebuild pass (profiles/r03_ab_small_update_chain_kernel.txt; rounds 3-4 served 1 025 ..
+        // 8 192 records with the round-1 kernel, ~5 % faster there - retired in round 5, experiments/r01_update_kernel_board_diff.hip.txt)
         ChainParams cp{};
         cp.nChains = uint32_t(n);
         cp.parentSlots = up.parentSlots;
@@ -1188,46 +1239,7 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
         SPX_HIP(launchUpdateChain(cp, s));
         return SPX_OK;
     }
-    // SPX_FTU=1 (round 4, opt-in): the INCREMENTAL pipeline on the column-sliced row table (spx_ftx.h: FtuParams) - delta lists of
-    // every record in a pass of their own, the shared counting sort + plan, then the apply kernel, XCD x updating columns
-    // {64 x ..} U {512 + 64 x ..} of every child. Fused update + eval batches only; passes of <= 65 536 records.
-    bool slicedUpdate = false;
-    if (!legacy && ctx->ftuEnabled && !up.nRecordsPtr && up.ftOut && up.stagedRecords && n >= ctx->ftuMin &&
-        ensureFtx(ctx, ctx->ftx, std::min(n, kFtxMaxPositions), s)) {
-        slicedUpdate = true;
-        const FtxScratch& scratch = ctx->ftx;
-        for (size_t lo = 0; lo < n; lo += scratch.capacity) {
-            const size_t m = std::min(scratch.capacity, n - lo);
-            FtuParams fu{};
-            fu.x.nPositions = uint32_t(m);
-            fu.x.t = up.t;
-            fu.x.rowS = ctx->dRowS;
-            fu.x.lists = scratch.lists;
-            fu.x.heads = scratch.heads;
-            fu.x.keys = scratch.keys;
-            fu.x.ranks = scratch.ranks;
-            fu.x.hist = scratch.hist;
-            fu.x.binStart = scratch.binStart;
-            fu.x.sorted = scratch.sorted;
-            fu.x.plan = scratch.plan;
-            fu.x.ftOut = up.ftOut + lo * size_t(kL1);
-            fu.x.listStride = kFtuListStride;
-            fu.parentSlots = up.parentSlots + lo;
-            fu.childSlots = up.childSlots ? up.childSlots + lo : nullptr;
-            fu.childPositions = static_cast<const char*>(up.childPositions) + lo * sizeof(spx_packed_pos);
-            fu.arena = up.arena;
-            fu.slotRecords = up.slotRecords;
-            fu.stagedRecords = up.stagedRecords + lo * 32;
-            fu.refreshList = up.refreshList;
-            fu.refreshCount = up.refreshCount;
-            fu.firstRecord = uint32_t(lo);
-            SPX_HIP(launchFtuDerive(fu, s));
-            SPX_HIP(launchFtxSortAndPlan(fu.x, s));
-            SPX_HIP(launchFtuApply(fu, s));
-        }
-    }
-    if (!slicedUpdate) SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, legacy, s));
-    if (legacy) return SPX_OK;
+    SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, s));
     FtParams fp{};
     fp.positions = up.childPositions;
     fp.nPositions = uint32_t(n);
@@ -1244,7 +1256,7 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
     // kernel - was measured here and loses: 4 456 items are more than the resident workgroups, so the pass runs in rounds and
     // pays table staging and list building four times over: update + rebuild 0.291 -> 0.319 ms per 65 536-record ply,
     // profiles/r03_ab_rebuild_pass_team_kernel.txt.)
-    // Grid: 4 096 waves at most, grid-stride beyond (SPX_REFRESH_WAVES overrides). Round 2 launched n / 4 waves - up to the
+    // Grid: 4 096 waves at most, grid-stride beyond (option refresh_waves overrides). Round 2 launched n / 4 waves - up to the
     // full 12 288-workgroup grid for self-play's capacity-sized batches; measured now (profiles/r03_ab_rebuild_pass_grid.txt):
     // 16 384 / 8 192 / 4 096 / 2 048 / 1 024 waves = self-play at 4 096 seats 2.39 / 2.39 / 2.41 / 2.43 / 2.37 x 10^8 and the
     // incremental bench's update + rebuild 0.290 / 0.291 / 0.290 / 0.297 / 0.320 ms: 4 096 suits both.
@@ -1350,9 +1362,9 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     // wavefront pair of spx_update_chain_kernel - the accumulator stays in registers from ply to ply, ~5.5 us per ply - and all
     // paths whose head's parent exists form one launch: 8 launches instead of 249 for that trace. Shallow wide trees (a
     // depth-first walk to depth 12) keep the level batches, whose big launches run at the update kernel's full rate.
-    // SPX_REPLAY_PATHS=0 / 1 forces the choice.
+    // option replay_paths = 0 / 1 forces the choice.
     bool byPaths = maxDepth >= 32 && nUpdates / std::max<uint32_t>(1, maxDepth) <= 4096;
-    if (const char* env = std::getenv("SPX_REPLAY_PATHS")) byPaths = env[0] == '1';
+    if (ctx->replayPaths >= 0) byPaths = ctx->replayPaths != 0;
     std::vector<uint32_t> hChainFirst, hChainCount, roundStart;  // paths mode: chains grouped by round; hParents = per chain
     if (!byPaths) {
         for (size_t k = 1; k < n_nodes; ++k) {
@@ -1373,8 +1385,7 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
         // Long paths are cut into SEGMENTS of `segment` plies, each a path of its own one round after the previous one: the
         // paths hanging off the first plies of a 249-ply spine then start after the spine's first segment instead of after
         // its last ply (a launch lasts as long as its longest path).
-        uint32_t segment = 32;
-        if (const char* env = std::getenv("SPX_REPLAY_SEGMENT")) segment = uint32_t(std::max(1, std::atoi(env)));
+        const uint32_t segment = ctx->replaySegment;
         for (size_t k = 1; k < n_nodes; ++k) {
             const uint32_t p = parents[k];
             if (p != 0 && heavy[p] == k && chainLen[chainOf[p]] < segment) {  // continues its parent's path

@@ -244,11 +244,7 @@ __device__ __forceinline__ uint64_t laneTargets(const LaneBoard& b, uint32_t lan
 // kNear (full-refresh kernel of a net that has near-compact rows): such rows take the 1 KiB path too; the remainders of
 // their <= kOutlierCap wide weights (FtTables::outlierTab) are summed per column into `nearAcc` (this wave's 1 024 i32 in
 // LDS; lane = the row's square, one LDS atomic per remainder) and folded in after the gather. Returns whether any was.
-// kMfma (the matrix-pipe gather, gatherFullMfma): EVERY piece-square row heads the 1 KiB-row list (its slot of the i8 row
-// table holds the row itself when it fits i8, the clamped copy of a near-compact row, the LOW-BYTE plane of a wide row);
-// wide rows are listed a second time in psqList, as offsets into the high-byte plane table. Both lists are padded with
-// all-zero rows to a multiple of 4 (one MFMA adds up four rows); nPsq / nThr are the unpadded counts.
-template <bool kNear = false, bool kMfma = false>
+template <bool kNear = false>
 __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32_t lane, const uint32_t* lut,
                                                uint32_t* psqList, uint32_t* thrList, uint32_t& nPsq, uint32_t& nThr,
                                                const uint64_t* pseudoTab = nullptr,
@@ -301,27 +297,16 @@ __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32
             }
         }
         const uint64_t compactMask = __ballot(occupied && compact), wideMask = b.occ & ~compactMask;
-        if constexpr (kMfma) {
-            const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
-            if (occupied && slot < kPsqCap) {
+        const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
+        if (occupied && slot < kPsqCap) {
+            if (compact) {
                 thrList[slot] = (kThreatRows + row) * kL1;
-                if (!compact && wideSlot < kPsqCap) psqList[wideSlot] = row * kL1;
+            } else {
+                psqList[slot] = row * (kL1 * 2);
             }
-            nCompact = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
-            nPsq = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-            if (lane < 3 && nPsq + lane < ((nPsq + 3u) & ~3u)) psqList[nPsq + lane] = kPsqRows * kL1;  // the plane's zero row
-        } else {
-            const uint32_t slot = prefixCount(compact ? compactMask : wideMask);
-            if (occupied && slot < kPsqCap) {
-                if (compact) {
-                    thrList[slot] = (kThreatRows + row) * kL1;
-                } else {
-                    psqList[slot] = row * (kL1 * 2);
-                }
-            }
-            nCompact = min(uint32_t(popc64(compactMask)), uint32_t(kPsqCap));
-            nPsq = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
         }
+        nCompact = min(uint32_t(popc64(compactMask)), uint32_t(kPsqCap));
+        nPsq = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
     }
     uint32_t* threatList = thrList + nCompact;  // the reference's <= 256-entry threat list proper
 
@@ -333,9 +318,6 @@ __device__ __forceinline__ bool buildFullLists(const LaneBoard& b, int c, uint32
     const bool own = isPawn && (piece & 1) == c;
     nThr = nCompact + emitPawnPairRows(threatList, nThr, pawnPartners(isPawn, own, lane, ownPawns, theirPawns),
                                        ppId(int(lane) ^ x, !own), ownPawns, x);
-    if constexpr (kMfma) {
-        if (lane < 3 && nThr + lane < ((nThr + 3u) & ~3u)) thrList[nThr + lane] = (kThreatRows + kPsqRows) * kL1;  // the table's zero row
-    }
     __builtin_amdgcn_wave_barrier();  // lists are produced and consumed by the same wave: LDS order suffices
     return hasNear;
 }
@@ -505,15 +487,11 @@ __device__ __forceinline__ u32x2 activate(const uint32_t (&acc)[8]) {
 //               (A[m][16 kb + i] = (i == m)), so D[m][n] = sum over kb of byte m of lane (n, kb);
 //   D         = lane (n, mb = lane >> 4), register r: m = 4 mb + r - the exact i32 sum of the four rows' column
 //               16 n + 4 mb + r of the 256 columns the instruction covers (checked on the device: tools/probes/mfma_rowsum_probe).
-// A 1 KiB row is four such 256-column quarters: a wave load fetches quarter q of four rows (lane (n, kb): 16 bytes at
-// row_kb + 256 q + 16 n; each 16-lane group reads 256 contiguous bytes), one MFMA accumulates it into D[q] - no VALU at all
-// where gatherFull spends 12 instructions per row on zero-extension and adds (850 of the kernel's 1 407 per perspective).
-// Rows are stored as plain i8 in natural column order (FtTables::rowI8: threat rows, then one slot per piece-square row:
-// the row itself if it fits i8, else its low-byte plane; the high-byte plane of wide rows in FtTables::psqHi, summed first
-// and shifted up - v = 256 h + l with l = int8(v), h = int8((v - l) >> 8), exact mod 2^16). Sums are exact in i32
-// (<= 288 rows x 128), reduced mod 2^16 with the bias at the end: the reference's wrapping i16 accumulators.
-// Lane (n, mb) ends up owning columns 256 q + 16 n + 4 mb + r (q, r < 4): the pairwise partners j, j + 512 are quarters q, q + 2
-// of the same lane.
+// No VALU at all where gatherFull spends 12 instructions per row on zero-extension and adds. Rows are stored as plain i8; a
+// piece-square row with weights outside i8 is two planes, v = 256 h + l with l = int8(v), h = int8((v - l) >> 8) (exact mod 2^16),
+// the high planes summed first and shifted up. Sums are exact in i32 (<= 288 rows x 128), reduced mod 2^16 with the bias at the
+// end: the reference's wrapping i16 accumulators. Used by the column-sliced gather (spx_ftx.hip); the whole-row form of round 4
+// (gatherFullMfma in spx_ft_kernel) is retired to experiments/r04_ft_kernel_gather_on_the_matrix_pipe.hip.txt.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ i32x4 mfmaSelector(uint32_t lane) {
     const uint32_t m = lane & 15u, one = 1u << (8 * (m & 3u));
@@ -523,83 +501,6 @@ __device__ __forceinline__ i32x4 mfmaSelector(uint32_t lane) {
     sel[2] = (m >> 2) == 2 ? int32_t(one) : 0;
     sel[3] = (m >> 2) == 3 ? int32_t(one) : 0;
     return sel;
-}
-
-// adds the rows of `list` (byte offsets into `table`, n padded to a multiple of 4 with zero rows) into d[0..3];
-// kQuartets row quartets (x four quarters = 4 kQuartets wave loads) are requested before the first MFMA waits for one
-#ifndef SPX_FT_MFMA_QUARTETS
-#define SPX_FT_MFMA_QUARTETS 1
-#endif
-template <int kQuartets>
-__device__ __forceinline__ void mfmaGatherBurst(const uint8_t* table, const uint32_t* list, uint32_t j, uint32_t kb,
-                                                uint32_t laneOff, const i32x4& sel, i32x4 (&d)[4]) {
-    i32x4 w[4 * kQuartets];
-#pragma unroll
-    for (int u = 0; u < kQuartets; ++u) {
-        const uint32_t e = list[j + 4 * u + kb] + laneOff;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[4 * u + q] = *reinterpret_cast<const i32x4*>(table + size_t(e) + 256 * q);
-    }
-    // all loads are requested before the first MFMA waits for one (left alone, the scheduler interleaves them with the
-    // MFMAs on two or three landing registers: two loads in flight)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < kQuartets; ++u) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[4 * u + q], d[q], 0, 0, 0);
-    }
-}
-__device__ __forceinline__ void mfmaGatherRows(const uint8_t* table, const uint32_t* list, uint32_t n, uint32_t lane,
-                                               const i32x4& sel, i32x4 (&d)[4]) {
-    const uint32_t kb = lane >> 4, laneOff = 16 * (lane & 15u);
-    uint32_t j = 0;
-    for (; j + 4 * SPX_FT_MFMA_QUARTETS <= n; j += 4 * SPX_FT_MFMA_QUARTETS) {
-        mfmaGatherBurst<SPX_FT_MFMA_QUARTETS>(table, list, j, kb, laneOff, sel, d);
-    }
-    if constexpr (SPX_FT_MFMA_QUARTETS >= 4) {
-        if (j + 8 <= n) {
-            mfmaGatherBurst<2>(table, list, j, kb, laneOff, sel, d);
-            j += 8;
-        }
-    }
-    if (j < n) mfmaGatherBurst<1>(table, list, j, kb, laneOff, sel, d);
-}
-
-// acc[2 q + h] = columns (c, c + 1), c = 256 q + 16 (lane & 15) + 4 (lane >> 4) + 2 h, as packed wrapping i16 = ftBias +
-// the rows' sums (+ the near-compact rows' remainders). acc[0..3] / acc[4..7] are pairwise partners, as activate() wants.
-__device__ __forceinline__ void gatherFullMfma(const FtTables& t, uint32_t lane, const uint32_t* hiList, uint32_t nHi,
-                                               const uint32_t* rowList, uint32_t nRows, uint32_t (&acc)[8],
-                                               const int32_t* nearAcc = nullptr) {
-    const i32x4 sel = mfmaSelector(lane);
-    i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (nHi) {  // high-byte planes of the wide piece-square rows first: their sum counts 256-fold
-        mfmaGatherRows(reinterpret_cast<const uint8_t*>(t.psqHi), hiList, (nHi + 3u) & ~3u, lane, sel, d);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = d[q] << 8;
-    }
-    mfmaGatherRows(reinterpret_cast<const uint8_t*>(t.rowI8), rowList, (nRows + 3u) & ~3u, lane, sel, d);
-    const uint32_t col = 16 * (lane & 15u) + 4 * (lane >> 4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32x2 bias = *reinterpret_cast<const u32x2*>(t.ftBias + 256 * q + col);
-        i32x4 s = d[q];
-        if (nearAcc) s += *reinterpret_cast<const i32x4*>(nearAcc + 256 * q + col);
-        acc[2 * q] = pkAdd16(bias[0], __builtin_amdgcn_perm(uint32_t(s[1]), uint32_t(s[0]), 0x05040100u));
-        acc[2 * q + 1] = pkAdd16(bias[1], __builtin_amdgcn_perm(uint32_t(s[3]), uint32_t(s[2]), 0x05040100u));
-    }
-}
-
-// the matrix-pipe layout's stores: activations (4 bytes per lane and quarter q < 2) and arena accumulators (8 bytes per quarter)
-__device__ __forceinline__ void storeActivationsMfma(uint8_t* ftRow, uint32_t lane, const uint32_t (&acc)[8]) {
-    const u32x2 o = activate(acc);
-    uint8_t* base = ftRow + 16 * (lane & 15u) + 4 * (lane >> 4);
-    *reinterpret_cast<uint32_t*>(base) = o[0];
-    *reinterpret_cast<uint32_t*>(base + 256) = o[1];
-}
-__device__ __forceinline__ void storeAccMfma(uint8_t* arena, uint32_t slot, int c, uint32_t lane, const uint32_t (&acc)[8]) {
-    uint8_t* base = arena + size_t(slot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 2 * (16 * (lane & 15u) + 4 * (lane >> 4));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(base + 512 * q) = u32x2{acc[2 * q], acc[2 * q + 1]};
 }
 
 // Accumulator arena slot: [colour 0: i16[1024]][colour 1: i16[1024]] = 4 KiB, natural column order. Lane l owns

@@ -72,28 +72,6 @@ struct FtxParams {
     uint32_t* sorted;        // [2 n + 128][4]
     uint32_t* plan;          // [kFtxPlanWords]
     uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
-    uint32_t listStride;     // words per list (kFtxListStride; the incremental pipeline: kFtuListStride)
-};
-
-// ---- the INCREMENTAL pipeline on the same tables (spx_ftu_*: derive -> rank / plan / scatter -> apply) ----
-// per-perspective delta lists written by spx_ftu_derive_kernel: [0, 8) high-byte planes of the wide piece-square rows to subtract,
-// [8, 16) ... to add, [16, 120) rows to subtract (threat / pawn-pair rows, compact piece-square rows, low-byte planes of the wide
-// ones), [120, 224) rows to add; slice offsets (row index * 128). heads[perspective] = {nHiSub | nHiAdd << 8 | nSub << 16 | nAdd << 24,
-// output slot}; a perspective that must be rebuilt instead (king changed bucket / mirror half) gets the key ~0 and is left out
-constexpr uint32_t kFtuListStride = 224, kFtuHiSub = 0, kFtuHiAdd = 8, kFtuSub = 16, kFtuAdd = 120, kFtuRowCap = 104;
-constexpr uint32_t kFtuSkipKey = 0xFFFFFFFFu;
-
-struct FtuParams {
-    FtxParams x;                   // scratch of the pass, tables, ftOut [records][1024] of the pass; x.nPositions = records of the pass
-    const uint32_t* parentSlots;   // [records] of the pass
-    const uint32_t* childSlots;    // [records] or nullptr (eval-only children)
-    const void* childPositions;    // spx_packed_pos[records]
-    uint8_t* arena;
-    uint8_t* slotRecords;
-    uint8_t* stagedRecords;        // [records][32] of the pass
-    uint32_t* refreshList;         // ids 2 * (firstRecord + record) + colour of the perspectives to rebuild ...
-    uint32_t* refreshCount;        // ... and their number
-    uint32_t firstRecord;          // index of the pass's first record in the whole call
 };
 
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
@@ -102,9 +80,6 @@ hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const 
 // everything before the gather (extract, rank, plan, scatter): may overlap another batch's gather
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);
 hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream);
-// the incremental pipeline: delta lists of every record (spx_kernels.hip), the shared counting sort + plan, the apply kernel
-hipError_t launchFtuDerive(const FtuParams& p, hipStream_t stream);
 hipError_t launchFtxSortAndPlan(const FtxParams& p, hipStream_t stream);
-hipError_t launchFtuApply(const FtuParams& p, hipStream_t stream);
 
 }  // namespace spx

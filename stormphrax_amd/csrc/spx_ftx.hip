@@ -23,8 +23,9 @@
 //                           the bucket's piece-square slab slice into LDS, then one wave per group of 8 perspectives: it reads the
 //                           8 lists itself, 2 perspectives x 4 rows x 128 B per wave load / LDS read, one MFMA each, pairwise
 //                           activation (multilayer.h:92-152) from the i32 sums, 2 output bytes per lane.
-// The incremental path on the same tables (opt-in): spx_ftu_derive_kernel (spx_kernels.hip) -> rank / plan / scatter ->
-// spx_ftu_apply_kernel (below).
+// (Round 4 also built the INCREMENTAL path on the same tables - spx_ftu_derive_kernel -> rank / plan / scatter ->
+// spx_ftu_apply_kernel -: bit-exact and slower than spx_update_kernel, 1.32 vs 2.15e8 updates+evals/s; retired in round 5 to
+// experiments/r04_incremental_pipeline_column_sliced.hip.txt.)
 // Results are bit-identical to spx_ft_kernel (sums of rows mod 2^16; tests/test_gpu_parity.py runs both).
 #include <hip/hip_runtime.h>
 
@@ -227,15 +228,16 @@ __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) sCount[k] = 0;
     __syncthreads();
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, nPersp = 2 * p.nPositions;
-    uint32_t key = kFtuSkipKey, local = 0;
-    if (q < nPersp) key = p.keys[q];
-    if (key != kFtuSkipKey) local = atomicAdd(&sCount[key], 1u);  // (the incremental pipeline leaves rebuilt perspectives out)
+    uint32_t key = 0, local = 0;
+    const bool mine = q < nPersp;
+    if (mine) key = p.keys[q];
+    if (mine) local = atomicAdd(&sCount[key], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) {
         if (sCount[k]) sBase[k] = atomicAdd(&p.hist[k], sCount[k]);
     }
     __syncthreads();
-    if (key != kFtuSkipKey) p.ranks[q] = sBase[key] + local;
+    if (mine) p.ranks[q] = sBase[key] + local;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -393,9 +395,8 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= 2 * p.nPositions) return;
     const uint32_t key = p.keys[q];
-    if (key == kFtuSkipKey) return;
     const u32x2 head = *reinterpret_cast<const u32x2*>(p.heads + 2 * size_t(q));
-    reinterpret_cast<u32x4*>(p.sorted)[p.binStart[key] + p.ranks[q]] = u32x4{head[0], head[1], q * (p.listStride * 4u), q};
+    reinterpret_cast<u32x4*>(p.sorted)[p.binStart[key] + p.ranks[q]] = u32x4{head[0], head[1], q * (kFtxListStride * 4u), q};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -565,164 +566,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
         }
     }
     if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes) + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Incremental apply: child accumulator = parent accumulator - removed rows + added rows (updatePsq, nnue_state.cpp:34-87;
-// applyThreatRows :89-145), column slice by column slice. The same machinery as the gather - workgroup b = (XCD b % 8 = slice, CU slot
-// b / 8) walks its planned range of groups of 8 perspectives, a wave per group reads the 8 delta lists itself, four rows per MFMA -
-// with a NEGATIVE selection matrix for the rows to subtract (A = -1 where the gather has +1: D -= the four rows), no LDS slab (a
-// move touches two or three piece-square rows), and the parent's 2 x 128 columns of the slice in place of the bias. The lane
-// layout of the sums (columns c, c + 1 and their partners c + 512, c + 513 in one lane) is the arena's natural column order:
-// two 4-byte loads and stores per perspective and lane. Sections: high-byte planes to subtract, to add (then << 8), rows to
-// subtract, rows to add.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(4, 8))) void spx_ftu_apply_kernel(FtuParams p) {
-    extern __shared__ __align__(16) uint8_t sDyn[];
-    uint32_t (*const sEnt)[2][256] = reinterpret_cast<uint32_t (*)[2][256]>(sDyn);  // per wave: two stages of 8 steps of entries
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
-    const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
-    const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
-    const uint32_t g = lane & 7u, ks = lane >> 3;
-    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);
-    const uint8_t* slice = p.x.rowS + size_t(xcd) * kFtxSliceStride;
-    const uint32_t laneOff = 16 * t;
-    const i32x4 selAdd = mfmaSelector(lane);
-    const i32x4 selSub = selAdd * 255;  // (+1 -> -1 in the one non-zero byte of every word)
-    const uint32_t col = 64 * xcd + 8 * t + 2 * kb;  // this lane's columns: (col, col + 1) and (col + 512, col + 513)
-    auto headOf = [&](uint32_t G) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.x.sorted) + 16u * (8u * G + g)); };
-    const uint32_t ownEnd = p.x.plan[cu + 1];
-    for (uint32_t seg = p.x.plan[cu]; seg < ownEnd; ++seg) {
-        const uint32_t gFirst = p.x.plan[64 + 3 * seg + 1], gEnd = p.x.plan[64 + 3 * seg + 2];
-        uint32_t G = gFirst + wave;
-        u32x4 headNext = {0, 0xFFFFFFFFu, 0, 0};
-        if (G < gEnd) headNext = headOf(G);
-        for (; G < gEnd; G += kGatherWaves) {
-            const u32x4 head = headNext;  // (asked for a group ahead: one round trip less on a short chain)
-            if (G + kGatherWaves < gEnd) headNext = headOf(G + kGatherWaves);
-            const bool hole = head[1] == 0xFFFFFFFFu;
-            // lanes 0 .. 7: perspective g of the group - its record's slots
-            const uint32_t rec = hole ? 0u : head[3] >> 1, colour = head[3] & 1u;
-            const uint32_t parentSlot = hole ? 0u : p.parentSlots[rec];
-            const uint32_t childSlot = (hole || !p.childSlots) ? 0u : p.childSlots[rec];
-            const uint32_t cHS = head[0] & 0xFFu, cHA = (head[0] >> 8) & 0xFFu, cS = (head[0] >> 16) & 0xFFu, cA = head[0] >> 24;
-            const uint32_t mine = head[2];  // (the list's byte offset)
-            uint32_t qA = ((cHS + 3) >> 2) | (((cHA + 3) >> 2) << 16), qB = ((cS + 3) >> 2) | (((cA + 3) >> 2) << 16);
-#pragma unroll
-            for (int dlt = 1; dlt < 8; dlt <<= 1) {
-                qA = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qA),
-                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qA), dlt, 64)))));
-                qB = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qB),
-                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qB), dlt, 64)))));
-            }
-            qA = __builtin_amdgcn_readfirstlane(qA);
-            qB = __builtin_amdgcn_readfirstlane(qB);
-            // section ends: high planes to subtract | to add | rows to subtract | to add
-            const uint32_t e1 = qA & 0xFFFFu, e2 = e1 + (qA >> 16), e3 = e2 + (qB & 0xFFFFu), nSteps = e3 + (qB >> 16);
-            // the parents' columns of this lane (perspectives 2 pr + u), asked for before the rows
-            uint32_t accLo[4], accHi[4], pSlotOf[4];
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const int src = 2 * pr + int(u);
-                pSlotOf[pr] = uint32_t(__shfl(int(parentSlot), src, 64));
-                const uint32_t c = uint32_t(__shfl(int(colour), src, 64));
-                const uint8_t* acc = p.arena + size_t(pSlotOf[pr]) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 2 * col;
-                accLo[pr] = *reinterpret_cast<const uint32_t*>(acc);
-                accHi[pr] = *reinterpret_cast<const uint32_t*>(acc + 1024);
-            }
-            auto place = [&](uint32_t j0, uint32_t& at, uint32_t& left) {
-                const uint32_t j = j0 + ks;
-                uint32_t base, count, first;
-                if (j < e1) {
-                    base = kFtuHiSub, count = cHS, first = 4 * j;
-                } else if (j < e2) {
-                    base = kFtuHiAdd, count = cHA, first = 4 * (j - e1);
-                } else if (j < e3) {
-                    base = kFtuSub, count = cS, first = 4 * (j - e2);
-                } else {
-                    base = kFtuAdd, count = cA, first = 4 * (j - e3);
-                }
-                at = base + first;
-                left = count > first ? count - first : 0u;
-            };
-            auto fetch = [&](uint32_t j0) -> u32x4 {
-                uint32_t at, left;
-                place(j0, at, left);
-                u32x4 v = {0, 0, 0, 0};
-                if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.x.lists) + (mine + 4 * at));
-                return v;
-            };
-            auto put = [&](uint32_t j0, const u32x4& v, uint32_t* stage) {
-                uint32_t at, left;
-                place(j0, at, left);
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) stage[fillAt + 8 * i] = i < left ? v[i] : kFtxZeroRow * 128u;
-            };
-            u32x4 ahead = fetch(0);
-            i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            uint32_t j = 0;
-            while (j < nSteps) {
-                uint32_t* stage = sEnt[wave][(j >> 3) & 1];
-                if ((j & 7u) == 0) {
-                    put(j, ahead, stage);
-                    if (j + 8 < nSteps) ahead = fetch(j + 8);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                // a burst = two steps unless the stage, the lists or the high-byte sections end in between
-                const uint32_t k = j & 7u;
-                const bool two = k < 7 && j + 1 < nSteps && j + 1 != e2;
-                const bool sub0 = j < e1 || (j >= e2 && j < e3), sub1 = j + 1 < e1 || (j + 1 >= e2 && j + 1 < e3);
-                const u32x4 en0 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e));
-                const u32x4 en1 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
-                i32x4 w[8];
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(en0[pr] + laneOff));
-                if (two) {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(slice + size_t(en1[pr] + laneOff));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const i32x4 s0 = sub0 ? selSub : selAdd, s1 = sub1 ? selSub : selAdd;
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(s0, w[pr], d[pr], 0, 0, 0);
-                if (two) {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(s1, w[4 + pr], d[pr], 0, 0, 0);
-                }
-                j += two ? 2u : 1u;
-                if (j == e2) {  // the high-byte planes' sums count 256-fold
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
-                }
-            }
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const int src = 2 * pr + int(u);
-                const uint32_t dst = uint32_t(__shfl(int(head[1]), src, 64));
-                const uint32_t cSlot = uint32_t(__shfl(int(childSlot), src, 64));
-                const uint32_t c = uint32_t(__shfl(int(colour), src, 64));
-                const uint32_t a = pkAdd16(accLo[pr], __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
-                const uint32_t b = pkAdd16(accHi[pr], __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
-                if (dst == 0xFFFFFFFFu) continue;
-                if (p.childSlots) {
-                    uint8_t* acc = p.arena + size_t(cSlot) * kAccSlotBytes + size_t(c) * (kL1 * 2) + 2 * col;
-                    *reinterpret_cast<uint32_t*>(acc) = a;
-                    *reinterpret_cast<uint32_t*>(acc + 1024) = b;
-                }
-                const i16x2 zero = {0, 0}, top = {255, 255};
-                const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
-                const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero), top));
-                const uint32_t o = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));
-                *reinterpret_cast<uint16_t*>(p.x.ftOut + size_t(dst) * kPairs + col) = uint16_t((o & 0xFFu) | ((o >> 8) & 0xFF00u));
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-hipError_t launchFtuApply(const FtuParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(spx_ftu_apply_kernel, dim3(256), dim3(64 * kGatherWaves), kGatherWaves * 2 * 256 * 4, stream, p);
-    return hipGetLastError();
 }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream) {

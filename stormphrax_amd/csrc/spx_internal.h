@@ -22,6 +22,7 @@ namespace spx {
 size_t ctxMaxBatch(const spx_ctx* ctx);
 int ctxDevice(const spx_ctx* ctx);
 void* ctxStream(const spx_ctx* ctx);  // the context's own hipStream_t (what a NULL stream argument means)
+int64_t ctxSelfplayOption(const spx_ctx* ctx, int which);  // 0 selfplay_graph, 1 selfplay_graph_plies, 2 selfplay_trace (spx_ctx_set_option)
 uint8_t* ctxSlotRecords(const spx_ctx* ctx);  // device pointer: the arena's [nSlots][32] record store (after spx_acc_reserve)
 // lanes: see spx_api.cpp (two scratch sets + streams; big kernels chained by events)
 // gates = false: the lane's big kernels are NOT chained to the other lane's by events (a stream that is being captured

@@ -23,11 +23,6 @@ struct FtTables {
     const uint32_t* lut;     // kLutWords threat LUT
     const uint64_t* deltaTab;  // kDeltaTabWords ray / knight masks + pseudo-attack sets (threat-delta derivation)
     const uint32_t* outlierTab;  // [kPsqRows][kOutlierCap] remainders of the near-compact rows, or nullptr (net has none)
-    // the matrix-pipe gather's tables (gatherFullMfma): plain i8, natural column order
-    const int8_t* rowI8;     // [64368 + 11264 + 1][1024]: threat rows; per piece-square row its i8 copy (compact), clamped copy
-                             // (near-compact) or low-byte plane (wide); one all-zero row
-    const int8_t* psqHi;     // [11264 + 1][1024]: high-byte planes of the piece-square rows (zero for compact rows); a zero row
-    bool mfmaGather;         // full refreshes gather on the matrix pipe (SPX_FT_MFMA_GATHER=1; rowI8 / psqHi are set then)
 };
 
 struct FtParams {
@@ -222,7 +217,7 @@ hipError_t launchFtTeam(const FtParams& p, uint32_t gridBlocks, hipStream_t stre
 hipError_t launchMlp(const MlpParams& p, bool smallL2Weights, MlpTiling tiling, hipStream_t stream);
 hipError_t launchSort(const SortParams& p, hipStream_t stream);
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
-                        bool legacy, hipStream_t stream);
+                        hipStream_t stream);
 hipError_t launchUpdateObserved(const UpdateParams& p, uint32_t gridBlocks, hipStream_t stream);
 hipError_t launchUpdateChain(const ChainParams& p, hipStream_t stream);
 hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_t stream);

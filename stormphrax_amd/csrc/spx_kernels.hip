@@ -36,16 +36,11 @@ namespace spx {
 // kNear: the net has near-compact piece-square rows (FtTables::outlierTab): they take the 1 KiB path, their wide weights'
 //        remainders are summed through 4 KiB of LDS per wave (buildFullLists). Nets without such rows run the kNear = false
 //        instantiation - the same code as before the feature existed.
-// kMfma: the gather runs on the matrix pipe (gatherFullMfma: one v_mfma_i32_16x16x64_i8 widens and adds up four gathered rows;
-//        plain-i8 row table, lane owns columns 256 q + 16 (lane & 15) + 4 (lane >> 4) + r). Round 4, opt-in (SPX_FT_MFMA_GATHER=1):
-//        VALU instructions per perspective 1 407 -> ~750, kernel time unchanged (0.419 vs 0.421 ms at 6 waves/SIMD x 4 loads; 5 x 8:
-//        0.472 with spills, 4 x 8: 0.436, 4 x 16: 0.502, 3 x 16: 0.460; profiles/r04_ab_ft_mfma_gather.txt) - this kernel waits for
-//        its row loads, not for the VALU. The column-sliced pipeline (spx_ftx.hip) is where the idea pays.
-#ifndef SPX_FT_MFMA_WAVES_PER_SIMD
-#define SPX_FT_MFMA_WAVES_PER_SIMD 6
-#endif
-template <bool kNear, bool kMfma>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kMfma ? (kNear ? 4 : SPX_FT_MFMA_WAVES_PER_SIMD) : SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
+// (Round 4 also ran this kernel's gather on the matrix pipe - gatherFullMfma, SPX_FT_MFMA_GATHER=1: half the VALU instructions, the
+// same time, 88 MB of extra tables; retired in round 5 to experiments/r04_ft_kernel_gather_on_the_matrix_pipe.hip.txt. The
+// column-sliced pipeline, spx_ftx.hip, is where that idea pays.)
+template <bool kNear>
+__global__ __launch_bounds__(64 * kWavesPerBlock, SPX_FT_WAVES_PER_SIMD) void spx_ft_kernel(FtParams p) {
     __shared__ uint32_t sLut[kLutWords];
     __shared__ __align__(16) int32_t sNear[kNear ? kWavesPerBlock : 1][kNear ? int(kL1) : 4];  // per-column remainder sums
     __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // byte offsets into the threat table
@@ -94,22 +89,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kMfma ? (kNear ? 4 : SPX_FT_MF
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(posIdx) * 32;
         const LaneBoard board = decodeBoard(rec, lane);
         uint32_t nPsq, nThr;
-        const bool hasNear = buildFullLists<kNear, kMfma>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
+        const bool hasNear = buildFullLists<kNear>(board, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr, sPseudo,
                                                           p.t.outlierTab, sNear[kNear ? wave : 0]);
         uint32_t acc[8];
-        if constexpr (kMfma) {
-            gatherFullMfma(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
-        } else {
-            gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
-        }
+        gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc, (kNear && hasNear) ? sNear[kNear ? wave : 0] : nullptr);
 
         if (p.accOut) {
             const uint32_t slot = __builtin_amdgcn_readfirstlane(p.slots[posIdx]);
-            if constexpr (kMfma) {
-                storeAccMfma(p.accOut, slot, c, lane, acc);
-            } else {
-                storeAcc(p.accOut, slot, c, lane, acc);
-            }
+            storeAcc(p.accOut, slot, c, lane, acc);
             if (c == 0 && lane < 8) {  // the record travels with the slot (parent of later incremental updates)
                 reinterpret_cast<uint32_t*>(p.slotRecords + size_t(slot) * 32)[lane] =
                     reinterpret_cast<const uint32_t*>(rec)[lane];
@@ -117,11 +104,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kMfma ? (kNear ? 4 : SPX_FT_MF
         }
         if (p.ftOut) {
             const uint32_t half = (c == board.stm) ? 0u : 1u;  // stm half first (nnue_state.cpp:396-438)
-            if constexpr (kMfma) {
-                storeActivationsMfma(p.ftOut + size_t(posIdx) * kL1 + half * kPairs, lane, acc);
-            } else {
-                *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
-            }
+            *reinterpret_cast<u32x2*>(p.ftOut + size_t(posIdx) * kL1 + half * kPairs + 8 * lane) = activate(acc);
         }
     }
 }
@@ -258,121 +241,9 @@ struct ItemWalk {
     }
 };
 
-template <bool kSplit, bool kStream>
-// (one wave per record, both perspectives - the A/B-only shape of this kernel - needs ~135 VGPRs: 3 waves/SIMD, no spills;
-// round 3 shipped it at 4 waves with 8 VGPRs and 30 SGPRs spilled)
-__global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? SPX_UPDATE_SPLIT_WAVES : 3) void spx_update_kernel_v1(UpdateParams p) {  // ~120 VGPRs: two boards live
-    __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint32_t sThr[kWavesPerBlock][kU8Cap];  // full rebuild: threat rows; incremental: rows to ADD
-    __shared__ uint32_t sPsq[kWavesPerBlock][kPsqCap];     // full rebuild: psq rows
-    __shared__ uint32_t sSub[kWavesPerBlock][kU8Cap];  // incremental: threat rows to SUBTRACT
-    __shared__ uint32_t sPsqDelta[kWavesPerBlock][2][8];   // incremental: psq rows to subtract / add (<= 4 each)
-
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) {
-        sLut[i] = p.t.lut[i];
-    }
-    __syncthreads();
-
-    const uint32_t lane = laneId();
-    const uint32_t wave = threadIdx.x >> 6;
-
-    const uint32_t nRecords = p.nRecordsPtr ? min(*p.nRecordsPtr, p.nRecords) : p.nRecords;
-    const uint32_t nItems = kSplit ? nRecords * 2 : nRecords;
-    for (ItemWalk<false> walk(nItems, wave); walk.t < walk.tEnd; walk.t += walk.stride) {
-        const uint32_t item = walk.item();
-        if (item >= nItems) continue;  // (the last chunk round may be partial)
-        const uint32_t it = kSplit ? item >> 1 : item;
-        const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
-        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
-        // childSlots == nullptr: EVAL-ONLY children - the activations leave through ftOut, no accumulator and no record is
-        // stored (the reference never keeps accumulators of nodes it only evaluates, nnue_state.cpp:598-610)
-        const uint32_t childSlot = p.childSlots ? __builtin_amdgcn_readfirstlane(p.childSlots[it]) : 0u;
-        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
-        const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
-        const LaneBoard pb = decodeBoard(parentRec, lane);
-        const LaneBoard cb = decodeBoard(childRec, lane);
-
-        const bool changedSq = pb.piece != cb.piece;
-        const uint64_t changed = __ballot(changedSq);
-        // attack sets are perspective independent: compute once per board
-        uint64_t tP = 0, tC = 0;
-        if (pb.piece != kNoPiece && (pb.piece >> 1) != 5) {
-            tP = pieceAttacks(pb.piece, int(lane), pb.occ) & pb.occ & ~pb.kingsBb;
-        }
-        if (cb.piece != kNoPiece && (cb.piece >> 1) != 5) {
-            tC = pieceAttacks(cb.piece, int(lane), cb.occ) & cb.occ & ~cb.kingsBb;
-        }
-        // pairs kept: attacker unchanged, victim unchanged, attacked before and after
-        const uint64_t keep = changedSq ? 0 : (tP & tC & ~changed);
-        const uint64_t subTargets = tP & ~keep, addTargets = tC & ~keep;
-
-#pragma unroll 1
-        for (int c = cFirst; c < cLast; ++c) {
-            const uint64_t kingMaskP = __ballot(pb.piece == (10 | c)), kingMaskC = __ballot(cb.piece == (10 | c));
-            const int kingP = kingMaskP ? ctz64(kingMaskP) : 0, kingC = kingMaskC ? ctz64(kingMaskC) : 0;
-            const int relP = c == 0 ? (kingP ^ 56) : kingP, relC = c == 0 ? (kingC ^ 56) : kingC;
-            // a legal move changes at most 4 squares (castling); anything larger is not a one-move delta (the caller
-            // paired unrelated boards) and is rebuilt from scratch rather than overflowing the small delta lists
-            const bool refresh = kingBucket(relP) != kingBucket(relC) || ((kingP & 7) >= 4) != ((kingC & 7) >= 4) ||
-                                 popc64(changed) > 4;
-            uint32_t acc[8];
-            if (refresh) {
-                uint32_t nPsq, nThr;
-                buildFullLists(cb, c, lane, sLut, sPsq[wave], sThr[wave], nPsq, nThr);
-                gatherFull(p.t, lane, sPsq[wave], nPsq, sThr[wave], nThr, acc);
-            } else {
-                const int x = perspXor(c, kingC);  // bucket and mirror half are those of the parent too
-                const int flipColour = (c == 0) ? 1 : 0;
-                // ---- piece-square delta: changed squares (updatePsq: <= 2 subs, <= 2 adds per move) ----
-                uint32_t nPsqSub, nPsqAdd;
-                const bool subLane = changedSq && pb.piece != kNoPiece, addLane = changedSq && cb.piece != kNoPiece;
-                uint32_t* subList = sSub[wave];
-                uint32_t* addList = sThr[wave];
-                const uint32_t nSubCompact = emitPsqDeltaRows(subLane, subLane ? psqRow(c, pb.piece, int(lane), kingC) : 0u,
-                                                              sLut, sPsqDelta[wave][0], subList, nPsqSub);
-                const uint32_t nAddCompact = emitPsqDeltaRows(addLane, addLane ? psqRow(c, cb.piece, int(lane), kingC) : 0u,
-                                                              sLut, sPsqDelta[wave][1], addList, nPsqAdd);
-                subList += nSubCompact;
-                addList += nAddCompact;
-                // ---- threat delta ----
-                uint32_t nSub = emitThreatRows(subList, 0, subTargets, pb.piece, lane, x, flipColour, sLut);
-                uint32_t nAdd = emitThreatRows(addList, 0, addTargets, cb.piece, lane, x, flipColour, sLut);
-                // ---- pawn-pair delta (generatePpRows): pairs that exist on one board only ----
-                {
-                    const uint64_t ownP = pb.pawnsBb & (c ? pb.whiteBb : ~pb.whiteBb), theirP = pb.pawnsBb & ~ownP;
-                    const uint64_t ownC = cb.pawnsBb & (c ? cb.whiteBb : ~cb.whiteBb), theirC = cb.pawnsBb & ~ownC;
-                    const bool pawnP = (pb.piece >> 1) == 0, pawnC = (cb.piece >> 1) == 0;
-                    const bool ownSideP = pawnP && (pb.piece & 1) == c, ownSideC = pawnC && (cb.piece & 1) == c;
-                    const uint64_t partP = pawnPartners(pawnP, ownSideP, lane, ownP, theirP);
-                    const uint64_t partC = pawnPartners(pawnC, ownSideC, lane, ownC, theirC);
-                    // a pair survives iff both pawns are unchanged (same square, same colour) and it is in both sets
-                    const uint64_t unchangedPawns = pb.pawnsBb & cb.pawnsBb & ~changed;
-                    const uint64_t kept = (pawnP && pawnC && !changedSq) ? (partP & partC & unchangedPawns) : 0;
-                    nSub = emitPawnPairRows(subList, nSub, partP & ~kept, ppId(int(lane) ^ x, !ownSideP), ownP, x);
-                    nAdd = emitPawnPairRows(addList, nAdd, partC & ~kept, ppId(int(lane) ^ x, !ownSideC), ownC, x);
-                }
-                __builtin_amdgcn_wave_barrier();
-
-                applyDelta<kStream>(p.t, p.arena, parentSlot, c, lane, sPsqDelta[wave][0], nPsqSub, sPsqDelta[wave][1],
-                                    nPsqAdd, sThr[wave], nAdd + nAddCompact, sSub[wave], nSub + nSubCompact, acc);
-            }
-            if (p.childSlots) storeAcc<kStream>(p.arena, childSlot, c, lane, acc);
-            if (p.ftOut) {  // fused evaluation of the child: activations straight from the registers
-                const uint32_t half = (c == cb.stm) ? 0u : 1u;
-                *reinterpret_cast<u32x2*>(p.ftOut + size_t(it) * kL1 + half * kPairs + 8 * lane) = activate(acc);
-            }
-        }
-        if (lane < 8 && cFirst == 0) {
-            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
-            if (p.childSlots) reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
-            if (p.ftOut) reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Incremental update kernel, second generation (round 2): same contract as spx_update_kernel_v1 above - child
+// Incremental update kernel, second generation (round 2; the round-1 kernel - two full attack generations, rebuilds inline - is retired to
+// experiments/r01_update_kernel_board_diff.hip.txt): child
 // accumulator = parent accumulator + added rows - removed rows, delta derived on the device from the two boards - but
 // the threat delta comes from RAY WALKS around the changed squares (deltaCandidates, spx_device_math.h: one lane per
 // (board, changed square, ray / knight slot), no loops) instead of two full attack generations and per-lane victim
@@ -681,83 +552,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The incremental pipeline's first pass (spx_ftx.h, FtuParams): one wavefront per record derives the delta lists of both
-// perspectives exactly as spx_update_kernel does and writes them - as offsets into the column-sliced row table - to HBM, with a
-// head and a sort key per perspective; spx_ftu_apply_kernel (spx_ftx.hip) reads them once per column slice.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void spx_ftu_derive_kernel(FtuParams p) {
-    __shared__ uint32_t sLut[kLutWords];
-    __shared__ uint64_t sTab[kDeltaTabWords];
-    __shared__ uint32_t sAdd[kWavesPerBlock][2][kDeltaCap];
-    __shared__ uint32_t sSub[kWavesPerBlock][2][kDeltaCap];
-    __shared__ uint32_t sWide[kWavesPerBlock][2][2][8];
-    __shared__ uint8_t sMail[kWavesPerBlock][2][64];
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.x.t.lut[i];
-    for (int i = threadIdx.x; i < kDeltaTabWords; i += blockDim.x) sTab[i] = p.x.t.deltaTab[i];
-    __syncthreads();
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
-    for (uint32_t it = blockIdx.x * kWavesPerBlock + wave; it < p.x.nPositions; it += gridDim.x * kWavesPerBlock) {
-        const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
-        const uint8_t* childRec = reinterpret_cast<const uint8_t*>(p.childPositions) + size_t(it) * 32;
-        const uint8_t* parentRec = p.slotRecords + size_t(parentSlot) * 32;
-        uint32_t nAdd[2] = {0, 0}, nSub[2] = {0, 0}, nWideSub[2] = {0, 0}, nWideAdd[2] = {0, 0};
-        bool refresh[2] = {false, false};
-        const int childStm = deriveDeltaLists(parentRec, childRec, lane, 0, 2, sLut, sTab, sMail[wave], sAdd[wave], sSub[wave],
-                                              sWide[wave], nAdd, nSub, nWideSub, nWideAdd, refresh);
-#pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
-            const uint32_t q = 2 * it + uint32_t(c);
-            if (c ? refresh[1] : refresh[0]) {
-                if (lane == 0) {
-                    p.refreshList[atomicAdd(p.refreshCount, 1u)] = 2 * (p.firstRecord + it) + uint32_t(c);
-                    p.x.keys[q] = kFtuSkipKey;
-                }
-                continue;
-            }
-            const uint32_t na = c ? nAdd[1] : nAdd[0], ns = c ? nSub[1] : nSub[0];
-            const uint32_t nws = c ? nWideSub[1] : nWideSub[0], nwa = c ? nWideAdd[1] : nWideAdd[0];
-            uint32_t* out = p.x.lists + size_t(q) * kFtuListStride;
-            // u8-table offsets are row * 1024 with the piece-square slots right behind the threat rows - as in the sliced table:
-            // row * 128 there; a wide piece-square row (offset row * 2048 into the i16 table) = its low-byte plane + its high-byte plane
-            for (uint32_t i = lane; i < ns; i += 64) out[kFtuSub + i] = sSub[wave][c][i] >> 3;
-            for (uint32_t i = lane; i < na; i += 64) out[kFtuAdd + i] = sAdd[wave][c][i] >> 3;
-            if (lane < nws) {
-                const uint32_t row = sWide[wave][c][0][lane] >> 11;
-                out[kFtuSub + ns + lane] = (kFtxPsqLoBase + row) * 128u;
-                out[kFtuHiSub + lane] = (kFtxPsqHiBase + row) * 128u;
-            }
-            if (lane < nwa) {
-                const uint32_t row = sWide[wave][c][1][lane] >> 11;
-                out[kFtuAdd + na + lane] = (kFtxPsqLoBase + row) * 128u;
-                out[kFtuHiAdd + lane] = (kFtxPsqHiBase + row) * 128u;
-            }
-            if (lane == 0) {
-                u32x2 head;
-                head[0] = nws | (nwa << 8) | ((ns + nws) << 16) | ((na + nwa) << 24);
-                head[1] = 2 * it + ((c == childStm) ? 0u : 1u);  // stm half first
-                *reinterpret_cast<u32x2*>(p.x.heads + 2 * size_t(q)) = head;
-                const uint32_t quartets = (nws + 3) / 4 + (nwa + 3) / 4 + (ns + nws + 3) / 4 + (na + nwa + 3) / 4;
-                p.x.keys[q] = min(max(quartets, 1u), kFtxQuartetBins) - 1;  // (one bucket: the order is by list length alone)
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // this record's lists are dead before the next record's are written
-        if (lane < 8) {
-            const uint32_t word = reinterpret_cast<const uint32_t*>(childRec)[lane];
-            if (p.childSlots) {
-                const uint32_t childSlot = __builtin_amdgcn_readfirstlane(p.childSlots[it]);
-                reinterpret_cast<uint32_t*>(p.slotRecords + size_t(childSlot) * 32)[lane] = word;
-            }
-            reinterpret_cast<uint32_t*>(p.stagedRecords + size_t(it) * 32)[lane] = word;
-        }
-    }
-}
-
-hipError_t launchFtuDerive(const FtuParams& p, hipStream_t stream) {
-    const uint32_t blocks = min((p.x.nPositions + kWavesPerBlock - 1) / kWavesPerBlock, 256u * 16u);
-    hipLaunchKernelGGL(spx_ftu_derive_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, p);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // A whole pending PATH per wavefront pair: NnueState::ensureUpToDate (nnue_state.cpp:636-697) walks forward from the last
@@ -1443,35 +1237,17 @@ hipError_t launchFtTeam(const FtParams& p, uint32_t gridBlocks, hipStream_t stre
 
 hipError_t launchFt(const FtParams& p, uint32_t gridBlocks, hipStream_t stream) {
     const dim3 grid(gridBlocks), block(64 * kWavesPerBlock);
-    if (!p.t.mfmaGather) {
-        if (p.t.outlierTab) {
-            hipLaunchKernelGGL((spx_ft_kernel<true, false>), grid, block, 0, stream, p);
-        } else {
-            hipLaunchKernelGGL((spx_ft_kernel<false, false>), grid, block, 0, stream, p);
-        }
-    } else if (p.t.outlierTab) {  // SPX_FT_MFMA_GATHER=1
-        hipLaunchKernelGGL((spx_ft_kernel<true, true>), grid, block, 0, stream, p);
+    if (p.t.outlierTab) {
+        hipLaunchKernelGGL((spx_ft_kernel<true>), grid, block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((spx_ft_kernel<false, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((spx_ft_kernel<false>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
 
 hipError_t launchUpdate(const UpdateParams& p, uint32_t gridBlocks, bool splitPerspectives, bool streamAccumulators,
-                        bool legacy, hipStream_t stream) {
+                        hipStream_t stream) {
     const dim3 grid(gridBlocks), block(64 * kWavesPerBlock);
-    if (legacy) {  // round-1 kernel, kept for A/B runs (SPX_UPDATE_V1=1)
-        if (splitPerspectives && streamAccumulators) {
-            hipLaunchKernelGGL((spx_update_kernel_v1<true, true>), grid, block, 0, stream, p);
-        } else if (splitPerspectives) {
-            hipLaunchKernelGGL((spx_update_kernel_v1<true, false>), grid, block, 0, stream, p);
-        } else if (streamAccumulators) {
-            hipLaunchKernelGGL((spx_update_kernel_v1<false, true>), grid, block, 0, stream, p);
-        } else {
-            hipLaunchKernelGGL((spx_update_kernel_v1<false, false>), grid, block, 0, stream, p);
-        }
-        return hipGetLastError();
-    }
     if (splitPerspectives && streamAccumulators) {
         hipLaunchKernelGGL((spx_update_kernel<true, true>), grid, block, 0, stream, p);
     } else if (splitPerspectives) {

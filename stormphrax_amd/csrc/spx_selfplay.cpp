@@ -876,11 +876,11 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     // graph; more plies per graph halve that but idle longer at the end of a run and want a deeper opening pool. Measured
     // (profiles/r03_ab_selfplay_plies_per_graph.txt; 2 / 4 / 8 / 16 plies): 4 096 seats x 65 536 games 2.42 / 2.46 / 2.46 / 2.41
     // x 10^8, 1 024 x 8 192 1.45 / 1.49 / 1.46 / 1.43, but 4 096 x 8 192 1.85 / 1.81 / 1.71 / 1.53 and 16 384 x 65 536 2.58 /
-    // 2.56 / 2.44 / 2.25: four for runs of at least eight games per seat, else two. SPX_SELFPLAY_GRAPH_PLIES overrides (even, 2..16).
+    // 2.56 / 2.44 / 2.25: four for runs of at least eight games per seat, else two. option selfplay_graph_plies overrides (even, 2..16).
     uint32_t kGraphPlies = p->target_games >= 8ull * G ? 4 : 2;
-    if (const char* env = std::getenv("SPX_SELFPLAY_GRAPH_PLIES")) {
-        const long v = std::atol(env);
-        if (v >= 2 && v <= long(kGraphPliesMax) && v % 2 == 0) kGraphPlies = uint32_t(v);
+    {
+        const int64_t v = ctxSelfplayOption(ctx, 1);
+        if (v >= 2 && v <= int64_t(kGraphPliesMax) && v % 2 == 0) kGraphPlies = uint32_t(v);
     }
     const uint32_t kStatusSlots = kGraphPlies * kGraphsInFlight;  // (>= kPliesInFlight)
     const uint32_t poolCap = (kStatusSlots + 3) * G + 32768;
@@ -1085,9 +1085,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     // a half ONCE per status-slot group (two plies, so that the context's alternating sort / refresh buffers are back in
     // phase at the end of a graph) and relaunches the instantiated graphs in turn, kGraphsInFlight of them ahead: one host
     // call per two plies. The lanes' cross-stream event gates cannot be part of a capture, so graph mode runs the lanes
-    // ungated. SPX_SELFPLAY_NO_GRAPH=1, or a HIP runtime that refuses the capture, means direct launches (one ply at a
+    // ungated. option selfplay_graph = 0, or a HIP runtime that refuses the capture, means direct launches (one ply at a
     // time, kPliesInFlight plies ahead).
-    bool useGraph = std::getenv("SPX_SELFPLAY_NO_GRAPH") == nullptr;
+    bool useGraph = ctxSelfplayOption(ctx, 0) != 0;
     auto enqueue = [&](DeviceHalf& hf) -> int {
         void* laneStream = nullptr;
         int lr = ctxLaneBegin(ctx, int(hf.index), &laneStream, /*gates=*/!useGraph);
@@ -1227,7 +1227,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     stats->steps = (steps + nHalves - 1) / nHalves;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
-    if (std::getenv("SPX_SELFPLAY_TRACE")) {
+    if (ctxSelfplayOption(ctx, 2)) {
         std::fprintf(stderr, "[spx_selfplay] %.3f s: waiting for the GPU %.3f, enqueue + openings %.3f; %llu openings discarded by "
                      "the verification filter, %u published; %s\n", stats->seconds, gpuWait, enqueueSeconds,
                      static_cast<unsigned long long>(latest.discarded), published,

@@ -97,17 +97,41 @@ class Network:
 class NnueState:
     """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
 
-    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=None):
+    CREATION_OPTIONS = ("scratch_cap", "compact_rows", "near_rows")  # shape what a context allocates: SPX_OPTIONS only
+
+    def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=None, options=None):
+        """options: {name: int} tuning knobs (spx_ctx_set_option, include/spx_nnue.h); the three that shape the context's
+        allocations travel through SPX_OPTIONS around its creation."""
+        import os
+
         lib = _lib.load()
         handle = ctypes.c_void_p()
         flags = (CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0) | (0 if sliced_ft is None else CTX_SLICED_FT if sliced_ft else CTX_ONE_KERNEL_FT)
-        check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
+        options = dict(options or {})
+        early = {k: options.pop(k) for k in self.CREATION_OPTIONS if k in options}
+        old = os.environ.get("SPX_OPTIONS")
+        if early:
+            os.environ["SPX_OPTIONS"] = ",".join(([old] if old else []) + [f"{k}={int(v)}" for k, v in early.items()])
+        try:
+            check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
+        finally:
+            if early:
+                if old is None:
+                    os.environ.pop("SPX_OPTIONS", None)
+                else:
+                    os.environ["SPX_OPTIONS"] = old
         self._h = handle
         self._net = network
-        # what one arena call (reset / update / evaluate) accepts: the scratch capacity (SPX_SCRATCH_CAP, 4 Mi positions by
+        for k, v in options.items():
+            self.set_option(k, v)
+        # what one arena call (reset / update / evaluate) accepts: the scratch capacity (option scratch_cap, 4 Mi positions by
         # default) when the context was created for a larger full-refresh batch - trace.replay chunks by this
         self.max_batch = min(max_batch, int(lib.spx_ctx_scratch_batch(handle)))
         self.call_limit = max_batch
+
+    def set_option(self, name, value):
+        """spx_ctx_set_option: one tuning knob of this context (never changes a result)."""
+        check(_lib.load().spx_ctx_set_option(self._h, name.encode(), int(value)))
 
     def evaluate_once(self, positions):
         """Batched NnueState::evaluateOnce: packed positions (PACKED_DTYPE array) -> int32 raw evals (stm view)."""

@@ -18,29 +18,17 @@ def preset_of(path):
         return f.readline().split()[2].rstrip(";")
 
 
-@pytest.fixture(scope="module", params=["default-kernels", "ray-walk-kernel", "column-sliced-pipeline"])
+@pytest.fixture(scope="module", params=["default-kernels", "ray-walk-kernel"])
 def states(sp, net_blob, request):
-    """Every test of this module runs three times: with the library's own choice of update kernel (batches this small take the
-    single-launch round-1 kernel), with the second-generation kernel forced (SPX_UPDATE_V1=0, read when the context is
-    created): ray-walk threat deltas + deferred rebuild pass, what batches above 8 192 records get - and with the opt-in incremental
-    pipeline on the column-sliced row table (SPX_FTU=1: spx_ftu_derive_kernel, counting sort + plan, spx_ftu_apply_kernel; fused
-    update + eval batches of 64 records and more here)."""
+    """Every test of this module runs twice: with the library's own choice of update kernel (batches of up to 1 024 records take the
+    single-launch chain kernel, rebuilds inline) and with spx_update_kernel forced onto every size (option update_chain_max = 0):
+    ray-walk threat deltas + deferred rebuild pass, what the big batches get."""
     cache = {}
-    env = {"default-kernels": {}, "ray-walk-kernel": {"SPX_UPDATE_V1": "0"},
-           "column-sliced-pipeline": {"SPX_UPDATE_V1": "0", "SPX_FTU": "1", "SPX_FTU_MIN": "64"}}[request.param]
+    options = {"default-kernels": {}, "ray-walk-kernel": {"update_chain_max": 0}}[request.param]
 
     def get(preset):
         if preset not in cache:
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
-            try:
-                cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
-            finally:
-                for k, v in old.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
+            cache[preset] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096, options=options)
         return cache[preset]
 
     yield get
@@ -417,7 +405,7 @@ def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob, monkeyp
     from the start position: 84 066 moves, 65 536 evaluates, lines down to ply 249 with the random-weight net) through
     spx_acc_replay_tree - every EVAL equals the reference's lazily updated NnueState::evaluate. A tree this deep and narrow
     is walked by heavy PATHS (one chain-kernel launch per round of paths) instead of level batches; both walks, forced through
-    SPX_REPLAY_PATHS, must give the reference's values - on this trace and on the shallow, wide depth-first one."""
+    option replay_paths, must give the reference's values - on this trace and on the shallow, wide depth-first one."""
     from stormphrax_amd.trace import Trace, replay_native
 
     st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=65536)
@@ -427,10 +415,7 @@ def test_native_tree_replay_of_the_alpha_beta_search_trace(sp, net_blob, monkeyp
             pos = trace.positions()
             times = {}
             for mode in ("default", "1", "0"):
-                if mode == "default":
-                    monkeypatch.delenv("SPX_REPLAY_PATHS", raising=False)
-                else:
-                    monkeypatch.setenv("SPX_REPLAY_PATHS", mode)
+                st.set_option("replay_paths", -1 if mode == "default" else int(mode))
                 got, want, ms = replay_native(st, trace, pos)
                 assert len(want) == 65536 and np.array_equal(got, want), (name, mode)
                 got2, _, ms2 = replay_native(st, trace, pos)
@@ -458,15 +443,13 @@ def test_selfplay_plays_the_same_games_for_the_same_seed(sp, net_blob, tmp_path)
 
 
 def test_selfplay_direct_launch_fallback(sp, net_blob, oracle, tmp_path, monkeypatch):
-    """SPX_SELFPLAY_NO_GRAPH=1 (what a HIP runtime that refuses the stream capture falls back to): the per-ply chain enqueued
+    """Option selfplay_graph = 0 (what a HIP runtime that refuses the stream capture falls back to): the per-ply chain enqueued
     launch by launch, lanes gated. Same rules, same verification; and the same SET of games as graph mode for the same seed."""
     from _datagen_rules import parse_games, verify_selfplay_file
 
     sets = {}
     for mode in ("graph", "direct"):
-        if mode == "direct":
-            monkeypatch.setenv("SPX_SELFPLAY_NO_GRAPH", "1")
-        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192) as st:
+        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=8192, options={"selfplay_graph": int(mode == "graph")}) as st:
             path = str(tmp_path / f"{mode}.vf")
             stats = st.selfplay(n_games=48, target_games=120, out_path=path, max_plies=90, dfrc=True, temperature_cp=20, seed=123)
             assert stats["games"] == 120
@@ -504,20 +487,9 @@ def test_native_replay_of_256_alpha_beta_search_trees_at_once(sp, net_blob):
     assert forest.n_trees == 256 and forest.n_nodes == 365000 and len(forest.eval_node) == 257400
     pos = forest.positions()
     assert len({bytes(pos[i]) for i in np.nonzero(forest.parent[1:] == 0)[0] + 1}) > 200  # the roots differ
-    for paths in ("0", "1", None):
-        old = os.environ.get("SPX_REPLAY_PATHS")
-        if paths is None:
-            os.environ.pop("SPX_REPLAY_PATHS", None)
-        else:
-            os.environ["SPX_REPLAY_PATHS"] = paths
-        try:
-            with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=1 << 17) as st:
-                got, want, ms = replay_forest(st, forest, pos)
-        finally:
-            if old is None:
-                os.environ.pop("SPX_REPLAY_PATHS", None)
-            else:
-                os.environ["SPX_REPLAY_PATHS"] = old
+    for paths in (0, 1, -1):
+        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=1 << 17, options={"replay_paths": paths}) as st:
+            got, want, ms = replay_forest(st, forest, pos)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (paths, bad.size, int(bad[0]))
-        print(f"SPX_REPLAY_PATHS={paths}: {ms:.3f} ms on the device, {(forest.n_nodes - 1 + len(want)) / (ms / 1e3):.3e} updates+evals/s")
+        print(f"replay_paths={paths}: {ms:.3f} ms on the device, {(forest.n_nodes - 1 + len(want)) / (ms / 1e3):.3e} updates+evals/s")

@@ -23,13 +23,67 @@ def states(sp, net_blob):
         s.close()
 
 
+PATHS = ["one_kernel", "sliced", "sliced_pipelined"]
+
+
+@pytest.fixture(scope="module")
+def path_states(sp, net_blob):
+    """One context per (preset, full-refresh path): `one_kernel` = spx_ft_kernel (SPX_CTX_ONE_KERNEL_FT), `sliced` = the
+    column-sliced pipeline of spx_ftx.hip - the default path of big batches - forced onto every batch of >= 1 024 positions,
+    `sliced_pipelined` = the same context driven through spx_eval_full_device_async (the reference's goldens
+    must travel the default path in what the driver re-runs)."""
+    cache = {}
+
+    def get(preset, path):
+        key = (preset, "one_kernel" if path == "one_kernel" else "sliced")
+        if key not in cache:
+            if path == "one_kernel":
+                cache[key] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=1 << 16, sliced_ft=False)
+            else:
+                cache[key] = _state_with_options(sp, net_blob(preset), {"ftx_min": 1024, "tiny_batch_max": 0}, max_batch=1 << 16)
+                assert cache[key].takes_sliced_pipeline(1024) and cache[key].takes_sliced_pipeline(1024, pipelined=True)
+        return cache[key]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+def _evaluate_through(sp, st, pos, path):
+    """evaluate_once over `path`; the pipelined entry point reads / writes page-locked host memory the device addresses."""
+    if path != "sliced_pipelined":
+        return st.evaluate_once(pos)
+    import ctypes
+
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    n = len(pos)
+    pin, pout = lib.spx_host_alloc(n * 32), lib.spx_host_alloc(n * 4)
+    assert pin and pout
+    try:
+        np.ctypeslib.as_array((ctypes.c_uint8 * (n * 32)).from_address(pin))[:] = pos.view(np.uint8).reshape(-1)
+        out = np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(pout))
+        out[:] = -1
+        # two calls in flight on the two lanes (the second one's preparation runs beside the first one's gather)
+        half = n // 2
+        assert st.evaluate_once_device_async(pin, half, pout)
+        assert st.evaluate_once_device_async(pin + 32 * half, n - half, pout + 4 * half)
+        st.synchronize()
+        return out.copy()
+    finally:
+        lib.spx_host_free(pin)
+        lib.spx_host_free(pout)
+
+
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("preset", ["tame", "wild", "extreme", "realistic"])
-def test_random_positions_bit_exact(sp, oracle, net_blob, states, preset):
+def test_random_positions_bit_exact(sp, oracle, net_blob, path_states, preset, path):
     pos = sp.random_positions(4096, seed=101, min_ply=0, max_ply=160, dfrc_every=3)
     mail, stm = sp.positions_to_mailboxes(pos)
     oracle.use(net_blob(preset), preset)
     want = oracle.eval_mailboxes(mail, stm)
-    got = states(preset).evaluate_once(pos)
+    got = _evaluate_through(sp, path_states(preset, path), pos, path)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, f"{bad.size} mismatches, first: {sp.position_to_fen(pos[bad[0]])} got {got[bad[0]]} want {want[bad[0]]}"
     assert len(set(want.tolist())) > (500 if preset == "realistic" else 1000)  # the batch is not degenerate (the heavy-tailed net spreads evals less)
@@ -72,16 +126,19 @@ def test_startpos_and_bare_kings(sp, oracle, net_blob, states):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("preset", ["tame", "wild", "extreme", "realistic"])
-def test_reference_golden_vectors(sp, net_blob, states, preset):
-    """GPU vs the COMPILED REFERENCE directly (tests/golden/evals.jsonl), without going through the oracle."""
+def test_reference_golden_vectors(sp, net_blob, path_states, preset, path):
+    """GPU vs the COMPILED REFERENCE directly (tests/golden/evals.jsonl), without going through the oracle - through the
+    one-kernel path, the column-sliced pipeline (spx_ftx_gather_kernel: the default path of big batches) and its pipelined
+    entry point."""
     import json
     import os
 
-    path = os.path.join(os.path.dirname(__file__), "golden", "evals.jsonl")
-    recs = [json.loads(line) for line in open(path)]
+    golden = os.path.join(os.path.dirname(__file__), "golden", "evals.jsonl")
+    recs = [json.loads(line) for line in open(golden)]
     pos = sp.positions_from_fens([r["fen"] for r in recs])
-    got = states(preset).evaluate_once(pos)
+    got = _evaluate_through(sp, path_states(preset, path), pos, path)
     want = np.array([r[preset] for r in recs], dtype=np.int32)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (recs[bad[0]]["fen"], int(got[bad[0]]), int(want[bad[0]]))
@@ -211,20 +268,10 @@ def test_near_compact_piece_square_rows(sp, oracle, net_blob, states):
 def test_team_kernel_matches_the_wave_kernel(sp, oracle, net_blob, preset):
     """Full refreshes of at most 512 perspectives run one WORKGROUP per perspective (spx_ft_team_kernel: four waves fetch a
     quarter of the rows each, partial accumulators summed through LDS), larger ones one wave per perspective. Both kernels,
-    forced onto the same batches through SPX_FT_TEAM_MAX (read when a context is created), must agree with the oracle and with
+    forced onto the same batches through option ft_team_max, must agree with the oracle and with
     each other: evaluations, u8 activations, and the accumulators they leave in the arena."""
-    import os
-
     def make(team_max):
-        old = os.environ.get("SPX_FT_TEAM_MAX")
-        os.environ["SPX_FT_TEAM_MAX"] = str(team_max)
-        try:
-            return sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096)
-        finally:
-            if old is None:
-                os.environ.pop("SPX_FT_TEAM_MAX", None)
-            else:
-                os.environ["SPX_FT_TEAM_MAX"] = old
+        return sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=4096, options={"ft_team_max": team_max})
 
     pos = sp.random_positions(3000, seed=404, min_ply=0, max_ply=160, dfrc_every=3)
     mail, stm = sp.positions_to_mailboxes(pos)
@@ -360,34 +407,23 @@ def test_pipelined_async_calls_equal_the_synchronous_path(sp, oracle, net_blob):
             lib.spx_host_free(q)
 
 
-def _state_with_env(sp, blob, env, **kw):
-    """A context created under extra environment switches (the library reads them in spx_ctx_create)."""
-    import os
-
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return sp.NnueState(sp.Network(blob), device=0, **kw)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _state_with_options(sp, blob, options, **kw):
+    """A context with tuning knobs set (spx_ctx_set_option; none changes a result)."""
+    return sp.NnueState(sp.Network(blob), device=0, options=options, **kw)
 
 
 @pytest.mark.parametrize("preset", ["tame", "extreme", "mixed", "near", "realistic"])
 def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net_blob, preset):
     """Big full refreshes take the column-sliced pipeline of spx_ftx.hip (extraction pass, counting sort by (king bucket, list
     length), plan, gather on the matrix pipe with the bucket's piece-square slab in LDS; the default from 16 384 positions up,
-    here from 8 192: SPX_FTX_MIN). Same sums mod 2^16, so the evaluations must equal those of spx_ft_kernel (a context created
+    here from 8 192: option ftx_min). Same sums mod 2^16, so the evaluations must equal those of spx_ft_kernel (a context created
     with sliced_ft=False: SPX_CTX_ONE_KERNEL_FT) and the oracle's bit for bit: batches at the pipeline's threshold,
     ragged ones, more than one pass (> 65 536 positions), nets with wide rows (low / high byte planes) and near-compact rows
     (taken as wide rows here), synchronous and pipelined calls."""
     blob = net_blob(preset)
     pos = sp.random_positions(70001, seed=909, min_ply=0, max_ply=160, dfrc_every=3)
     with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 17, sliced_ft=False) as plain, \
-            _state_with_env(sp, blob, {"SPX_FTX_MIN": "8200"}, max_batch=1 << 17) as sliced:
+            _state_with_options(sp, blob, {"ftx_min": 8200}, max_batch=1 << 17) as sliced:
         assert not plain.takes_sliced_pipeline(70001) and sliced.takes_sliced_pipeline(8200) and not sliced.takes_sliced_pipeline(8199)
         assert not plain.takes_sliced_pipeline(70001, pipelined=True) and sliced.takes_sliced_pipeline(8200, pipelined=True)
         want = plain.evaluate_once(pos)
@@ -441,7 +477,7 @@ def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net
 
 def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_blob):
     """The column-sliced pipeline allocates its table and scratch sets on first use; when one does not fit (a context sized to
-    fill the HBM: simulated with SPX_FTX_FAIL_AFTER) that call and all later ones take spx_ft_kernel - another GPU path, same
+    fill the HBM: simulated with option ftx_fail_after) that call and all later ones take spx_ft_kernel - another GPU path, same
     results - while a gather already issued on the other lane finishes on the scratch set it has."""
     import ctypes
 
@@ -460,7 +496,7 @@ def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_bl
         np.ctypeslib.as_array((ctypes.c_uint8 * (n * 32)).from_address(pin))[:] = pos.view(np.uint8).reshape(-1)
         outs = [np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(q)) for q in pouts]
         for fail_after in (0, 1):  # (0: the first scratch set already; 1: the second lane's)
-            with _state_with_env(sp, blob, {"SPX_FTX_FAIL_AFTER": str(fail_after)}, max_batch=65536) as st:
+            with _state_with_options(sp, blob, {"ftx_fail_after": fail_after}, max_batch=65536) as st:
                 assert st.takes_sliced_pipeline(n)
                 for o in outs:
                     o[:] = -1
@@ -476,29 +512,3 @@ def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_bl
             lib.spx_host_free(q)
 
 
-@pytest.mark.parametrize("preset", ["tame", "extreme", "near", "realistic"])
-def test_matrix_pipe_gather_of_the_one_kernel_path(sp, oracle, net_blob, preset):
-    """SPX_FT_MFMA_GATHER=1: spx_ft_kernel adds its rows up on the matrix pipe (one v_mfma_i32_16x16x64_i8 per four gathered
-    rows x 256 columns, plain-i8 row table, high-byte planes for wide piece-square rows) - evaluations, activations and the
-    accumulators it leaves in the arena equal the VALU gather's and the oracle's."""
-    blob = net_blob(preset)
-    pos = sp.random_positions(6000, seed=910, min_ply=0, max_ply=160, dfrc_every=3)
-    oracle.use(blob, preset)
-    mail, stm = sp.positions_to_mailboxes(pos)
-    want = oracle.eval_mailboxes(mail, stm)
-    with _state_with_env(sp, blob, {"SPX_FT_MFMA_GATHER": "1"}, max_batch=8192) as st, \
-            sp.NnueState(sp.Network(blob), device=0, max_batch=8192) as plain:
-        for n in (6000, 513, 1500):
-            assert np.array_equal(st.evaluate_once(pos[:n]), want[:n]), n
-        st.evaluate_once(pos)
-        plain.evaluate_once(pos)
-        assert np.array_equal(st.debug_ft(6000), plain.debug_ft(6000))
-        slots = np.arange(6000, dtype=np.uint32)
-        st.reserve_slots(12000)
-        st.reset(pos, slots)
-        assert np.array_equal(st.evaluate(slots), want)
-        nxt, moved = sp.random_successors(pos, seed=6)  # incremental updates on top of the accumulators it wrote
-        idx = np.nonzero(moved)[0]
-        got = st.update_evaluate(slots[idx], slots[idx] + 6000, nxt[idx])
-        m2, s2 = sp.positions_to_mailboxes(nxt[idx])
-        assert np.array_equal(got, oracle.eval_mailboxes(m2, s2))

@@ -22,7 +22,6 @@ python bench.py --no-pipeline --no-cpu-baseline > $OUT/bench_n1_strict_stream_or
 python bench.py --device-positions --no-cpu-baseline --no-wide > $OUT/bench_n1_device_positions.json 2> $OUT/bench_devpos.err
 python bench.py --mode incremental --no-cpu-baseline > $OUT/bench_incremental_n1.json 2> $OUT/bench_incremental_n1.err
 python bench.py --mode incremental --no-pipeline --no-cpu-baseline > $OUT/bench_incremental_n1_strict_stream_order.json 2>> $OUT/bench_incremental_n1.err
-SPX_UPDATE_V1=1 python bench.py --mode incremental --no-pipeline --no-cpu-baseline > $OUT/bench_incremental_n1_round1_kernel.json 2>> $OUT/bench_incremental_n1.err
 python bench.py --mode incremental --batch 262144 --steps 100 --no-cpu-baseline > $OUT/bench_incremental_n1_262144.json 2>> $OUT/bench_incremental_n1.err
 python bench.py --batch 4194304 --steps 20 --warmup 3 --no-cpu-baseline --no-wide > $OUT/bench_n1_batch4M.json 2> $OUT/bench_4m.err
 python tools/gpu_measure.py > $OUT/secondary.json 2> $OUT/secondary.err
@@ -62,11 +61,11 @@ rm -rf $OUT/sp_pmc_*
 SPX_BENCH_SHARE_GPU=1 SPX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-wide > $OUT/bench_n2_two_ranks_sharing_one_gpu.json 2> $OUT/bench_n2.err
 python tests/_config5_worker.py > $OUT/config5.log 2>&1 && cp $REPO/gpurun_out/config5_hbm_filling.json $OUT/bench_n1_config5_hbm_filling.json
 bash tools/gpu_kstats.sh sliced_$TAG --no-pipeline > $OUT/kstats_sliced_pipeline_stream_ordered.txt 2>&1
-SPX_FTX=0 bash tools/gpu_kstats.sh onekernel_$TAG --no-pipeline > $OUT/kstats_one_kernel_path_stream_ordered.txt 2>&1
+SPX_OPTIONS=ftx=0 bash tools/gpu_kstats.sh onekernel_$TAG --no-pipeline > $OUT/kstats_one_kernel_path_stream_ordered.txt 2>&1
 bash tools/gpu_pmc_ftx.sh $TAG > /dev/null 2>&1; cp $REPO/gpurun_out/pmc_ftx_$TAG.txt $OUT/pmc_sliced_pipeline.txt
 bash tools/gpu_timeline.sh > $OUT/timeline_pipelined_steps.txt 2>&1
 bash tools/gpu_ftx_crossover.sh > $OUT/sliced_pipeline_crossover.txt 2>&1
-SPX_FTX=0 python tools/gpu_ref_differential.py --positions 4000000 --pack-positions 100000 > $OUT/reference_differential_one_kernel_path.json 2>> $OUT/differential.err
+SPX_OPTIONS=ftx=0 python tools/gpu_ref_differential.py --positions 4000000 --pack-positions 100000 > $OUT/reference_differential_one_kernel_path.json 2>> $OUT/differential.err
 ( for mode in cpu gpu; do $REPO/oracle/_ref/sp_ref_gpu_tame bench 6 $mode | grep -v "^info\|^fen:\|^bestmove\|^$"; done
   $REPO/oracle/_ref/sp_ref_gpu_tame bench 4 both | grep -v "^info\|^fen:\|^bestmove\|^$"
   $REPO/oracle/_ref/sp_ref_gpu_tame game 3000 5 ) > $OUT/reference_engine_on_gpu_evaluator.txt 2>&1

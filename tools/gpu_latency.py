@@ -10,7 +10,7 @@ for n in (1, 64, 256, 512, 1024, 2048, 4096, 8192):
     t0 = time.perf_counter()
     for _ in range(500): st.evaluate_once(pos[:n])
     out[n] = round((time.perf_counter() - t0) / 500 * 1e6, 1)
-print(os.environ.get("SPX_TINY_BATCH_MAX", "default"), out)
+print(os.environ.get("SPX_OPTIONS", "default"), out)
 # push + evaluate of n nodes (spx_acc_update_eval, the search's own step) and evaluate of materialised slots
 st.reserve_slots(8192)
 slots = np.arange(2048, dtype=np.uint32)

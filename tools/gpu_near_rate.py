@@ -1,6 +1,6 @@
 """What near-compact piece-square rows buy (GPU box): the tame synthetic net with K weights per piece-square row pushed
 outside i8 (a stand-in for a trained net whose rows almost fit) evaluated (a) with the rows served as 1 KiB copies +
-remainders (default), (b) with SPX_NO_NEAR=1: every such row fetched as its 2 KiB i16 row. Same scores, checked against
+remainders (default), (b) with SPX_OPTIONS=near_rows=0: every such row fetched as its 2 KiB i16 row. Same scores, checked against
 each other and, on a sample, against the CPU oracle (test infrastructure).
 
     gpurun -- 'python tools/gpu_near_rate.py > gpurun_out/near_rate.json'
@@ -59,18 +59,18 @@ def main():
     mail, stm = sp.positions_to_mailboxes(pos[:2048])
     for per_row in (2, 8, 16, 32):
         blob = outlier_net(sp, per_row)
-        os.environ.pop("SPX_NO_NEAR", None)
+        os.environ.pop("SPX_OPTIONS", None)
         near, s_near, c1, q1 = rate(sp, torch, blob, d_pos, n)
-        os.environ["SPX_NO_NEAR"] = "1"
+        os.environ["SPX_OPTIONS"] = "near_rows=0"
         wide, s_wide, c2, q2 = rate(sp, torch, blob, d_pos, n)
-        os.environ.pop("SPX_NO_NEAR", None)
+        os.environ.pop("SPX_OPTIONS", None)
         assert oracle.spxo_init(blob.ctypes.data, blob.size) == 0
         want = np.empty(2048, dtype=np.int32)
         oracle.spxo_eval_mailboxes(mail.ctypes.data, stm.ctypes.data, 2048, want.ctypes.data)
         report["cases"].append({
             "net": f"tame + {per_row} weights outside i8 in every piece-square row",
             "near_path_evals_per_s": near, "near_rows": q1, "compact_rows": c1,
-            "wide_rows_evals_per_s": wide, "near_rows_with_SPX_NO_NEAR": q2,
+            "wide_rows_evals_per_s": wide, "near_rows_with_near_rows_0": q2,
             "speedup": near / wide, "identical_scores": bool(np.array_equal(s_near, s_wide)),
             "oracle_sample_ok": bool(np.array_equal(s_near[:2048], want)),
         })

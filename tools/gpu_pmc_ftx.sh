@@ -1,10 +1,10 @@
-# PMC passes of the column-sliced pipeline's kernels (SPX_FTX=1, stream-ordered calls): bash tools/gpu_pmc_ftx.sh <tag>
+# PMC passes of the column-sliced pipeline's kernels (stream-ordered calls): bash tools/gpu_pmc_ftx.sh <tag>
 TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_ftx_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export SPX_FTX=1
+export SPX_OPTIONS=ftx=1
 i=0
 for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY" \
@@ -16,7 +16,7 @@ for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" \
 done
 python3 - <<PY > $REPO/gpurun_out/pmc_ftx_$TAG.txt
 import glob, sqlite3
-print("# rocprofv3 --pmc <group> --kernel-trace (one counter group per pass) of: SPX_FTX=1 bench.py --steps 20 --warmup 5 --no-pipeline --no-settle --no-wide --no-secondary")
+print("# rocprofv3 --pmc <group> --kernel-trace (one counter group per pass) of: SPX_OPTIONS=ftx=1 bench.py --steps 20 --warmup 5 --no-pipeline --no-settle --no-wide --no-secondary")
 print("# mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x 2 on gfx950); 65 536 positions per step, tame net")
 for f in sorted(glob.glob("$OUT/g*/*.db")):
     c = sqlite3.connect(f).cursor()

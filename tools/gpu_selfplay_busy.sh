@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/sp_busy
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SPX_SELFPLAY_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/trace -o t -- python $REPO/tools/spx_selfplay.py --games ${1:-4096} --target ${2:-8192} > $OUT/run.log 2>&1
+SPX_OPTIONS=selfplay_trace=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/trace -o t -- python $REPO/tools/spx_selfplay.py --games ${1:-4096} --target ${2:-8192} > $OUT/run.log 2>&1
 grep "spx_selfplay\]" $OUT/run.log
 python3 - <<PY
 import glob, sqlite3
