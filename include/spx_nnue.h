@@ -100,6 +100,14 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
  * threshold, no failed allocation of its tables so far)? Bit 0: a stream-ordered call (spx_eval_full[_device]) does; bit 1: a
  * pipelined call (spx_eval_full_device_async) does - its threshold is lower. 0 = the one-kernel path either way. */
 int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n);
+/* The pipeline's gather keeps the context's most popular threat / pawn-pair rows (option ftx_hot_rows, default 256 of 64 368) in
+ * LDS beside the king bucket's piece-square slab: an LDS read costs half a trip through the CU's texture path, and on random legal
+ * positions 256 rows serve 35 % of those fetches. The set is chosen from DATA: by default from the first batch that takes the
+ * pipeline (one extra extraction pass + a histogram + a stream synchronisation inside that call), or from the device-resident batch
+ * handed to spx_ctx_calibrate (the first <= 65 536 positions of it; call it while no evaluation of this context is in flight - it
+ * waits for the context's streams). Results never depend on the set (a row is added from wherever it lives); a self-play or data
+ * rescoring host calibrates once on a sample of ITS positions. No reference counterpart: the reference has no cache to configure. */
+int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
 /* Tuning knobs of a context - the analogue of the reference's tunable constants (src/tunable.h:161-169) and UCI options for this
  * path; none changes a result. spx_ctx_set_option changes one knob of one context between calls (not while a call of that context is
  * in flight); SPX_OPTIONS="name=value,name=value" in the environment - the only environment variable the library reads besides

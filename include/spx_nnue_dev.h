@@ -89,6 +89,13 @@ int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, i
 int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
                             const spx_packed_pos* pos, int* insufficient);
 
+/* The hot set of the column-sliced gather, given instead of measured / read back (in slot order; *n = 0 before the first
+ * calibration). spx_ctx_set_hot_rows takes up to 384 distinct row ids < 64 368 (n = 0: an empty set - every row through the
+ * texture path) and waits for the context's streams; tests run the measured set, an empty one and an adversarial random one and
+ * expect the same evaluations. */
+int spx_ctx_set_hot_rows(spx_ctx* ctx, const uint32_t* rows, size_t n);
+int spx_ctx_get_hot_rows(const spx_ctx* ctx, uint32_t* rows, size_t capacity, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif

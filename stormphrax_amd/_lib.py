@@ -132,6 +132,9 @@ SYMBOLS = {
     "spx_count_rows": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_ctx_count_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int64]),
+    "spx_ctx_calibrate": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
+    "spx_ctx_set_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
+    "spx_ctx_get_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     "spx_debug_gather_probe": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]),
     "spx_debug_gather_probe_variants": (ctypes.c_int, []),

@@ -73,6 +73,17 @@ struct spx_ctx {
     uint8_t* dThrW = nullptr;
     uint8_t* dRowS = nullptr;   // the column-sliced row table of spx_ftx.hip (built on first use)
     FtxScratch ftx;             // its scratch (the lanes hold their own)
+    // the gather's hot set: the threat / pawn-pair rows it keeps in LDS beside the piece-square slab (spx_ftx.h). Chosen from DATA - a
+    // histogram over the first batch that takes the pipeline (calibrateHotRows) or over the batch handed to spx_ctx_calibrate -;
+    // results never depend on it. Per context: the ranks of a multi-GPU job calibrate independently.
+    uint16_t* dHotSlot = nullptr;    // [kThreatRows] row -> LDS slot, 0xFFFF = cold
+    uint8_t* dHotS = nullptr;        // [8][hotRows][128 B]
+    uint32_t* dHotIds = nullptr;     // [kFtxHotRowsMax]
+    uint32_t* dHotCounts = nullptr;  // [kThreatRows + 16] the calibration's histogram (+ statistics)
+    std::vector<uint32_t> hotIds;    // host copy of the set, in slot order
+    uint32_t hotRowsWanted = kFtxHotRowsDefault;  // option ftx_hot_rows
+    uint32_t hotRows = 0, coldShift = 1;
+    bool hotCalibrated = false;      // the set was chosen (or given: spx_ctx_set_hot_rows); false: the next big batch chooses it
     bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); option ftx = 0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // option ftx_min: smallest batch that takes the sliced pipeline
     int ftxFailAfter = -1, ftxScratchSets = 0;  // (option ftx_fail_after: simulated allocation failure)
@@ -503,6 +514,15 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         ctx->ftxMinForced = true;
         return SPX_OK;
     }
+    if (key == "ftx_hot_rows") {  // rows of the gather's hot set; takes effect with the next calibration (the next big batch)
+        if (value < 0 || value > int64_t(kFtxHotRowsMax)) {
+            setError("option ftx_hot_rows must be in [0, " + std::to_string(kFtxHotRowsMax) + "]");
+            return SPX_ERR_INVALID_ARG;
+        }
+        ctx->hotRowsWanted = uint32_t(value);
+        ctx->hotCalibrated = false;
+        return SPX_OK;
+    }
     if (key == "ftx_fail_after") {  // test hook: the k-th scratch set of the pipeline "does not fit" (-1: never)
         ctx->ftxFailAfter = int(value);
         return SPX_OK;
@@ -734,7 +754,10 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         if (p) (void)hipFree(p);
     }
     ctx->ftx.release();
-    if (ctx->dRowS) (void)hipFree(ctx->dRowS);
+    for (void* q : {static_cast<void*>(ctx->dRowS), static_cast<void*>(ctx->dHotSlot), static_cast<void*>(ctx->dHotS),
+                    static_cast<void*>(ctx->dHotIds), static_cast<void*>(ctx->dHotCounts)}) {
+        if (q) (void)hipFree(q);
+    }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
     if (ctx->hTinyIo) (void)hipHostFree(ctx->hTinyIo);
     if (ctx->fallbackDone) (void)hipEventDestroy(ctx->fallbackDone);
@@ -829,6 +852,67 @@ static int runTinyMlp(spx_ctx* ctx, const void* d_records, size_t n, void* d_out
     return SPX_OK;
 }
 
+// ---- the gather's hot set ----
+// the tables of a chosen set: row -> slot map, the rows' slices in slot order. The caller guarantees that no gather of this context is
+// in flight (lists hold LDS offsets of the set they were extracted under).
+static int installHotRows(spx_ctx* ctx, const std::vector<uint32_t>& ids, hipStream_t s) {
+    const uint32_t n = uint32_t(std::min<size_t>(ids.size(), kFtxHotRowsMax));
+    // no gather of this context may be in flight: lists hold LDS offsets of the set they were extracted under
+    SPX_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& lane : ctx->lanes) {
+        if (lane.stream) SPX_HIP(hipStreamSynchronize(lane.stream));
+    }
+    SPX_HIP(hipMemsetAsync(ctx->dHotSlot, 0xFF, kThreatRows * sizeof(uint16_t), s));
+    if (n) SPX_HIP(hipMemcpyAsync(ctx->dHotIds, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    SPX_HIP(launchFtxBuildHot(ctx->dRowS, ctx->dHotIds, n, ctx->dHotSlot, ctx->dHotS, s));
+    SPX_HIP(hipStreamSynchronize(s));  // (the host buffer may go; other streams may use the tables next)
+    ctx->hotRows = n;
+    return SPX_OK;
+}
+
+// Chooses the set from the batch `xp` describes: its lists extracted with an EMPTY set, a histogram of their threat / pawn-pair
+// rows, the most popular hotRowsWanted of them (ties: the lower row id - the choice is deterministic for a batch).
+static int calibrateHotRows(spx_ctx* ctx, FtxParams xp, hipStream_t s) {
+    ctx->hotCalibrated = true;
+    ctx->hotRows = 0;
+    ctx->coldShift = 1;
+    ctx->hotIds.clear();
+    const uint32_t wanted = std::min(ctx->hotRowsWanted, kFtxHotRowsMax);
+    if (!wanted || xp.nPositions == 0) return SPX_OK;
+    xp.hotSlot = ctx->dHotSlot;
+    xp.hotS = ctx->dHotS;
+    xp.hotRows = 0;
+    xp.coldShift = 1;
+    SPX_HIP(hipMemsetAsync(ctx->dHotCounts, 0, (kThreatRows + 16) * sizeof(uint32_t), s));
+    SPX_HIP(launchFtxExtract(xp, s));
+    SPX_HIP(launchFtxHistogram(xp, ctx->dHotCounts, ctx->dHotCounts + kThreatRows, s));
+    std::vector<uint32_t> counts(kThreatRows + 16);
+    SPX_HIP(hipMemcpyAsync(counts.data(), ctx->dHotCounts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    std::vector<uint32_t> order;
+    order.reserve(8192);
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < kThreatRows; ++r) {
+        total += counts[r];
+        if (counts[r]) order.push_back(r);
+    }
+    const size_t take = std::min<size_t>(wanted, order.size());
+    std::partial_sort(order.begin(), order.begin() + take, order.end(),
+                      [&](uint32_t a, uint32_t b) { return counts[a] != counts[b] ? counts[a] > counts[b] : a < b; });
+    order.resize(take);
+    uint64_t covered = 0;
+    for (uint32_t r : order) covered += counts[r];
+    ctx->hotIds = order;
+    const int rc = installHotRows(ctx, ctx->hotIds, s);
+    if (rc != SPX_OK) return rc;
+    // sort key: global quartets (high planes + cold rows) in 16 classes; with more than ~9 of them per perspective on average the
+    // classes are two quartets wide
+    const double perPersp = 2.0 * xp.nPositions;
+    const double globalQ = double(total - covered) / perPersp / 4.0 + double(counts[kThreatRows]) / perPersp / 4.0 + 1.0;
+    ctx->coldShift = globalQ > 9.0 ? 1u : 0u;
+    return SPX_OK;
+}
+
 // the column-sliced pipeline's table (per context) and scratch (per lane; `ctx->ftx` is the set swapped in): allocated on
 // first use; a context sized to fill the HBM that has no room for them keeps the one-kernel path (false)
 static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStream_t s) {
@@ -840,10 +924,22 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
         return false;
     };
     if (!ctx->dRowS) {
+        // the gather needs a full-size MI355X: 256 workgroups = (XCD b % 8 = column slice, CU slot b / 8), one per CU, each with
+        // ~140 KiB of LDS. On a partitioned / CU-masked device they would still add up the right sums but lose the slicing of the
+        // L2s (and may not be co-resident): such devices keep the one-kernel path
+        if (ctx->computeUnits != 256 || prepareFtxGather(ctx->device) != hipSuccess) return fail();
         if (hipMalloc(reinterpret_cast<void**>(&ctx->dRowS), kFtxTableBytes) != hipSuccess) return fail();
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->dHotSlot), kThreatRows * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->dHotS), size_t(8) * kFtxHotRowsMax * 128) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->dHotIds), kFtxHotRowsMax * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->dHotCounts), (kThreatRows + 16) * sizeof(uint32_t)) != hipSuccess) {
+            return fail();
+        }
+        if (hipMemsetAsync(ctx->dHotSlot, 0xFF, kThreatRows * sizeof(uint16_t), s) != hipSuccess) return fail();
         if (launchFtxBuildTable(ctx->dThrW, ctx->dPsqW, ctx->dLut, ctx->dRowS, s) != hipSuccess) return fail();
-        // (other streams may use the table next: the lanes' streams do not wait for this one)
+        // (other streams may use the tables next: the lanes' streams do not wait for this one)
         if (hipStreamSynchronize(s) != hipSuccess) return fail();
+        if (!ctx->hotIds.empty() && installHotRows(ctx, ctx->hotIds, s) != SPX_OK) return fail();  // (a set given before the first batch)
     }
     if (x.capacity >= passPositions) return true;
     x.release();
@@ -919,6 +1015,13 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
+            if (!ctx->hotCalibrated) {  // the first big batch of this context chooses the hot set (synchronises the stream once)
+                if ((rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;
+            }
+            xp.hotSlot = ctx->dHotSlot;
+            xp.hotS = ctx->dHotS;
+            xp.hotRows = ctx->hotRows;
+            xp.coldShift = ctx->coldShift;
             // a pipelined call: the preparation is not gated - it runs beside the other lane's gather and MLP -, the gather is
             // (the two lanes' gathers are chained). Gating the preparation too: 1.58 instead of 1.81e8 evals/s; no gate at all: 1.83e8,
             // but then the gather's event interval includes its wait for free CUs
@@ -1819,6 +1922,55 @@ int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n) {
     if (!ctx || !ctx->ftxEnabled || ctx->ftxUnavailable || n <= ctx->tinyBatchMax) return 0;
     const size_t pipelinedFrom = ctx->ftxMinForced ? ctx->ftxMin : std::min(ctx->ftxMin, kFtxMinPositionsPipelined);
     return (n >= ctx->ftxMin ? 1 : 0) | (n >= pipelinedFrom ? 2 : 0);
+}
+
+int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n) {
+    if (!ctx || (n && !d_positions)) {
+        setError("spx_ctx_calibrate: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    const size_t m = std::min({n, ctx->maxBatch, kFtxMaxPositions});
+    if (!m || !ensureFtx(ctx, ctx->ftx, m, ctx->stream)) return SPX_OK;  // (no pipeline on this context: nothing to choose)
+    FtxParams xp{};
+    xp.positions = d_positions;
+    xp.nPositions = uint32_t(m);
+    xp.t = tablesOf(ctx);
+    xp.rowS = ctx->dRowS;
+    xp.lists = ctx->ftx.lists;
+    xp.heads = ctx->ftx.heads;
+    xp.keys = ctx->ftx.keys;
+    return calibrateHotRows(ctx, xp, ctx->stream);
+}
+
+int spx_ctx_set_hot_rows(spx_ctx* ctx, const uint32_t* rows, size_t n) {
+    if (!ctx || (n && !rows) || n > kFtxHotRowsMax) {
+        setError("spx_ctx_set_hot_rows: null argument or more than " + std::to_string(kFtxHotRowsMax) + " rows");
+        return SPX_ERR_INVALID_ARG;
+    }
+    std::vector<uint32_t> ids(rows, rows + n);
+    std::vector<uint32_t> sorted(ids);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end() || (n && sorted.back() >= kThreatRows)) {
+        setError("spx_ctx_set_hot_rows: rows must be distinct threat / pawn-pair row ids below " + std::to_string(kThreatRows));
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    ctx->hotIds = ids;
+    ctx->hotCalibrated = true;
+    ctx->coldShift = n >= 128 ? 0u : 1u;
+    if (!ctx->dRowS) return SPX_OK;  // (installed when the pipeline's tables are built)
+    return installHotRows(ctx, ctx->hotIds, ctx->stream);
+}
+
+int spx_ctx_get_hot_rows(const spx_ctx* ctx, uint32_t* rows, size_t capacity, size_t* n) {
+    if (!ctx || !n || (capacity && !rows)) {
+        setError("spx_ctx_get_hot_rows: null argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    *n = ctx->hotCalibrated ? ctx->hotIds.size() : 0;
+    for (size_t i = 0; i < std::min(capacity, *n); ++i) rows[i] = ctx->hotIds[i];
+    return SPX_OK;
 }
 
 size_t spx_ctx_scratch_batch(const spx_ctx* ctx) {

@@ -28,15 +28,33 @@ constexpr uint32_t kFtxRows = kFtxZeroRow + 1;
 constexpr uint32_t kFtxSliceStride = kFtxRows * 128u;
 constexpr size_t kFtxTableBytes = size_t(8) * kFtxSliceStride;
 constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket: 88 KiB per slice, LDS resident in the gather
+// ---- the gather's LDS: [slab: 704 rows + an all-zero row][hot rows: the context's most popular threat / pawn-pair rows][ring] ----
+// Round 5: a wave load holds the CU's texture path ~17 cycles whatever its width or exec mask
+// (tools/probes/tcp_mask_probe.hip), an LDS read of the same 1 KiB 8.8 - so every row that is LDS resident leaves the binding unit.
+// The hot set comes from DATA (a histogram over the first big batch, or spx_ctx_calibrate): on the bench distribution the 256 most
+// popular of the 64 368 rows serve 35 % of the threat / pawn-pair fetches, 320 serve 40 % (tools/sim_gather_steps.py). Results do not
+// depend on the set: a row is added from wherever it lives.
+constexpr uint32_t kFtxSlabBytes = (kFtxSlabRows + 1) * 128;
+constexpr uint32_t kFtxHotRowsMax = 384;       // capacity of the tables; what a context uses: option ftx_hot_rows
+constexpr uint32_t kFtxHotRowsDefault = 256;   // slab 88.1 + hot 32 + ring 16 = 136.1 KiB: one 14 / 16 KiB co-runner workgroup fits beside it
+constexpr uint32_t kFtxRingBytesPerWave = 1024;  // one stage of 8 steps x 8 perspectives x 4 entries
 
 // ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
-// [0, 32) piece-square rows as slab offsets ((row - 704 bucket) * 128); [32, 64) high-byte planes of the wide ones and
-// [64, 320) threat / pawn-pair rows as slice offsets (row index * 128). Words behind a section's count are undefined.
-// heads[perspective] = {nHi | nPsq << 8 | nThr << 16, 2 * position + (0 = side-to-move half, 1 = other half)}
-constexpr uint32_t kFtxListStride = 320, kFtxListPsq = 0, kFtxListHi = 32, kFtxListThr = 64;
-// sort key of a perspective: king bucket * 80 + (row quartets - 1): groups of 8 neighbours in this order share a bucket
-// (one LDS slab) and have almost equal list lengths (one wave walks the 8 lists in lockstep)
-constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins;
+// [0, 32) piece-square rows as LDS offsets ((row - 704 bucket) * 128, into the slab); [32, 64) high-byte planes of the wide ones as
+// slice offsets (row index * 128); [64, 320) the COLD threat / pawn-pair rows as slice offsets; [320, 576) the HOT ones as LDS offsets
+// (kFtxSlabBytes + slot * 128). Words behind a section's count are undefined.
+// heads[perspective] = {nHi | nPsq << 6 | nHot << 12 | nCold << 21, 2 * position + (0 = side-to-move half, 1 = other half)}
+constexpr uint32_t kFtxListStride = 576, kFtxListPsq = 0, kFtxListHi = 32, kFtxListThr = 64, kFtxListHot = 320;
+// sort key of a perspective: king bucket * 80 + min(global quartets >> coldShift, 15) * 5 + min(LDS quartets >> 2, 4) - the quartets
+// fetched through the texture path (high planes + cold rows) first: they cost twice an LDS step, and a group of 8 neighbours
+// walks as many of them as its longest list has. With the round-4 key (total quartets) the hot / cold split of the lists pads
+// away half of what the hot rows save: 65.5 instead of 52.0 wave loads per position at 320 hot rows (tools/sim_gather_steps.py).
+constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins, kFtxLdsClasses = 5;
+// cost of a group whose last member lies in bin `kk` of its bucket, in LDS steps (a global step counts 2)
+__host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) {
+    const uint32_t cq = kk / kFtxLdsClasses, lc = kk % kFtxLdsClasses;
+    return 2u * (cq << coldShift) + coldShift + 4u * lc + 2u;
+}
 
 // ---- sorted[position in the sorted order] = {head word 0, output slot (~0 = hole), list offset in bytes, -} ----
 // the gather's wave reads the 8 entries of its group and then the 8 lists themselves, a stage of 8 steps at a time
@@ -44,11 +62,11 @@ constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins;
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
 #ifndef SPX_FTX_GROUP_COST
-#define SPX_FTX_GROUP_COST 1  // (A/B over 0, 1, 3, 6, 10: 1 is best by 1 %; many of a group's steps are cheap LDS steps)
+#define SPX_FTX_GROUP_COST 2  // in LDS steps (round 4, in its unit - a step: A/B over 0, 1, 3, 6, 10, 1 best by 1 %)
 #endif
 constexpr uint32_t kFtxGroupCost = SPX_FTX_GROUP_COST;  // plan: a group costs its steps + this
 #ifndef SPX_FTX_SEGMENT_COST
-#define SPX_FTX_SEGMENT_COST 256  // (A/B over 0 .. 1 500: flat optimum between 200 and 440, +2 % stream-ordered, +3.5 % pipelined over 0)
+#define SPX_FTX_SEGMENT_COST 512  // in LDS steps (round 4, in steps: A/B over 0 .. 1 500, flat optimum between 200 and 440, +2 % stream-ordered, +3.5 % pipelined over 0)
 #endif
 constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // plan: a slab reload inside a CU slot's range, in steps (a group costs its steps + 3)
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
@@ -72,11 +90,21 @@ struct FtxParams {
     uint32_t* sorted;        // [2 n + 128][4]
     uint32_t* plan;          // [kFtxPlanWords]
     uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
+    const uint16_t* hotSlot; // [kThreatRows] LDS slot of a hot threat / pawn-pair row, 0xFFFF = cold
+    const uint8_t* hotS;     // [8 slices][hotRows][128 B] the hot rows' slices, in slot order
+    uint32_t hotRows;        // rows of the hot set (0: none - every row is fetched through the texture path)
+    uint32_t coldShift;      // sort key: global quartets >> this (1 for nets / sets with long cold sections)
 };
 
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
+// the hot set: counts[row] += fetches of threat / pawn-pair row `row` in the lists of p (extracted with hotRows = 0), stats[0] +=
+// high-byte planes fetched; then the tables of a chosen set (hotSlot must be all 0xFFFF on entry)
+hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream);
+hipError_t launchFtxHistogram(const FtxParams& p, uint32_t* counts, uint32_t* stats, hipStream_t stream);
+hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS, hipStream_t stream);
+hipError_t prepareFtxGather(int device);  // allows the gather its dynamic LDS on this device (once; > 64 KiB needs the attribute)
 // everything before the gather (extract, rank, plan, scatter): may overlap another batch's gather
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);
 hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream);

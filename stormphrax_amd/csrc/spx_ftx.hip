@@ -39,12 +39,6 @@ namespace spx {
 
 namespace {
 
-#ifndef SPX_FTX_STATIC_LDS
-#define SPX_FTX_STATIC_LDS 0
-#endif
-#ifndef SPX_FTX_QUEUES
-#define SPX_FTX_QUEUES 0  // 1: the gather's groups are claimed from queues and finished workgroups help (below); measured, not the default
-#endif
 #ifndef SPX_FTX_GATHER_WAVES
 #define SPX_FTX_GATHER_WAVES 16
 #endif
@@ -52,8 +46,8 @@ namespace {
 #define SPX_FTX_GATHER_WAVES_PER_SIMD 5  // register budget: 512 / this = 96 (a workgroup brings 4 waves per SIMD: the rest is room for two of the extraction's)
 #endif
 constexpr uint32_t kGatherWaves = SPX_FTX_GATHER_WAVES;
-constexpr uint32_t kGatherSlabBytes = (kFtxSlabRows + 1) * 128;
-constexpr uint32_t kGatherLdsBytes = kGatherSlabBytes + kGatherWaves * 2 * 256 * 4;  // (+ 16 bytes behind it: the helping phase's choice)
+// LDS of the gather: slab + hot rows + one ring stage per wave
+constexpr uint32_t gatherLdsBytes(uint32_t hotRows) { return kFtxSlabBytes + hotRows * 128u + kGatherWaves * kFtxRingBytesPerWave; }
 
 // column of byte m of chunk t of slice x (see spx_ftx.h)
 __device__ __forceinline__ uint32_t sliceColumn(uint32_t x, uint32_t t, uint32_t m) {
@@ -170,16 +164,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             const uint64_t wideMask = __ballot(wide);
             const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
             if (occupied && slot < kPsqCap) {
-                out[kFtxListPsq + slot] = (row - bucket * kFtxSlabRows) * 128u;
+                out[kFtxListPsq + slot] = (row - bucket * kFtxSlabRows) * 128u;  // (an LDS offset: the slab heads the gather's LDS)
                 if (wide && wideSlot < kPsqCap) out[kFtxListHi + wideSlot] = (kFtxPsqHiBase + row) * 128u;
             }
             const uint32_t nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
             const uint32_t nHi = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-            uint32_t nThr = 0;
+            // threat / pawn-pair rows: a row of the context's hot set (LDS resident in the gather) goes to the hot section as an LDS
+            // offset, any other to the cold section as a slice offset; 256 rows in all, in the order of enumeration, like the
+            // reference's StaticVector<u16, 256> (nnue_state.cpp:315)
+            uint32_t nThr = 0, nHot = 0, nCold = 0;
             auto emit = [&](int32_t r) {
                 const uint64_t valid = __ballot(r >= 0);
-                const uint32_t at = nThr + prefixCount(valid);
-                if (r >= 0 && at < kThreatCap) out[kFtxListThr + at] = uint32_t(r) * 128u;
+                const bool taken = r >= 0 && nThr + prefixCount(valid) < kThreatCap;
+                uint32_t slot = 0xFFFFu;
+                if (taken && p.hotRows) slot = p.hotSlot[r];
+                const bool hot = taken && slot != 0xFFFFu, cold = taken && !hot;
+                const uint64_t hotMask = __ballot(hot), coldMask = __ballot(cold);
+                if (hot) out[kFtxListHot + nHot + prefixCount(hotMask)] = kFtxSlabBytes + slot * 128u;
+                if (cold) out[kFtxListThr + nCold + prefixCount(coldMask)] = uint32_t(r) * 128u;
+                nHot += uint32_t(popc64(hotMask));
+                nCold += uint32_t(popc64(coldMask));
                 nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
             };
             // threat rows (addThreatFeatures, nnue_state.cpp:309-328): the reference drops the pairs whose index is negative
@@ -209,11 +213,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             }
             if (lane == 0) {
                 u32x2 head;
-                head[0] = nHi | (nPsq << 8) | (nThr << 16);
+                head[0] = nHi | (nPsq << 6) | (nHot << 12) | (nCold << 21);
                 head[1] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
                 *reinterpret_cast<u32x2*>(p.heads + 2 * size_t(q)) = head;
-                const uint32_t quartets = (nHi + 3) / 4 + (nPsq + 3) / 4 + (nThr + 3) / 4;
-                p.keys[q] = bucket * kFtxQuartetBins + min(max(quartets, 1u), kFtxQuartetBins) - 1;
+                const uint32_t globalQ = (nHi + 3) / 4 + (nCold + 3) / 4, ldsQ = (nPsq + 3) / 4 + (nHot + 3) / 4;
+                p.keys[q] = bucket * kFtxQuartetBins + min(globalQ >> p.coldShift, kFtxQuartetBins / kFtxLdsClasses - 1) * kFtxLdsClasses +
+                            min(ldsQ >> 2, kFtxLdsClasses - 1);
             }
         }
         __builtin_amdgcn_wave_barrier();  // (the next position's items overwrite these)
@@ -291,8 +296,9 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
     for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) p.binStart[k] = sBin[k];
     if (tid < 17) p.binStart[kFtxBins + tid] = sBucketStart[tid];
 
-    // Cost of a group = the quartets of its longest list (its last valid perspective: bins ascend inside a bucket) + a constant
-    // for the group's fixed work - piecewise constant over the BINS, so everything below runs over 1 280 bins, not 16 K groups.
+    // Cost of a group = the steps of its last valid perspective's bin (ftxBinCost: global steps count double; bins ascend inside a
+    // bucket, global quartets first - the section every member pads to the group's longest) + a constant for the group's fixed work -
+    // piecewise constant over the BINS, so everything below runs over 1 280 bins, not 16 K groups.
     // Inside bucket b (relative positions, groups of 8 from its start) the groups whose last member lies in [s, e) are
     // G' = s / 8 .. e / 8 - 1, plus the bucket's final partial group, whose last member is the bucket's last perspective.
     const uint32_t nGroups = sBucketStart[16] / 8;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         // bucket's first group carries it; a cut that falls into it goes to the bucket's start (below)
         const bool bucketHead = ng > 0 && s0 / 8 == 0 && base > 0;
         sHead[k] = bucketHead;
-        sCost[k] = ng * (kk + 1 + kFtxGroupCost) + (bucketHead ? kFtxSegmentCost : 0u);
+        sCost[k] = ng * (ftxBinCost(kk, p.coldShift) + kFtxGroupCost) + (bucketHead ? kFtxSegmentCost : 0u);
     }
     __syncthreads();
     uint32_t g2[2] = {0, 0}, w2[2] = {0, 0};
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
                 const uint32_t mid = (lo + hi + 1) / 2;
                 if (uint64_t(sCost[mid]) * 32 < target32) lo = mid; else hi = mid - 1;
             }
-            const uint32_t w = lo % kFtxQuartetBins + 1 + kFtxGroupCost;
+            const uint32_t w = ftxBinCost(lo % kFtxQuartetBins, p.coldShift) + kFtxGroupCost;
             const uint64_t need = target32 - uint64_t(sCost[lo]) * 32;  // > 0
             const uint64_t extra = sHead[lo] ? 32ull * kFtxSegmentCost : 0ull;
             // groups of this bin up to and including the one that reaches it; inside a bucket head's surcharge: none - the bucket
@@ -403,30 +409,30 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 // Gather.
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket:
-// its slab slice goes to LDS once), its 16 waves striding over the segment's groups. A wave reads its group's 8 lists
-// itself, a STAGE of 8 steps at a time: lane (g = lane & 7, ks = lane >> 3) fetches the four rows of step ks of perspective
-// g (16 bytes of its list; rows past the list's end become the all-zero row) and puts them where the burst's lanes expect them -
-// word 32 k + 4 e + pr of the stage = row 4 j + kb of perspective 2 pr + u, e = 2 kb + u. The next stage's 16 bytes and the
-// next group's 8 heads are asked for a stage / a group ahead.
+// its slab slice goes to LDS once; the hot rows' slices went there when the workgroup started), its 16 waves striding over the
+// segment's groups. A wave reads its group's 8 lists itself, a STAGE of 8 steps at a time: lane (g = lane >> 3, ks = lane & 7)
+// fetches the four rows of step ks of perspective g - 16 bytes of its list, 8 consecutive lanes one 128-byte line; rows past the
+// list's end become an all-zero row - and puts them where the burst's lanes expect them - word 32 k + 4 e + pr of the stage =
+// row 4 j + kb of perspective 2 pr + u, e = 2 kb + u. The next stage's 16 bytes and the next group's 8 heads are asked for a
+// stage / a group ahead. Sections of a group's walk: high-byte planes (global) | << 8 | piece-square rows (LDS slab) | hot
+// threat / pawn-pair rows (LDS) | cold ones (global); each as long as the longest of the 8 lists there.
 // (Rounds of measurements that shaped it, profiles/r04_sliced_pipeline_overlap_attempts.txt: a separate pack kernel writing
 // the interleaved stages to memory first - 36 us per 64 Ki positions for what the gather's idle VALU does here; groups claimed
 // from work queues with finished workgroups helping - 301 us instead of 283 alone and no gain when other kernels share the
 // CUs, every workgroup slows down alike, there is no tail; chunks of groups through the hardware dispatcher - a slab reload
-// per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse.)
+// per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse. Round 5: the list fetch's lanes
+// were (g = lane & 7, ks = lane >> 3) - every quad of lanes touched four different lines, 64 texture-path accesses per instruction
+// where 16 do.)
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(SPX_FTX_GATHER_WAVES_PER_SIMD, 8))) void spx_ftx_gather_kernel(FtxParams p) {
-    // LDS is DYNAMIC on purpose: with a static 120 KiB the compiler knows that only four waves per SIMD can be resident and
-    // pads the kernel's register count up to that occupancy's floor
-#if SPX_FTX_STATIC_LDS
-    __shared__ __align__(16) uint8_t sDyn[kGatherLdsBytes + 16];
-#else
+    // LDS is DYNAMIC on purpose: its size depends on the context's hot set - and with a static 120 KiB the compiler knows that
+    // only four waves per SIMD can be resident and pads the kernel's register count up to that occupancy's floor
     extern __shared__ __align__(16) uint8_t sDyn[];
-#endif
-    uint8_t* const sSlab = sDyn;                                                             // the bucket's slab slice + an all-zero row
-    uint32_t (*const sEnt)[2][256] = reinterpret_cast<uint32_t (*)[2][256]>(sDyn + kGatherSlabBytes);  // per wave: two stages of 8 steps of entries
+    uint8_t* const sSlab = sDyn;                                   // the bucket's slab slice + an all-zero row, then the hot rows
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(sDyn + kFtxSlabBytes + p.hotRows * 128u) + wave * (kFtxRingBytesPerWave / 4);
     const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
     const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
-    const uint32_t g = lane & 7u, ks = lane >> 3;              // the lane's part in filling a stage
+    const uint32_t g = lane >> 3, ks = lane & 7u;              // the lane's part in filling a stage
     const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
     // diagnostics (spx_debug_ftx_block_times): when did this workgroup start and end (constant 100 MHz clock)
     if (threadIdx.x == 0) {
@@ -441,6 +447,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
     const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
     for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
+    {   // the hot rows' slices: once per workgroup (the first segment's barrier publishes them)
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.hotS + size_t(xcd) * p.hotRows * 128u);
+        for (uint32_t i = threadIdx.x; i < p.hotRows * 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabBytes)[i] = src[i];
+    }
     // (32-bit byte offsets from a scalar base: one address register per load instead of two)
     auto headOf = [&](uint32_t G) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.sorted) + 16u * (8u * G + g)); };
     uint32_t loaded = 0xFFFFFFFFu;
@@ -461,29 +471,33 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             const u32x4 head = headNext;
             const uint32_t nextG = G + kGatherWaves;
             if (nextG < gEnd) headNext = headOf(nextG);
-            // this lane's perspective g: its counts and its list; the group's sections are as long as its longest list
-            const uint32_t cHi = head[0] & 0xFFu, cPsq = (head[0] >> 8) & 0xFFu, cThr = head[0] >> 16;
+            // this lane's perspective g: its counts and its list; the group's sections are as long as its longest list there
+            const uint32_t cHi = head[0] & 0x3Fu, cPsq = (head[0] >> 6) & 0x3Fu, cHot = (head[0] >> 12) & 0x1FFu, cCold = head[0] >> 21;
             const uint32_t mine = head[2];  // (its byte offset)
-            uint32_t qA = ((cHi + 3) >> 2) | (((cPsq + 3) >> 2) << 16), qB = (cThr + 3) >> 2;
+            uint32_t qA = ((cHi + 3) >> 2) | (((cPsq + 3) >> 2) << 16), qB = ((cHot + 3) >> 2) | (((cCold + 3) >> 2) << 16);
 #pragma unroll
-            for (int dlt = 1; dlt < 8; dlt <<= 1) {
+            for (int dlt = 8; dlt < 64; dlt <<= 1) {
                 qA = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qA),
                                                                          __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qA), dlt, 64)))));
-                qB = max(qB, uint32_t(__shfl_xor(int(qB), dlt, 64)));
+                qB = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qB),
+                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qB), dlt, 64)))));
             }
             qA = __builtin_amdgcn_readfirstlane(qA);
-            const uint32_t nHiQ = qA & 0xFFFFu, nPsqQ = qA >> 16, nHiPsqQ = nHiQ + nPsqQ;
-            const uint32_t nSteps = nHiPsqQ + __builtin_amdgcn_readfirstlane(qB);
+            qB = __builtin_amdgcn_readfirstlane(qB);
+            // section ends: high planes (global) | piece-square rows (LDS) | hot rows (LDS) | cold rows (global)
+            const uint32_t e1 = qA & 0xFFFFu, e2 = e1 + (qA >> 16), e3 = e2 + (qB & 0xFFFFu), nSteps = e3 + (qB >> 16);
             // step j0 + ks of this lane's list: which section, which quartet of it, how many rows the list has there
             auto place = [&](uint32_t j0, uint32_t& at, uint32_t& left, uint32_t& zero) {
                 const uint32_t j = j0 + ks;
                 uint32_t base, count, first;
-                if (j < nHiQ) {
+                if (j < e1) {
                     base = kFtxListHi, count = cHi, first = 4 * j, zero = kFtxZeroRow * 128u;
-                } else if (j < nHiPsqQ) {
-                    base = kFtxListPsq, count = cPsq, first = 4 * (j - nHiQ), zero = kFtxSlabRows * 128u;  // (the slab's zero row)
+                } else if (j < e2) {
+                    base = kFtxListPsq, count = cPsq, first = 4 * (j - e1), zero = kFtxSlabRows * 128u;  // (the slab's zero row)
+                } else if (j < e3) {
+                    base = kFtxListHot, count = cHot, first = 4 * (j - e2), zero = kFtxSlabRows * 128u;
                 } else {
-                    base = kFtxListThr, count = cThr, first = 4 * (j - nHiPsqQ), zero = kFtxZeroRow * 128u;
+                    base = kFtxListThr, count = cCold, first = 4 * (j - e3), zero = kFtxZeroRow * 128u;
                 }
                 at = base + first;
                 left = count > first ? count - first : 0u;  // (0 too for the steps behind the group's last one)
@@ -495,7 +509,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                 if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.lists) + (mine + 4 * at));
                 return v;
             };
-            auto put = [&](uint32_t j0, const u32x4& v, uint32_t* stage) {
+            auto put = [&](uint32_t j0, const u32x4& v) {
                 uint32_t at, left, zero;
                 place(j0, at, left, zero);
 #pragma unroll
@@ -505,19 +519,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
             uint32_t j = 0;
             while (j < nSteps) {
-                uint32_t* stage = sEnt[wave][(j >> 3) & 1];
-                if ((j & 7u) == 0) {  // a new stage of 8 steps
-                    put(j, ahead, stage);
+                if ((j & 7u) == 0) {  // a new stage of 8 steps (the wave's LDS operations are in order: the last stage's reads came first)
+                    put(j, ahead);
                     if (j + 8 < nSteps) ahead = fetch(j + 8);
                     __builtin_amdgcn_wave_barrier();
                 }
                 // a burst = two steps (8 loads in flight) unless the stage, the list or the high-byte section ends in between
                 const uint32_t k = j & 7u;
-                const bool two = k < 7 && j + 1 < nSteps && j + 1 != nHiQ;
+                const bool two = k < 7 && j + 1 < nSteps && j + 1 != e1;
                 const u32x4 e0 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e));
-                const u32x4 e1 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
+                const u32x4 en = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
                 i32x4 w[8];
-                if (j >= nHiQ && j < nHiPsqQ) {
+                if (j >= e1 && j < e3) {
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(sSlab + e0[pr] + laneOff);
                 } else {
@@ -525,12 +538,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                     for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e0[pr] + laneOff));
                 }
                 if (two) {
-                    if (j + 1 >= nHiQ && j + 1 < nHiPsqQ) {
+                    if (j + 1 >= e1 && j + 1 < e3) {
 #pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(sSlab + e1[pr] + laneOff);
+                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(sSlab + en[pr] + laneOff);
                     } else {
 #pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e1[pr] + laneOff));
+                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(slice + size_t(en[pr] + laneOff));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // every load of the burst is requested before the first MFMA waits
@@ -541,7 +554,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                     for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[4 + pr], d[pr], 0, 0, 0);
                 }
                 j += two ? 2u : 1u;
-                if (j == nHiQ) {  // the high-byte planes' sums count 256-fold
+                if (j == e1) {  // the high-byte planes' sums count 256-fold
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
                 }
@@ -549,7 +562,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
-                const uint32_t dst = uint32_t(__shfl(int(head[1]), 2 * pr + int(u), 64));  // (lanes 0 .. 7 hold perspectives 0 .. 7)
+                const uint32_t dst = uint32_t(__shfl(int(head[1]), 8 * (2 * pr + int(u)), 64));  // (lanes 8 g .. 8 g + 7 hold perspective g)
                 const uint32_t a = pkAdd16(biasA, __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
                 const uint32_t b = pkAdd16(biasB, __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
                 const i16x2 zero = {0, 0}, top = {255, 255};
@@ -568,14 +581,58 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes) + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The hot set (round 5). spx_ftx_hist_kernel counts how often every threat / pawn-pair row is fetched by the lists of a batch
+// that was extracted with an EMPTY hot set (all such rows sit in the cold sections); the host picks the most popular rows
+// (spx_api.cpp: calibrateHotRows) and spx_ftx_build_hot_kernel lays their slices out in slot order and fills the row -> slot map.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void spx_ftx_hist_kernel(FtxParams p, uint32_t* counts, uint32_t* stats) {
+    const uint32_t lane = laneId(), nPersp = 2 * p.nPositions;
+    uint32_t hi = 0;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nPersp; q += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t head = p.heads[2 * size_t(q)];
+        const uint32_t nCold = head >> 21;
+        const uint32_t* list = p.lists + size_t(q) * kFtxListStride + kFtxListThr;
+        for (uint32_t i = lane; i < nCold; i += 64) atomicAdd(&counts[list[i] >> 7], 1u);
+        if (lane == 0) hi += head & 0x3Fu;
+    }
+    if (hi) atomicAdd(&stats[0], hi);
+}
+
+__global__ void spx_ftx_build_hot_kernel(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+    if (idx >= hotRows * 64u) return;
+    const uint32_t slot = idx >> 6, x = (idx >> 3) & 7u, t = idx & 7u, row = hotIds[slot];
+    *reinterpret_cast<u32x4*>(hotS + (size_t(x) * hotRows + slot) * 128 + 16 * t) =
+        *reinterpret_cast<const u32x4*>(rowS + (size_t(x) * kFtxRows + row) * 128 + 16 * t);
+    if ((idx & 63u) == 0) hotSlot[row] = uint16_t(slot);
+}
+
+hipError_t launchFtxHistogram(const FtxParams& p, uint32_t* counts, uint32_t* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_ftx_hist_kernel, dim3(1024), dim3(256), 0, stream, p, counts, stats);
+    return hipGetLastError();
+}
+
+hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS, hipStream_t stream) {
+    if (!hotRows) return hipSuccess;
+    hipLaunchKernelGGL(spx_ftx_build_hot_kernel, dim3((hotRows * 64u + 255) / 256), dim3(256), 0, stream, rowS, hotIds, hotRows, hotSlot, hotS);
+    return hipGetLastError();
+}
+
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream) {
     hipLaunchKernelGGL(spx_ftx_build_table_kernel, dim3((kFtxRows * 64u + 255) / 256), dim3(256), 0, stream, thrU8, psqW, lut, rowS);
     return hipGetLastError();
 }
 
-hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
+hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream) {
     const uint32_t extractBlocks = min((p.nPositions + kWavesPerBlock - 1) / kWavesPerBlock, 256u * 16u);
     hipLaunchKernelGGL(spx_ftx_extract_kernel, dim3(extractBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
+    const hipError_t e = launchFtxExtract(p, stream);
+    if (e != hipSuccess) return e;
     return launchFtxSortAndPlan(p, stream);
 }
 
@@ -587,19 +644,20 @@ hipError_t launchFtxSortAndPlan(const FtxParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream) {
-    const uint32_t gridBlocks = 256;
-    // more than 64 KiB of dynamic LDS has to be allowed once per device
+// more than 64 KiB of dynamic LDS has to be allowed once per device (ensureFtx calls this: a failure there leaves the context on
+// the one-kernel path)
+hipError_t prepareFtxGather(int device) {
     static std::atomic<uint64_t> allowed{0};
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return hipGetLastError();
-    if (!SPX_FTX_STATIC_LDS && !(allowed.load() >> (device & 63) & 1u)) {
-        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_ftx_gather_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kGatherLdsBytes + 16));
-        if (attr != hipSuccess) return attr;
-        allowed.fetch_or(uint64_t(1) << (device & 63));
-    }
-    hipLaunchKernelGGL(spx_ftx_gather_kernel, dim3(gridBlocks), dim3(64 * kGatherWaves), SPX_FTX_STATIC_LDS ? 0 : kGatherLdsBytes + 16, stream, p);
+    if (allowed.load() >> (device & 63) & 1u) return hipSuccess;
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&spx_ftx_gather_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(gatherLdsBytes(kFtxHotRowsMax)));
+    if (attr != hipSuccess) return attr;
+    allowed.fetch_or(uint64_t(1) << (device & 63));
+    return hipSuccess;
+}
+
+hipError_t launchFtxGather(const FtxParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_ftx_gather_kernel, dim3(256), dim3(64 * kGatherWaves), gatherLdsBytes(p.hotRows), stream, p);
     return hipGetLastError();
 }
 

@@ -133,6 +133,22 @@ class NnueState:
         """spx_ctx_set_option: one tuning knob of this context (never changes a result)."""
         check(_lib.load().spx_ctx_set_option(self._h, name.encode(), int(value)))
 
+    def calibrate(self, d_positions_ptr, n):
+        """spx_ctx_calibrate: choose the gather's hot set (the threat / pawn-pair rows kept in LDS) from a device-resident batch."""
+        check(_lib.load().spx_ctx_calibrate(self._h, d_positions_ptr, n))
+
+    def set_hot_rows(self, rows):
+        """spx_ctx_set_hot_rows (test entry point): the hot set given instead of measured; rows = distinct ids < 64 368."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        check(_lib.load().spx_ctx_set_hot_rows(self._h, rows.ctypes.data if rows.size else None, rows.size))
+
+    def hot_rows(self):
+        """The hot set in slot order (empty before the first calibration)."""
+        out = np.empty(1024, dtype=np.uint32)
+        n = ctypes.c_size_t()
+        check(_lib.load().spx_ctx_get_hot_rows(self._h, out.ctypes.data, out.size, ctypes.byref(n)))
+        return out[: n.value].copy()
+
     def evaluate_once(self, positions):
         """Batched NnueState::evaluateOnce: packed positions (PACKED_DTYPE array) -> int32 raw evals (stm view)."""
         pos = np.ascontiguousarray(positions, dtype=PACKED_DTYPE)

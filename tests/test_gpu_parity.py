@@ -475,6 +475,53 @@ def test_column_sliced_pipeline_equals_the_kernel_and_the_oracle(sp, oracle, net
                 lib.spx_host_free(q)
 
 
+@pytest.mark.parametrize("preset", ["tame", "realistic", "extreme"])
+def test_hot_row_sets_do_not_change_results(sp, oracle, net_blob, preset):
+    """The gather keeps a HOT SET of threat / pawn-pair rows in LDS beside the piece-square slab (spx_ftx.h; chosen from a histogram
+    over the first big batch, or by spx_ctx_calibrate). A row is added from wherever it lives, so the set must not matter: the
+    measured set, an empty one, the largest the tables hold, an adversarial random one and a deliberately BAD one (the rarest rows of
+    the calibration batch) all give the evaluations of the one-kernel path and of the oracle - on the batch the set was measured
+    on and on another one. (nnue_state.cpp:89-145, 309-354: the sums the reference adds up, in any order.)"""
+    blob = net_blob(preset)
+    pos = sp.random_positions(40000, seed=4242, min_ply=0, max_ply=160, dfrc_every=3)
+    other = sp.random_positions(20000, seed=77, min_ply=8, max_ply=120, dfrc_every=4)
+    oracle.use(blob, preset)
+    with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 16, sliced_ft=False) as plain:
+        want, want_other = plain.evaluate_once(pos), plain.evaluate_once(other)
+    mail, stm = sp.positions_to_mailboxes(pos[:2000])
+    assert np.array_equal(want[:2000], oracle.eval_mailboxes(mail, stm))
+    rng = np.random.default_rng(12)
+    with _state_with_options(sp, blob, {"ftx_min": 1024, "tiny_batch_max": 0}, max_batch=1 << 16) as st:
+        assert st.hot_rows().size == 0                       # nothing chosen before the first big batch
+        assert np.array_equal(st.evaluate_once(pos), want)   # the call that measures the set
+        measured = st.hot_rows()
+        assert measured.size == 256 and len(set(measured.tolist())) == 256 and measured.max() < 64368
+        assert np.array_equal(st.evaluate_once(other), want_other)
+        assert np.array_equal(st.evaluate_once(pos[:1500]), want[:1500])
+        sets = {"empty": np.zeros(0, dtype=np.uint32),
+                "random": rng.choice(64368, 384, replace=False).astype(np.uint32),
+                "one row": measured[:1],
+                "reversed": measured[::-1].copy(),
+                "pawn pairs only": np.arange(300, dtype=np.uint32)}
+        for name, rows in sets.items():
+            st.set_hot_rows(rows)
+            assert np.array_equal(st.hot_rows(), rows), name
+            for batch, ref in ((pos, want), (other, want_other), (pos[:1111], want[:1111])):
+                got = st.evaluate_once(batch)
+                bad = np.nonzero(got != ref)[0]
+                assert bad.size == 0, f"{name}: {bad.size} mismatches, first {sp.position_to_fen(batch[bad[0]])}"
+        # other sizes of the measured set (option ftx_hot_rows; the next big batch re-measures)
+        for rows in (0, 64, 384):
+            st.set_option("ftx_hot_rows", rows)
+            assert np.array_equal(st.evaluate_once(other), want_other), rows
+            assert st.hot_rows().size == rows
+            assert np.array_equal(st.evaluate_once(pos), want), rows
+        # pipelined calls on a freshly calibrated context
+        st.set_option("ftx_hot_rows", 256)
+        assert np.array_equal(_evaluate_through(sp, st, pos, "sliced_pipelined"), want)
+        assert np.array_equal(_evaluate_through(sp, st, other, "sliced_pipelined"), want_other)
+
+
 def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_blob):
     """The column-sliced pipeline allocates its table and scratch sets on first use; when one does not fit (a context sized to
     fill the HBM: simulated with option ftx_fail_after) that call and all later ones take spx_ft_kernel - another GPU path, same
