@@ -52,10 +52,10 @@ constexpr size_t kProfEventsPerCall = 5;
 // scratch of the column-sliced full refresh (spx_ftx.hip): one set per context and per lane, allocated on first use
 struct FtxScratch {
     uint32_t *lists = nullptr, *heads = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
-             *sorted = nullptr, *plan = nullptr;
+             *sorted = nullptr, *plan = nullptr, *groupHead = nullptr, *stages = nullptr;
     size_t capacity = 0;  // positions per pass
     void release() {
-        for (uint32_t* q : {lists, heads, keys, ranks, hist, binStart, sorted, plan}) {
+        for (uint32_t* q : {lists, heads, keys, ranks, hist, binStart, sorted, plan, groupHead, stages}) {
             if (q) (void)hipFree(q);
         }
         *this = FtxScratch{};
@@ -949,7 +949,8 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
     if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 8) || !alloc(x.keys, 2 * cap * 4) ||
         !alloc(x.ranks, 2 * cap * 4) || !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) ||
-        !alloc(x.sorted, (2 * cap + 128) * 16) || !alloc(x.plan, kFtxPlanWords * 4)) {
+        !alloc(x.sorted, (2 * cap + 128) * 16) || !alloc(x.plan, kFtxPlanWords * 4) ||
+        !alloc(x.groupHead, ftxGroups(cap) * kFtxGroupHeadWords * 4) || !alloc(x.stages, ftxStageBytes(cap))) {
         return fail();
     }
     if (hipMemsetAsync(x.hist, 0, kFtxBins * 4, s) != hipSuccess) return fail();
@@ -1014,6 +1015,8 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.binStart = scratch.binStart;
             xp.sorted = scratch.sorted;
             xp.plan = scratch.plan;
+            xp.groupHead = scratch.groupHead;
+            xp.stages = scratch.stages;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
             if (!ctx->hotCalibrated) {  // the first big batch of this context chooses the hot set (synchronises the stream once)
                 if ((rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;

@@ -37,14 +37,14 @@ constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket:
 constexpr uint32_t kFtxSlabBytes = (kFtxSlabRows + 1) * 128;
 constexpr uint32_t kFtxHotRowsMax = 384;       // capacity of the tables; what a context uses: option ftx_hot_rows
 constexpr uint32_t kFtxHotRowsDefault = 256;   // slab 88.1 + hot 32 + ring 16 = 136.1 KiB: one 14 / 16 KiB co-runner workgroup fits beside it
-constexpr uint32_t kFtxRingBytesPerWave = 1024;  // one stage of 8 steps x 8 perspectives x 4 entries
+constexpr uint32_t kFtxRingBytesPerWave = 1024 + 64;  // one stage of 8 steps x 8 perspectives x 4 entries + the group's head
 
 // ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
-// [0, 32) piece-square rows as LDS offsets ((row - 704 bucket) * 128, into the slab); [32, 64) high-byte planes of the wide ones as
-// slice offsets (row index * 128); [64, 320) the COLD threat / pawn-pair rows as slice offsets; [320, 576) the HOT ones as LDS offsets
-// (kFtxSlabBytes + slot * 128). Words behind a section's count are undefined.
-// heads[perspective] = {nHi | nPsq << 6 | nHot << 12 | nCold << 21, 2 * position + (0 = side-to-move half, 1 = other half)}
-constexpr uint32_t kFtxListStride = 576, kFtxListPsq = 0, kFtxListHi = 32, kFtxListThr = 64, kFtxListHot = 320;
+// [0, 288) the LDS section: the piece-square rows ((row - 704 bucket) * 128, into the slab), then the HOT threat / pawn-pair rows
+// (kFtxSlabBytes + slot * 128) - byte offsets into the gather's LDS; [288, 320) high-byte planes of the wide piece-square rows and
+// [320, 576) the COLD threat / pawn-pair rows as slice offsets (row index * 128). Words behind a section's count are undefined.
+// heads[perspective] = {nHi | nLds << 6 | nCold << 15, 2 * position + (0 = side-to-move half, 1 = other half)}
+constexpr uint32_t kFtxListStride = 576, kFtxListLds = 0, kFtxListHi = 288, kFtxListCold = 320;
 // sort key of a perspective: king bucket * 80 + min(global quartets >> coldShift, 15) * 5 + min(LDS quartets >> 2, 4) - the quartets
 // fetched through the texture path (high planes + cold rows) first: they cost twice an LDS step, and a group of 8 neighbours
 // walks as many of them as its longest list has. With the round-4 key (total quartets) the hot / cold split of the lists pads
@@ -57,7 +57,16 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 }
 
 // ---- sorted[position in the sorted order] = {head word 0, output slot (~0 = hole), list offset in bytes, -} ----
-// the gather's wave reads the 8 entries of its group and then the 8 lists themselves, a stage of 8 steps at a time
+// ---- the packed walk of a group of 8 neighbours of that order (spx_ftx_pack_kernel; what the gather reads) ----
+// A group's walk has three SECTIONS - high-byte planes (global), the LDS section, cold rows (global) -, each as long as the
+// longest of the 8 lists there (in quartets of rows = steps), cut into STAGES of 8 steps. groupHead[G] = 16 words: {hiQ | ldsQ << 8
+// | coldQ << 16, output slots of the 8 perspectives (~0 = hole), -}; stages[G][q] = 256 words, stage q in the order of the
+// sections: word 32 k + 4 e + pr = the row (byte offset, as in the lists) that row kb of step k adds to perspective 2 pr + u,
+// e = 2 kb + u; rows past a list's end are the section's all-zero row. Every XCD's gather walks every group: packing once what
+// round 4 made each of the eight find out for itself (section boundaries per lane, list gathers, padding) took 40 % of the
+// gather's instructions off it (profiles/r05_gather_anatomy.txt).
+constexpr uint32_t kFtxMaxStages = 1 + 9 + 8;  // <= 32 high planes, <= 32 + 256 LDS rows, <= 256 cold rows
+constexpr uint32_t kFtxGroupHeadWords = 16;
 
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
@@ -89,6 +98,8 @@ struct FtxParams {
     uint32_t* binStart;      // [kFtxBins + 17] first sorted position of each bin; then bucketStart[17]
     uint32_t* sorted;        // [2 n + 128][4]
     uint32_t* plan;          // [kFtxPlanWords]
+    uint32_t* groupHead;     // [(2 n + 128) / 8][kFtxGroupHeadWords]
+    uint32_t* stages;        // [(2 n + 128) / 8][kFtxMaxStages][256]
     uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
     const uint16_t* hotSlot; // [kThreatRows] LDS slot of a hot threat / pawn-pair row, 0xFFFF = cold
     const uint8_t* hotS;     // [8 slices][hotRows][128 B] the hot rows' slices, in slot order
@@ -97,6 +108,8 @@ struct FtxParams {
 };
 
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
+inline size_t ftxGroups(size_t n) { return (2 * n + 128) / 8; }
+inline size_t ftxStageBytes(size_t n) { return ftxGroups(n) * kFtxMaxStages * 1024; }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
 // the hot set: counts[row] += fetches of threat / pawn-pair row `row` in the lists of p (extracted with hotRows = 0), stats[0] +=

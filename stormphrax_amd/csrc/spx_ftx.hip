@@ -42,6 +42,10 @@ namespace {
 #ifndef SPX_FTX_GATHER_WAVES
 #define SPX_FTX_GATHER_WAVES 16
 #endif
+#ifndef SPX_FTX_SKIP
+#define SPX_FTX_SKIP 0  // measurement builds only (wrong sums): 1 no LDS row reads, 2 no global row loads, 4 no MFMAs, 8 no output stores,
+#endif                  // 32 no ring writes (tools/build_variants.sh; profiles/r05_gather_anatomy.txt)
+
 #ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
 #define SPX_FTX_GATHER_WAVES_PER_SIMD 5  // register budget: 512 / this = 96 (a workgroup brings 4 waves per SIMD: the rest is room for two of the extraction's)
 #endif
@@ -164,14 +168,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             const uint64_t wideMask = __ballot(wide);
             const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
             if (occupied && slot < kPsqCap) {
-                out[kFtxListPsq + slot] = (row - bucket * kFtxSlabRows) * 128u;  // (an LDS offset: the slab heads the gather's LDS)
+                out[kFtxListLds + slot] = (row - bucket * kFtxSlabRows) * 128u;  // (an LDS offset: the slab heads the gather's LDS)
                 if (wide && wideSlot < kPsqCap) out[kFtxListHi + wideSlot] = (kFtxPsqHiBase + row) * 128u;
             }
             const uint32_t nPsq = min(uint32_t(popc64(b.occ)), uint32_t(kPsqCap));
             const uint32_t nHi = min(uint32_t(popc64(wideMask)), uint32_t(kPsqCap));
-            // threat / pawn-pair rows: a row of the context's hot set (LDS resident in the gather) goes to the hot section as an LDS
-            // offset, any other to the cold section as a slice offset; 256 rows in all, in the order of enumeration, like the
-            // reference's StaticVector<u16, 256> (nnue_state.cpp:315)
+            // threat / pawn-pair rows: a row of the context's hot set (LDS resident in the gather) joins the piece-square rows in the
+            // LDS section as an LDS offset, any other goes to the cold section as a slice offset; 256 rows in all, in the order of
+            // enumeration, like the reference's StaticVector<u16, 256> (nnue_state.cpp:315)
             uint32_t nThr = 0, nHot = 0, nCold = 0;
             auto emit = [&](int32_t r) {
                 const uint64_t valid = __ballot(r >= 0);
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
                 if (taken && p.hotRows) slot = p.hotSlot[r];
                 const bool hot = taken && slot != 0xFFFFu, cold = taken && !hot;
                 const uint64_t hotMask = __ballot(hot), coldMask = __ballot(cold);
-                if (hot) out[kFtxListHot + nHot + prefixCount(hotMask)] = kFtxSlabBytes + slot * 128u;
-                if (cold) out[kFtxListThr + nCold + prefixCount(coldMask)] = uint32_t(r) * 128u;
+                if (hot) out[kFtxListLds + nPsq + nHot + prefixCount(hotMask)] = kFtxSlabBytes + slot * 128u;
+                if (cold) out[kFtxListCold + nCold + prefixCount(coldMask)] = uint32_t(r) * 128u;
                 nHot += uint32_t(popc64(hotMask));
                 nCold += uint32_t(popc64(coldMask));
                 nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             }
             if (lane == 0) {
                 u32x2 head;
-                head[0] = nHi | (nPsq << 6) | (nHot << 12) | (nCold << 21);
+                head[0] = nHi | ((nPsq + nHot) << 6) | (nCold << 15);
                 head[1] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
                 *reinterpret_cast<u32x2*>(p.heads + 2 * size_t(q)) = head;
-                const uint32_t globalQ = (nHi + 3) / 4 + (nCold + 3) / 4, ldsQ = (nPsq + 3) / 4 + (nHot + 3) / 4;
+                const uint32_t globalQ = (nHi + 3) / 4 + (nCold + 3) / 4, ldsQ = (nPsq + nHot + 3) / 4;
                 p.keys[q] = bucket * kFtxQuartetBins + min(globalQ >> p.coldShift, kFtxQuartetBins / kFtxLdsClasses - 1) * kFtxLdsClasses +
                             min(ldsQ >> 2, kFtxLdsClasses - 1);
             }
@@ -406,34 +410,127 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Pack: one wave per group of 8 neighbours of the sorted order writes the group's walk (spx_ftx.h) - the sections' lengths, the
+// output slots, and the lists cut into interleaved stages with their padding. Lane (g = lane >> 3, ks = lane & 7) carries the
+// four rows of step ks of perspective g: 16 bytes of its list, 8 consecutive lanes one 128-byte line.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxParams p) {
+    const uint32_t lane = laneId(), G = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (G >= p.plan[33]) return;
+    const uint32_t g = lane >> 3, ks = lane & 7u;
+    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
+    const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + g];
+    const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
+    uint32_t hiQ = (cHi + 3) >> 2, ldsQ = (cLds + 3) >> 2, coldQ = (cCold + 3) >> 2;
+#pragma unroll
+    for (int dlt = 8; dlt < 64; dlt <<= 1) {
+        hiQ = max(hiQ, uint32_t(__shfl_xor(int(hiQ), dlt, 64)));
+        ldsQ = max(ldsQ, uint32_t(__shfl_xor(int(ldsQ), dlt, 64)));
+        coldQ = max(coldQ, uint32_t(__shfl_xor(int(coldQ), dlt, 64)));
+    }
+    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
+    if (lane == 0) gh[0] = hiQ | (ldsQ << 8) | (coldQ << 16);
+    if (ks == 0) gh[1 + g] = head[1];
+    const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
+    uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
+    for (uint32_t q = 0; q < Q; ++q, out += 256) {
+        const uint32_t sec = q < H ? 0u : (q < H + L ? 1u : 2u), s = q - (sec == 0 ? 0u : (sec == 1 ? H : H + L));
+        const uint32_t count = sec == 0 ? cHi : (sec == 1 ? cLds : cCold);
+        const uint32_t base = sec == 0 ? kFtxListHi : (sec == 1 ? kFtxListLds : kFtxListCold);
+        const uint32_t zero = sec == 1 ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
+        const uint32_t first = 4 * (8 * s + ks), left = count > first ? count - first : 0u;
+        u32x4 v = {0, 0, 0, 0};
+        if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.lists) + (head[2] + 4 * (base + first)));
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) out[fillAt + 8 * i] = i < left ? v[i] : zero;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Gather.
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 persistent workgroups: CU slot `cu` of XCD `xcd` walks its planned share, segment by segment (a segment = one bucket:
 // its slab slice goes to LDS once; the hot rows' slices went there when the workgroup started), its 16 waves striding over the
-// segment's groups. A wave reads its group's 8 lists itself, a STAGE of 8 steps at a time: lane (g = lane >> 3, ks = lane & 7)
-// fetches the four rows of step ks of perspective g - 16 bytes of its list, 8 consecutive lanes one 128-byte line; rows past the
-// list's end become an all-zero row - and puts them where the burst's lanes expect them - word 32 k + 4 e + pr of the stage =
-// row 4 j + kb of perspective 2 pr + u, e = 2 kb + u. The next stage's 16 bytes and the next group's 8 heads are asked for a
-// stage / a group ahead. Sections of a group's walk: high-byte planes (global) | << 8 | piece-square rows (LDS slab) | hot
-// threat / pawn-pair rows (LDS) | cold ones (global); each as long as the longest of the 8 lists there.
-// (Rounds of measurements that shaped it, profiles/r04_sliced_pipeline_overlap_attempts.txt: a separate pack kernel writing
-// the interleaved stages to memory first - 36 us per 64 Ki positions for what the gather's idle VALU does here; groups claimed
-// from work queues with finished workgroups helping - 301 us instead of 283 alone and no gain when other kernels share the
-// CUs, every workgroup slows down alike, there is no tail; chunks of groups through the hardware dispatcher - a slab reload
-// per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse. Round 5: the list fetch's lanes
-// were (g = lane & 7, ks = lane >> 3) - every quad of lanes touched four different lines, 64 texture-path accesses per instruction
-// where 16 do.)
+// segment's groups. A wave walks a group's packed stages (spx_ftx_pack_kernel): one coalesced 1 KiB load per stage of 8 steps -
+// the next stage's, at a group's last stage the next group's first, travels while the stage is walked - parked in the wave's
+// 1 KiB of LDS, from where every step's lanes pick the four rows they fetch (lane (n = 8 u + t, kb): row kb of perspectives
+// 2 pr + u, 16-byte chunk t): 2 perspectives x 4 rows x 128 B per wave load / LDS read, ONE v_mfma_i32_16x16x64_i8 each.
+// Round 5 rebuilt the walk after measuring what it is made of (profiles/r05_gather_anatomy.txt: with its row loads AND its
+// MFMAs removed the round-4 kernel still took 160 of 281 us; without its global row loads as long as with them):
+//   * every XCD found out for itself what a group's walk looks like - section boundaries searched per lane and stage, list
+//     gathers, padding: now packed once per batch by a pass of its own;
+//   * the loop issued 8 row loads, waited for all of them, fed 8 MFMAs and started over: now a stage's steps run as a ROLLING
+//     window of two (the loads of step k + 2 are issued right behind the MFMAs of step k: 8 in flight all the time), and every
+//     loop body has ONE kind of load, so the compiler's s_waitcnt are exact (a join of paths with different numbers of loads in
+//     flight waits for the smaller number);
+//   * a group ended with four 2-byte stores per lane behind four cross-lane shuffles: now the wave's LDS transposes its 512
+//     output bytes and every lane stores 8.
+// (Round-4 measurements that still shape it, profiles/r04_sliced_pipeline_overlap_attempts.txt: groups claimed from work queues
+// with finished workgroups helping - no gain, every workgroup slows down alike, there is no tail; chunks of groups through the
+// hardware dispatcher - a slab reload per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse.)
+namespace {
+
+// one stage - n <= 8 steps of ONE section - of a group's walk: rows from LDS (kLds) or through the texture path. The steps run in
+// PAIRS as a rolling window: the loads of steps k + 2, k + 3 are issued right behind the MFMAs of steps k, k + 1 - 8 loads in flight
+// all the time -, and the loop body has no branch: a stage holds 8 steps whatever the section's length (the pack kernel fills the
+// rest with the all-zero row), so an odd n walks one step of zero rows. With branches for the odd step the compiler's s_waitcnt
+// at their joins wait for ALL loads (paths with different numbers of loads in flight), and the accumulators travel through
+// copies (16 + 32 v_mov per stage and 48 spilled registers at the 96 the co-runners leave room for).
+template <bool kLds>
+__device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, const uint8_t* ldsRows, const uint8_t* slice, uint32_t e,
+                                          uint32_t laneOff, const i32x4& sel, i32x4 (&d)[4]) {
+    auto entries = [&](uint32_t k) { return *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e)); };
+    auto issue = [&](const u32x4& en, i32x4 (&w)[4]) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if constexpr (kLds) {
+                if (SPX_FTX_SKIP & 1) w[pr] = i32x4{int(en[pr]), 0, 0, 0};
+                else w[pr] = *reinterpret_cast<const i32x4*>(ldsRows + en[pr] + laneOff);
+            } else {
+                if (SPX_FTX_SKIP & 2) w[pr] = i32x4{int(en[pr]), 0, 0, 0};
+                else w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(en[pr] + laneOff));
+            }
+        }
+    };
+    auto add = [&](const i32x4 (&w)[4]) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (SPX_FTX_SKIP & 4) d[pr] += w[pr];
+            else d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[pr], d[pr], 0, 0, 0);
+        }
+    };
+    const uint32_t nEven = (n + 1) & ~1u;
+    i32x4 wa[4], wb[4];
+    u32x4 en = entries(0);
+    issue(en, wa);
+    en = entries(1);
+    issue(en, wb);
+    for (uint32_t k = 2; k < nEven; k += 2) {  // steps k - 2, k - 1 are in flight
+        en = entries(k);  // (asked for before the wait for step k - 2's rows)
+        add(wa);
+        issue(en, wa);
+        en = entries(k + 1);
+        add(wb);
+        issue(en, wb);
+    }
+    add(wa);
+    add(wb);
+}
+
+}  // namespace
+
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(SPX_FTX_GATHER_WAVES_PER_SIMD, 8))) void spx_ftx_gather_kernel(FtxParams p) {
     // LDS is DYNAMIC on purpose: its size depends on the context's hot set - and with a static 120 KiB the compiler knows that
     // only four waves per SIMD can be resident and pads the kernel's register count up to that occupancy's floor
     extern __shared__ __align__(16) uint8_t sDyn[];
     uint8_t* const sSlab = sDyn;                                   // the bucket's slab slice + an all-zero row, then the hot rows
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    // (the wave's index as a SCALAR: everything derived from it - group indices, stage addresses - stays in SGPRs)
+    const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // per wave: the current stage (1 KiB; at a group's end its 512 output bytes pass through it), then the group's head (64 B)
     uint32_t* const stage = reinterpret_cast<uint32_t*>(sDyn + kFtxSlabBytes + p.hotRows * 128u) + wave * (kFtxRingBytesPerWave / 4);
+    uint32_t* const sHead = stage + 256;
     const uint32_t xcd = blockIdx.x & 7u, cu = blockIdx.x >> 3;
     const uint32_t n = lane & 15u, kb = lane >> 4, u = n >> 3, t = n & 7u, e = 2 * kb + u;
-    const uint32_t g = lane >> 3, ks = lane & 7u;              // the lane's part in filling a stage
-    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
     // diagnostics (spx_debug_ftx_block_times): when did this workgroup start and end (constant 100 MHz clock)
     if (threadIdx.x == 0) {
         reinterpret_cast<unsigned long long*>(p.plan + kFtxPlanTimes)[2 * blockIdx.x] = wall_clock64();
@@ -444,15 +541,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     const i32x4 sel = mfmaSelector(lane);
     // this lane's output columns: D registers (0, 1) = columns (c, c + 1), (2, 3) = their partners (c + 512, c + 513)
     const uint32_t col = 64 * xcd + 8 * t + 2 * kb;
-    const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
-    const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
     for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabRows * 128)[i] = u32x4{0, 0, 0, 0};
     {   // the hot rows' slices: once per workgroup (the first segment's barrier publishes them)
         const u32x4* src = reinterpret_cast<const u32x4*>(p.hotS + size_t(xcd) * p.hotRows * 128u);
         for (uint32_t i = threadIdx.x; i < p.hotRows * 8; i += blockDim.x) reinterpret_cast<u32x4*>(sSlab + kFtxSlabBytes)[i] = src[i];
     }
     // (32-bit byte offsets from a scalar base: one address register per load instead of two)
-    auto headOf = [&](uint32_t G) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.sorted) + 16u * (8u * G + g)); };
+    auto stageOfGroup = [&](uint32_t G, uint32_t q) {
+        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.stages) + (size_t(G) * kFtxMaxStages + q) * 1024 + 16 * lane);
+    };
+    auto headOfGroup = [&](uint32_t G) { return lane < 9 ? p.groupHead[size_t(G) * kFtxGroupHeadWords + lane] : 0u; };
     uint32_t loaded = 0xFFFFFFFFu;
     const uint32_t ownEnd = p.plan[cu + 1];
     for (uint32_t seg = p.plan[cu]; seg < ownEnd; ++seg) {
@@ -465,116 +563,67 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             loaded = bucket;
         }
         uint32_t G = gFirst + wave;
-        u32x4 headNext = {0, 0xFFFFFFFFu, 0, 0};
-        if (G < gEnd) headNext = headOf(G);
-        while (G < gEnd) {
-            const u32x4 head = headNext;
+        if (G >= gEnd) continue;
+        uint32_t headNext = headOfGroup(G);
+        u32x4 ents = stageOfGroup(G, 0);
+        while (true) {
+            // the group's head: from the registers it travelled in to the wave's LDS (the lanes' LDS operations are in order)
+            if (lane < 9) sHead[lane] = headNext;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t dims = __builtin_amdgcn_readfirstlane(sHead[0]);
+            const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
+            const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
             const uint32_t nextG = G + kGatherWaves;
-            if (nextG < gEnd) headNext = headOf(nextG);
-            // this lane's perspective g: its counts and its list; the group's sections are as long as its longest list there
-            const uint32_t cHi = head[0] & 0x3Fu, cPsq = (head[0] >> 6) & 0x3Fu, cHot = (head[0] >> 12) & 0x1FFu, cCold = head[0] >> 21;
-            const uint32_t mine = head[2];  // (its byte offset)
-            uint32_t qA = ((cHi + 3) >> 2) | (((cPsq + 3) >> 2) << 16), qB = ((cHot + 3) >> 2) | (((cCold + 3) >> 2) << 16);
-#pragma unroll
-            for (int dlt = 8; dlt < 64; dlt <<= 1) {
-                qA = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qA),
-                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qA), dlt, 64)))));
-                qB = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, qB),
-                                                                         __builtin_bit_cast(u16x2, uint32_t(__shfl_xor(int(qB), dlt, 64)))));
-            }
-            qA = __builtin_amdgcn_readfirstlane(qA);
-            qB = __builtin_amdgcn_readfirstlane(qB);
-            // section ends: high planes (global) | piece-square rows (LDS) | hot rows (LDS) | cold rows (global)
-            const uint32_t e1 = qA & 0xFFFFu, e2 = e1 + (qA >> 16), e3 = e2 + (qB & 0xFFFFu), nSteps = e3 + (qB >> 16);
-            // step j0 + ks of this lane's list: which section, which quartet of it, how many rows the list has there
-            auto place = [&](uint32_t j0, uint32_t& at, uint32_t& left, uint32_t& zero) {
-                const uint32_t j = j0 + ks;
-                uint32_t base, count, first;
-                if (j < e1) {
-                    base = kFtxListHi, count = cHi, first = 4 * j, zero = kFtxZeroRow * 128u;
-                } else if (j < e2) {
-                    base = kFtxListPsq, count = cPsq, first = 4 * (j - e1), zero = kFtxSlabRows * 128u;  // (the slab's zero row)
-                } else if (j < e3) {
-                    base = kFtxListHot, count = cHot, first = 4 * (j - e2), zero = kFtxSlabRows * 128u;
-                } else {
-                    base = kFtxListThr, count = cCold, first = 4 * (j - e3), zero = kFtxZeroRow * 128u;
-                }
-                at = base + first;
-                left = count > first ? count - first : 0u;  // (0 too for the steps behind the group's last one)
-            };
-            auto fetch = [&](uint32_t j0) -> u32x4 {
-                uint32_t at, left, zero;
-                place(j0, at, left, zero);
-                u32x4 v = {0, 0, 0, 0};
-                if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.lists) + (mine + 4 * at));
-                return v;
-            };
-            auto put = [&](uint32_t j0, const u32x4& v) {
-                uint32_t at, left, zero;
-                place(j0, at, left, zero);
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) stage[fillAt + 8 * i] = i < left ? v[i] : zero;
-            };
-            u32x4 ahead = fetch(0);
+            const bool haveNext = nextG < gEnd;
+            if (haveNext) headNext = headOfGroup(nextG);
             i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            uint32_t j = 0;
-            while (j < nSteps) {
-                if ((j & 7u) == 0) {  // a new stage of 8 steps (the wave's LDS operations are in order: the last stage's reads came first)
-                    put(j, ahead);
-                    if (j + 8 < nSteps) ahead = fetch(j + 8);
-                    __builtin_amdgcn_wave_barrier();
+            for (uint32_t q = 0; q < Q; ++q) {
+                if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
+                __builtin_amdgcn_wave_barrier();
+                // what travels while this stage is walked: the next stage - at the last one: the next group's first
+                if (q + 1 < Q) {
+                    ents = stageOfGroup(G, q + 1);
+                } else if (haveNext) {
+                    ents = stageOfGroup(nextG, 0);
                 }
-                // a burst = two steps (8 loads in flight) unless the stage, the list or the high-byte section ends in between
-                const uint32_t k = j & 7u;
-                const bool two = k < 7 && j + 1 < nSteps && j + 1 != e1;
-                const u32x4 e0 = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * k + e));
-                const u32x4 en = *reinterpret_cast<const u32x4*>(stage + 4 * (8 * (k < 7 ? k + 1 : k) + e));
-                i32x4 w[8];
-                if (j >= e1 && j < e3) {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(sSlab + e0[pr] + laneOff);
+                const uint32_t sec = q < H ? 0u : (q < H + L ? 1u : 2u), s = q - (sec == 0 ? 0u : (sec == 1 ? H : H + L));
+                const uint32_t steps = (sec == 0 ? hiQ : (sec == 1 ? ldsQ : coldQ)) - 8 * s;
+                if (sec == 1) {
+                    walkStage<true>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
                 } else {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(e0[pr] + laneOff));
+                    walkStage<false>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
                 }
-                if (two) {
-                    if (j + 1 >= e1 && j + 1 < e3) {
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(sSlab + en[pr] + laneOff);
-                    } else {
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) w[4 + pr] = *reinterpret_cast<const i32x4*>(slice + size_t(en[pr] + laneOff));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);  // every load of the burst is requested before the first MFMA waits
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[pr], d[pr], 0, 0, 0);
-                if (two) {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[4 + pr], d[pr], 0, 0, 0);
-                }
-                j += two ? 2u : 1u;
-                if (j == e1) {  // the high-byte planes' sums count 256-fold
+                if (sec == 0 && s + 1 == H) {  // the high-byte planes' sums count 256-fold
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
                 }
             }
-            // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u
+            if (Q == 0 && haveNext) ents = stageOfGroup(nextG, 0);  // (a group of records without a single piece: malformed input)
+            // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u; the 2 output bytes go
+            // to byte 64 (2 pr + u) + 8 t + 2 kb of the wave's LDS, from where lane l stores bytes 8 l .. 8 l + 7: perspective l >> 3
+            {
+                const uint32_t biasA = *reinterpret_cast<const uint32_t*>(p.t.ftBias + col);
+                const uint32_t biasB = *reinterpret_cast<const uint32_t*>(p.t.ftBias + 512 + col);
+                uint16_t* const outBytes = reinterpret_cast<uint16_t*>(stage);
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const uint32_t dst = uint32_t(__shfl(int(head[1]), 8 * (2 * pr + int(u)), 64));  // (lanes 8 g .. 8 g + 7 hold perspective g)
-                const uint32_t a = pkAdd16(biasA, __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
-                const uint32_t b = pkAdd16(biasB, __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
-                const i16x2 zero = {0, 0}, top = {255, 255};
-                const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
-                const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero), top));
-                const uint32_t o = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));
-                if (dst != 0xFFFFFFFFu) {
-                    *reinterpret_cast<uint16_t*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * t + 2 * kb) =
-                        uint16_t((o & 0xFFu) | ((o >> 8) & 0xFF00u));
+                for (int pr = 0; pr < 4; ++pr) {
+                    const uint32_t a = pkAdd16(biasA, __builtin_amdgcn_perm(uint32_t(d[pr][1]), uint32_t(d[pr][0]), 0x05040100u));
+                    const uint32_t b = pkAdd16(biasB, __builtin_amdgcn_perm(uint32_t(d[pr][3]), uint32_t(d[pr][2]), 0x05040100u));
+                    const i16x2 zero = {0, 0}, top = {255, 255};
+                    const u16x2 i1 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
+                    const u16x2 i2 = __builtin_bit_cast(u16x2, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero), top));
+                    const uint32_t o = __builtin_bit_cast(uint32_t, u16x2((i1 * i2) >> 9));
+                    outBytes[32 * (2 * pr + u) + 4 * t + kb] = uint16_t((o & 0xFFu) | ((o >> 8) & 0xFF00u));
+                }
+                __builtin_amdgcn_wave_barrier();
+                const u32x2 mine = *reinterpret_cast<const u32x2*>(stage + 2 * lane);
+                const uint32_t dst = sHead[1 + (lane >> 3)];
+                if ((SPX_FTX_SKIP & 8) ? (mine[0] == 0x12345678u && dst == 77u) : (dst != 0xFFFFFFFFu)) {
+                    *reinterpret_cast<u32x2*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * (lane & 7u)) = mine;
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (!haveNext) break;
             G = nextG;
         }
     }
@@ -591,8 +640,8 @@ __global__ void spx_ftx_hist_kernel(FtxParams p, uint32_t* counts, uint32_t* sta
     uint32_t hi = 0;
     for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nPersp; q += (gridDim.x * blockDim.x) >> 6) {
         const uint32_t head = p.heads[2 * size_t(q)];
-        const uint32_t nCold = head >> 21;
-        const uint32_t* list = p.lists + size_t(q) * kFtxListStride + kFtxListThr;
+        const uint32_t nCold = head >> 15;
+        const uint32_t* list = p.lists + size_t(q) * kFtxListStride + kFtxListCold;
         for (uint32_t i = lane; i < nCold; i += 64) atomicAdd(&counts[list[i] >> 7], 1u);
         if (lane == 0) hi += head & 0x3Fu;
     }
@@ -641,6 +690,7 @@ hipError_t launchFtxSortAndPlan(const FtxParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_ftx_rank_kernel, dim3((nPersp + 1023) / 1024), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_scatter_kernel, dim3((nPersp + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_pack_kernel, dim3((uint32_t(ftxGroups(p.nPositions)) + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -1067,12 +1067,20 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 template <bool kSmallL2W, int kTiling>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
     constexpr bool kShareTile = kTiling == kMlpTileShared;
-    __shared__ int32_t sSum[4][16][kL2 + 1];  // L1 sums of this wave's tile, padded against bank conflicts
-    __shared__ __align__(16) int32_t sIn[4][16][kL2Full];  // L2 inputs of the tile's positions (broadcast reads); then L3 terms
+    // Per wave 4 KiB of LDS, used twice: the L1 sums of the wave's tile ([16][33], padded against bank conflicts) sit at its END, the
+    // L2 inputs of the tile's positions ([16][64]; broadcast reads; later the L3 terms) grow from its start while the sums are
+    // consumed row by row - row k of the inputs ends at byte 256 (k + 1), row k + 1 of the sums starts at 1984 + 132 (k + 1), never
+    // below it. (Round 5: 16 instead of 24.3 KiB per workgroup, so that one fits beside the column-sliced gather's 136 KiB.)
+    __shared__ __align__(16) int32_t sBuf[4][16 * kL2Full];
+    static_assert(kL2Full * 16 - (kL2 + 1) * 16 + (kL2 + 1) * 16 == kL2Full * 16 && (kL2Full - (kL2 + 1)) * 16 >= 0, "the sums fit");
+    static_assert(kL2Full * 16 >= (kL2Full - (kL2 + 1)) * 16 + (kL2 + 1) * 16 && kL2Full * 15 <= (kL2Full - (kL2 + 1)) * 16 + (kL2 + 1) * 15,
+                  "input row k never reaches sum row k + 1");
 
     const uint32_t lane = laneId();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = kShareTile ? blockIdx.x : blockIdx.x * 4 + wave;
+    int32_t (*const sSumW)[kL2 + 1] = reinterpret_cast<int32_t (*)[kL2 + 1]>(sBuf[wave] + 16 * (kL2Full - (kL2 + 1)));
+    int32_t (*const sInW)[kL2Full] = reinterpret_cast<int32_t (*)[kL2Full]>(sBuf[wave]);
 
     // ---- locate this tile: bucket, first sorted index, number of real positions ----
     uint32_t bucket = 0, sortedBase = 0, count = 0;
@@ -1131,8 +1139,8 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     // C/D layout of the 16x16 MFMA: lane holds column (lane & 15), rows (lane >> 4) * 4 + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        sSum[wave][kGroup * 4 + r][rowInTile] = acc0[r];
-        sSum[wave][kGroup * 4 + r][16 + rowInTile] = acc1[r];
+        sSumW[kGroup * 4 + r][rowInTile] = acc0[r];
+        sSumW[kGroup * 4 + r][16 + rowInTile] = acc1[r];
     }
 
     // ---- per-lane constants of this bucket: lane = L2/L3 output neuron o, L1 neuron = lane & 31 ----
@@ -1164,14 +1172,14 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
         const uint32_t r = rowBegin + uint32_t(k) * rowStep;
         mine[k] = 0;
         if (r < count) {
-            const int32_t s = sSum[wave][r][o1];
+            const int32_t s = sSumW[r][o1];
             const uint32_t t = uint32_t(s >> kL1Shift) + uint32_t(l1Bias);  // wraps
             const int32_t ts = int32_t(t);
             const int32_t c0 = min(max(ts, 0), 4096) << kQBits;  // CReLU side, pre-shifted for the skip connection
             const int32_t sq = int32_t(t * t);                    // mullo wraps BEFORE the signed min
             const int32_t c1 = min(sq, 1 << 24) >> kQBits;        // SCReLU side
             mine[k] = lane < kL2 ? c0 : c1;                       // l1o[lane] = [CReLU(32) | SCReLU(32)]
-            sIn[wave][k][lane] = mine[k] >> kQBits;               // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
+            sInW[k][lane] = mine[k] >> kQBits;               // L2 input (multilayer.h:281-283), in (-2^20, 2^12]
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 #pragma unroll
         for (int k = 0; k < kRows; ++k) {
             if (rowBegin + uint32_t(k) * rowStep < count) {  // wave-uniform
-                const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sIn[wave][k][i]);
+                const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sInW[k][i]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if constexpr (kSmallL2W) {
@@ -1201,7 +1209,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const int32_t l2v = min(max(int32_t(acc2[k]), 0), 262144);
-        sIn[wave][k][lane] = int32_t((uint32_t(l2v) + uint32_t(mine[k])) * uint32_t(l3Weight));
+        sInW[k][lane] = int32_t((uint32_t(l2v) + uint32_t(mine[k])) * uint32_t(l3Weight));
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
         if (k < uint32_t(kRows)) {
 #pragma unroll
             for (int j = 0; j < 16; j += 4) {
-                const i32x4 t4 = *reinterpret_cast<const i32x4*>(&sIn[wave][k][q * 16 + j]);
+                const i32x4 t4 = *reinterpret_cast<const i32x4*>(&sInW[k][q * 16 + j]);
                 sum += uint32_t(t4[0]) + uint32_t(t4[1]) + uint32_t(t4[2]) + uint32_t(t4[3]);
             }
         }
