@@ -33,6 +33,9 @@
 #include <cstdint>
 
 #include "spx_ft_device.h"
+#ifndef SPX_CORUNNER_PRIO
+#define SPX_CORUNNER_PRIO 0
+#endif
 #include "spx_ftx.h"
 
 namespace spx {
@@ -101,10 +104,15 @@ constexpr uint32_t kItemCap = 256;  // per kind: <= 30 attackers x 8 targets; ma
 // colours: a feature of the perspective that owns `from`, whose mask it is - nnue_state.cpp:330-351) << 12
 
 __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel(FtxParams p) {
-    __shared__ uint32_t sLut[kLutWords];
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
+    // 11.4 KB of LDS per workgroup: TWO of them fit beside a gather workgroup with 256 hot rows (136 of the CU's 160 KiB); the
+    // compact-row bitmap (2.8 KB with its near-compact twin) is read from memory instead (one word per occupied square, L1 resident)
+    __shared__ uint32_t sLut[kLutCompactBase];
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];
     __shared__ uint16_t sItems[kWavesPerBlock][2][kItemCap];
-    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) sLut[i] = p.t.lut[i];
+    for (int i = threadIdx.x; i < kLutCompactBase; i += blockDim.x) sLut[i] = p.t.lut[i];
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
     __syncthreads();
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             bool wide = false;
             if (occupied) {
                 row = psqRow(c, piece, int(lane), kingSq);
-                wide = !((sLut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
+                wide = !((p.t.lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
             }
             const uint64_t wideMask = __ballot(wide);
             const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
@@ -233,6 +241,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
 // Counting sort by key, part 1: block-local ranks through an LDS histogram, one global atomic per block and non-empty bin.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     __shared__ uint32_t sCount[kFtxBins], sBase[kFtxBins];
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) sCount[k] = 0;
     __syncthreads();
@@ -250,32 +261,50 @@ __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Bin starts and the plan. One workgroup.
+// Bin starts and the plan. One workgroup of FOUR waves: it has to find room beside a gather workgroup when the other lane's
+// gather is running (16 waves x 96 registers leave 128 registers per SIMD lane: one wave of this kernel each). As 16 waves x 39
+// registers (round 4) it waited for the first gather workgroup to exit: 190 us per step
+// (profiles/r05_timeline_pipelined_steps_first_version.txt).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
+constexpr uint32_t kPlanThreads = 256, kPlanWaves = kPlanThreads / 64;
+constexpr uint32_t kPlanBinsPerLane = (kFtxQuartetBins + 63) / 64, kPlanBinsPerThread = (kFtxBins + kPlanThreads - 1) / kPlanThreads;
+
+__global__ __launch_bounds__(kPlanThreads) void spx_ftx_plan_kernel(FtxParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     __shared__ uint32_t sBin[kFtxBins + 1];    // counts, then starts
     __shared__ uint32_t sBucketStart[17], sBucketCount[16];
     __shared__ uint32_t sGroups[kFtxBins];     // per bin: groups whose longest list ends in it; then the index of the first of them
     __shared__ uint32_t sCost[kFtxBins];       // per bin: their cost; then the exclusive prefix of it
-    __shared__ uint32_t sWaveSum[32];
+    __shared__ uint32_t sWaveSum[2 * kPlanWaves];
     __shared__ uint8_t sHead[kFtxBins];
     __shared__ uint32_t sCut[33];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
+    for (uint32_t k = tid; k < kFtxBins; k += kPlanThreads) {
         sBin[k] = p.hist[k];
         p.hist[k] = 0;  // ready for the next batch's rank kernel
     }
     __syncthreads();
-    // bucket totals and bin starts: one wave per bucket, 80 bins = two per lane (lanes 0 .. 39), a wave scan
+    // bucket totals and the bins' starts inside their bucket: a wave per bucket (four buckets each), kPlanBinsPerLane bins per lane
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    uint32_t c0 = 0, c1 = 0, mineIncl = 0;
-    {
-        if (lane < kFtxQuartetBins / 2) {
-            c0 = sBin[wave * kFtxQuartetBins + 2 * lane];
-            c1 = sBin[wave * kFtxQuartetBins + 2 * lane + 1];
+    for (uint32_t b = wave; b < 16; b += kPlanWaves) {
+        uint32_t c[kPlanBinsPerLane], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kPlanBinsPerLane; ++i) {
+            const uint32_t kk = kPlanBinsPerLane * lane + i;
+            c[i] = kk < kFtxQuartetBins ? sBin[b * kFtxQuartetBins + kk] : 0u;
+            sum += c[i];
         }
-        mineIncl = waveInclusiveScan(c0 + c1);
-        if (lane == 63) sBucketCount[wave] = mineIncl;
+        const uint32_t incl = waveInclusiveScan(sum);
+        uint32_t at = incl - sum;
+#pragma unroll
+        for (uint32_t i = 0; i < kPlanBinsPerLane; ++i) {
+            const uint32_t kk = kPlanBinsPerLane * lane + i;
+            if (kk < kFtxQuartetBins) sBin[b * kFtxQuartetBins + kk] = at;
+            at += c[i];
+        }
+        if (lane == 63) sBucketCount[b] = incl;
     }
     __syncthreads();
     if (wave == 0) {
@@ -285,28 +314,25 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         if (lane == 16) sBucketStart[16] = incl;
     }
     __syncthreads();
-    {
-        const uint32_t base = sBucketStart[wave];
-        if (lane < kFtxQuartetBins / 2) {
-            sBin[wave * kFtxQuartetBins + 2 * lane] = base + mineIncl - c0 - c1;
-            sBin[wave * kFtxQuartetBins + 2 * lane + 1] = base + mineIncl - c1;
-        }
-        const uint32_t end = base + sBucketCount[wave];
-        if (lane < 8 && end + lane < sBucketStart[wave + 1]) {  // holes that pad the bucket to whole groups
-            reinterpret_cast<u32x4*>(p.sorted)[end + lane] = u32x4{0u, 0xFFFFFFFFu, 0u, 0u};
-        }
+    for (uint32_t k = tid; k < kFtxBins; k += kPlanThreads) {
+        const uint32_t start = sBin[k] + sBucketStart[k / kFtxQuartetBins];
+        sBin[k] = start;
+        p.binStart[k] = start;
     }
-    __syncthreads();
-    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) p.binStart[k] = sBin[k];
+    if (tid < 16 * 8) {  // holes that pad a bucket to whole groups
+        const uint32_t b = tid >> 3, hole = sBucketStart[b] + sBucketCount[b] + (tid & 7u);
+        if (hole < sBucketStart[b + 1]) reinterpret_cast<u32x4*>(p.sorted)[hole] = u32x4{0u, 0xFFFFFFFFu, 0u, 0u};
+    }
     if (tid < 17) p.binStart[kFtxBins + tid] = sBucketStart[tid];
+    __syncthreads();
 
     // Cost of a group = the steps of its last valid perspective's bin (ftxBinCost: global steps count double; bins ascend inside a
     // bucket, global quartets first - the section every member pads to the group's longest) + a constant for the group's fixed work -
-    // piecewise constant over the BINS, so everything below runs over 1 280 bins, not 16 K groups.
+    // piecewise constant over the BINS, so everything below runs over the bins, not the 16 K groups.
     // Inside bucket b (relative positions, groups of 8 from its start) the groups whose last member lies in [s, e) are
     // G' = s / 8 .. e / 8 - 1, plus the bucket's final partial group, whose last member is the bucket's last perspective.
     const uint32_t nGroups = sBucketStart[16] / 8;
-    for (uint32_t k = tid; k < kFtxBins; k += blockDim.x) {
+    for (uint32_t k = tid; k < kFtxBins; k += kPlanThreads) {
         const uint32_t b = k / kFtxQuartetBins, kk = k % kFtxQuartetBins, base = sBucketStart[b], count = sBucketCount[b];
         const uint32_t s0 = sBin[k] - base, e0 = (kk + 1 < kFtxQuartetBins ? sBin[k + 1] : base + count) - base;
         uint32_t ng = e0 / 8 - s0 / 8;
@@ -320,27 +346,38 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
         sCost[k] = ng * (ftxBinCost(kk, p.coldShift) + kFtxGroupCost) + (bucketHead ? kFtxSegmentCost : 0u);
     }
     __syncthreads();
-    uint32_t g2[2] = {0, 0}, w2[2] = {0, 0};
-    if (tid < kFtxBins / 2) {
-        g2[0] = sGroups[2 * tid], g2[1] = sGroups[2 * tid + 1];
-        w2[0] = sCost[2 * tid], w2[1] = sCost[2 * tid + 1];
+    // exclusive prefixes of the costs and of the group counts over the bins: kPlanBinsPerThread consecutive bins per thread, wave
+    // scans of the threads' sums, the waves' totals
+    uint32_t gMine[kPlanBinsPerThread], wMine[kPlanBinsPerThread], gSum = 0, wSum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kPlanBinsPerThread; ++i) {
+        const uint32_t k = kPlanBinsPerThread * tid + i;
+        gMine[i] = k < kFtxBins ? sGroups[k] : 0u;
+        wMine[i] = k < kFtxBins ? sCost[k] : 0u;
+        gSum += gMine[i];
+        wSum += wMine[i];
     }
-    // exclusive prefixes of the costs and of the group counts over the bins (two per thread): wave scans + the 16 wave totals
-    const uint32_t wIncl = waveInclusiveScan(w2[0] + w2[1]), gIncl = waveInclusiveScan(g2[0] + g2[1]);
-    if (lane == 63) sWaveSum[wave] = wIncl, sWaveSum[16 + wave] = gIncl;
+    const uint32_t wIncl = waveInclusiveScan(wSum), gIncl = waveInclusiveScan(gSum);
+    if (lane == 63) sWaveSum[wave] = wIncl, sWaveSum[kPlanWaves + wave] = gIncl;
     __syncthreads();
     uint32_t wBase = 0, gBase = 0, total = 0;
-    for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t w = sWaveSum[i], g = sWaveSum[16 + i];
+    for (uint32_t i = 0; i < kPlanWaves; ++i) {
+        const uint32_t w = sWaveSum[i], g = sWaveSum[kPlanWaves + i];
         total += w;
         if (i < wave) wBase += w, gBase += g;
     }
-    if (tid < kFtxBins / 2) {
-        const uint32_t costBefore = wBase + wIncl - (w2[0] + w2[1]), groupsBefore = gBase + gIncl - (g2[0] + g2[1]);
-        sCost[2 * tid] = costBefore;
-        sCost[2 * tid + 1] = costBefore + w2[0];
-        sGroups[2 * tid] = groupsBefore;  // (bins follow the sorted order, so the running count IS the group index)
-        sGroups[2 * tid + 1] = groupsBefore + g2[0];
+    {
+        uint32_t costBefore = wBase + wIncl - wSum, groupsBefore = gBase + gIncl - gSum;
+#pragma unroll
+        for (uint32_t i = 0; i < kPlanBinsPerThread; ++i) {
+            const uint32_t k = kPlanBinsPerThread * tid + i;
+            if (k < kFtxBins) {
+                sCost[k] = costBefore;
+                sGroups[k] = groupsBefore;  // (bins follow the sorted order, so the running count IS the group index)
+            }
+            costBefore += wMine[i];
+            groupsBefore += gMine[i];
+        }
     }
     __syncthreads();
     // CU slot c - 1 ends with the group at which the running cost reaches total * c / 32: bisect the bins' cost prefix
@@ -402,6 +439,9 @@ __global__ __launch_bounds__(1024) void spx_ftx_plan_kernel(FtxParams p) {
 
 // counting sort, part 2: the perspective's head and list at its place in the sorted order
 __global__ void spx_ftx_scatter_kernel(FtxParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= 2 * p.nPositions) return;
     const uint32_t key = p.keys[q];
@@ -415,6 +455,9 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 // four rows of step ks of perspective g: 16 bytes of its list, 8 consecutive lanes one 128-byte line.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     const uint32_t lane = laneId(), G = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (G >= p.plan[33]) return;
     const uint32_t g = lane >> 3, ks = lane & 7u;
@@ -688,7 +731,7 @@ hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
 hipError_t launchFtxSortAndPlan(const FtxParams& p, hipStream_t stream) {
     const uint32_t nPersp = 2 * p.nPositions;
     hipLaunchKernelGGL(spx_ftx_rank_kernel, dim3((nPersp + 1023) / 1024), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_scatter_kernel, dim3((nPersp + 255) / 256), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(spx_ftx_pack_kernel, dim3((uint32_t(ftxGroups(p.nPositions)) + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, stream, p);
     return hipGetLastError();

@@ -21,6 +21,9 @@
 #include <cstdint>
 
 #include "spx_ft_device.h"
+#ifndef SPX_CORUNNER_PRIO
+#define SPX_CORUNNER_PRIO 0
+#endif
 #include "spx_ftx.h"
 
 namespace spx {
@@ -908,6 +911,9 @@ constexpr int kOutKeys = 8;
 constexpr int kHistOut = 256, kCursorKing = 512, kCursorOut = 768;
 
 __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     __shared__ uint32_t sHist[kPairKeys + kOutKeys];
     for (uint32_t i = threadIdx.x; i < kPairKeys + kOutKeys; i += blockDim.x) sHist[i] = 0;
     __syncthreads();
@@ -947,6 +953,9 @@ __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
 
 // blocks [0, nb) scatter the first key (perspectives by king key); blocks [nb, nb + nb2) scatter positions by output key
 __global__ __launch_bounds__(256) void spx_sort_scatter_kernel(SortParams p, uint32_t firstBlocks) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     __shared__ uint32_t sCount[kPairKeys];
     __shared__ uint32_t sBase[kPairKeys];
     sCount[threadIdx.x] = 0;  // blockDim.x == kPairKeys
@@ -1066,6 +1075,9 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 // its bucket from its record - the handful-of-positions drop-in call, where a sort launch costs more than it saves.
 template <bool kSmallL2W, int kTiling>
 __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
+#if SPX_CORUNNER_PRIO
+    __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
+#endif
     constexpr bool kShareTile = kTiling == kMlpTileShared;
     // Per wave 4 KiB of LDS, used twice: the L1 sums of the wave's tile ([16][33], padded against bank conflicts) sit at its END, the
     // L2 inputs of the tile's positions ([16][64]; broadcast reads; later the L3 terms) grow from its start while the sums are

@@ -58,7 +58,7 @@ def simulate(lists, hot_rank, n_hot, key_mode, form, wide_rows=None, hi_slot=Non
         persp.append((b, len(psq), hot, cold, hi_cold, hi_hot))
     persp = np.array(persp, dtype=np.int64)
     b, npsq, hot, cold, hic, hih = persp.T
-    lds_q = q4(npsq) + q4(hot) + q4(hih)
+    lds_q = q4(npsq + hot + hih) if form.startswith("stages") else q4(npsq) + q4(hot) + q4(hih)
     glob_q = q4(cold) + q4(hic)
     if key_mode == "total":
         key = b * 100000 + np.minimum(lds_q + glob_q, 79)
@@ -80,6 +80,17 @@ def simulate(lists, hot_rank, n_hot, key_mode, form, wide_rows=None, hi_slot=Non
             secs_g = [q4(cold[grp]), q4(hic[grp])]
             if form == "group":      # 4 wave loads per step, steps = the longest list's quartets, per section
                 l_reads += 4 * sum(int(x.max()) for x in secs_l)
+                g_loads += 4 * sum(int(x.max()) for x in secs_g)
+            elif form == "stages":   # round 5: the LDS section merged (piece-square + hot rows), stages of 8 steps walked in pairs
+                def even_stages(q):
+                    full, rest = divmod(int(q), 8)
+                    return 8 * full + ((rest + 1) & ~1)
+                lq = q4(npsq[grp] + hot[grp] + hih[grp])
+                l_reads += 4 * even_stages(lq.max())
+                g_loads += 4 * sum(even_stages(x.max()) for x in secs_g)
+            elif form == "stages_exact":  # ... without the padding to pairs
+                lq = q4(npsq[grp] + hot[grp] + hih[grp])
+                l_reads += 4 * int(lq.max())
                 g_loads += 4 * sum(int(x.max()) for x in secs_g)
             elif form == "pairs":    # every perspective pair walks its own quartets
                 pad = np.zeros(8, dtype=np.int64)
@@ -132,8 +143,8 @@ def main():
     base = simulate(lists, hot_rank, 0, "total", "group", wide)
     print(f"{'base (round 4)':58s} {base[0]:20.1f} {base[1]:18.1f}")
     for n in (256, 320):
-        for key_mode in ("total", "cold_exact", "bins20x4x2", "bins16x5x2", "bins20x4x3", "bins26x3x3", "bins40x2x3", "bins80x1x0", "bins32x8x1"):
-            for form in ("group",):
+        for key_mode in ("cold_exact", "bins16x5x2"):
+            for form in ("group", "stages_exact", "stages"):
                 g, l = simulate(lists, hot_rank, n, key_mode, form, wide)
                 print(f"{'hot %d, key %s, %s' % (n, key_mode, form):58s} {g:20.1f} {l:18.1f}   global x {g / base[0]:.3f}")
 
