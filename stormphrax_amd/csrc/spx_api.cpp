@@ -51,11 +51,11 @@ constexpr size_t kProfEventsPerCall = 5;
 
 // scratch of the column-sliced full refresh (spx_ftx.hip): one set per context and per lane, allocated on first use
 struct FtxScratch {
-    uint32_t *lists = nullptr, *heads = nullptr, *keys = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
+    uint32_t *lists = nullptr, *heads = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
              *sorted = nullptr, *plan = nullptr, *groupHead = nullptr, *stages = nullptr;
     size_t capacity = 0;  // positions per pass
     void release() {
-        for (uint32_t* q : {lists, heads, keys, ranks, hist, binStart, sorted, plan, groupHead, stages}) {
+        for (uint32_t* q : {lists, heads, ranks, hist, binStart, sorted, plan, groupHead, stages}) {
             if (q) (void)hipFree(q);
         }
         *this = FtxScratch{};
@@ -76,7 +76,8 @@ struct spx_ctx {
     // the gather's hot set: the threat / pawn-pair rows it keeps in LDS beside the piece-square slab (spx_ftx.h). Chosen from DATA - a
     // histogram over the first batch that takes the pipeline (calibrateHotRows) or over the batch handed to spx_ctx_calibrate -;
     // results never depend on it. Per context: the ranks of a multi-GPU job calibrate independently.
-    uint16_t* dHotSlot = nullptr;    // [kThreatRows] row -> LDS slot, 0xFFFF = cold
+    uint32_t* dHotHash = nullptr;    // [kFtxHotHashWords] row -> LDS slot as a hash (FtxParams::hotHash)
+    uint32_t hotHashMul = 1;
     uint8_t* dHotS = nullptr;        // [8][hotRows][128 B]
     uint32_t* dHotIds = nullptr;     // [kFtxHotRowsMax]
     uint32_t* dHotCounts = nullptr;  // [kThreatRows + 16] the calibration's histogram (+ statistics)
@@ -754,7 +755,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         if (p) (void)hipFree(p);
     }
     ctx->ftx.release();
-    for (void* q : {static_cast<void*>(ctx->dRowS), static_cast<void*>(ctx->dHotSlot), static_cast<void*>(ctx->dHotS),
+    for (void* q : {static_cast<void*>(ctx->dRowS), static_cast<void*>(ctx->dHotHash), static_cast<void*>(ctx->dHotS),
                     static_cast<void*>(ctx->dHotIds), static_cast<void*>(ctx->dHotCounts)}) {
         if (q) (void)hipFree(q);
     }
@@ -862,9 +863,26 @@ static int installHotRows(spx_ctx* ctx, const std::vector<uint32_t>& ids, hipStr
     for (auto& lane : ctx->lanes) {
         if (lane.stream) SPX_HIP(hipStreamSynchronize(lane.stream));
     }
-    SPX_HIP(hipMemsetAsync(ctx->dHotSlot, 0xFF, kThreatRows * sizeof(uint16_t), s));
+    // the extraction's view of the set: a hash of 256 buckets x 4 entries (row | slot << 16), the multiplier that leaves the fewest
+    // rows without a place (such a row is simply cold: its slot in the gather's LDS goes unused)
+    std::vector<uint32_t> best(kFtxHotHashWords, 0xFFFFFFFFu);
+    uint32_t bestMul = 1, bestLost = n + 1;
+    for (uint32_t trial = 0; trial < 64 && bestLost; ++trial) {
+        const uint32_t mul = (0x9E3779u + 0x3C6EF3u * trial) | 1u;  // (24-bit odd multipliers: the kernel uses v_mul_u32_u24)
+        std::vector<uint32_t> table(kFtxHotHashWords, 0xFFFFFFFFu);
+        uint32_t lost = 0;
+        for (uint32_t slot = 0; slot < n; ++slot) {
+            const uint32_t bucket = (((ids[slot] & 0xFFFFFFu) * (mul & 0xFFFFFFu)) >> 16) & (kFtxHotHashWords / 4 - 1);
+            uint32_t i = 0;
+            while (i < 4 && table[4 * bucket + i] != 0xFFFFFFFFu) ++i;
+            if (i < 4) table[4 * bucket + i] = ids[slot] | (slot << 16); else ++lost;
+        }
+        if (lost < bestLost) bestLost = lost, bestMul = mul & 0xFFFFFFu, best.swap(table);
+    }
+    ctx->hotHashMul = bestMul;
+    SPX_HIP(hipMemcpyAsync(ctx->dHotHash, best.data(), kFtxHotHashWords * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (n) SPX_HIP(hipMemcpyAsync(ctx->dHotIds, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    SPX_HIP(launchFtxBuildHot(ctx->dRowS, ctx->dHotIds, n, ctx->dHotSlot, ctx->dHotS, s));
+    SPX_HIP(launchFtxBuildHot(ctx->dRowS, ctx->dHotIds, n, ctx->dHotS, s));
     SPX_HIP(hipStreamSynchronize(s));  // (the host buffer may go; other streams may use the tables next)
     ctx->hotRows = n;
     return SPX_OK;
@@ -879,7 +897,8 @@ static int calibrateHotRows(spx_ctx* ctx, FtxParams xp, hipStream_t s) {
     ctx->hotIds.clear();
     const uint32_t wanted = std::min(ctx->hotRowsWanted, kFtxHotRowsMax);
     if (!wanted || xp.nPositions == 0) return SPX_OK;
-    xp.hotSlot = ctx->dHotSlot;
+    xp.hotHash = ctx->dHotHash;
+    xp.hotHashMul = ctx->hotHashMul;
     xp.hotS = ctx->dHotS;
     xp.hotRows = 0;
     xp.coldShift = 1;
@@ -929,13 +948,13 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
         // L2s (and may not be co-resident): such devices keep the one-kernel path
         if (ctx->computeUnits != 256 || prepareFtxGather(ctx->device) != hipSuccess) return fail();
         if (hipMalloc(reinterpret_cast<void**>(&ctx->dRowS), kFtxTableBytes) != hipSuccess) return fail();
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->dHotSlot), kThreatRows * sizeof(uint16_t)) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->dHotHash), kFtxHotHashWords * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&ctx->dHotS), size_t(8) * kFtxHotRowsMax * 128) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&ctx->dHotIds), kFtxHotRowsMax * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&ctx->dHotCounts), (kThreatRows + 16) * sizeof(uint32_t)) != hipSuccess) {
             return fail();
         }
-        if (hipMemsetAsync(ctx->dHotSlot, 0xFF, kThreatRows * sizeof(uint16_t), s) != hipSuccess) return fail();
+        if (hipMemsetAsync(ctx->dHotHash, 0xFF, kFtxHotHashWords * sizeof(uint32_t), s) != hipSuccess) return fail();
         if (launchFtxBuildTable(ctx->dThrW, ctx->dPsqW, ctx->dLut, ctx->dRowS, s) != hipSuccess) return fail();
         // (other streams may use the tables next: the lanes' streams do not wait for this one)
         if (hipStreamSynchronize(s) != hipSuccess) return fail();
@@ -947,7 +966,7 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     if (ctx->ftxFailAfter >= 0 && ctx->ftxScratchSets++ >= ctx->ftxFailAfter) return fail();
     const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
-    if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 8) || !alloc(x.keys, 2 * cap * 4) ||
+    if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 16) ||
         !alloc(x.ranks, 2 * cap * 4) || !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) ||
         !alloc(x.sorted, (2 * cap + 128) * 16) || !alloc(x.plan, kFtxPlanWords * 4) ||
         !alloc(x.groupHead, ftxGroups(cap) * kFtxGroupHeadWords * 4) || !alloc(x.stages, ftxStageBytes(cap))) {
@@ -1009,7 +1028,6 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.rowS = ctx->dRowS;
             xp.lists = scratch.lists;
             xp.heads = scratch.heads;
-            xp.keys = scratch.keys;
             xp.ranks = scratch.ranks;
             xp.hist = scratch.hist;
             xp.binStart = scratch.binStart;
@@ -1021,7 +1039,8 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             if (!ctx->hotCalibrated) {  // the first big batch of this context chooses the hot set (synchronises the stream once)
                 if ((rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;
             }
-            xp.hotSlot = ctx->dHotSlot;
+            xp.hotHash = ctx->dHotHash;
+            xp.hotHashMul = ctx->hotHashMul;
             xp.hotS = ctx->dHotS;
             xp.hotRows = ctx->hotRows;
             xp.coldShift = ctx->coldShift;
@@ -1942,7 +1961,6 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n) {
     xp.rowS = ctx->dRowS;
     xp.lists = ctx->ftx.lists;
     xp.heads = ctx->ftx.heads;
-    xp.keys = ctx->ftx.keys;
     return calibrateHotRows(ctx, xp, ctx->stream);
 }
 

@@ -139,6 +139,33 @@ __device__ __forceinline__ LaneBoard decodeBoardWord(uint32_t w, uint32_t lane) 
     return b;
 }
 
+// The same from a record that sits in SGPRs (a wave that walks records by a wave-uniform index fetches them through the SCALAR
+// cache - s_load_dwordx8, its own counter: the vector-memory counter is in order, so a record asked for through it cannot be
+// waited for without waiting for every store issued since).
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x8 scalarLoadRecord(const void* rec) {  // (rec must be wave-uniform; returns before the data does)
+    u32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(rec));
+    return r;
+}
+__device__ __forceinline__ void scalarLoadWait(u32x8& r) {  // (every outstanding scalar / LDS operation of the wave, in fact)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+}
+__device__ __forceinline__ LaneBoard decodeBoardScalar(const u32x8& r, uint32_t lane) {
+    LaneBoard b;
+    b.occ = (uint64_t(r[1]) << 32) | r[0];
+    b.stm = (r[6] & 0x80u) ? 0 : 1;
+    const bool occupied = (b.occ >> lane) & 1;
+    const uint32_t nibIdx = min(prefixCount(b.occ), 31u), k = nibIdx >> 3;  // (> 32 pieces: malformed, stay inside the 16 bytes)
+    const uint32_t word = k == 0 ? r[2] : (k == 1 ? r[3] : (k == 2 ? r[4] : r[5]));
+    b.piece = occupied ? nibbleToPiece(int((word >> ((nibIdx & 7) * 4)) & 0xF)) : int(kNoPiece);
+    const int type = b.piece >> 1;  // 6 for empty
+    b.kingsBb = __ballot(type == 5);
+    b.whiteBb = __ballot(occupied && (b.piece & 1) == 1);
+    b.pawnsBb = __ballot(type == 0) & 0x00FFFFFFFFFFFF00ull;  // (see decodeBoardWord)
+    return b;
+}
+
 __device__ __forceinline__ LaneBoard decodeBoard(const uint8_t* rec, uint32_t lane) {
     return decodeBoardWord(loadRecordWord(rec, lane), lane);
 }

@@ -37,19 +37,25 @@ constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket:
 constexpr uint32_t kFtxSlabBytes = (kFtxSlabRows + 1) * 128;
 constexpr uint32_t kFtxHotRowsMax = 384;       // capacity of the tables; what a context uses: option ftx_hot_rows
 constexpr uint32_t kFtxHotRowsDefault = 256;   // slab 88.1 + hot 32 + ring 16 = 136.1 KiB: one 14 / 16 KiB co-runner workgroup fits beside it
+constexpr uint32_t kFtxHotHashWords = 1024;    // the extraction's LDS copy of the set: 256 buckets x 4 entries
 constexpr uint32_t kFtxRingBytesPerWave = 1024 + 64;  // one stage of 8 steps x 8 perspectives x 4 entries + the group's head
 
 // ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
 // [0, 288) the LDS section: the piece-square rows ((row - 704 bucket) * 128, into the slab), then the HOT threat / pawn-pair rows
 // (kFtxSlabBytes + slot * 128) - byte offsets into the gather's LDS; [288, 320) high-byte planes of the wide piece-square rows and
 // [320, 576) the COLD threat / pawn-pair rows as slice offsets (row index * 128). Words behind a section's count are undefined.
-// heads[perspective] = {nHi | nLds << 6 | nCold << 15, 2 * position + (0 = side-to-move half, 1 = other half)}
+// heads[perspective] = {nHi | nLds << 6 | nCold << 15, 2 * position + (0 = side-to-move half, 1 = other half), sort key, -}
 constexpr uint32_t kFtxListStride = 576, kFtxListLds = 0, kFtxListHi = 288, kFtxListCold = 320;
 // sort key of a perspective: king bucket * 80 + min(global quartets >> coldShift, 15) * 5 + min(LDS quartets >> 2, 4) - the quartets
 // fetched through the texture path (high planes + cold rows) first: they cost twice an LDS step, and a group of 8 neighbours
 // walks as many of them as its longest list has. With the round-4 key (total quartets) the hot / cold split of the lists pads
 // away half of what the hot rows save: 65.5 instead of 52.0 wave loads per position at 320 hot rows (tools/sim_gather_steps.py).
 constexpr uint32_t kFtxQuartetBins = 80, kFtxBins = 16 * kFtxQuartetBins, kFtxLdsClasses = 5;
+__host__ __device__ inline uint32_t ftxSortKey(uint32_t bucket, uint32_t globalQ, uint32_t ldsQ, uint32_t coldShift) {
+    const uint32_t gc = globalQ >> coldShift, lc = ldsQ >> 2;
+    return bucket * kFtxQuartetBins + (gc < kFtxQuartetBins / kFtxLdsClasses - 1 ? gc : kFtxQuartetBins / kFtxLdsClasses - 1) * kFtxLdsClasses +
+           (lc < kFtxLdsClasses - 1 ? lc : kFtxLdsClasses - 1);
+}
 // cost of a group whose last member lies in bin `kk` of its bucket, in LDS steps (a global step counts 2)
 __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) {
     const uint32_t cq = kk / kFtxLdsClasses, lc = kk % kFtxLdsClasses;
@@ -91,8 +97,7 @@ struct FtxParams {
     FtTables t;              // lut, deltaTab (pseudo-attack sets), ftBias
     const uint8_t* rowS;     // the sliced row table
     uint32_t* lists;         // [2 n][kFtxListStride]
-    uint32_t* heads;         // [2 n][2]
-    uint32_t* keys;          // [2 n] sort keys
+    uint32_t* heads;         // [2 n][4]
     uint32_t* ranks;         // [2 n] rank inside the key's bin
     uint32_t* hist;          // [kFtxBins] counts per key; zero on entry of the rank kernel, zeroed again by the plan kernel
     uint32_t* binStart;      // [kFtxBins + 17] first sorted position of each bin; then bucketStart[17]
@@ -101,7 +106,9 @@ struct FtxParams {
     uint32_t* groupHead;     // [(2 n + 128) / 8][kFtxGroupHeadWords]
     uint32_t* stages;        // [(2 n + 128) / 8][kFtxMaxStages][256]
     uint8_t* ftOut;          // [n][1024] activations (side-to-move half first)
-    const uint16_t* hotSlot; // [kThreatRows] LDS slot of a hot threat / pawn-pair row, 0xFFFF = cold
+    const uint32_t* hotHash; // [kFtxHotHashWords] the hot set as a hash: bucket ((row * hotHashMul) >> 16) & 255, four entries
+                             // row | slot << 16 (0xFFFFFFFF = empty); a row that is in no entry is cold
+    uint32_t hotHashMul;
     const uint8_t* hotS;     // [8 slices][hotRows][128 B] the hot rows' slices, in slot order
     uint32_t hotRows;        // rows of the hot set (0: none - every row is fetched through the texture path)
     uint32_t coldShift;      // sort key: global quartets >> this (1 for nets / sets with long cold sections)
@@ -113,10 +120,10 @@ inline size_t ftxStageBytes(size_t n) { return ftxGroups(n) * kFtxMaxStages * 10
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
 // the hot set: counts[row] += fetches of threat / pawn-pair row `row` in the lists of p (extracted with hotRows = 0), stats[0] +=
-// high-byte planes fetched; then the tables of a chosen set (hotSlot must be all 0xFFFF on entry)
+// high-byte planes fetched; then the slices of a chosen set in slot order (its hash is built on the host: spx_api.cpp)
 hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream);
 hipError_t launchFtxHistogram(const FtxParams& p, uint32_t* counts, uint32_t* stats, hipStream_t stream);
-hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS, hipStream_t stream);
+hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint8_t* hotS, hipStream_t stream);
 hipError_t prepareFtxGather(int device);  // allows the gather its dynamic LDS on this device (once; > 64 KiB needs the attribute)
 // everything before the gather (extract, rank, plan, scatter): may overlap another batch's gather
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream);

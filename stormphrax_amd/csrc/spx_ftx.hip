@@ -103,24 +103,39 @@ constexpr uint32_t kItemCap = 256;  // per kind: <= 30 attackers x 8 targets; ma
 // threat items: attacker square | victim square << 6; pawn items: from | to << 6 | (1 = same colour (from < to), 0 = different
 // colours: a feature of the perspective that owns `from`, whose mask it is - nnue_state.cpp:330-351) << 12
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel(FtxParams p) {
+// Beside a gather workgroup (its 16 waves x 96 registers and ~136 KiB of LDS) a CU has room for 128 registers per SIMD lane and
+// ~23 KB of LDS: one workgroup of EIGHT waves here (two per SIMD), sharing one copy of the tables - 20.9 KB. The kernel is bound by
+// its chains of dependent round trips, not by the VALU (a quarter of the resident waves: 3.4 x the time, profiles/
+// r05_timeline_pipelined_steps_first_version.txt), so nothing a wave waits for may come from further away than LDS: the next
+// record travels while this one is taken apart, and the hot set is looked up in an LDS hash (256 buckets of four row | slot << 16
+// entries, built on the host; a round-5 first version asked a 64 368-entry table in memory once per 64 rows).
+constexpr uint32_t kExtractWaves = 8;
+
+__global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(FtxParams p) {
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
-    // 11.4 KB of LDS per workgroup: TWO of them fit beside a gather workgroup with 256 hot rows (136 of the CU's 160 KiB); the
-    // compact-row bitmap (2.8 KB with its near-compact twin) is read from memory instead (one word per occupied square, L1 resident)
-    __shared__ uint32_t sLut[kLutCompactBase];
+    __shared__ uint32_t sLut[kLutCompactBase + kLutCompactWords];  // threat LUT + the compact-row bitmap
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];
-    __shared__ uint16_t sItems[kWavesPerBlock][2][kItemCap];
-    for (int i = threadIdx.x; i < kLutCompactBase; i += blockDim.x) sLut[i] = p.t.lut[i];
+    __shared__ __align__(16) uint32_t sHot[kFtxHotHashWords];
+    __shared__ uint16_t sItems[kExtractWaves][2][kItemCap];
+    for (int i = threadIdx.x; i < kLutCompactBase + kLutCompactWords; i += blockDim.x) sLut[i] = p.t.lut[i];
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
+    for (int i = threadIdx.x; i < int(kFtxHotHashWords); i += blockDim.x) sHot[i] = p.hotRows ? p.hotHash[i] : 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint16_t* const threatItems = sItems[wave][0];
     uint16_t* const pawnItems = sItems[wave][1];
-    for (uint32_t pos = blockIdx.x * kWavesPerBlock + wave; pos < p.nPositions; pos += gridDim.x * kWavesPerBlock) {
-        const uint8_t* rec = reinterpret_cast<const uint8_t*>(p.positions) + size_t(pos) * 32;
-        const LaneBoard b = decodeBoard(rec, lane);
+    // records through the scalar cache, one position ahead: the vector-memory counter is in order, a record asked for through it
+    // could only be waited for together with all the list stores of the position before (their round trip, once per position)
+    const uint32_t posStride = gridDim.x * kExtractWaves;
+    uint32_t pos = blockIdx.x * kExtractWaves + wave;
+    const uint8_t* const records = reinterpret_cast<const uint8_t*>(p.positions);
+    u32x8 record = scalarLoadRecord(records + size_t(min(pos, p.nPositions - 1)) * 32);
+    for (; pos < p.nPositions; pos += posStride) {
+        scalarLoadWait(record);
+        const LaneBoard b = decodeBoardScalar(record, lane);
+        record = scalarLoadRecord(records + size_t(min(pos + posStride, p.nPositions - 1)) * 32);
         const int piece = b.piece;
         const bool occupied = piece != kNoPiece;
         uint32_t nThreatItems, nPawnItems;
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
             bool wide = false;
             if (occupied) {
                 row = psqRow(c, piece, int(lane), kingSq);
-                wide = !((p.t.lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
+                wide = !((sLut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u);
             }
             const uint64_t wideMask = __ballot(wide);
             const uint32_t slot = prefixCount(b.occ), wideSlot = prefixCount(wideMask);
@@ -189,11 +204,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
                 const uint64_t valid = __ballot(r >= 0);
                 const bool taken = r >= 0 && nThr + prefixCount(valid) < kThreatCap;
                 uint32_t slot = 0xFFFFu;
-                if (taken && p.hotRows) slot = p.hotSlot[r];
+                if (taken) {  // the hot set's hash: bucket (row * multiplier) >> 24 mod 256, four entries row | slot << 16
+                    const u32x4 e = *reinterpret_cast<const u32x4*>(sHot + 4 * ((__umul24(uint32_t(r), p.hotHashMul) >> 16) & (kFtxHotHashWords / 4 - 1)));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if ((e[i] & 0xFFFFu) == uint32_t(r)) slot = e[i] >> 16;
+                    }
+                }
                 const bool hot = taken && slot != 0xFFFFu, cold = taken && !hot;
                 const uint64_t hotMask = __ballot(hot), coldMask = __ballot(cold);
-                if (hot) out[kFtxListLds + nPsq + nHot + prefixCount(hotMask)] = kFtxSlabBytes + slot * 128u;
-                if (cold) out[kFtxListCold + nCold + prefixCount(coldMask)] = uint32_t(r) * 128u;
+                // ONE store for both kinds (beside a gather every vector-memory instruction of this kernel queues behind the gather's
+                // row loads: without the list stores the pass took 223 instead of 272 us there, profiles/r05_gather_anatomy.txt)
+                if (taken) {
+                    out[hot ? kFtxListLds + nPsq + nHot + prefixCount(hotMask) : kFtxListCold + nCold + prefixCount(coldMask)] =
+                        hot ? kFtxSlabBytes + slot * 128u : uint32_t(r) * 128u;
+                }
                 nHot += uint32_t(popc64(hotMask));
                 nCold += uint32_t(popc64(coldMask));
                 nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
@@ -224,13 +249,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void spx_ftx_extract_kernel
                 emit(r);
             }
             if (lane == 0) {
-                u32x2 head;
+                u32x4 head;
                 head[0] = nHi | ((nPsq + nHot) << 6) | (nCold << 15);
                 head[1] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
-                *reinterpret_cast<u32x2*>(p.heads + 2 * size_t(q)) = head;
                 const uint32_t globalQ = (nHi + 3) / 4 + (nCold + 3) / 4, ldsQ = (nPsq + nHot + 3) / 4;
-                p.keys[q] = bucket * kFtxQuartetBins + min(globalQ >> p.coldShift, kFtxQuartetBins / kFtxLdsClasses - 1) * kFtxLdsClasses +
-                            min(ldsQ >> 2, kFtxLdsClasses - 1);
+                head[2] = ftxSortKey(bucket, globalQ, ldsQ, p.coldShift);
+                head[3] = 0;
+                *reinterpret_cast<u32x4*>(p.heads + 4 * size_t(q)) = head;
             }
         }
         __builtin_amdgcn_wave_barrier();  // (the next position's items overwrite these)
@@ -250,7 +275,7 @@ __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, nPersp = 2 * p.nPositions;
     uint32_t key = 0, local = 0;
     const bool mine = q < nPersp;
-    if (mine) key = p.keys[q];
+    if (mine) key = p.heads[4 * size_t(q) + 2];
     if (mine) local = atomicAdd(&sCount[key], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) {
@@ -444,9 +469,8 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 #endif
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= 2 * p.nPositions) return;
-    const uint32_t key = p.keys[q];
-    const u32x2 head = *reinterpret_cast<const u32x2*>(p.heads + 2 * size_t(q));
-    reinterpret_cast<u32x4*>(p.sorted)[p.binStart[key] + p.ranks[q]] = u32x4{head[0], head[1], q * (kFtxListStride * 4u), q};
+    const u32x4 head = *reinterpret_cast<const u32x4*>(p.heads + 4 * size_t(q));
+    reinterpret_cast<u32x4*>(p.sorted)[p.binStart[head[2]] + p.ranks[q]] = u32x4{head[0], head[1], q * (kFtxListStride * 4u), q};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -458,34 +482,65 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
-    const uint32_t lane = laneId(), G = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    __shared__ __align__(16) uint32_t sStage[kWavesPerBlock][256];
+    const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), G = blockIdx.x * kWavesPerBlock + wave;
     if (G >= p.plan[33]) return;
     const uint32_t g = lane >> 3, ks = lane & 7u;
     const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
     const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + g];
     const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
-    uint32_t hiQ = (cHi + 3) >> 2, ldsQ = (cLds + 3) >> 2, coldQ = (cCold + 3) >> 2;
+    // the sections' lengths: the longest of the 8 lists, in quartets (9 + 7 + 7 bits of one word per lane, three shuffles)
+    uint32_t dims = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
 #pragma unroll
     for (int dlt = 8; dlt < 64; dlt <<= 1) {
-        hiQ = max(hiQ, uint32_t(__shfl_xor(int(hiQ), dlt, 64)));
-        ldsQ = max(ldsQ, uint32_t(__shfl_xor(int(ldsQ), dlt, 64)));
-        coldQ = max(coldQ, uint32_t(__shfl_xor(int(coldQ), dlt, 64)));
+        const uint32_t other = uint32_t(__shfl_xor(int(dims), dlt, 64));
+        dims = max(dims & 0xFFu, other & 0xFFu) | max(dims & 0xFF00u, other & 0xFF00u) | max(dims & 0xFF0000u, other & 0xFF0000u);
     }
+    dims = __builtin_amdgcn_readfirstlane(dims);
+    const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
     uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
-    if (lane == 0) gh[0] = hiQ | (ldsQ << 8) | (coldQ << 16);
+    if (lane == 0) gh[0] = dims;
     if (ks == 0) gh[1 + g] = head[1];
     const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
     uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
-    for (uint32_t q = 0; q < Q; ++q, out += 256) {
-        const uint32_t sec = q < H ? 0u : (q < H + L ? 1u : 2u), s = q - (sec == 0 ? 0u : (sec == 1 ? H : H + L));
-        const uint32_t count = sec == 0 ? cHi : (sec == 1 ? cLds : cCold);
-        const uint32_t base = sec == 0 ? kFtxListHi : (sec == 1 ? kFtxListLds : kFtxListCold);
-        const uint32_t zero = sec == 1 ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
-        const uint32_t first = 4 * (8 * s + ks), left = count > first ? count - first : 0u;
-        u32x4 v = {0, 0, 0, 0};
-        if (left) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.lists) + (head[2] + 4 * (base + first)));
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) out[fillAt + 8 * i] = i < left ? v[i] : zero;
+    // stage q: which section, where this lane's four rows sit in its list, how many of them there are
+    auto place = [&](uint32_t q, uint32_t& at, uint32_t& left, uint32_t& zero) {
+        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS - 14 KB of it)
+        const uint32_t isLds = (q >= H && q < H + L) ? 1u : 0u, isCold = q >= H + L ? 1u : 0u, isHi = 1u - isLds - isCold;
+        const uint32_t s = q - isLds * H - isCold * (H + L);
+        const uint32_t count = (head[0] >> (6u * isLds + 15u * isCold)) & (0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u));
+        const uint32_t base = isHi * kFtxListHi + isLds * kFtxListLds + isCold * kFtxListCold;
+        const uint32_t first = 4 * (8 * s + ks);
+        zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
+        left = count > first ? count - first : 0u;
+        at = head[2] + 4 * (base + first);
+    };
+    const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
+    // the next stage's lists travel while this one is written; a stage passes through LDS so that it leaves as ONE coalesced 1 KiB
+    // store (beside a gather every vector-memory instruction queues behind the gather's row loads)
+    uint32_t at, left, zero;
+    u32x4 next = {0, 0, 0, 0};
+    if (Q > 0) {
+        place(0, at, left, zero);
+        if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
+    }
+    for (uint32_t q = 0; q < Q; ++q) {
+        const u32x4 v = next;
+        const uint32_t leftNow = left, zeroNow = zero;
+        if (q + 1 < Q) {
+            place(q + 1, at, left, zero);
+            next = u32x4{0, 0, 0, 0};
+            if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
+        }
+        uint32_t* st = &sStage[wave][fillAt];
+        st[0] = leftNow > 0 ? v[0] : zeroNow;
+        st[8] = leftNow > 1 ? v[1] : zeroNow;
+        st[16] = leftNow > 2 ? v[2] : zeroNow;
+        st[24] = leftNow > 3 ? v[3] : zeroNow;
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 line = *reinterpret_cast<const u32x4*>(&sStage[wave][4 * lane]);
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4*>(out + size_t(q) * 256 + 4 * lane) = line;
     }
 }
 
@@ -682,7 +737,7 @@ __global__ void spx_ftx_hist_kernel(FtxParams p, uint32_t* counts, uint32_t* sta
     const uint32_t lane = laneId(), nPersp = 2 * p.nPositions;
     uint32_t hi = 0;
     for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nPersp; q += (gridDim.x * blockDim.x) >> 6) {
-        const uint32_t head = p.heads[2 * size_t(q)];
+        const uint32_t head = p.heads[4 * size_t(q)];
         const uint32_t nCold = head >> 15;
         const uint32_t* list = p.lists + size_t(q) * kFtxListStride + kFtxListCold;
         for (uint32_t i = lane; i < nCold; i += 64) atomicAdd(&counts[list[i] >> 7], 1u);
@@ -691,13 +746,12 @@ __global__ void spx_ftx_hist_kernel(FtxParams p, uint32_t* counts, uint32_t* sta
     if (hi) atomicAdd(&stats[0], hi);
 }
 
-__global__ void spx_ftx_build_hot_kernel(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS) {
+__global__ void spx_ftx_build_hot_kernel(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint8_t* hotS) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
     if (idx >= hotRows * 64u) return;
     const uint32_t slot = idx >> 6, x = (idx >> 3) & 7u, t = idx & 7u, row = hotIds[slot];
     *reinterpret_cast<u32x4*>(hotS + (size_t(x) * hotRows + slot) * 128 + 16 * t) =
         *reinterpret_cast<const u32x4*>(rowS + (size_t(x) * kFtxRows + row) * 128 + 16 * t);
-    if ((idx & 63u) == 0) hotSlot[row] = uint16_t(slot);
 }
 
 hipError_t launchFtxHistogram(const FtxParams& p, uint32_t* counts, uint32_t* stats, hipStream_t stream) {
@@ -705,9 +759,9 @@ hipError_t launchFtxHistogram(const FtxParams& p, uint32_t* counts, uint32_t* st
     return hipGetLastError();
 }
 
-hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint16_t* hotSlot, uint8_t* hotS, hipStream_t stream) {
+hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32_t hotRows, uint8_t* hotS, hipStream_t stream) {
     if (!hotRows) return hipSuccess;
-    hipLaunchKernelGGL(spx_ftx_build_hot_kernel, dim3((hotRows * 64u + 255) / 256), dim3(256), 0, stream, rowS, hotIds, hotRows, hotSlot, hotS);
+    hipLaunchKernelGGL(spx_ftx_build_hot_kernel, dim3((hotRows * 64u + 255) / 256), dim3(256), 0, stream, rowS, hotIds, hotRows, hotS);
     return hipGetLastError();
 }
 
@@ -717,8 +771,8 @@ hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const 
 }
 
 hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream) {
-    const uint32_t extractBlocks = min((p.nPositions + kWavesPerBlock - 1) / kWavesPerBlock, 256u * 16u);
-    hipLaunchKernelGGL(spx_ftx_extract_kernel, dim3(extractBlocks), dim3(64 * kWavesPerBlock), 0, stream, p);
+    const uint32_t extractBlocks = min((p.nPositions + kExtractWaves - 1) / kExtractWaves, 256u * 4u);
+    hipLaunchKernelGGL(spx_ftx_extract_kernel, dim3(extractBlocks), dim3(64 * kExtractWaves), 0, stream, p);
     return hipGetLastError();
 }
 
