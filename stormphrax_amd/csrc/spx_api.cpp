@@ -138,7 +138,8 @@ struct spx_ctx {
         void *dIn = nullptr, *hIn = nullptr;
         int32_t *dOutStage = nullptr, *hOut = nullptr;
         FtxScratch ftx;
-    } lanes[2];
+    } lanes[3];  // (the third one serves spx_eval_full_device_async alone: option eval_lanes)
+    unsigned evalLanes = 3;
     bool lanesReady = false;
     bool lanesUnavailable = false;   // the lanes did not fit into the device memory: async calls run stream-ordered
     hipEvent_t fallbackDone = nullptr;
@@ -522,6 +523,17 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         }
         ctx->hotRowsWanted = uint32_t(value);
         ctx->hotCalibrated = false;
+        return SPX_OK;
+    }
+    if (key == "eval_lanes") {  // scratch sets spx_eval_full_device_async rotates its batches over (the preparation of up to N - 1 batches beside a gather)
+        if (value < 2 || value > 3) {
+            setError("option eval_lanes must be 2 or 3");
+            return SPX_ERR_INVALID_ARG;
+        }
+        const int rc = spx_ctx_synchronize(ctx);
+        if (rc != SPX_OK) return rc;
+        ctx->evalLanes = unsigned(value);
+        ctx->laneNext = 0;
         return SPX_OK;
     }
     if (key == "ftx_fail_after") {  // test hook: the k-th scratch set of the pipeline "does not fit" (-1: never)
@@ -1106,8 +1118,10 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dRefreshList), ctx->maxBatch * 2 * sizeof(uint32_t)));
-        SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking,
-                                            laneIndex++ == 0 ? leastPriority : greatestPriority));
+        // (lanes 0 / 1: the two ends of the range; lane 2: the level between them, where the device has one)
+        const int priority = laneIndex == 0 ? leastPriority : (laneIndex == 1 ? greatestPriority : (leastPriority + greatestPriority) / 2);
+        ++laneIndex;
+        SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking, priority));
         SPX_HIP(hipEventCreateWithFlags(&lane.ftDone, hipEventDisableTiming));
         SPX_HIP(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
     }
@@ -1169,9 +1183,11 @@ int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, 
     spx_ctx::EvalLane* last = nullptr;
     for (size_t lo = 0; lo < n || lo == 0; lo += chunk) {
         const size_t m = std::min(chunk, n - lo);
-        spx_ctx::EvalLane& lane = ctx->lanes[ctx->laneNext & 1];
-        spx_ctx::EvalLane& other = ctx->lanes[(ctx->laneNext & 1) ^ 1];
-        ++ctx->laneNext;
+        // the batches go round the lanes; a batch's big kernel waits for that of the batch before it (the lane before this one)
+        const unsigned nLanes = ctx->evalLanes, li = ctx->laneNext % nLanes;
+        spx_ctx::EvalLane& lane = ctx->lanes[li];
+        spx_ctx::EvalLane& other = ctx->lanes[(li + nLanes - 1) % nLanes];
+        ctx->laneNext = (ctx->laneNext + 1) % 6;
         swapLane(ctx, lane);
         ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
         ctx->ftGateRecord = lane.ftDone;
