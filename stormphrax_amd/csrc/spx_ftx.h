@@ -77,7 +77,7 @@ constexpr uint32_t kFtxGroupHeadWords = 16;
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:
 // {bucket, first group, end group} per segment ----
 #ifndef SPX_FTX_GROUP_COST
-#define SPX_FTX_GROUP_COST 2  // in LDS steps (round 4, in its unit - a step: A/B over 0, 1, 3, 6, 10, 1 best by 1 %)
+#define SPX_FTX_GROUP_COST 6  // in LDS steps (A/B over 2, 6, 12 on the packed walk: 6 is best by 1.5-2 %; round 4, in its unit: 1 of 0 .. 10)
 #endif
 constexpr uint32_t kFtxGroupCost = SPX_FTX_GROUP_COST;  // plan: a group costs its steps + this
 #ifndef SPX_FTX_SEGMENT_COST
