@@ -44,6 +44,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 HBM_ACHIEVABLE_GBS = 6300.0  # same guide: "~6.3 TB/s achievable" - the rate the L2-miss path is judged against
 L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
 N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # same guide: peak engine clock
+L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9  # the CU's texture / L1 path: 64 B per clock and CU = 39.3 TB/s
+LDS_PEAK_GBS = 256 * 128 * CLOCK_HZ / 1e9  # LDS: 128 B per clock and CU = 78.6 TB/s
+# tools/probes/tcp_mask_probe.hip (profiles/r05_probe_texture_path_cost_of_masked_and_narrow_loads.txt): cycles one wave instruction
+# of 16 bytes per lane holds the texture path / the LDS pipe of its CU, whatever its exec mask or width
+L1_CYCLES_PER_WAVE_LOAD, LDS_CYCLES_PER_WAVE_READ, MFMA_CYCLES = 17.5, 8.8, 16.0
 # committed rocprofv3 PMC passes of this command, newest round first (tools/gpu_final.sh puts this round's in place before the
 # bench lines are taken; the kernels these counters describe did not change in round 3)
 PMC_FILES = {"full": ["r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
@@ -392,27 +398,6 @@ def self_launch(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def gather_ceiling(state, d_pos, n, iters=30):
-    """roofline.ceiling: load-only replays of this batch's row fetches (spx_probe.hip) next to the kernels they bound, all timed
-    the same way (alone, stream-ordered): whole 1 KiB rows with the one-kernel path's own lists, grid and traversal
-    (global_load_dwordx4 at 5 waves/SIMD - the fastest whole-row variant) against spx_ft_kernel; and the column-sliced form - slice x
-    of every row on XCD x, the king bucket's piece-square slab in LDS - which the pipeline's gather kernel implements (its own
-    time: secondary.full_refresh_paths.sliced_pipeline.stream_ordered.main_kernel_ms)."""
-    name, probe_ms, _ = state.gather_probe(d_pos.data_ptr(), n, 0, iters)
-    _, ft_ms, _ = state.gather_probe(d_pos.data_ptr(), n, -1, iters)
-    out = {"probe": name, "probe_us": probe_ms * 1e3, "ft_kernel_alone_us": ft_ms * 1e3, "frac_of_probe": probe_ms / ft_ms,
-           "note": "frac_of_probe = load-only replay time / spx_ft_kernel (the one-kernel path) time, both alone on the stream: what "
-                   "that kernel reaches of the rate this chip sustains for the same row fetches with no extraction, no widening, "
-                   "no activation (a measured ceiling for this access pattern, unlike the guide's streaming L2 figure)"}
-    for v in range(state.gather_probe_variants() - 1, -1, -1):
-        if "slab in LDS" in state.gather_probe_name(v):
-            sname, sliced_ms, _ = state.gather_probe(d_pos.data_ptr(), n, v, iters)
-            out["sliced_probe"] = sname
-            out["sliced_probe_us"] = sliced_ms * 1e3
-            break
-    return out
-
-
 def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
     """Third headline: the same timed run on the `realistic` preset (heavy-tailed weights: ~42 % of the piece-square rows fit
     i8, ~38 % have <= 32 weights outside it, ~20 % are wide) - what a trained net should expect rather than the all-compact
@@ -681,8 +666,6 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
         out[name]["leg_seconds"] = time.perf_counter() - t0
 
-    if args.batch <= state.scratch_batch:
-        run("gather_ceiling", lambda: gather_ceiling(state, d_pos, args.batch))
     run("realistic_rows", lambda: realistic_leg(args, sp, torch, group, d_pos, positions, pipelined))
     if args.batch <= state.scratch_batch and args.batch >= 16384 and not args.net:
         run("full_refresh_paths", lambda: paths_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
@@ -899,6 +882,47 @@ def main():
             roofline["lds_served_bytes_per_launch"] = lds_served
             roofline["rows_incl_lds_gbs"] = (requested + lds_served) / ft_avg_s / 1e9
             roofline["before_gather_ms"] = timed_prepare_ms
+            # Round 5: what BINDS the gather is not a byte rate but instruction slots of three units of a CU - the texture / L1 path
+            # (a 16-byte-per-lane wave load holds it ~17.5 cycles whatever its mask or width), the LDS pipe (8.8 cycles per 1 KiB wave
+            # read) and the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8, PMC) -, so the roofline is stated in them. The counts are
+            # EXACT: the pack kernel sums what it lays out for the gather to walk (spx_debug_ftx_walk; steps per column slice x 8).
+            walk = state.ftx_walk(0 if pipelined else -1)
+            steps_g, steps_l = 8 * walk["global_steps"], 8 * walk["lds_steps"]
+            l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
+            lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes
+            mfma_instr = 4 * (steps_g + steps_l)
+            floors = {"texture_path": l1_instr * L1_CYCLES_PER_WAVE_LOAD / 256 / CLOCK_HZ,
+                      "lds": lds_instr * LDS_CYCLES_PER_WAVE_READ / 256 / CLOCK_HZ,
+                      "matrix_pipe": mfma_instr * MFMA_CYCLES / N_SIMDS / CLOCK_HZ}
+            bound = max(floors, key=floors.get)
+            rows_walked = 32 * (walk["global_steps"] + walk["lds_steps"])
+            units = {
+                "texture_path": {"wave_instructions_per_launch": l1_instr, "cycles_each": L1_CYCLES_PER_WAVE_LOAD,
+                                 "floor_us": floors["texture_path"] * 1e6, "busy_frac": floors["texture_path"] / ft_avg_s},
+                "lds": {"wave_instructions_per_launch": lds_instr, "cycles_each": LDS_CYCLES_PER_WAVE_READ,
+                        "floor_us": floors["lds"] * 1e6, "busy_frac": floors["lds"] / ft_avg_s},
+                "matrix_pipe": {"v_mfma_i32_16x16x64_i8_per_launch": mfma_instr, "cycles_each": MFMA_CYCLES,
+                                "floor_us": floors["matrix_pipe"] * 1e6, "busy_frac": floors["matrix_pipe"] / ft_avg_s},
+            }
+            l1_bytes = l1_instr * 1024
+            roofline.update({
+                "bound": "l1", "achieved": l1_bytes / ft_avg_s / 1e9, "peak": L1_PEAK_GBS * 16.0 / L1_CYCLES_PER_WAVE_LOAD, "unit": "GB/s",
+                "frac": floors["texture_path"] / ft_avg_s, "binding_unit": bound, "units": units,
+                "walk": dict(walk, rows_useful=walk["global_rows"] + walk["lds_rows"], rows_walked_per_slice=rows_walked,
+                             padding_efficiency=(walk["global_rows"] + walk["lds_rows"]) / max(rows_walked, 1),
+                             hot_rows=int(state.hot_rows().size),
+                             lds_share_of_rows=walk["lds_rows"] / max(walk["global_rows"] + walk["lds_rows"], 1)),
+                "l2": {"achieved": l2_gbs, "peak": L2_PEAK_GBS, "frac": l2_gbs / L2_PEAK_GBS, "requested_bytes_per_launch": requested},
+                "note": ("bound = the CU's texture / L1 path: achieved = 1 KiB x the gather's vector-memory wave instructions per launch "
+                         "(cold rows and high-byte planes 4 per step, one stage load per 8 steps, a head load and an output store per "
+                         "group; counted by the pack kernel, all 8 column slices) / the gather's HIP-event duration IN THE TIMED REGION "
+                         "(pipelined steps: beside two other batches' preparation), peak = 256 CUs x 1 KiB / 17.5 cycles x 2.4 GHz "
+                         "(tools/probes/tcp_mask_probe.hip); frac = that unit's floor / the duration. units = the same for the LDS pipe "
+                         "and the matrix pipe; binding_unit = the largest floor. Rows the gather adds from LDS (piece-square slab + "
+                         "hot threat / pawn-pair rows: walk.lds_share_of_rows) never touch the texture path. l2 = round 4's figure "
+                         "(bytes the row loads ask the L2s for / aggregate L2 bandwidth): the kernel got faster by asking for LESS. "
+                         "secondary.full_refresh_paths has the kernel alone (stream-ordered)"),
+            })
             roofline["pipeline"] = ("spx_ftx_extract_kernel -> spx_ftx_rank_kernel -> spx_ftx_plan_kernel -> spx_ftx_scatter_kernel "
                                     "-> spx_ftx_gather_kernel; before_gather_ms = HIP-event time between the sorts and the gather "
                                     "(stream-ordered steps: the four preparation kernels; pipelined steps: they run on a stream "
@@ -979,9 +1003,6 @@ def main():
         if wide:
             line["wide_psq_rows"] = wide
         if secondary:
-            ceiling = secondary.pop("gather_ceiling", None)
-            if ceiling:
-                roofline["ceiling"] = ceiling
             realistic = secondary.pop("realistic_rows", None)
             if realistic:
                 line["realistic_rows"] = realistic

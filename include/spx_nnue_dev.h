@@ -3,9 +3,10 @@
  * NOT part of the drop-in boundary (include/spx_nnue.h is): nothing here replaces a call of Stormphrax's src/eval. These are
  * the synthetic network presets every golden of this repository is pinned on (the reference's default net cannot be
  * fetched offline), generators of random legal positions and games for the harnesses, host emulations of the kernels'
- * per-lane code that let the CPU test suite check device logic without a GPU, the activations of the last call, and the
- * load-only gather probe behind bench.py's roofline ceiling. They live in the same shared library so that tests and
- * bench.py exercise exactly the code the product runs. */
+ * per-lane code that let the CPU test suite check device logic without a GPU, the activations of the last call and what the
+ * column-sliced pipeline's last walk held. They live in the same shared library so that tests and bench.py exercise exactly the
+ * code the product runs; none of them launches a kernel the product path does not launch (the load-only gather probe of rounds
+ * 2-4 and its 26 kernels left the library in round 5: experiments/r04_spx_probe.hip.txt). */
 #ifndef SPX_NNUE_DEV_H
 #define SPX_NNUE_DEV_H
 
@@ -27,24 +28,13 @@ int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
  * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
 int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);
 
-/* Gather-ceiling probe (measurement infrastructure; stormphrax_amd/csrc/spx_probe.hip): replays the row fetches of a
- * full refresh of `d_positions` (device pointer, n <= spx_ctx_scratch_batch) - same king-bucket order, same grid and XCD
- * traversal, same rows - with LOADS ONLY (one xor per loaded dword), `iters` launches timed with HIP events on the
- * context's stream. variant 0 .. spx_debug_gather_probe_variants() - 1 selects the memory path / occupancy
- * (spx_debug_gather_probe_name); variant -1 times the product feature-transformer kernel in the same way.
- * `sink_checksum` (optional) receives a checksum of what the loads xor-ed to: equal for every variant >= 0.
- * No reference counterpart: it measures what bounds nnue_state.cpp:89-145 / input.h:283-293 style row gathers on gfx950. */
-int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
-                           uint64_t* sink_checksum);
-int spx_debug_gather_probe_variants(void);
-/* Diagnostics of the column-sliced pipeline (SPX_CTX_SLICED_FT): start / end of each of the 256 workgroups of the last gather that
- * used scratch set `slot` (-1: the context's own, 0 / 1: the pipelined calls' lanes), device clock ticks of 10 ns; out[512]. */
+/* Diagnostics of the column-sliced pipeline: start / end of each of the 256 workgroups of the last gather that used scratch set
+ * `slot` (-1: the context's own, 0 .. 2: the pipelined calls' lanes), device clock ticks of 10 ns; out[512]. */
 int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out);
 /* ... and the plan those workgroups walked: out[0 .. 256) = plan words (CU slot c -> first segment at [c], number of segments at [32],
  * number of groups at [33], segments {king bucket, first group, end group} from word 64), then 1 280 + 17 words: the first sorted
- * position of every (king bucket, list length) bin and the buckets' starts. out[256 + 1 297]. */
+ * position of every (king bucket, section lengths) bin and the buckets' starts. out[256 + 1 297]. */
 int spx_debug_ftx_plan(spx_ctx* ctx, int slot, uint32_t* out);
-const char* spx_debug_gather_probe_name(int variant);
 
 /* `count` random legal positions (host chess core): game i plays min_ply .. max_ply uniformly random plies from the standard
  * start or, every dfrc_every-th game (0 = never), from a double-Chess960 start. Seeded and reproducible. */
@@ -88,6 +78,12 @@ int spx_debug_wdl(const spx_packed_pos* pos, int32_t score, int32_t* material, i
  * Position::isDrawn for `pos` (src/position.cpp:639-666). Either output group may be skipped with NULL. Test-only. */
 int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply, uint32_t* outcome,
                             const spx_packed_pos* pos, int* insufficient);
+
+/* What the last packed walk of scratch set `slot` (-1 = the context's own, 0 .. 2 = a lane's) holds, 8 words: [0] groups of 8
+ * perspectives, [1] stages, [2] global steps and [3] LDS steps as the gather walks them PER COLUMN SLICE (a step = 4 wave loads /
+ * LDS reads + 4 MFMAs; sections walk in pairs of steps), [4] rows fetched through the texture path (high-byte planes + cold threat /
+ * pawn-pair rows), [5] rows read from LDS (piece-square + hot rows). bench.py derives the gather's instruction counts from it. */
+int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out);
 
 /* The hot set of the column-sliced gather, given instead of measured / read back (in slot order; *n = 0 before the first
  * calibration). spx_ctx_set_hot_rows takes up to 384 distinct row ids < 64 368 (n = 0: an empty set - every row through the

@@ -136,11 +136,9 @@ SYMBOLS = {
     "spx_ctx_set_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "spx_ctx_get_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
-    "spx_debug_gather_probe": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]),
-    "spx_debug_gather_probe_variants": (ctypes.c_int, []),
     "spx_debug_ftx_block_times": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_debug_ftx_plan": (ctypes.c_int, [_P, ctypes.c_int, _P]),
-    "spx_debug_gather_probe_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "spx_debug_ftx_walk": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),

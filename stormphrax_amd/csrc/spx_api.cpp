@@ -19,7 +19,6 @@
 #include "spx_internal.h"
 #include "spx_kernels.h"
 #include "spx_ftx.h"
-#include "spx_probe.h"
 
 namespace spx {
 
@@ -1958,7 +1957,8 @@ int spx_profile_begin(spx_ctx* ctx, size_t max_calls) {
 
 int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n) {
     if (!ctx || !ctx->ftxEnabled || ctx->ftxUnavailable || n <= ctx->tinyBatchMax) return 0;
-    const size_t pipelinedFrom = ctx->ftxMinForced ? ctx->ftxMin : std::min(ctx->ftxMin, kFtxMinPositionsPipelined);
+    // (per chunk of a call; pipelined calls of a context whose lanes did not fit run stream-ordered: the same threshold then)
+    const size_t pipelinedFrom = (ctx->ftxMinForced || ctx->lanesUnavailable) ? ctx->ftxMin : std::min(ctx->ftxMin, kFtxMinPositionsPipelined);
     return (n >= ctx->ftxMin ? 1 : 0) | (n >= pipelinedFrom ? 2 : 0);
 }
 
@@ -2282,182 +2282,10 @@ int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out) {
     return SPX_OK;
 }
 
-// Gather-ceiling probe (spx_probe.hip): see include/spx_nnue.h. variant -1 = the product feature-transformer kernel itself
-// (stream-ordered, alone), so the probe's numbers and the kernel's come from the same loop on the same device buffers.
-int spx_debug_gather_probe(spx_ctx* ctx, const void* d_positions, size_t n, int variant, int iters, float* ms_per_launch,
-                           uint64_t* sink_checksum) {
-    if (!ctx || !d_positions || !ms_per_launch || n == 0 || n > ctx->maxBatch || iters <= 0 || variant < -1 ||
-        variant >= probeVariantCount()) {
-        setError("spx_debug_gather_probe: invalid argument");
-        return SPX_ERR_INVALID_ARG;
-    }
-    SPX_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    int rc = runSortAndMlp(ctx, d_positions, n, nullptr, s, false);  // the product path's king-bucket order
-    if (rc != SPX_OK) return rc;
-    ProbeParams pp{};
-    pp.positions = d_positions;
-    pp.nPositions = uint32_t(n);
-    pp.order = ctx->kingSortEnabled ? ctx->dPerspOrder : nullptr;
-    pp.t = tablesOf(ctx);
-    struct Scratch {
-        void *lists = nullptr, *sink = nullptr, *sliced = nullptr, *groups = nullptr, *order = nullptr, *wide = nullptr, *plan = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~Scratch() {
-            for (void* q : {lists, sink, sliced, groups, order, wide, plan}) {
-                if (q) (void)hipFree(q);
-            }
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-        }
-    } scratch;
-    SPX_HIP(hipMalloc(&scratch.lists, (2 * n + 256) * size_t(kProbeListWords) * sizeof(uint32_t)));  // (+ holes of a padded order)
-    SPX_HIP(hipMalloc(&scratch.sink, 2 * n * size_t(512)));
-    SPX_HIP(hipMemsetAsync(scratch.sink, 0, 2 * n * size_t(512), s));
-    SPX_HIP(hipEventCreate(&scratch.e0));
-    SPX_HIP(hipEventCreate(&scratch.e1));
-    pp.lists = static_cast<uint32_t*>(scratch.lists);
-    pp.sink = static_cast<uint8_t*>(scratch.sink);
-    const uint32_t grid = ftGrid(ctx, 2 * n);
-    const bool sliced = variant >= 0 && probeVariant(variant).path >= 2;
-    const uint32_t* const kingOrder = pp.order;
-    if (sliced) {  // column-sliced replay: its own order of the perspectives, the re-laid table, interleaved group lists
-        const int orderMode = probeVariant(variant).order;
-        if (orderMode == 1) {
-            pp.order = nullptr;
-        } else if (orderMode == 2) {
-            SPX_HIP(hipMalloc(&scratch.order, 2 * n * sizeof(uint32_t)));
-            SPX_HIP(launchProbePerspOrder(ctx->dPosOrder, static_cast<uint32_t*>(scratch.order), uint32_t(n), s));
-            pp.order = static_cast<uint32_t*>(scratch.order);
-        } else if (orderMode == 3) {  // perspectives ordered by their number of rows: groups of equals (host sort; not timed)
-            pp.order = nullptr;
-            SPX_HIP(launchProbeLists(pp, grid, s));
-            std::vector<uint32_t> counts(2 * n), ids(2 * n);
-            SPX_HIP(hipMemcpy2DAsync(counts.data(), 4, pp.lists, kProbeListWords * 4, 4, 2 * n, hipMemcpyDeviceToHost, s));
-            SPX_HIP(hipStreamSynchronize(s));
-            for (size_t i = 0; i < 2 * n; ++i) ids[i] = uint32_t(i);
-            std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return counts[a] < counts[b]; });
-            SPX_HIP(hipMalloc(&scratch.order, 2 * n * sizeof(uint32_t)));
-            SPX_HIP(hipMemcpyAsync(scratch.order, ids.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            SPX_HIP(hipStreamSynchronize(s));
-            pp.order = static_cast<uint32_t*>(scratch.order);
-        } else if (orderMode == 4) {
-            // (king bucket, row count) order, every bucket padded to whole groups of 8 with holes; then the plan: the groups
-            // cut into 32 contiguous, equally heavy ranges (one per CU of an XCD), each a list of one-bucket segments
-            pp.order = nullptr;
-            SPX_HIP(launchProbeLists(pp, grid, s));
-            std::vector<uint32_t> counts(2 * n), head(2 * n), ids(2 * n);
-            SPX_HIP(hipMemcpy2DAsync(counts.data(), 4, pp.lists, kProbeListWords * 4, 4, 2 * n, hipMemcpyDeviceToHost, s));
-            SPX_HIP(hipMemcpy2DAsync(head.data(), 4, pp.lists + 4, kProbeListWords * 4, 4, 2 * n, hipMemcpyDeviceToHost, s));
-            SPX_HIP(hipStreamSynchronize(s));
-            auto bucketOf = [&](uint32_t i) { return (head[i] / kL1 - kThreatRows) / 704u; };  // the list is headed by a compact piece-square row
-            for (size_t i = 0; i < 2 * n; ++i) ids[i] = uint32_t(i);
-            std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
-                return bucketOf(a) != bucketOf(b) ? bucketOf(a) < bucketOf(b) : counts[a] < counts[b];
-            });
-            std::vector<uint32_t> order, groupBucket, groupCost;
-            for (size_t i = 0; i < ids.size();) {
-                const uint32_t b = bucketOf(ids[i]);
-                size_t j = i;
-                while (j < ids.size() && bucketOf(ids[j]) == b) ++j;
-                for (size_t k = i; k < j; k += 8) {
-                    uint32_t cost = 0;
-                    for (size_t m = k; m < k + 8; ++m) {
-                        order.push_back(m < j ? ids[m] : 0xFFFFFFFFu);
-                        if (m < j) cost = std::max(cost, counts[ids[m]]);
-                    }
-                    groupBucket.push_back(b);
-                    groupCost.push_back(cost + 4);
-                }
-                i = j;
-            }
-            if (order.size() > 2 * n + 256) {
-                setError("spx_debug_gather_probe: padded order too long");
-                return SPX_ERR_INVALID_ARG;
-            }
-            uint64_t total = 0;
-            for (uint32_t c : groupCost) total += c;
-            std::vector<uint32_t> plan(64, 0), segs;
-            uint64_t acc = 0;
-            size_t gi = 0;
-            for (uint32_t cu = 0; cu < 32; ++cu) {
-                plan[cu] = uint32_t(segs.size() / 3);
-                const uint64_t target = total * (cu + 1) / 32;
-                while (gi < groupCost.size() && (acc < target || cu == 31)) {
-                    const uint32_t b = groupBucket[gi];
-                    const size_t g0 = gi;
-                    while (gi < groupCost.size() && groupBucket[gi] == b && (acc < target || cu == 31)) acc += groupCost[gi++];
-                    segs.insert(segs.end(), {b, uint32_t(g0), uint32_t(gi)});
-                }
-            }
-            plan[32] = uint32_t(segs.size() / 3);
-            plan.insert(plan.end(), segs.begin(), segs.end());
-            SPX_HIP(hipMalloc(&scratch.order, order.size() * sizeof(uint32_t)));
-            SPX_HIP(hipMemcpyAsync(scratch.order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            SPX_HIP(hipMalloc(&scratch.plan, plan.size() * sizeof(uint32_t)));
-            SPX_HIP(hipMemcpyAsync(scratch.plan, plan.data(), plan.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            SPX_HIP(hipStreamSynchronize(s));
-            pp.order = static_cast<uint32_t*>(scratch.order);
-            pp.nItems = uint32_t(order.size());
-            pp.plan = static_cast<uint32_t*>(scratch.plan);
-        }
-        const uint32_t nRows = kThreatRows + kPsqRows;
-        pp.sliceStride = (nRows + 1) * 128u;
-        SPX_HIP(hipMalloc(&scratch.sliced, size_t(8) * pp.sliceStride));
-        SPX_HIP(hipMemsetAsync(scratch.sliced, 0, size_t(8) * pp.sliceStride, s));
-        SPX_HIP(launchProbeSliceTable(pp.t.thrW, static_cast<uint8_t*>(scratch.sliced), nRows, s));
-        pp.sliced = static_cast<const uint8_t*>(scratch.sliced);
-        const size_t nGroups = ((pp.nItems ? pp.nItems : 2 * n) + 7) / 8;
-        SPX_HIP(hipMalloc(&scratch.groups, nGroups * size_t(kProbeGroupWords) * sizeof(uint32_t)));
-        SPX_HIP(hipMalloc(&scratch.wide, sizeof(uint32_t)));
-        SPX_HIP(hipMemsetAsync(scratch.wide, 0, sizeof(uint32_t), s));
-        pp.groupLists = static_cast<uint32_t*>(scratch.groups);
-        pp.wideRows = static_cast<uint32_t*>(scratch.wide);
-    }
-    SPX_HIP(launchProbeLists(pp, grid, s));
-    if (sliced) {
-        if (probeVariant(variant).order == 4) {
-            SPX_HIP(launchProbePackSlabGroups(pp, (kThreatRows + kPsqRows) * 128u, s));
-        } else {
-            SPX_HIP(launchProbePackGroups(pp, (kThreatRows + kPsqRows) * 128u, s));
-        }
-        uint32_t wide = 0;
-        SPX_HIP(hipMemcpyAsync(&wide, scratch.wide, sizeof(wide), hipMemcpyDeviceToHost, s));
-        SPX_HIP(hipStreamSynchronize(s));
-        if (wide) {
-            setError("spx_debug_gather_probe: the column-sliced replay covers 1 KiB rows only (this batch has wide piece-square rows)");
-            return SPX_ERR_INVALID_ARG;
-        }
-    }
-    FtParams fp{};
-    fp.positions = d_positions;
-    fp.nPositions = uint32_t(n);
-    fp.order = kingOrder;
-    fp.t = pp.t;
-    fp.ftOut = ctx->dFtOut;
-    auto launch = [&]() -> hipError_t { return variant < 0 ? launchFt(fp, grid, s) : launchProbeGather(pp, variant, grid, s); };
-    for (int i = 0; i < 3; ++i) SPX_HIP(launch());  // warm-up
-    SPX_HIP(hipEventRecord(scratch.e0, s));
-    for (int i = 0; i < iters; ++i) SPX_HIP(launch());
-    SPX_HIP(hipEventRecord(scratch.e1, s));
-    SPX_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    SPX_HIP(hipEventElapsedTime(&ms, scratch.e0, scratch.e1));
-    *ms_per_launch = ms / float(iters);
-    if (sink_checksum) {
-        std::vector<uint64_t> host(variant < 0 ? 0 : 2 * n * 64);
-        if (!host.empty()) SPX_HIP(hipMemcpy(host.data(), scratch.sink, host.size() * 8, hipMemcpyDeviceToHost));
-        uint64_t sum = 0;
-        for (size_t i = 0; i < host.size(); ++i) sum += host[i] * (2 * i + 1);
-        *sink_checksum = sum;
-    }
-    return SPX_OK;
-}
-
 // start / end of every workgroup of the LAST column-sliced gather that used the given scratch set (slot -1: the context's own,
 // 0 / 1: the pipelined calls' lanes), on the device's constant 100 MHz clock: out[2 b] = start, out[2 b + 1] = end of workgroup b
 int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
-    if (!ctx || !out || slot < -1 || slot > 1) {
+    if (!ctx || !out || slot < -1 || slot > 2) {
         setError("spx_debug_ftx_block_times: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -2472,11 +2300,29 @@ int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
     return SPX_OK;
 }
 
+// what the LAST packed walk of that scratch set holds (spx_ftx.h: kFtxPlanStats): out[0] groups, [1] stages, [2] global steps and [3] LDS
+// steps as walked per column slice, [4] rows fetched through the texture path (high planes + cold rows), [5] rows read from LDS
+int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
+    if (!ctx || !out || slot < -1 || slot > 2) {
+        setError("spx_debug_ftx_walk: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->lanes[slot].ftx;
+    if (!x.plan) {
+        setError("spx_debug_ftx_walk: that scratch set was never used");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipDeviceSynchronize());
+    SPX_HIP(hipMemcpy(out, x.plan + kFtxPlanStats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
 // the plan and the bin starts of the LAST column-sliced gather of that scratch set: out[0 .. kFtxPlanTimes) = plan words (CU slot ->
 // first segment, segments {bucket, first group, end group}), then kFtxBins + 17 words: first sorted position of every (bucket, length)
 // bin, then the buckets' starts. tools/gpu_ftx_block_times.py fits the plan's cost model against the workgroups' times with it.
 int spx_debug_ftx_plan(spx_ctx* ctx, int slot, uint32_t* out) {
-    if (!ctx || !out || slot < -1 || slot > 1) {
+    if (!ctx || !out || slot < -1 || slot > 2) {
         setError("spx_debug_ftx_plan: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }
@@ -2492,13 +2338,6 @@ int spx_debug_ftx_plan(spx_ctx* ctx, int slot, uint32_t* out) {
     return SPX_OK;
 }
 
-int spx_debug_gather_probe_variants(void) {
-    return probeVariantCount();
-}
-
-const char* spx_debug_gather_probe_name(int variant) {
-    return variant >= 0 && variant < probeVariantCount() ? probeVariant(variant).name : "spx_ft_kernel (the product kernel, alone)";
-}
 
 // ---- host helpers ----
 int spx_pos_from_fen(const char* fen, spx_packed_pos* out) {

@@ -85,7 +85,10 @@ constexpr uint32_t kFtxGroupCost = SPX_FTX_GROUP_COST;  // plan: a group costs i
 #endif
 constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // plan: a slab reload inside a CU slot's range, in steps (a group costs its steps + 3)
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
-constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
+constexpr uint32_t kFtxPlanStats = kFtxPlanTimes + 4 * 256;  // what the last packed walk holds: [0] groups, [1] stages, [2] global steps and [3] LDS
+                                                             // steps as walked (pairs: odd sections walk one step of zero rows), [4] rows
+                                                             // fetched through the texture path (high planes + cold), [5] rows from LDS
+constexpr uint32_t kFtxPlanWords = kFtxPlanStats + 8;
 
 constexpr size_t kFtxMinPositions = 16384;    // smaller full refreshes keep the one-kernel path (the paths cross at ~14 Ki: profiles/r04_sliced_pipeline_crossover.txt)
 constexpr size_t kFtxMinPositionsPipelined = 12288;  // ... of spx_eval_full_device_async (the preparation runs beside the other lane's gather)

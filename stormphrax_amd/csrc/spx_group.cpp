@@ -5,6 +5,7 @@
 // its shard through the ordinary spx_eval_full on its own host thread: the H2D / kernels / D2H of the members overlap,
 // and there is no collective on the data path. The weights are uploaded once per member (the "N H2D copies" variant of
 // the reference-side ncclBroadcast in SURVEY 8e); an 89 MB image per 288 GB device.
+#include <cstdio>
 #include <algorithm>
 #include <memory>
 #include <string>
@@ -157,13 +158,16 @@ int spx_group_selfplay_run(spx_group* group, const spx_selfplay_params* params, 
         // is empty sit the run out instead of playing one game each beyond the target
         size_t tLo, tHi;
         shardBounds(params->target_games, r, active, tLo, tHi);
+        const std::string path = (out_path && out_path[0]) ? std::string(out_path) + "." + std::to_string(r) + ".vf" : std::string();
         if (tHi == tLo) {
             part[r] = spx_selfplay_stats{};
+            if (!path.empty()) {  // (one file per member, whatever its share: an empty one here)
+                if (std::FILE* f = std::fopen(path.c_str(), "wb")) std::fclose(f);
+            }
             return int(SPX_OK);
         }
         mine.target_games = uint32_t(tHi - tLo);
         mine.seed = params->seed + r;
-        const std::string path = (out_path && out_path[0]) ? std::string(out_path) + "." + std::to_string(r) + ".vf" : std::string();
         return spx_selfplay_run(group->members[r], &mine, path.empty() ? nullptr : path.c_str(), &part[r]);
     });
     if (rc != SPX_OK) return rc;

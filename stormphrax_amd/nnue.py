@@ -133,6 +133,13 @@ class NnueState:
         """spx_ctx_set_option: one tuning knob of this context (never changes a result)."""
         check(_lib.load().spx_ctx_set_option(self._h, name.encode(), int(value)))
 
+    def ftx_walk(self, slot=-1):
+        """spx_debug_ftx_walk: what the last packed walk of a scratch set holds -> dict (steps are per column slice)."""
+        out = np.zeros(8, dtype=np.uint32)
+        check(_lib.load().spx_debug_ftx_walk(self._h, slot, out.ctypes.data))
+        keys = ("groups", "stages", "global_steps", "lds_steps", "global_rows", "lds_rows")
+        return {k: int(v) for k, v in zip(keys, out)}
+
     def calibrate(self, d_positions_ptr, n):
         """spx_ctx_calibrate: choose the gather's hot set (the threat / pawn-pair rows kept in LDS) from a device-resident batch."""
         check(_lib.load().spx_ctx_calibrate(self._h, d_positions_ptr, n))
@@ -344,22 +351,6 @@ class NnueState:
         out = np.empty((n, 1024), dtype=np.uint8)
         check(_lib.load().spx_debug_copy_ft(self._h, n, out.ctypes.data))
         return out
-
-    def gather_probe(self, d_positions_ptr, n, variant, iters=20):
-        """Load-only replay of the full refresh's row fetches (spx_debug_gather_probe). variant -1 = the product
-        feature-transformer kernel timed the same way. -> (name, ms per launch, sink checksum)."""
-        lib = _lib.load()
-        ms, sink = ctypes.c_float(0), ctypes.c_uint64(0)
-        check(lib.spx_debug_gather_probe(self._h, d_positions_ptr, n, variant, iters, ctypes.byref(ms), ctypes.byref(sink)))
-        return lib.spx_debug_gather_probe_name(variant).decode(), float(ms.value), int(sink.value)
-
-    @staticmethod
-    def gather_probe_variants():
-        return int(_lib.load().spx_debug_gather_probe_variants())
-
-    @staticmethod
-    def gather_probe_name(variant):
-        return _lib.load().spx_debug_gather_probe_name(variant).decode()
 
     def __enter__(self):
         return self

@@ -8,7 +8,7 @@ SRC=stormphrax_amd/csrc
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-      $SRC/spx_kernels.hip $SRC/spx_ftx.hip $SRC/spx_movegen.hip $SRC/spx_probe.hip $SRC/spx_api.cpp $SRC/spx_chess.cpp $SRC/spx_luts.cpp $SRC/spx_synth.cpp $SRC/spx_selfplay.cpp $SRC/spx_group.cpp \
+      $SRC/spx_kernels.hip $SRC/spx_ftx.hip $SRC/spx_movegen.hip $SRC/spx_api.cpp $SRC/spx_chess.cpp $SRC/spx_luts.cpp $SRC/spx_synth.cpp $SRC/spx_selfplay.cpp $SRC/spx_group.cpp \
       -o variants/libspx_$name.so -ldl &
 done
 wait
