@@ -596,6 +596,29 @@ def selfplay_leg(sp, net, device, seats=4096, games=32768, seed=1):
         st.close()
 
 
+def selfplay_search_leg(sp, net, device, seats=4096, games=4096, nodes=64, seed=1):
+    """secondary.config4_selfplay_search: the same device-resident games with a LIVE
+    fixed-node search in place of the depth-1 policy - every seat runs its own iterative-deepening alpha-beta, one node
+    expanded per seat and round (spx_search_step_kernel), the node's children evaluated together with every other seat's.
+    `nodes` = expansions after which a search stops at the end of an iteration. tests/test_gpu_incremental.py replays such
+    games through a recursive restatement of the search (tests/_search_rules.py); this leg only measures."""
+    st = sp.NnueState(net, device=device, max_batch=seats * 64)
+    try:
+        stats = st.selfplay(n_games=seats, target_games=games, out_path=None, max_plies=300, dfrc=True, temperature_cp=0, seed=seed,
+                            search_nodes=nodes)
+        return {"value": stats["evals"] / stats["seconds"], "unit": "leaf evals/s", "concurrent_games": seats, "evals": stats["evals"],
+                "node_budget": nodes, "nodes_expanded": stats["steps"], "games": stats["games"], "positions": stats["positions"],
+                "nodes_per_move": stats["steps"] / max(1, stats["positions"]), "leaves_per_node": stats["evals"] / max(1, stats["steps"]),
+                "seconds": stats["seconds"], "gpu_call_fraction": stats["gpu_seconds"] / stats["seconds"],
+                "outcomes_white_loss_draw_win": stats["outcomes"],
+                "policy": "iterative-deepening alpha-beta over explicit per-seat stacks, leaves = NNUE(child) through the fused "
+                          "eval-only update, children ordered by value, no transposition table; rules in csrc/spx_kernels.h "
+                          "(SearchStepParams); openings, verification filter, adjudication, Position::isDrawn, viriformat "
+                          "records as src/datagen/datagen.cpp"}
+    finally:
+        st.close()
+
+
 def secondary_legs_multi(sp, torch, group, net, device, rank, world, preset):
     """N > 1: BASELINE configs[3] as it is worded - 4 096 concurrent self-play games SHARDED over the GPUs (rank r plays
     its share of the seats and of the target with its own seed: game_id mod N), no collective in the game loop -
@@ -677,6 +700,7 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
             "the reference's own alpha-beta search, depth <= 12 from the start position, recorded through link-time interposition"))
         run("config3_alpha_beta_replay_x256", lambda: forest_leg(sp, net, device))
     run("config4_selfplay", lambda: selfplay_leg(sp, net, device))
+    run("config4_selfplay_search", lambda: selfplay_search_leg(sp, net, device))
     return out
 
 

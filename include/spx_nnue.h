@@ -440,7 +440,7 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * launches, SPX_SELFPLAY_GRAPH_PLIES = plies per graph), and the host reads ~100
  * bytes of counters plus the finished games per ply. SPX_SELFPLAY_HOST_MOVEGEN selects the host chess core for moves, openings and bookkeeping (the
  * same rules; the validation path). Needs a context whose max_batch holds a ply's children of half the seats (48 * n_games
- * is always enough); reserves 2 * n_games + 1 arena slots (129 * n_games with host move generation).
+ * is always enough); reserves 2 * n_games + 1 arena slots (129 * n_games with host move generation, 9 * n_games + 1 with a search).
  * Multi-GPU: games are independent - run one process per GPU with its own seed / slice of games.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct spx_selfplay_params {
@@ -452,10 +452,19 @@ typedef struct spx_selfplay_params {
     int32_t temperature_cp;  /* pick uniformly among moves within this margin of the best (0 = greedy) */
     uint32_t host_threads;   /* host worker threads of the HOST move generation path; 0 = auto: min(16, usable CPUs = cgroup quota /
                               * LOCAL_WORLD_SIZE). The device-resident games need one host thread */
-    uint32_t flags;          /* 0 = moves generated on the device; SPX_SELFPLAY_HOST_MOVEGEN = host chess core instead */
+    uint32_t flags;          /* 0 = moves generated on the device; SPX_SELFPLAY_HOST_MOVEGEN = host chess core instead;
+                              * | SPX_SELFPLAY_SEARCH_NODES(k): a live fixed-node search picks the moves (device path only) */
     uint64_t seed;
 } spx_selfplay_params;
 enum { SPX_SELFPLAY_HOST_MOVEGEN = 1 };
+/* Live fixed-node search in place of the depth-1 policy (datagen's Searcher::runDatagenSearch with its soft node limit,
+ * search.cpp:212-239, datagen.cpp:78-80): every game runs its own iterative-deepening alpha-beta, ONE node expanded per game
+ * and round, the node's children evaluated in the same batch as every other game's - k = nodes a search may expand before it
+ * stops at the end of an iteration (1 .. 2^24 - 1; k = 1 plays exactly the depth-1 games, temperature included; k > 1 plays
+ * the search's best move and records its score; a decisive score ends the game, datagen.cpp:224-226). The rules are with
+ * SearchStepParams in csrc/spx_kernels.h and restated in tests/_search_rules.py. 7 more arena slots per game;
+ * stats.evals = leaves evaluated, stats.steps = nodes expanded. */
+#define SPX_SELFPLAY_SEARCH_NODES(k) ((uint32_t)(k) << 8)
 typedef struct spx_selfplay_stats {
     uint64_t games, positions, evals, steps;
     uint64_t outcomes[3];    /* white loss / draw / white win (datagen/common.h:24-28) */

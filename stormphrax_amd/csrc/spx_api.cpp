@@ -2300,7 +2300,7 @@ int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
     return SPX_OK;
 }
 
-// what the LAST packed walk of that scratch set holds (spx_ftx.h: kFtxPlanStats): out[0] groups, [1] stages, [2] global steps and [3] LDS
+// what the LAST packed walk of that scratch set holds (summed over the group heads, spx_ftx.h): out[0] groups, [1] stages, [2] global steps and [3] LDS
 // steps as walked per column slice, [4] rows fetched through the texture path (high planes + cold rows), [5] rows read from LDS
 int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
     if (!ctx || !out || slot < -1 || slot > 2) {
@@ -2314,7 +2314,15 @@ int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
     }
     SPX_HIP(hipSetDevice(ctx->device));
     SPX_HIP(hipDeviceSynchronize());
-    SPX_HIP(hipMemcpy(out, x.plan + kFtxPlanStats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t nGroups = 0;
+    SPX_HIP(hipMemcpy(&nGroups, x.plan + 33, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> heads(size_t(nGroups) * kFtxGroupHeadWords);
+    SPX_HIP(hipMemcpy(heads.data(), x.groupHead, heads.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t sums[6] = {nGroups, 0, 0, 0, 0, 0};  // (the pack kernel leaves every group's own figures in its head's spare words)
+    for (uint32_t g = 0; g < nGroups; ++g) {
+        for (int k = 1; k < 6; ++k) sums[k] += heads[size_t(g) * kFtxGroupHeadWords + 8 + k];
+    }
+    for (int k = 0; k < 8; ++k) out[k] = k < 6 ? uint32_t(std::min<uint64_t>(sums[k], 0xFFFFFFFFull)) : 0u;
     return SPX_OK;
 }
 

@@ -66,7 +66,9 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 // ---- the packed walk of a group of 8 neighbours of that order (spx_ftx_pack_kernel; what the gather reads) ----
 // A group's walk has three SECTIONS - high-byte planes (global), the LDS section, cold rows (global) -, each as long as the
 // longest of the 8 lists there (in quartets of rows = steps), cut into STAGES of 8 steps. groupHead[G] = 16 words: {hiQ | ldsQ << 8
-// | coldQ << 16, output slots of the 8 perspectives (~0 = hole), -}; stages[G][q] = 256 words, stage q in the order of the
+// | coldQ << 16, output slots of the 8 perspectives (~0 = hole), then what the group costs (spx_debug_ftx_walk sums these): stages, global
+// steps and LDS steps as walked (pairs: odd sections walk one step of zero rows), rows through the texture path (high planes +
+// cold), rows from LDS, -}; stages[G][q] = 256 words, stage q in the order of the
 // sections: word 32 k + 4 e + pr = the row (byte offset, as in the lists) that row kb of step k adds to perspective 2 pr + u,
 // e = 2 kb + u; rows past a list's end are the section's all-zero row. Every XCD's gather walks every group: packing once what
 // round 4 made each of the eight find out for itself (section boundaries per lane, list gathers, padding) took 40 % of the
@@ -85,10 +87,7 @@ constexpr uint32_t kFtxGroupCost = SPX_FTX_GROUP_COST;  // plan: a group costs i
 #endif
 constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // plan: a slab reload inside a CU slot's range, in steps (a group costs its steps + 3)
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
-constexpr uint32_t kFtxPlanStats = kFtxPlanTimes + 4 * 256;  // what the last packed walk holds: [0] groups, [1] stages, [2] global steps and [3] LDS
-                                                             // steps as walked (pairs: odd sections walk one step of zero rows), [4] rows
-                                                             // fetched through the texture path (high planes + cold), [5] rows from LDS
-constexpr uint32_t kFtxPlanWords = kFtxPlanStats + 8;
+constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
 
 constexpr size_t kFtxMinPositions = 16384;    // smaller full refreshes keep the one-kernel path (the paths cross at ~14 Ki: profiles/r04_sliced_pipeline_crossover.txt)
 constexpr size_t kFtxMinPositionsPipelined = 12288;  // ... of spx_eval_full_device_async (the preparation runs beside the other lane's gather)

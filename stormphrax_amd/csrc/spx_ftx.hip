@@ -310,7 +310,6 @@ __global__ __launch_bounds__(kPlanThreads) void spx_ftx_plan_kernel(FtxParams p)
         sBin[k] = p.hist[k];
         p.hist[k] = 0;  // ready for the next batch's rank kernel
     }
-    if (tid < 8) p.plan[kFtxPlanStats + tid] = 0;  // (the pack kernel's counts of what the gather will walk)
     __syncthreads();
     // bucket totals and the bins' starts inside their bucket: a wave per bucket (four buckets each), kPlanBinsPerLane bins per lane
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -504,17 +503,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
     if (ks == 0) gh[1 + g] = head[1];
     const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
     uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
-    {   // what the gather will walk (spx_debug_ftx_walk: bench.py's instruction counts come from here)
+    {   // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
+        // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
         uint32_t rowsG = ks == 0 ? cHi + cCold : 0u, rowsL = ks == 0 ? cLds : 0u;
 #pragma unroll
         for (int dlt = 8; dlt < 64; dlt <<= 1) {
             rowsG += uint32_t(__shfl_xor(int(rowsG), dlt, 64));
             rowsL += uint32_t(__shfl_xor(int(rowsL), dlt, 64));
         }
-        if (lane < 6) {
-            const uint32_t evenG = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u), evenL = (ldsQ + 1) & ~1u;
-            const uint32_t v = lane == 0 ? 1u : (lane == 1 ? Q : (lane == 2 ? evenG : (lane == 3 ? evenL : (lane == 4 ? rowsG : rowsL))));
-            atomicAdd(&p.plan[kFtxPlanStats + lane], v);
+        if (lane == 0) {
+            gh[9] = Q;
+            gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
+            gh[11] = (ldsQ + 1) & ~1u;
+            gh[12] = rowsG;
+            gh[13] = rowsL;
         }
     }
     // stage q: which section, where this lane's four rows sit in its list, how many of them there are

@@ -170,6 +170,50 @@ struct GameStepParams {
     uint64_t* updPositions;         // [nSeats] ... and the seat's new current record (empty for an idle seat)
 };
 
+// ---- live fixed-node search in the device self-play driver (spx_search_step_kernel, spx_movegen.hip) ----
+// What replaces datagen's Searcher::runDatagenSearch (search.cpp:212-239, soft node limit datagen.cpp:78-80) here: iterative
+// deepening alpha-beta over the seat's own explicit stack, ONE node expanded per seat and round - the node's children are
+// generated by spx_movegen_kernel and evaluated by the fused eval-only update together with every other seat's, exactly
+// like the depth-1 driver's plies. The rules (also restated in tests/_search_rules.py, which the games are replayed through):
+//   value(child)  = network output of the child from the mover's side, clamped like eval::adjustStatic (eval.cpp:24-27)
+//   search(node, depth, alpha, beta, ply): no legal move -> -(kScoreMate - ply) in check, else 0; depth 1 -> the best child
+//     value; else the children in the order (value descending, viriformat move word ascending) - at the root of iteration
+//     >= 2 the previous iteration's best move first -, fail-soft negamax with cut-off at alpha >= beta
+//   iterations 1, 2, ... until the expansions of this search reach the node budget K, the depth reaches kSearchLevels, or
+//     the score is decisive (core.h:722-724); the root's own expansion is shared by all iterations
+//   K <= 1: the depth-1 policy of spx_game_step_kernel (incl. its temperature), move for move
+// No transposition table, no repetition / 50-move detection inside the tree (the game loop's own rules apply to the moves played).
+constexpr uint32_t kSearchLevels = 8;       // frames per seat: the root (level 0) .. level 7
+constexpr uint32_t kSearchChildren = 224;   // children kept per frame (the legal maximum is 218)
+constexpr int32_t kSearchInf = 32767, kSearchMate = 32766;  // core.h:705-706
+struct SearchSeat {          // one per seat
+    uint32_t top;            // level of the node expanded this round (its children are this round's batch)
+    uint32_t iter;           // depth of the running iteration
+    uint32_t nodes;          // expansions of this search so far
+    int32_t prevBest;        // root child the last completed iteration chose (-1: none yet)
+};
+struct SearchFrame {         // one per seat and level, 64 bytes
+    uint32_t count, depth;   // children; remaining depth (>= 1)
+    int32_t alpha, beta, best, bestIdx;
+    int32_t cur;             // the child being searched below this frame
+    uint32_t reserved;
+    uint64_t visited[4];     // children already searched in this visit
+};
+struct SearchStepParams {
+    GameStepParams game;            // (positions / slots: the games' CURRENT positions; first / count / inCheck / evals /
+                                    //  moves / children: this round's batch, i.e. the children of every seat's `pending` node)
+    uint32_t nodeBudget;            // K
+    SearchSeat* seats;              // [nSeats]
+    SearchFrame* frames;            // [nSeats][kSearchLevels]
+    uint64_t* frameRecords;         // [nSeats][kSearchLevels][kSearchChildren] records as u64[4]
+    int32_t* frameValues;           // [nSeats][kSearchLevels][kSearchChildren]
+    uint16_t* frameWords;           // [nSeats][kSearchLevels][kSearchChildren] viriformat move words
+    uint64_t* pending;              // [nSeats] records: the node each seat expands next (the next move generation's input)
+    uint32_t* pendingSlots;         // [nSeats] its accumulator slot
+    uint32_t levelSlotBase;         // accumulator slot of (seat, level L >= 1) = levelSlotBase + (L - 1) * nSeatsTotal + seat
+    unsigned long long* expansions; // run-wide count of expanded nodes
+};
+
 struct ViriExpandParams {          // spx_viri_expand_kernel (spx_movegen.hip)
     const uint8_t* data;            // the viriformat stream
     uint32_t nGames;
@@ -224,6 +268,7 @@ hipError_t launchMovegen(const MovegenParams& p, uint32_t gridBlocks, hipStream_
 hipError_t launchViriExpand(const ViriExpandParams& p, hipStream_t stream);
 hipError_t launchPick(const PickParams& p, hipStream_t stream);
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream);
+hipError_t launchSearchStep(const SearchStepParams& p, hipStream_t stream);
 // hostStatus: device view of page-locked host memory laid out as { SelfplayCounters, u64 streamWords of the half, u64 total }
 hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, const unsigned long long* streamWords,
                             void* hostStatus, hipStream_t stream);

@@ -439,6 +439,167 @@ __device__ void writeGame(const GameStepParams& p, uint32_t g, uint32_t lane, co
     }
 }
 
+struct MoveResult {
+    uint32_t outcome;        // the current game ended with this outcome (kNoOutcome: it goes on or was discarded)
+    bool discard;            // ... or was discarded by the verification filter
+    bool moved;              // the move was played and the game goes on
+    uint32_t nWords, lastWord;  // the finished game's move words: gm[0 .. nWords - 2], then lastWord
+};
+
+// The depth-1 policy: score(move) = -staticEval(child), uniformly among the moves within `temperature` of the best (one
+// splitmix64 draw per move played, the new state in rngState). evals = the position's children. -> child index, `best`.
+__device__ uint32_t pickDepthOne(const int32_t* evals, uint32_t count, int32_t temperature, uint64_t rngIn, uint32_t lane,
+                                 uint64_t& rngState, int32_t& best) {
+    best = INT32_MIN;
+    for (uint32_t k = lane; k < count; k += 64) best = max(best, clampStaticEval(-evals[k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+    uint32_t nCandidates = 0;
+    for (uint32_t base = 0; base < count; base += 64) {
+        const uint32_t k = base + lane;
+        const bool cand = k < count && clampStaticEval(-evals[k]) >= best - temperature;
+        nCandidates += uint32_t(popc64(__ballot(cand)));
+    }
+    rngState = rngIn + 0x9E3779B97F4A7C15ull;
+    uint64_t z = rngState;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint32_t target = temperature == 0 ? 0u : uint32_t(z >> 32) % nCandidates;
+    uint32_t pick = 0;
+    for (uint32_t base = 0; base < count; base += 64) {
+        const uint32_t k = base + lane;
+        const bool cand = k < count && clampStaticEval(-evals[k]) >= best - temperature;
+        const uint64_t mask = __ballot(cand);
+        const uint32_t here = uint32_t(popc64(mask));
+        if (target < here) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            pick = base + uint32_t(ctz64(__ballot(cand && rank == target)));
+            break;
+        }
+        target -= here;
+    }
+    return pick;
+}
+
+// One searched move of a game (datagen.cpp:176-190,224-300): verification of the opening on the first ply, a decisive
+// score ends the game at once (datagen.cpp:224-226), else the adjudication counters; the key history, Position::isDrawn of
+// the new position, the recorded word. (p0..p3) = the position searched, (c0..c3) = the chosen child, `score` / `best` from
+// the mover's point of view (best = the search's best score: what the verification filter looks at).
+__device__ void playMove(const GameStepParams& p, SeatState& st, uint32_t lane, uint64_t p0, uint64_t p1, uint64_t p2,
+                         uint64_t p3, uint64_t c0, uint64_t c1, uint64_t c2, uint64_t c3, uint32_t moveWord, int32_t score,
+                         int32_t best, uint32_t* gm, uint64_t* keys, MoveResult& r) {
+    const bool whiteToMove = !(p3 & 0x80u);
+    // Position::classicalMaterial of the position searched (lane k sums nibble k)
+    int32_t material = 0;
+    {
+        const uint32_t pieces = min(uint32_t(popc64(p0)), 32u);
+        if (lane < pieces) material = classicalMaterialOfNibble(int(((lane < 16 ? p1 : p2) >> ((lane & 15) * 4)) & 0xF));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) material += __shfl_xor(material, off, 64);
+    }
+    const int32_t whiteScore = whiteToMove ? score : -score;
+    const int32_t normScore = wdlNormalize(whiteScore, material);
+    const int32_t normBest = wdlNormalize(whiteToMove ? best : -best, material);
+    if (st.plies == 0 && (normBest > kVerificationScoreLimit || normBest < -kVerificationScoreLimit)) {
+        r.discard = true;
+        return;
+    }
+    uint32_t outcome;
+    if (whiteScore > kScoreWin || whiteScore < -kScoreWin) {  // isDecisive (core.h:722-724): never true of a clamped static eval
+        outcome = whiteScore > 0 ? 2u : 0u;
+    } else {
+        AdjCounters adj{st.win, st.loss, st.draw};
+        outcome = adjudicate(adj, normScore, st.startPly + st.plies);
+        st.win = adj.win, st.loss = adj.loss, st.draw = adj.draw;
+    }
+    const uint64_t newKey = recordKey(c0, c1, c2, uint32_t(c3));
+    const uint32_t halfmove = uint32_t((c3 >> 8) & 0xFFu);
+    // key history: the position searched is pushed, then the new position is looked for (isDrawnByRepetition, ply 0)
+    const uint32_t size = st.plies + 1;
+    if (lane == 0) keys[st.plies] = recordKey(p0, p1, p2, uint32_t(p3));
+    const int32_t limit = max(0, int32_t(size) - int32_t(halfmove) - 2);
+    const int32_t i = int32_t(size) - 4 - 2 * int32_t(lane);
+    const bool hit = i >= limit && keys[i] == newKey;
+    const bool repetition = popc64(__ballot(hit)) >= 2;
+    // halfmove clock at 100: Position::isDrawn looks at nothing else (position.cpp:622-633) and the answer - a
+    // draw unless checkmate - needs the next move generation: the seat goes on for one ply (pendingFifty) with
+    // the adjudicated result, if any, parked in `reserved`
+    const bool fifty = halfmove >= 100;
+    const bool capped = st.plies + 1 >= p.maxPlies;
+    const bool drawn = capped || (!fifty && (repetition || insufficientMaterial(c0, c1, c2)));
+    if (drawn) outcome = 1;
+    const int32_t recorded = drawn ? 0 : (whiteScore >= -2 && whiteScore <= 2 ? 0 : whiteScore);
+    r.lastWord = moveWord | (uint32_t(uint16_t(int16_t(recorded))) << 16);
+    r.nWords = st.plies + 1;
+    st.pendingFifty = 0;
+    st.reserved = 0;
+    if (fifty && !drawn) {
+        st.pendingFifty = 1;
+        st.reserved = outcome == kNoOutcome ? 0u : outcome + 1;
+        outcome = kNoOutcome;
+    }
+    r.outcome = outcome;
+    if (outcome == kNoOutcome) {
+        r.moved = true;
+        if (lane == 0) gm[st.plies] = r.lastWord;
+        st.plies += 1;
+    }
+}
+
+// What the position a seat is about to search says before any search: the parked 50-move decision and mate / stalemate
+// (datagen.cpp:213-221). -> true when the game is over (r filled in).
+__device__ bool terminalBeforeSearch(const SeatState& st, uint32_t count, bool inCheck, bool whiteToMove, const uint32_t* gm,
+                                     MoveResult& r) {
+    if (st.pendingFifty && !(count == 0 && inCheck)) {
+        r.outcome = 1;
+        r.nWords = st.plies;
+        r.lastWord = st.plies ? (gm[st.plies - 1] & 0xFFFFu) : 0u;  // that move led to a drawn position: score 0
+        return true;
+    }
+    if (st.pendingFifty && st.reserved) {
+        r.outcome = st.reserved - 1;  // checkmate on the board, so not drawn: the result adjudicated with that move stands
+        r.nWords = st.plies;
+        r.lastWord = st.plies ? gm[st.plies - 1] : 0u;
+        return true;
+    }
+    if (count == 0) {
+        r.outcome = inCheck ? (whiteToMove ? 0u : 2u) : 1u;
+        r.nWords = st.plies;
+        r.lastWord = st.plies ? gm[st.plies - 1] : 0u;
+        return true;
+    }
+    return false;
+}
+
+// A free seat takes the next opening while the run's target allows. A discarded game hands its ticket on; the host keeps
+// the pool ahead of every claim a step can make (spx_selfplay.cpp), so a claim beyond it only idles the seat.
+__device__ bool claimOpening(const GameStepParams& p, uint32_t lane, bool discard, SeatState& st, uint64_t& r0, uint64_t& r1,
+                             uint64_t& r2, uint64_t& r3, uint64_t& seed) {
+    uint32_t claim = 0xFFFFFFFFu;
+    if (lane == 0) {
+        SelfplayCounters* c = p.counters;
+        if (discard) atomicAdd(&c->discarded, 1ull);
+        // (a plain look first: once the target is reached the drained seats stop adding to the counter every ply - it could
+        // wrap on a very long tail - and stop queueing on one global atomic)
+        const bool ticket = discard || (*reinterpret_cast<volatile uint32_t*>(&c->started) < p.targetGames &&
+                                        atomicAdd(&c->started, 1u) < p.targetGames);
+        if (ticket) {
+            const uint32_t k = atomicAdd(&c->poolCursor, 1u);
+            if (k < *reinterpret_cast<volatile uint32_t*>(&c->poolSize)) claim = k;
+        }
+    }
+    claim = uniform(claim);
+    st = SeatState{};
+    if (claim == 0xFFFFFFFFu) return false;
+    const uint64_t* rec = p.poolRecords + size_t(claim % p.poolCap) * 4;
+    r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    seed = p.poolSeeds[claim % p.poolCap];
+    st.active = 1;
+    st.startPly = plyFromStartpos(uint32_t((r3 >> 16) & 0xFFFFu), !(r3 & 0x80u));
+    return true;
+}
+
 __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
     const uint32_t lane = laneId();
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -451,157 +612,38 @@ __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
     const uint32_t oldSlot = uniform(p.slots[g]);
     const uint32_t otherSlot = oldSlot == seat ? p.nSeatsTotal + seat : seat;
 
-    uint32_t outcome = kNoOutcome;  // the current game ended with this outcome
-    bool discard = false;           // ... or was discarded by the verification filter
-    bool moved = false;
-    uint32_t nWords = 0, lastWord = 0;
+    MoveResult mr{kNoOutcome, false, false, 0, 0};
     uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen child
     if (st.active) {
         const uint32_t count = uniform(p.count[g]);
         const bool inCheck = uniform(p.inCheck[g]) != 0;
         const uint64_t p0 = pos[0], p1 = pos[1], p2 = pos[2], p3 = pos[3];
-        const bool whiteToMove = !(p3 & 0x80u);
-        if (st.pendingFifty && !(count == 0 && inCheck)) {
-            outcome = 1;
-            nWords = st.plies;
-            lastWord = st.plies ? (gm[st.plies - 1] & 0xFFFFu) : 0u;  // that move led to a drawn position: score 0
-        } else if (st.pendingFifty && st.reserved) {
-            outcome = st.reserved - 1;  // checkmate on the board, so not drawn: the result adjudicated with that move stands
-            nWords = st.plies;
-            lastWord = st.plies ? gm[st.plies - 1] : 0u;
-        } else if (count == 0) {
-            outcome = inCheck ? (whiteToMove ? 0u : 2u) : 1u;
-            nWords = st.plies;
-            lastWord = st.plies ? gm[st.plies - 1] : 0u;
-        } else {
+        if (!terminalBeforeSearch(st, count, inCheck, !(p3 & 0x80u), gm, mr)) {
             const uint32_t lo = uniform(p.first[g]);
-            int32_t best = INT32_MIN;
-            for (uint32_t k = lane; k < count; k += 64) best = max(best, clampStaticEval(-p.evals[lo + k]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
-            uint32_t nCandidates = 0;
-            for (uint32_t base = 0; base < count; base += 64) {
-                const uint32_t k = base + lane;
-                const bool cand = k < count && clampStaticEval(-p.evals[lo + k]) >= best - p.temperature;
-                nCandidates += uint32_t(popc64(__ballot(cand)));
-            }
-            const uint64_t rngState = p.rng[g] + 0x9E3779B97F4A7C15ull;
-            uint64_t z = rngState;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-            z ^= z >> 31;
-            uint32_t target = p.temperature == 0 ? 0u : uint32_t(z >> 32) % nCandidates;
-            uint32_t pick = 0;
-            for (uint32_t base = 0; base < count; base += 64) {
-                const uint32_t k = base + lane;
-                const bool cand = k < count && clampStaticEval(-p.evals[lo + k]) >= best - p.temperature;
-                const uint64_t mask = __ballot(cand);
-                const uint32_t here = uint32_t(popc64(mask));
-                if (target < here) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-                    pick = base + uint32_t(ctz64(__ballot(cand && rank == target)));
-                    break;
-                }
-                target -= here;
-            }
-            const uint32_t c = lo + pick;
+            int32_t best;
+            uint64_t rngState;
+            const uint32_t c = lo + pickDepthOne(p.evals + lo, count, p.temperature, p.rng[g], lane, rngState, best);
             const uint64_t* child = p.children + size_t(c) * 4;
             c0 = child[0], c1 = child[1], c2 = child[2], c3 = child[3];
-            // Position::classicalMaterial of the position searched (lane k sums nibble k)
-            int32_t material = 0;
-            {
-                const uint32_t pieces = min(uint32_t(popc64(p0)), 32u);
-                if (lane < pieces) material = classicalMaterialOfNibble(int(((lane < 16 ? p1 : p2) >> ((lane & 15) * 4)) & 0xF));
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) material += __shfl_xor(material, off, 64);
-            }
-            const int32_t score = clampStaticEval(-p.evals[c]);
-            const int32_t whiteScore = whiteToMove ? score : -score;
-            const int32_t normScore = wdlNormalize(whiteScore, material);
-            const int32_t normBest = wdlNormalize(whiteToMove ? best : -best, material);
-            if (st.plies == 0 && (normBest > kVerificationScoreLimit || normBest < -kVerificationScoreLimit)) {
-                discard = true;
-            } else {
-                AdjCounters adj{st.win, st.loss, st.draw};
-                outcome = adjudicate(adj, normScore, st.startPly + st.plies);
-                st.win = adj.win, st.loss = adj.loss, st.draw = adj.draw;
-                const uint64_t newKey = recordKey(c0, c1, c2, uint32_t(c3));
-                const uint32_t halfmove = uint32_t((c3 >> 8) & 0xFFu);
-                // key history: the position searched is pushed, then the new position is looked for (isDrawnByRepetition, ply 0)
-                const uint32_t size = st.plies + 1;
-                if (lane == 0) keys[st.plies] = recordKey(p0, p1, p2, uint32_t(p3));
-                const int32_t limit = max(0, int32_t(size) - int32_t(halfmove) - 2);
-                const int32_t i = int32_t(size) - 4 - 2 * int32_t(lane);
-                const bool hit = i >= limit && keys[i] == newKey;
-                const bool repetition = popc64(__ballot(hit)) >= 2;
-                // halfmove clock at 100: Position::isDrawn looks at nothing else (position.cpp:622-633) and the answer - a
-                // draw unless checkmate - needs the next move generation: the seat goes on for one ply (pendingFifty) with
-                // the adjudicated result, if any, parked in `reserved`
-                const bool fifty = halfmove >= 100;
-                const bool capped = st.plies + 1 >= p.maxPlies;
-                const bool drawn = capped || (!fifty && (repetition || insufficientMaterial(c0, c1, c2)));
-                if (drawn) outcome = 1;
-                const int32_t recorded = drawn ? 0 : (whiteScore >= -2 && whiteScore <= 2 ? 0 : whiteScore);
-                lastWord = uint32_t(p.moves[c]) | (uint32_t(uint16_t(int16_t(recorded))) << 16);
-                nWords = st.plies + 1;
-                st.pendingFifty = 0;
-                st.reserved = 0;
-                if (fifty && !drawn) {
-                    st.pendingFifty = 1;
-                    st.reserved = outcome == kNoOutcome ? 0u : outcome + 1;
-                    outcome = kNoOutcome;
-                }
-                if (outcome == kNoOutcome) {
-                    moved = true;
-                    if (lane == 0) {
-                        gm[st.plies] = lastWord;
-                        p.rng[g] = rngState;
-                    }
-                    st.plies += 1;
-                }
-            }
+            playMove(p, st, lane, p0, p1, p2, p3, c0, c1, c2, c3, uint32_t(p.moves[c]), clampStaticEval(-p.evals[c]), best, gm,
+                     keys, mr);
+            if (mr.moved && lane == 0) p.rng[g] = rngState;
         }
     }
 
-    if (outcome != kNoOutcome) writeGame(p, g, lane, gm, nWords, lastWord, outcome);
+    if (mr.outcome != kNoOutcome) writeGame(p, g, lane, gm, mr.nWords, mr.lastWord, mr.outcome);
     bool started = false;
     uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, seed = 0;
-    if (!st.active || outcome != kNoOutcome || discard) {
-        // the seat is free: take the next opening while the run's target allows. A discarded game hands its ticket on; the
-        // host keeps the pool ahead of every claim a step can make (spx_selfplay.cpp), so a claim beyond it only idles the seat.
-        uint32_t claim = 0xFFFFFFFFu;
-        if (lane == 0) {
-            SelfplayCounters* c = p.counters;
-            if (discard) atomicAdd(&c->discarded, 1ull);
-            // (a plain look first: once the target is reached the drained seats stop adding to the counter every ply - it could
-            // wrap on a very long tail - and stop queueing on one global atomic)
-            const bool ticket = discard || (*reinterpret_cast<volatile uint32_t*>(&c->started) < p.targetGames &&
-                                            atomicAdd(&c->started, 1u) < p.targetGames);
-            if (ticket) {
-                const uint32_t k = atomicAdd(&c->poolCursor, 1u);
-                if (k < *reinterpret_cast<volatile uint32_t*>(&c->poolSize)) claim = k;
-            }
-        }
-        claim = uniform(claim);
-        st = SeatState{};
-        if (claim != 0xFFFFFFFFu) {
-            const uint64_t* rec = p.poolRecords + size_t(claim % p.poolCap) * 4;
-            r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            seed = p.poolSeeds[claim % p.poolCap];
-            started = true;
-            st.active = 1;
-            st.startPly = plyFromStartpos(uint32_t((r3 >> 16) & 0xFFFFu), !(r3 & 0x80u));
-        }
-    }
+    if (!st.active || mr.outcome != kNoOutcome || mr.discard) started = claimOpening(p, lane, mr.discard, st, r0, r1, r2, r3, seed);
     if (lane == 0) p.state[g] = st;
     // The half's materialising update has one record per SEAT, at the seat's own index (no compaction: thousands of atomic
     // adds on one counter per launch cost more than the whole ply - ~116 ns each on this chip): the move played (parent =
     // old slot), a new game (parent = the null slot's empty board: the update kernel rebuilds the child from scratch), or,
     // for an idle seat, empty board -> empty board into the seat's spare slot (no rows, nothing read back).
-    const bool live = started || moved;
+    const bool live = started || mr.moved;
     const uint64_t n0 = started ? r0 : c0, n1 = started ? r1 : c1, n2 = started ? r2 : c2, n3 = started ? r3 : c3;
     if (lane == 0) {
-        p.updParents[g] = moved ? oldSlot : 2u * p.nSeatsTotal;
+        p.updParents[g] = mr.moved ? oldSlot : 2u * p.nSeatsTotal;
         p.updChildren[g] = otherSlot;
         if (live) p.slots[g] = otherSlot;
         if (started) p.rng[g] = seed;
@@ -610,6 +652,246 @@ __global__ __launch_bounds__(256) void spx_game_step_kernel(GameStepParams p) {
         const uint64_t w = !live ? 0ull : (lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3)));
         pos[lane] = w;  // (idle seat: an empty record generates no moves)
         p.updPositions[size_t(g) * 4 + lane] = w;
+        if (started) p.initial[size_t(g) * 4 + lane] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One ROUND of the live fixed-node search for every seat of one half (SearchStepParams, spx_kernels.h, has the rules): this
+// round's batch holds the children of every seat's `pending` node with their evaluations. One wavefront per seat consumes
+// them - a terminal node or a depth-1 node returns its value to its parent frame, possibly through several levels; a
+// deeper node keeps its children (records, move words, values) in the seat's frame storage - and walks on to the next node
+// to expand: a materialising update (its parent's accumulator slot -> the slot of its level) and the next move generation's
+// input. When an iteration ends at the root and the search is over, the move goes through the same bookkeeping as a depth-1
+// move (playMove) and the new position - or a new game's opening - becomes the next pending node.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long childKey(int32_t value, uint32_t word) {  // value descending, then move word ascending
+    return (static_cast<long long>(value) << 16) | static_cast<long long>(0xFFFFu - word);
+}
+__device__ __forceinline__ long long waveMax(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor(uint32_t(v), off, 64);
+        const int32_t hi = __shfl_xor(int32_t(v >> 32), off, 64);
+        const long long o = (static_cast<long long>(hi) << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void spx_search_step_kernel(SearchStepParams sp) {
+    const GameStepParams& p = sp.game;
+    const uint32_t lane = laneId();
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.nSeats) return;
+    SeatState st = p.state[g];
+    SearchSeat ss = sp.seats[g];
+    uint64_t* pos = p.positions + size_t(g) * 4;
+    uint32_t* gm = p.gameMoves + size_t(g) * p.maxPlies;
+    uint64_t* keys = p.keys + size_t(g) * p.maxPlies;
+    const uint32_t seat = p.seatBase + g;
+    const uint32_t oldSlot = uniform(p.slots[g]);
+    const uint32_t otherSlot = oldSlot == seat ? p.nSeatsTotal + seat : seat;
+    SearchFrame* frames = sp.frames + size_t(g) * kSearchLevels;
+    uint64_t* fRecords = sp.frameRecords + size_t(g) * kSearchLevels * kSearchChildren * 4;
+    int32_t* fValues = sp.frameValues + size_t(g) * kSearchLevels * kSearchChildren;
+    uint16_t* fWords = sp.frameWords + size_t(g) * kSearchLevels * kSearchChildren;
+
+    MoveResult mr{kNoOutcome, false, false, 0, 0};
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen child when a move is played / the next node when the search goes on
+    bool descend = false;
+    uint32_t nextLevel = 0;
+    if (st.active) {
+        const uint32_t count = min(uniform(p.count[g]), kSearchChildren);
+        const bool inCheck = uniform(p.inCheck[g]) != 0;
+        const uint32_t lo = uniform(p.first[g]);
+        const uint64_t p0 = pos[0], p1 = pos[1], p2 = pos[2], p3 = pos[3];
+        const bool over = ss.top == 0 && terminalBeforeSearch(st, count, inCheck, !(p3 & 0x80u), gm, mr);
+        if (!over) {
+            ss.nodes += 1;
+            if (lane == 0) sp.expansions[g] += 1;
+            uint32_t L = ss.top;
+            const uint32_t batchLevel = L;  // the frame whose children are this round's batch (its storage is written below:
+                                            // reads of it in THIS round go to the batch instead)
+            // the running frame lives in registers (wave-uniform); frames are read from memory when a child returns into them
+            // and written when the search descends below them
+            uint32_t fCount = count, fDepth = frames[L].depth;
+            int32_t fAlpha = frames[L].alpha, fBeta = frames[L].beta, fBest = -kSearchInf, fBestIdx = -1, fCur = -1;
+            uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // visited
+            fDepth = uniform(fDepth), fAlpha = int32_t(uniform(uint32_t(fAlpha))), fBeta = int32_t(uniform(uint32_t(fBeta)));
+            int32_t res = 0;
+            enum { kReturn, kDescend, kPlay } action;
+            if (count == 0) {
+                res = inCheck ? -(kSearchMate - int32_t(L)) : 0;
+                action = kReturn;
+            } else {
+                if (L == 0 || fDepth >= 2) {  // the children stay: the root's always (the move played comes from them)
+                    for (uint32_t k = lane; k < count; k += 64) {
+                        const size_t at = size_t(L) * kSearchChildren + k;
+                        fValues[at] = clampStaticEval(-p.evals[lo + k]);
+                        fWords[at] = p.moves[lo + k];
+                        for (int w = 0; w < 4; ++w) fRecords[at * 4 + w] = p.children[size_t(lo + k) * 4 + w];
+                    }
+                }
+                if (fDepth == 1) {
+                    long long key = INT64_MIN;
+                    for (uint32_t k = lane; k < count; k += 64) {
+                        const long long mine = childKey(clampStaticEval(-p.evals[lo + k]), p.moves[lo + k]);
+                        key = mine > key ? mine : key;
+                    }
+                    const long long top = waveMax(key);
+                    res = int32_t(top >> 16);
+                    if (L == 0) {  // iteration 1 at the root: which child it is
+                        uint32_t idx = 0xFFFFFFFFu;
+                        for (uint32_t k = lane; k < count; k += 64) {
+                            if (childKey(clampStaticEval(-p.evals[lo + k]), p.moves[lo + k]) == top) idx = k;
+                        }
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) idx = min(idx, uint32_t(__shfl_xor(idx, off, 64)));
+                        fBestIdx = int32_t(idx);
+                    }
+                    fBest = res;
+                    action = kReturn;
+                } else {
+                    action = kDescend;
+                }
+            }
+            for (;;) {
+                if (action == kReturn && L != 0) {  // frame L returns `res` to its parent
+                    --L;
+                    const SearchFrame& f = frames[L];
+                    fCount = uniform(f.count), fDepth = uniform(f.depth);
+                    fAlpha = int32_t(uniform(uint32_t(f.alpha))), fBeta = int32_t(uniform(uint32_t(f.beta)));
+                    fBest = int32_t(uniform(uint32_t(f.best))), fBestIdx = int32_t(uniform(uint32_t(f.bestIdx)));
+                    fCur = int32_t(uniform(uint32_t(f.cur)));
+                    v0 = f.visited[0], v1 = f.visited[1], v2 = f.visited[2], v3 = f.visited[3];
+                    const int32_t v = -res;
+                    if (v > fBest) fBest = v, fBestIdx = fCur;
+                    if (v > fAlpha) fAlpha = v;
+                    const uint32_t seen = uint32_t(popc64(v0) + popc64(v1) + popc64(v2) + popc64(v3));
+                    if (fAlpha >= fBeta || seen >= fCount) {
+                        res = fBest;
+                        continue;
+                    }
+                    action = kDescend;
+                }
+                if (action == kReturn) {  // (L == 0) an iteration is complete
+                    ss.prevBest = fBestIdx;
+                    const bool decisive = fBest > kScoreWin || fBest < -kScoreWin;
+                    if (ss.nodes >= sp.nodeBudget || ss.iter >= kSearchLevels || decisive) {
+                        action = kPlay;
+                        break;
+                    }
+                    ss.iter += 1;
+                    fDepth = ss.iter;
+                    fAlpha = -kSearchInf, fBeta = kSearchInf, fBest = -kSearchInf, fBestIdx = -1;
+                    v0 = v1 = v2 = v3 = 0;
+                    action = kDescend;
+                }
+                // search the next child of frame L: the best of the children not yet visited (the previous iteration's choice
+                // first at the root)
+                const bool fromBatch = L == batchLevel;
+                long long key = INT64_MIN;
+                for (uint32_t k = lane; k < fCount; k += 64) {
+                    const uint64_t word = k < 64 ? v0 : (k < 128 ? v1 : (k < 192 ? v2 : v3));
+                    if ((word >> (k & 63)) & 1) continue;
+                    const size_t at = size_t(L) * kSearchChildren + k;
+                    long long mine = fromBatch ? childKey(clampStaticEval(-p.evals[lo + k]), p.moves[lo + k])
+                                               : childKey(fValues[at], fWords[at]);
+                    if (L == 0 && int32_t(k) == ss.prevBest) mine = INT64_MAX;
+                    key = mine > key ? mine : key;
+                }
+                const long long top = waveMax(key);
+                uint32_t idx = 0xFFFFFFFFu;
+                for (uint32_t k = lane; k < fCount; k += 64) {
+                    const uint64_t word = k < 64 ? v0 : (k < 128 ? v1 : (k < 192 ? v2 : v3));
+                    if ((word >> (k & 63)) & 1) continue;
+                    const size_t at = size_t(L) * kSearchChildren + k;
+                    long long mine = fromBatch ? childKey(clampStaticEval(-p.evals[lo + k]), p.moves[lo + k])
+                                               : childKey(fValues[at], fWords[at]);
+                    if (L == 0 && int32_t(k) == ss.prevBest) mine = INT64_MAX;
+                    if (mine == top) idx = k;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) idx = min(idx, uint32_t(__shfl_xor(idx, off, 64)));
+                const uint64_t bit = 1ull << (idx & 63);
+                v0 |= idx < 64 ? bit : 0ull;
+                v1 |= (idx >= 64 && idx < 128) ? bit : 0ull;
+                v2 |= (idx >= 128 && idx < 192) ? bit : 0ull;
+                v3 |= idx >= 192 ? bit : 0ull;
+                fCur = int32_t(idx);
+                if (lane == 0) {
+                    SearchFrame f{};
+                    f.count = fCount, f.depth = fDepth, f.alpha = fAlpha, f.beta = fBeta, f.best = fBest, f.bestIdx = fBestIdx;
+                    f.cur = fCur;
+                    f.visited[0] = v0, f.visited[1] = v1, f.visited[2] = v2, f.visited[3] = v3;
+                    frames[L] = f;
+                    SearchFrame below{};
+                    below.depth = fDepth - 1, below.alpha = -fBeta, below.beta = -fAlpha, below.best = -kSearchInf;
+                    below.bestIdx = below.cur = -1;
+                    frames[L + 1] = below;
+                }
+                const uint64_t* rec = fromBatch ? p.children + size_t(lo + idx) * 4
+                                                : fRecords + (size_t(L) * kSearchChildren + idx) * 4;
+                c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+                descend = true;
+                nextLevel = L + 1;
+                break;
+            }
+            if (action == kPlay) {
+                int32_t score = fBest, best = fBest;
+                uint32_t pick = uint32_t(fBestIdx);
+                uint64_t rngState = 0;
+                const bool policy = sp.nodeBudget <= 1;  // the depth-1 policy, temperature included (the root is this round's batch)
+                if (policy) {
+                    pick = pickDepthOne(p.evals + lo, count, p.temperature, p.rng[g], lane, rngState, best);
+                    score = clampStaticEval(-p.evals[lo + pick]);
+                }
+                const bool fromBatch = batchLevel == 0;
+                const uint64_t* rec = fromBatch ? p.children + size_t(lo + pick) * 4 : fRecords + size_t(pick) * 4;
+                c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+                const uint32_t word = fromBatch ? uint32_t(p.moves[lo + pick]) : uint32_t(fWords[pick]);
+                playMove(p, st, lane, p0, p1, p2, p3, c0, c1, c2, c3, word, score, best, gm, keys, mr);
+                if (mr.moved && policy && lane == 0) p.rng[g] = rngState;
+            }
+        }
+    }
+
+    if (mr.outcome != kNoOutcome) writeGame(p, g, lane, gm, mr.nWords, mr.lastWord, mr.outcome);
+    bool started = false;
+    uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, seed = 0;
+    if (!st.active || mr.outcome != kNoOutcome || mr.discard) started = claimOpening(p, lane, mr.discard, st, r0, r1, r2, r3, seed);
+    if (lane == 0) p.state[g] = st;
+    // One materialising update per seat and round, as in the depth-1 driver: the node the search walks on to (its parent's
+    // slot -> the slot of its level), the move played (old root slot -> the seat's other root slot), a new game (null slot:
+    // rebuilt from scratch) or, for an idle seat, empty board -> empty board.
+    const bool newRoot = started || mr.moved;
+    const bool live = newRoot || descend;
+    const uint64_t n0 = started ? r0 : c0, n1 = started ? r1 : c1, n2 = started ? r2 : c2, n3 = started ? r3 : c3;
+    const uint32_t levelSlot = sp.levelSlotBase + (nextLevel - 1) * p.nSeatsTotal + seat;  // (descend only: nextLevel >= 1)
+    const uint32_t parentSlot = nextLevel <= 1 ? oldSlot : levelSlot - p.nSeatsTotal;
+    if (lane == 0) {
+        p.updParents[g] = descend ? parentSlot : (mr.moved ? oldSlot : 2u * p.nSeatsTotal);
+        p.updChildren[g] = descend ? levelSlot : otherSlot;
+        sp.pendingSlots[g] = descend ? levelSlot : otherSlot;
+        if (newRoot) {
+            p.slots[g] = otherSlot;
+            SearchFrame root{};
+            root.depth = 1, root.alpha = -kSearchInf, root.beta = kSearchInf, root.best = -kSearchInf;
+            root.bestIdx = root.cur = -1;
+            frames[0] = root;
+            ss = SearchSeat{0u, 1u, 0u, -1};
+        } else if (descend) {
+            ss.top = nextLevel;
+        }
+        if (started) p.rng[g] = seed;
+        sp.seats[g] = ss;
+    }
+    if (lane < 4) {
+        const uint64_t w = !live ? 0ull : (lane == 0 ? n0 : (lane == 1 ? n1 : (lane == 2 ? n2 : n3)));
+        sp.pending[size_t(g) * 4 + lane] = w;  // (idle seat: an empty record generates no moves)
+        p.updPositions[size_t(g) * 4 + lane] = w;
+        if (newRoot || !live) pos[lane] = w;
         if (started) p.initial[size_t(g) * 4 + lane] = w;
     }
 }
@@ -737,6 +1019,11 @@ hipError_t launchGameStatus(const SelfplayCounters* counters, uint32_t* total, c
 
 hipError_t launchGameStep(const GameStepParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(spx_game_step_kernel, dim3((p.nSeats + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launchSearchStep(const SearchStepParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(spx_search_step_kernel, dim3((p.game.nSeats + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

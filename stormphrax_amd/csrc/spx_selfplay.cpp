@@ -850,7 +850,13 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         setError("spx_selfplay_run: too many games for 32-bit slot ids");
         return SPX_ERR_INVALID_ARG;
     }
-    int rc = spx_acc_reserve(ctx, size_t(G) * 2 + 1);  // two slots per seat (current / next position) + the null slot
+    // Live fixed-node search (SPX_SELFPLAY_SEARCH_NODES(k) in flags; SearchStepParams in spx_kernels.h has the rules): the
+    // per-ply chain below becomes a per-ROUND chain - every seat expands one node of its own search tree per round - with
+    // spx_search_step_kernel in place of spx_game_step_kernel and one more accumulator slot per seat and tree level.
+    const uint32_t searchNodes = p->flags >> 8;
+    const bool search = searchNodes != 0;
+    // two slots per seat (current / next position) + the null slot (+ the search levels below the root)
+    int rc = spx_acc_reserve(ctx, size_t(G) * 2 + 1 + (search ? size_t(G) * (kSearchLevels - 1) : 0));
     if (rc != SPX_OK) return rc;
     SPX_SP_HIP(hipSetDevice(ctxDevice(ctx)));
     SPX_SP_HIP(hipMemset(ctxSlotRecords(ctx) + size_t(G) * 2 * 32, 0, 32));  // the null slot holds the empty board
@@ -905,6 +911,17 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     auto* hPoolRecords = pinned.get<spx_packed_pos>(16384);
     auto* hPoolSeeds = pinned.get<uint64_t>(16384);
     auto* hPoolSize = pinned.get<uint32_t>(1);
+    // search mode: the seats' stacks (57 KiB of child records per seat and level: 1.8 GiB at 4 096 seats - HBM is not the
+    // scarce resource here), the nodes to expand next and their slots
+    const size_t frameSlots = search ? size_t(G) * kSearchLevels : 0;
+    auto* dSeats = dev.get<SearchSeat>(search ? G : 0);
+    auto* dFrames = dev.get<SearchFrame>(frameSlots);
+    auto* dFrameRecords = dev.get<uint64_t>(frameSlots * kSearchChildren * 4);
+    auto* dFrameValues = dev.get<int32_t>(frameSlots * kSearchChildren);
+    auto* dFrameWords = dev.get<uint16_t>(frameSlots * kSearchChildren);
+    auto* dPending = dev.get<uint64_t>(search ? size_t(G) * 4 : 0);
+    auto* dPendingSlots = dev.get<uint32_t>(search ? G : 0);
+    auto* dExpansions = dev.get<unsigned long long>(search ? G : 0);
     std::vector<DeviceHalf> halves(nHalves);
     struct RingCloser {  // the halves' output rings
         std::vector<DeviceHalf>& h;
@@ -915,7 +932,8 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         }
     } ringCloser{halves};
     bool ok = dPositions && dSlots && dRng && dFirst && dCount && dInCheck && dState && dInitial && dGameMoves && dKeys &&
-              dPoolRecords && dPoolSeeds && dCounters && hPoolRecords && hPoolSeeds && hPoolSize;
+              dPoolRecords && dPoolSeeds && dCounters && hPoolRecords && hPoolSeeds && hPoolSize && dSeats && dFrames &&
+              dFrameRecords && dFrameValues && dFrameWords && dPending && dPendingSlots && dExpansions;
     for (uint32_t h = 0; h < nHalves && ok; ++h) {
         DeviceHalf& hf = halves[h];
         hf.index = h;
@@ -974,6 +992,13 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         std::vector<uint32_t> iota(G);
         for (uint32_t i = 0; i < G; ++i) iota[i] = i;  // every seat starts on its home slot
         SPX_SP_HIP(hipMemcpy(dSlots, iota.data(), size_t(G) * 4, hipMemcpyHostToDevice));
+        if (search) SPX_SP_HIP(hipMemcpy(dPendingSlots, iota.data(), size_t(G) * 4, hipMemcpyHostToDevice));
+    }
+    if (search) {
+        SPX_SP_HIP(hipMemset(dSeats, 0, size_t(G) * sizeof(SearchSeat)));
+        SPX_SP_HIP(hipMemset(dFrames, 0, frameSlots * sizeof(SearchFrame)));
+        SPX_SP_HIP(hipMemset(dPending, 0, size_t(G) * 32));
+        SPX_SP_HIP(hipMemset(dExpansions, 0, size_t(G) * 8));
     }
     SPX_SP_HIP(hipMemset(dPositions, 0, size_t(G) * 32));  // empty records generate no moves
     SPX_SP_HIP(hipMemset(dState, 0, size_t(G) * sizeof(SeatState)));
@@ -1026,9 +1051,9 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         const uint32_t seats = hf.end - hf.begin;
         {   // (spx_movegen_device without its cursor memset: the status kernel of the half's previous ply zeroed it)
             MovegenParams mp{};
-            mp.positions = dPositions + size_t(hf.begin) * 4;
+            mp.positions = (search ? dPending : dPositions) + size_t(hf.begin) * 4;
             mp.nPositions = seats;
-            mp.parentValues = dSlots + hf.begin;
+            mp.parentValues = (search ? dPendingSlots : dSlots) + hf.begin;
             mp.children = hf.dChildren;
             mp.moves = hf.dMoves;
             mp.parents = hf.dParents;
@@ -1072,7 +1097,23 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
         gp.updParents = hf.dUpdParents;
         gp.updChildren = hf.dUpdChildren;
         gp.updPositions = hf.dUpdPositions;
-        SPX_SP_HIP(launchGameStep(gp, s));
+        if (search) {
+            SearchStepParams sp{};
+            sp.game = gp;
+            sp.nodeBudget = searchNodes;
+            sp.seats = dSeats + hf.begin;
+            sp.frames = dFrames + size_t(hf.begin) * kSearchLevels;
+            sp.frameRecords = dFrameRecords + size_t(hf.begin) * kSearchLevels * kSearchChildren * 4;
+            sp.frameValues = dFrameValues + size_t(hf.begin) * kSearchLevels * kSearchChildren;
+            sp.frameWords = dFrameWords + size_t(hf.begin) * kSearchLevels * kSearchChildren;
+            sp.pending = dPending + size_t(hf.begin) * 4;
+            sp.pendingSlots = dPendingSlots + hf.begin;
+            sp.levelSlotBase = 2 * G + 1;
+            sp.expansions = dExpansions + hf.begin;
+            SPX_SP_HIP(launchSearchStep(sp, s));
+        } else {
+            SPX_SP_HIP(launchGameStep(gp, s));
+        }
         // the one accumulator per seat that has to exist next ply: the move played (parent -> the seat's other slot) or
         // the new game's opening (null slot -> rebuilt from scratch by the update kernel)
         r = spx_acc_update_device(ctx, hf.dUpdParents, hf.dUpdChildren, hf.dUpdPositions, seats, s);
@@ -1225,6 +1266,12 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
     for (int k = 0; k < 3; ++k) stats->outcomes[k] = latest.outcomes[k];
     stats->evals = evals;
     stats->steps = (steps + nHalves - 1) / nHalves;
+    if (search) {  // nodes expanded by all searches together
+        std::vector<unsigned long long> expanded(G);
+        SPX_SP_HIP(hipMemcpy(expanded.data(), dExpansions, size_t(G) * 8, hipMemcpyDeviceToHost));
+        stats->steps = 0;
+        for (unsigned long long e : expanded) stats->steps += e;
+    }
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->gpu_seconds = gpuWait;
     if (ctxSelfplayOption(ctx, 2)) {
@@ -1244,7 +1291,8 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
 extern "C" int spx_selfplay_run(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_path,
                                 spx_selfplay_stats* stats) {
     if (!ctx || !p || !stats || p->n_games == 0 || p->target_games == 0 ||
-        (p->flags & ~uint32_t(SPX_SELFPLAY_HOST_MOVEGEN))) {
+        (p->flags & 0xFFu & ~uint32_t(SPX_SELFPLAY_HOST_MOVEGEN)) ||
+        ((p->flags & SPX_SELFPLAY_HOST_MOVEGEN) && (p->flags >> 8))) {  // the search lives in the device-resident driver
         setError("spx_selfplay_run: invalid argument");
         return SPX_ERR_INVALID_ARG;
     }

@@ -336,11 +336,13 @@ class NnueState:
         return out
 
     def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1,
-                 host_threads=0, host_movegen=False):
-        """Batched depth-1 self-play (config 4 shape); returns the stats dict. See spx_selfplay_run.
-        host_movegen=True generates moves with the host chess core instead of the device kernel."""
+                 host_threads=0, host_movegen=False, search_nodes=0):
+        """Batched self-play (config 4 shape); returns the stats dict. See spx_selfplay_run.
+        host_movegen=True generates moves with the host chess core instead of the device kernel.
+        search_nodes=k: a live fixed-node search of k expanded nodes picks every move (SPX_SELFPLAY_SEARCH_NODES; 0 = the
+        depth-1 policy; k = 1 plays the same games through the search driver); stats["steps"] then counts expanded nodes."""
         params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, host_threads,
-                                     1 if host_movegen else 0, seed)
+                                     (1 if host_movegen else 0) | (int(search_nodes) << 8), seed)
         stats = _lib.SelfplayStats()
         check(_lib.load().spx_selfplay_run(self._h, ctypes.byref(params), out_path.encode() if out_path else None,
                                            ctypes.byref(stats)))
@@ -410,10 +412,12 @@ class DeviceGroup:
                                            None if corr is None else corr.ctypes.data, out.ctypes.data))
         return out
 
-    def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1):
+    def selfplay(self, n_games, target_games, out_path=None, max_plies=300, dfrc=False, temperature_cp=30, seed=1,
+                 search_nodes=0):
         """spx_group_selfplay_run: the games dealt to the members, one host thread and one device each; output files
         <out_path>.<member>.vf; summed stats."""
-        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, 0, 0, seed)
+        params = _lib.SelfplayParams(n_games, target_games, max_plies, 0, int(dfrc), temperature_cp, 0,
+                                     int(search_nodes) << 8, seed)
         stats = _lib.SelfplayStats()
         check(_lib.load().spx_group_selfplay_run(self._h, ctypes.byref(params), out_path.encode() if out_path else None,
                                                  ctypes.byref(stats)))

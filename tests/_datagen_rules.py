@@ -115,8 +115,10 @@ def replay_game(before, after_last, mover_scores, normalize, max_plies, final_is
         white_score = int(mover_scores[k]) if white else -int(mover_scores[k])
         norm = normalize(white_score, int(material[k]))
         outcome = None
-        # datagen.cpp:224-252 (isDecisive never holds for clamped static evals)
-        if norm > WIN_ADJ_MIN_SCORE:
+        # datagen.cpp:224-252 (isDecisive never holds for clamped static evals: only a search that found a mate gets there)
+        if abs(white_score) > K_SCORE_WIN:
+            outcome = WIN if white_score > 0 else LOSS
+        elif norm > WIN_ADJ_MIN_SCORE:
             win, loss, draw = win + 1, 0, 0
         elif norm < -WIN_ADJ_MIN_SCORE:
             win, loss, draw = 0, loss + 1, 0
@@ -152,7 +154,7 @@ def replay_game(before, after_last, mover_scores, normalize, max_plies, final_is
             return DRAW, k + 1, recorded
         recorded.append(0 if abs(white_score) <= 2 else white_score)
         if outcome is not None:
-            count("adjudicated " + ("white loss", "draw", "white win")[outcome])
+            count(("decisive score: " if abs(white_score) > K_SCORE_WIN else "adjudicated ") + ("white loss", "draw", "white win")[outcome])
             return outcome, k + 1, recorded
     # the loop went on: the position after the last recorded move must be terminal (datagen.cpp:213-221)
     assert not final_has_moves, "the recorded game stops although the reference's loop would have played on"

@@ -442,6 +442,55 @@ def test_selfplay_plays_the_same_games_for_the_same_seed(sp, net_blob, tmp_path)
     assert runs[0] == runs[1] and len(runs[0]) == 500
 
 
+def test_search_with_a_budget_of_one_node_plays_the_depth_one_games(sp, net_blob, tmp_path):
+    """SPX_SELFPLAY_SEARCH_NODES(1): the search driver (spx_search_step_kernel, one expanded node per seat and round) stops
+    after its first iteration and must then play exactly the games of the depth-1 driver - temperature, verification filter,
+    adjudication, records - for the same seed."""
+    from _datagen_rules import parse_games
+
+    runs = []
+    for nodes in (0, 1):
+        with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=16384) as st:
+            path = str(tmp_path / f"k{nodes}.vf")
+            stats = st.selfplay(n_games=160, target_games=400, out_path=path, max_plies=100, dfrc=True, temperature_cp=25, seed=31,
+                                search_nodes=nodes)
+            assert stats["games"] == 400
+            if nodes:
+                assert stats["steps"] >= stats["positions"]  # one expansion per move played (+ discarded openings, terminal roots)
+            runs.append(sorted((h, m.tobytes(), s.tobytes()) for h, m, s, _ in parse_games(open(path, "rb").read())))
+    assert runs[0] == runs[1] and len(runs[0]) == 400
+
+
+@pytest.mark.parametrize("budget,n_games,target,max_plies,graph", [(20, 24, 40, 70, 1), (48, 6, 8, 40, 1), (150, 3, 3, 24, 0)])
+def test_live_search_games_follow_the_restated_search(sp, net_blob, oracle, tmp_path, budget, n_games, target, max_plies, graph):
+    """VERDICT r4 item 5 / SURVEY 8 row f-3: a live fixed-node search inside the device-resident self-play driver. Every
+    recorded game is replayed through tests/_search_rules.py - a recursive restatement of the search's rules that shares
+    nothing with the device's explicit-stack state machine: at every ply the restated search (leaf values = the GPU's
+    from-scratch evaluations, sampled against the CPU oracle) must choose the recorded move, and its scores through
+    tests/_datagen_rules.py (datagen.cpp:213-300, decisive scores included) must give the recorded scores, lengths and outcomes.
+    Budgets of 20 / 48 / 150 expansions stop after iterations of depth 2 / 3 / 3-4 (returns through several levels, cut-offs,
+    the previous best move first)."""
+    from _search_rules import verify_search_file
+
+    st = sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=16384, options={"selfplay_graph": graph})
+    try:
+        path = str(tmp_path / "search.vf")
+        stats = st.selfplay(n_games=n_games, target_games=target, out_path=path, max_plies=max_plies, dfrc=True, temperature_cp=0,
+                            seed=budget, search_nodes=budget)
+        assert stats["games"] == target and sum(stats["outcomes"]) == target
+        oracle.use(net_blob("tame"), "tame")
+        tally = {}
+        checked, expanded, deepest = verify_search_file(sp, st, oracle, open(path, "rb").read(), max_plies, budget, tally)
+        assert checked == stats["positions"]
+        assert deepest >= (2 if budget < 40 else 3)
+        # the driver also expanded the roots of discarded openings and of positions that turned out terminal
+        assert expanded <= stats["steps"] <= expanded + 4 * (target + n_games) * budget
+        print(f"budget {budget}: {checked} plies, {expanded} nodes restated ({stats['steps']} expanded by the driver, "
+              f"{stats['evals']} leaves), deepest iteration {deepest}; {tally}")
+    finally:
+        st.close()
+
+
 def test_selfplay_direct_launch_fallback(sp, net_blob, oracle, tmp_path, monkeypatch):
     """Option selfplay_graph = 0 (what a HIP runtime that refuses the stream capture falls back to): the per-ply chain enqueued
     launch by launch, lanes gated. Same rules, same verification; and the same SET of games as graph mode for the same seed."""

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--dfrc", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--host-movegen", action="store_true", help="generate moves with the host chess core instead of on the GPU")
+    ap.add_argument("--search-nodes", type=int, default=0,
+                    help="live fixed-node search: expansions per search (SPX_SELFPLAY_SEARCH_NODES; 0 = the depth-1 policy)")
     ap.add_argument("--preset", default="tame")
     ap.add_argument("--net")
     ap.add_argument("--out")
@@ -57,7 +59,7 @@ def main():
     out = f"{args.out}.{group.rank}.vf" if args.out else None
     stats = state.selfplay(args.games, args.target, out_path=out, max_plies=args.max_plies, dfrc=args.dfrc,
                            temperature_cp=args.temperature, seed=args.seed + group.rank, host_threads=args.threads,
-                           host_movegen=args.host_movegen)
+                           host_movegen=args.host_movegen, search_nodes=args.search_nodes)
     written = None
     if out and args.format != "viriformat":
         data = open(out, "rb").read()
@@ -82,7 +84,10 @@ def main():
             "seconds": slowest, "gpu_call_seconds": gpu_seconds, "gpu_call_fraction": gpu_seconds / slowest,
             "outcomes_white_loss_draw_win": outcomes, "host_threads": args.threads or "auto", "format": args.format,
             "move_generation": "host chess core" if args.host_movegen else "device (spx_movegen_kernel)",
-            "policy": "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
+            "policy": ("live fixed-node search, %d expansions (iterative-deepening alpha-beta, leaves = NNUE(child))" % args.search_nodes)
+                      if args.search_nodes else
+                      "depth-1: score(move) = -NNUE(child), uniform among moves within %d cp of the best" % args.temperature,
+            "nodes_expanded": total["steps"] if args.search_nodes else None,
         }))
     group.close()
 
