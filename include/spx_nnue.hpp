@@ -22,7 +22,9 @@
 #include <vector>
 
 #include "spx_nnue.h"
-#include "spx_nnue_dev.h"  // (Network::synthetic only: the repo's synthetic presets, for tools and tests)
+#ifdef SPX_NNUE_DEV
+#include "spx_nnue_dev.h"  // (Network::synthetic only: the repo's synthetic presets, for tools and tests - libspx_nnue_dev.so)
+#endif
 
 namespace spx_nnue {
 
@@ -41,11 +43,13 @@ public:
     Network(const void* blob, size_t nbytes) {
         check(spx_net_load(blob, nbytes, &net_));
     }
+#ifdef SPX_NNUE_DEV
     static Network synthetic(int preset, uint64_t seed = 20260927) {  // 0 tame, 1 wild, 2 extreme (spx_synth_net)
         std::vector<unsigned char> buf(spx_synth_net_bytes());
         check(spx_synth_net(seed, preset, buf.data(), buf.size()));
         return Network(buf.data(), buf.size());
     }
+#endif
     Network(Network&& o) noexcept : net_(o.net_) {
         o.net_ = nullptr;
     }

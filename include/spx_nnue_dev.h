@@ -85,6 +85,14 @@ int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply
  * pawn-pair rows), [5] rows read from LDS (piece-square + hot rows). bench.py derives the gather's instruction counts from it. */
 int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out);
 
+/* The row lists the column-sliced pipeline's extraction pass wrote for the LAST batch of scratch set `slot`, decoded back to the
+ * net's row numbering (the reference's feature indices, psq.h:338-365 / nnue_state.cpp:309-354): for perspective 2 i + c of
+ * position i (c = the perspective's colour, 1 = white) counts[3] = {piece-square rows, threat / pawn-pair rows, high-byte planes listed}
+ * and rows[576] = the piece-square rows, then the threat / pawn-pair rows, then the piece-square rows whose high-byte plane is
+ * fetched (rows behind the three counts are undefined). Order within a section is the extraction's, not the reference's:
+ * compare as multisets. */
+int spx_debug_ftx_lists(spx_ctx* ctx, int slot, size_t n_positions, uint32_t* counts, uint32_t* rows);
+
 /* The hot set of the column-sliced gather, given instead of measured / read back (in slot order; *n = 0 before the first
  * calibration). spx_ctx_set_hot_rows takes up to 384 distinct row ids < 64 368 (n = 0: an empty set - every row through the
  * texture path) and waits for the context's streams; tests run the measured set, an empty one and an adversarial random one and

@@ -49,9 +49,11 @@
 
 #include "../include/spx_nnue.hpp"
 
-#ifndef SPX_REF_PRESET_ID
-#define SPX_REF_PRESET_ID 0
-#endif
+// the net the GPU evaluator loads: the file the reference objects embed (there in the reference's permuted layout, here as the
+// net file itself), through spx_net_load like any net a user would hand over
+__asm__(".section .rodata\n.balign 64\n.global spx_ref_net_begin\nspx_ref_net_begin:\n.incbin \"" SPX_REF_NET_FILE "\"\n"
+        ".global spx_ref_net_end\nspx_ref_net_end:\n.previous\n");
+extern "C" const unsigned char spx_ref_net_begin[], spx_ref_net_end[];
 
 using namespace stormphrax;
 
@@ -60,7 +62,7 @@ namespace {
     unsigned long long g_evals = 0, g_mismatches = 0, g_nullMoveEvals = 0, g_pushes = 0, g_pendingSum = 0, g_pendingMax = 0;
 
     spx_nnue::Network& network() {
-        static spx_nnue::Network net = spx_nnue::Network::synthetic(SPX_REF_PRESET_ID);
+        static spx_nnue::Network net(spx_ref_net_begin, size_t(spx_ref_net_end - spx_ref_net_begin));
         return net;
     }
 

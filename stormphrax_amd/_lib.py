@@ -1,14 +1,17 @@
-"""ctypes binding of libspx_nnue.so (C ABI declared in include/spx_nnue.h).
+"""ctypes binding of the C ABI (include/spx_nnue.h) and of the test / measurement entry points (include/spx_nnue_dev.h).
 
-The shared library is the product; this module is plumbing for the Python harnesses (tests, bench.py). It fails
-loudly when the in-tree library is missing - there is no Python or CPU fallback for the evaluation path.
+The shared library is the product; this module is plumbing for the Python harnesses (tests, bench.py, tools). Two builds of
+the same objects sit in the tree (csrc/Makefile): libspx_nnue.so exports the boundary and nothing else, libspx_nnue_dev.so adds
+the dev entry points the harnesses need (synthetic nets, random positions, spx_debug_*) - the one loaded here. The module
+fails loudly when the in-tree library is missing - there is no Python or CPU fallback for the evaluation path.
 """
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPX_LIB lets kernel experiments point the harness at an alternative build of the same ABI (A/B runs on the GPU box)
-LIB_PATH = os.environ.get("SPX_LIB") or os.path.join(_HERE, "libspx_nnue.so")
+LIB_PATH = os.environ.get("SPX_LIB") or os.path.join(_HERE, "libspx_nnue_dev.so")
+PRODUCT_PATH = os.path.join(_HERE, "libspx_nnue.so")  # the boundary alone (tests/test_abi.py, tests/test_gpu_native_host.py)
 
 
 class PackedPos(ctypes.Structure):
@@ -139,6 +142,7 @@ SYMBOLS = {
     "spx_debug_ftx_block_times": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_debug_ftx_plan": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_debug_ftx_walk": (ctypes.c_int, [_P, ctypes.c_int, _P]),
+    "spx_debug_ftx_lists": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, _P, _P]),
     "spx_pos_from_fen": (ctypes.c_int, [ctypes.c_char_p, _P]),
     "spx_pos_to_fen": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "spx_pos_to_mailbox": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
@@ -167,7 +171,7 @@ _lib = None
 
 
 def load():
-    """Load libspx_nnue.so and declare prototypes. Raises if the library has not been built."""
+    """Load libspx_nnue_dev.so and declare prototypes. Raises if the library has not been built."""
     global _lib
     if _lib is not None:
         return _lib

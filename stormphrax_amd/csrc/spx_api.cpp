@@ -152,7 +152,7 @@ struct spx_ctx {
                                    // unit paths (one launch, rebuilds inline); larger ones spx_update_kernel + the rebuild pass
     int64_t selfplayOptions[3] = {1, 0, 0};  // options selfplay_graph (0: direct launches), selfplay_graph_plies (0: automatic), selfplay_trace
     int replayPaths = -1;          // option replay_paths: spx_acc_replay_tree by heavy paths (1) / by levels (0) / its own choice (-1)
-    uint32_t replaySegment = 32;   // option replay_segment: plies per path segment of the replay
+    uint32_t replaySegment = 8;    // option replay_segment: plies per path segment of the replay
     size_t updateSplitMaxV2 = 0;   // second-generation kernel: records up to which the perspectives get separate waves
     size_t refreshWaves = 0;       // option refresh_waves: waves of the rebuild pass (0 = automatic)
     size_t teamMaxPersp = 512;     // option ft_team_max: full refreshes of at most this many perspectives run one workgroup per
@@ -1506,6 +1506,7 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     bool byPaths = maxDepth >= 32 && nUpdates / std::max<uint32_t>(1, maxDepth) <= 4096;
     if (ctx->replayPaths >= 0) byPaths = ctx->replayPaths != 0;
     std::vector<uint32_t> hChainFirst, hChainCount, roundStart;  // paths mode: chains grouped by round; hParents = per chain
+    std::vector<uint32_t> rebuilt;  // paths mode: nodes materialised from scratch beside the root (heads of the later segments of long paths)
     if (!byPaths) {
         for (size_t k = 1; k < n_nodes; ++k) {
             const uint32_t at = cursor[depth[k]]++;  // levelStart[1] == 0: depth-1 nodes come first
@@ -1520,28 +1521,42 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
             const uint32_t p = parents[k];
             if (heavy[p] == 0 || size[k] > size[heavy[p]]) heavy[p] = uint32_t(k);
         }
-        std::vector<uint32_t> chainHead, chainLen, chainRound;
+        std::vector<uint32_t> chainParent, chainLen, chainRound;
+        std::vector<uint8_t> isRebuilt(n_nodes, 0);
         uint32_t maxRound = 0;
-        // Long paths are cut into SEGMENTS of `segment` plies, each a path of its own one round after the previous one: the
-        // paths hanging off the first plies of a 249-ply spine then start after the spine's first segment instead of after
-        // its last ply (a launch lasts as long as its longest path).
+        // Long paths are cut into SEGMENTS of `segment` plies that run SIDE BY SIDE in their path's round: the node a later
+        // segment starts from is not waited for but REBUILT FROM SCRATCH in the launch that materialises the root (a full
+        // refresh gives the same accumulator bit for bit, as it does for the reference on a king-bucket change) - 328 of the
+        // 84 067 nodes of the reference's own depth-12 search at 8 plies per segment. A launch lasts as long as its longest
+        // path: 249 + 26 + 15 + ... = 336 dependent plies become 8 + 8 + 8 + ... = 54 (round 4 started a spine's segments one
+        // round after the other: 311): 1.61 -> 0.80 ms on that trace (tools/gpu_replay_segment_ab.py: 4 / 8 / 16 / 32 plies
+        // 0.76 / 0.80 / 0.85 / 0.94 ms; shorter segments rebuild more nodes - 3 022 at 4).
         const uint32_t segment = ctx->replaySegment;
         for (size_t k = 1; k < n_nodes; ++k) {
             const uint32_t p = parents[k];
-            if (p != 0 && heavy[p] == k && chainLen[chainOf[p]] < segment) {  // continues its parent's path
+            const bool continues = p != 0 && heavy[p] == k;
+            if (continues && (chainLen[chainOf[p]] < segment || heavy[k] == 0)) {  // goes on along its parent's path (a leaf never starts a segment)
                 chainOf[k] = chainOf[p];
                 roundOf[k] = roundOf[p];
                 ++chainLen[chainOf[k]];
+            } else if (continues) {         // a full segment lies behind: k is rebuilt and starts the next one, in the same round
+                isRebuilt[k] = 1;
+                rebuilt.push_back(uint32_t(k));
+                chainOf[k] = uint32_t(chainParent.size());
+                roundOf[k] = roundOf[p];
+                chainParent.push_back(uint32_t(k));
+                chainLen.push_back(0);
+                chainRound.push_back(roundOf[k]);
             } else {                        // heads a path of its own, one round after the path its parent is on
-                chainOf[k] = uint32_t(chainHead.size());
+                chainOf[k] = uint32_t(chainParent.size());
                 roundOf[k] = roundOf[p] + 1;
-                chainHead.push_back(uint32_t(k));
+                chainParent.push_back(p);
                 chainLen.push_back(1);
                 chainRound.push_back(roundOf[k]);
                 maxRound = std::max(maxRound, roundOf[k]);
             }
         }
-        const size_t nChains = chainHead.size();
+        const size_t nChains = chainParent.size();
         roundStart.assign(maxRound + 2, 0);  // rounds are 1-based: roundStart[r] = first chain of round r
         for (size_t c = 0; c < nChains; ++c) ++roundStart[chainRound[c] + 1];
         for (uint32_t r = 1; r <= maxRound + 1; ++r) roundStart[r] += roundStart[r - 1];
@@ -1559,8 +1574,9 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
                 at += lenAt[j];
             }
         }
-        for (size_t c = 0; c < nChains; ++c) hParents[place[c]] = parents[chainHead[c]];
+        for (size_t c = 0; c < nChains; ++c) hParents[place[c]] = chainParent[c];
         for (size_t k = 1; k < n_nodes; ++k) {  // visiting order = increasing depth along every path
+            if (isRebuilt[k]) continue;
             const uint32_t j = place[chainOf[k]], at = hChainFirst[j] + hChainCount[j]++;
             hChildren[at] = uint32_t(k);
             hRecords[at] = positions[k];
@@ -1592,11 +1608,25 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     SPX_HIP(alloc(hChainCount.size() * 4, &dChainCount));
     SPX_HIP(alloc(n_evals * 4, &dEvalNodes));
     SPX_HIP(alloc(n_evals * 4, &dOut));
-    SPX_HIP(alloc(sizeof(spx_packed_pos) + 4, &dRoot));
+    // the nodes built from scratch: the root and the heads of the later segments of long paths (records, then slots = node ids)
+    const size_t nScratch = 1 + rebuilt.size();
+    if (nScratch > ctx->maxBatch) {
+        setError("spx_acc_replay_tree: more path segments than the context's batch capacity (raise option replay_segment)");
+        return SPX_ERR_CAPACITY;
+    }
+    std::vector<spx_packed_pos> hScratchPos(nScratch);
+    std::vector<uint32_t> hScratchSlots(nScratch);
+    hScratchPos[0] = positions[0];
+    hScratchSlots[0] = 0;
+    for (size_t i = 0; i < rebuilt.size(); ++i) {
+        hScratchPos[1 + i] = positions[rebuilt[i]];
+        hScratchSlots[1 + i] = rebuilt[i];
+    }
+    SPX_HIP(alloc(nScratch * (sizeof(spx_packed_pos) + 4), &dRoot));
     hipStream_t s = ctx->stream;
-    const uint32_t rootSlot = 0;
-    SPX_HIP(hipMemcpyAsync(dRoot, &positions[0], sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
-    SPX_HIP(hipMemcpyAsync(static_cast<char*>(dRoot) + sizeof(spx_packed_pos), &rootSlot, 4, hipMemcpyHostToDevice, s));
+    char* dScratchSlots = static_cast<char*>(dRoot) + nScratch * sizeof(spx_packed_pos);
+    SPX_HIP(hipMemcpyAsync(dRoot, hScratchPos.data(), nScratch * sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
+    SPX_HIP(hipMemcpyAsync(dScratchSlots, hScratchSlots.data(), nScratch * 4, hipMemcpyHostToDevice, s));
     if (nUpdates) {
         SPX_HIP(hipMemcpyAsync(dRecords, hRecords.data(), nUpdates * sizeof(spx_packed_pos), hipMemcpyHostToDevice, s));
         SPX_HIP(hipMemcpyAsync(dParents, hParents.data(), hParents.size() * 4, hipMemcpyHostToDevice, s));
@@ -1610,7 +1640,7 @@ int spx_acc_replay_tree(spx_ctx* ctx, const spx_packed_pos* positions, const uin
     SPX_HIP(hipEventCreate(&temp.e0));
     SPX_HIP(hipEventCreate(&temp.e1));
     SPX_HIP(hipEventRecord(temp.e0, s));
-    rc = spx_acc_refresh_device(ctx, dRoot, static_cast<char*>(dRoot) + sizeof(spx_packed_pos), 1, s);
+    rc = spx_acc_refresh_device(ctx, dRoot, dScratchSlots, nScratch, s);
     if (rc != SPX_OK) return rc;
     if (byPaths) {  // one chain launch per round: every path whose head's parent has been materialised
         for (size_t r = 1; r + 1 < roundStart.size(); ++r) {
@@ -2323,6 +2353,57 @@ int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
         for (int k = 1; k < 6; ++k) sums[k] += heads[size_t(g) * kFtxGroupHeadWords + 8 + k];
     }
     for (int k = 0; k < 8; ++k) out[k] = k < 6 ? uint32_t(std::min<uint64_t>(sums[k], 0xFFFFFFFFull)) : 0u;
+    return SPX_OK;
+}
+
+// The row lists the extraction pass wrote for the LAST batch of that scratch set, decoded back to the net's row numbering (the
+// reference's feature indices: psq.h:338-365, nnue_state.cpp:309-354): per perspective 2 i + c (c = its colour, 1 = white)
+// counts[3] = {piece-square rows, threat / pawn-pair rows, high-byte planes} and rows[kFtxListStride] = the piece-square rows
+// (bucket * 704 + slab row), then the threat / pawn-pair rows (hot slots through the context's hot set, cold ones from their slice
+// offsets), then the piece-square rows whose high-byte plane is listed. tests compare them as multisets with tests/golden/features.jsonl.
+int spx_debug_ftx_lists(spx_ctx* ctx, int slot, size_t n, uint32_t* counts, uint32_t* rows) {
+    if (!ctx || !counts || !rows || slot < -1 || slot > 2) {
+        setError("spx_debug_ftx_lists: invalid argument");
+        return SPX_ERR_INVALID_ARG;
+    }
+    const FtxScratch& x = slot < 0 ? ctx->ftx : ctx->lanes[slot].ftx;
+    if (!x.lists || n > x.capacity) {
+        setError("spx_debug_ftx_lists: that scratch set was never used (or holds fewer positions)");
+        return SPX_ERR_INVALID_ARG;
+    }
+    SPX_HIP(hipSetDevice(ctx->device));
+    SPX_HIP(hipDeviceSynchronize());
+    std::vector<uint32_t> lists(2 * n * kFtxListStride), heads(2 * n * 4);
+    SPX_HIP(hipMemcpy(lists.data(), x.lists, lists.size() * 4, hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpy(heads.data(), x.heads, heads.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < 2 * n; ++q) {
+        const uint32_t head = heads[4 * q], bucket = heads[4 * q + 2] / kFtxQuartetBins;
+        const uint32_t nHi = head & 0x3Fu, nLds = (head >> 6) & 0x1FFu, nCold = (head >> 15) & 0x1FFu;
+        const uint32_t* list = lists.data() + q * kFtxListStride;
+        uint32_t* out = rows + q * kFtxListStride;
+        uint32_t nPsq = 0, nThr = 0, k = 0;
+        for (uint32_t i = 0; i < nLds; ++i) {  // piece-square rows first, then the hot rows
+            const uint32_t off = list[kFtxListLds + i];
+            if (off < kFtxSlabBytes) {
+                out[k++] = bucket * kFtxSlabRows + off / 128;
+                ++nPsq;
+            }
+        }
+        for (uint32_t i = 0; i < nLds; ++i) {
+            const uint32_t off = list[kFtxListLds + i];
+            if (off >= kFtxSlabBytes) {
+                const uint32_t hot = (off - kFtxSlabBytes) / 128;
+                out[k++] = hot < ctx->hotIds.size() ? ctx->hotIds[hot] : 0xFFFFFFFFu;
+                ++nThr;
+            }
+        }
+        for (uint32_t i = 0; i < nCold; ++i) {
+            out[k++] = list[kFtxListCold + i] / 128;
+            ++nThr;
+        }
+        for (uint32_t i = 0; i < nHi; ++i) out[k++] = list[kFtxListHi + i] / 128 - kFtxPsqHiBase;
+        counts[3 * q] = nPsq, counts[3 * q + 1] = nThr, counts[3 * q + 2] = nHi;
+    }
     return SPX_OK;
 }
 

@@ -140,6 +140,18 @@ class NnueState:
         keys = ("groups", "stages", "global_steps", "lds_steps", "global_rows", "lds_rows")
         return {k: int(v) for k, v in zip(keys, out)}
 
+    def ftx_lists(self, n, slot=-1):
+        """spx_debug_ftx_lists: the extraction pass's row lists of the last batch (n positions) in the net's row numbering ->
+        per perspective 2 i + c (c = colour, 1 = white) a tuple (piece-square rows, threat / pawn-pair rows, piece-square rows with a high plane listed)."""
+        counts = np.zeros((2 * n, 3), dtype=np.uint32)
+        rows = np.zeros((2 * n, 576), dtype=np.uint32)
+        check(_lib.load().spx_debug_ftx_lists(self._h, slot, n, counts.ctypes.data, rows.ctypes.data))
+        out = []
+        for q in range(2 * n):
+            a, b, c = (int(v) for v in counts[q])
+            out.append((rows[q, :a].copy(), rows[q, a:a + b].copy(), rows[q, a + b:a + b + c].copy()))
+        return out
+
     def calibrate(self, d_positions_ptr, n):
         """spx_ctx_calibrate: choose the gather's hot set (the threat / pawn-pair rows kept in LDS) from a device-resident batch."""
         check(_lib.load().spx_ctx_calibrate(self._h, d_positions_ptr, n))

@@ -1,8 +1,10 @@
-"""The C-ABI library loads and exports every symbol include/spx_nnue.h (the drop-in boundary) and include/spx_nnue_dev.h (test /
-measurement entry points of the same library) declare (no compute calls without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/spx_nnue.h (the drop-in boundary) declares - and nothing else -; its
+dev build (libspx_nnue_dev.so: the same objects plus the test / measurement entry points of include/spx_nnue_dev.h) exports both
+headers' symbols (no compute calls without a GPU)."""
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -15,6 +17,11 @@ def declared_symbols(header="spx_nnue.h"):
     return sorted(set(re.findall(r"\b(spx_[a-z0-9_]+)\s*\(", text)))
 
 
+def exported_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-2] in "TWBDR")
+
+
 def test_header_and_library_agree(sp):
     from stormphrax_amd import _lib
 
@@ -22,11 +29,26 @@ def test_header_and_library_agree(sp):
     names, dev = declared_symbols(), declared_symbols("spx_nnue_dev.h")
     assert len(names) >= 18 and len(dev) >= 12 and not set(names) & set(dev)
     # the boundary header carries no test scaffolding
-    assert not [n for n in names if "debug" in n or "synth" in n or "random" in n or "perft" in n]
+    assert not [n for n in names if "debug" in n or "probe" in n or "synth" in n or "random" in n or "perft" in n]
     for name in names + dev:
         assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
     assert sorted(_lib.SYMBOLS) == sorted(names + dev), "ctypes prototypes drifted from the headers"
     assert ctypes.sizeof(_lib.PackedPos) == 32 and sp.PACKED_DTYPE.itemsize == 32
+
+
+def test_product_library_exports_the_boundary_and_nothing_else():
+    """libspx_nnue.so - what an engine links - exports exactly the functions of include/spx_nnue.h: no
+    spx_debug_*, no probe kernels' launchers, no synthetic nets, no C++ internals. The dev build exports the dev header on top."""
+    from stormphrax_amd import _lib
+
+    names, dev = declared_symbols(), declared_symbols("spx_nnue_dev.h")
+    product = exported_symbols(_lib.PRODUCT_PATH)
+    assert product == names, sorted(set(product) ^ set(names))
+    assert not [n for n in product if "debug" in n or "probe" in n]
+    exported_dev = set(exported_symbols(_lib.LIB_PATH))
+    assert set(names + dev) <= exported_dev
+    handle = ctypes.CDLL(_lib.PRODUCT_PATH)  # loads on its own (no unresolved reference into the dev build)
+    assert all(hasattr(handle, n) for n in names) and not hasattr(handle, "spx_debug_copy_ft")
 
 
 def test_no_cpu_fallback_without_device(sp, net_blob):
@@ -101,8 +123,9 @@ def test_cpp_mirror_reports_the_missing_device_as_an_exception(tmp_path):
                    '  return 1; }\n')
     exe = tmp_path / "t"
     lib_dir = os.path.join(ROOT, "stormphrax_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
-                           "-L", lib_dir, "-lspx_nnue", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    # (Network::synthetic: the dev build of the library and the mirror's SPX_NNUE_DEV part)
+    subprocess.check_call(["g++", "-std=c++17", "-DSPX_NNUE_DEV", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-lspx_nnue_dev", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("4 "), out.stdout + out.stderr
     assert "no CPU fallback" in out.stdout

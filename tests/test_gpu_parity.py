@@ -144,6 +144,40 @@ def test_reference_golden_vectors(sp, net_blob, path_states, preset, path):
     assert bad.size == 0, (recs[bad[0]]["fen"], int(got[bad[0]]), int(want[bad[0]]))
 
 
+@pytest.mark.parametrize("preset", ["tame", "realistic"])
+def test_extraction_lists_equal_the_reference_feature_rows(sp, net_blob, path_states, preset):
+    """what spx_ftx_extract_kernel lists for a perspective - piece-square rows (LDS slab), hot and cold
+    threat / pawn-pair rows, and on the heavy-tailed net the high-byte planes of the wide piece-square rows - decoded back
+    to the net's row numbering (spx_debug_ftx_lists) and compared AS MULTISETS with the COMPILED REFERENCE's active features
+    (tests/golden/features.jsonl: psq.h:338-365, threats.cpp:170-221, nnue_state.cpp:309-354). No oracle in between."""
+    import json
+    import os
+    from collections import Counter
+
+    recs = [json.loads(line) for line in open(os.path.join(os.path.dirname(__file__), "golden", "features.jsonl"))]
+    assert len(recs) >= 300
+    fens = [r["fen"] for r in recs]
+    pos = sp.positions_from_fens(fens * (1 + 1024 // len(fens)))  # (the sliced pipeline takes batches of >= 1 024 here)
+    st = path_states(preset, "sliced")
+    st.evaluate_once(pos)
+    lists = st.ftx_lists(len(pos))
+    blob = net_blob(preset)
+    psq_w = blob[64:64 + 11264 * 1024 * 2].view("<i2").reshape(11264, 1024)
+    wide = (psq_w.min(axis=1) < -128) | (psq_w.max(axis=1) > 127)
+    assert bool(wide.any()) == (preset == "realistic")
+    hot = set(int(r) for r in st.hot_rows())
+    from_hot = 0
+    for i in range(len(pos)):
+        r = recs[i % len(recs)]
+        for c in (0, 1):  # (the lists are kept per COLOUR, 0 = black; the head's output slot puts the side to move's half first)
+            psq, thr, high = lists[2 * i + c]
+            assert Counter(psq.tolist()) == Counter(r["psq"][c]), (r["fen"], c)
+            assert Counter(thr.tolist()) == Counter(r["thr"][c]), (r["fen"], c)
+            assert Counter(high.tolist()) == Counter(row for row in r["psq"][c] if wide[row]), (r["fen"], c)
+            from_hot += sum(1 for row in r["thr"][c] if row in hot)
+    assert from_hot > 0  # the lists went through the hot-set split
+
+
 def test_full_size_batch_properties(sp, oracle, net_blob, states):
     """BASELINE config 2 at full size (65 536 positions): size-independent properties instead of a full oracle pass.
     (1) order independence: a shuffled batch gives the shuffled result; (2) batch-split independence: two halves equal
