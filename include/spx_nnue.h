@@ -128,6 +128,8 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  *   selfplay_graph 0|1, selfplay_graph_plies N, selfplay_trace 0|1    spx_selfplay_run: plies captured into hipGraphs (default) or
  *                           launched one by one; plies per graph (0 = automatic; even, 2..16); a timing line on stderr at the end
  *   ftx_fail_after K        test hook: the K-th scratch set of the pipeline "does not fit" (default -1: never)
+ *   ftx_fail_launch K       test hook: the K-th pass of the pipeline from now on "fails to launch" (default -1: never); either
+ *                           way the batch and all later ones are served by the one-kernel path
  * SPX_OPTIONS only (they shape what a context allocates): scratch_cap N (below), compact_rows 0|1, near_rows 0|1 (A/B of the
  * lossless 1 KiB copies of piece-square rows that fit i8 / almost fit i8). */
 int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value);
@@ -393,10 +395,10 @@ int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packe
  *     game's outcome, back to back (Marlinformat::push / writeAllWithOutcome, marlinformat.cpp:32-57);
  *   spx_viri_to_fen: one text line per unfiltered position, "<fen> | <score> | <0.0 / 0.5 / 1.0>" + '\n' (fen.cpp:32-66).
  * out = NULL counts only (*n_records / *n_bytes); SPX_ERR_CAPACITY when `capacity` (records / bytes) is too small.
- * One known difference (viriformat does not record it): the reference marks the move that ends a game through
- * Position::isDrawn or a tablebase probe as filtered whatever the move (datagen.cpp:264-281), so for a game that ended that
- * way with a quiet, non-checking last move these converters keep one position - that move's, with score 0 - the reference's
- * writers would have dropped; the per-position filter (in check / noisy move, datagen.cpp:254) is applied exactly. */
+ * The reference's two filters are both applied: per position (in check / noisy move, datagen.cpp:254) and per game - the move
+ * that ends a game through Position::isDrawn is pushed as filtered whatever it is (datagen.cpp:264-268); viriformat does not
+ * record that flag, so the converters look at the position after a game's last move themselves (50-move clock, repetition
+ * against the game's own positions, insufficient material). Tablebase adjudication (datagen.cpp:270-281) does not exist here. */
 int spx_viri_to_marlinformat(const void* data, size_t nbytes, spx_packed_pos* out, size_t capacity, size_t* n_records,
                              size_t* n_games);
 int spx_viri_to_fen(const void* data, size_t nbytes, char* out, size_t capacity, size_t* n_bytes, size_t* n_games);

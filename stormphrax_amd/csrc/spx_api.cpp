@@ -87,6 +87,7 @@ struct spx_ctx {
     bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); option ftx = 0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // option ftx_min: smallest batch that takes the sliced pipeline
     int ftxFailAfter = -1, ftxScratchSets = 0;  // (option ftx_fail_after: simulated allocation failure)
+    int ftxFailLaunch = -1;  // (option ftx_fail_launch: the k-th sliced pass from now reports a launch failure; -1: never)
     bool ftxMinForced = false;    // (ftx_min given: the same threshold for stream-ordered and pipelined calls)
     bool ftxUnavailable = false;  // its table or scratch did not fit the device memory
     // (spx_eval_full_device_async: each lane has its own scratch set - swapLane -, so one lane's preparation runs beside the
@@ -537,6 +538,10 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
     }
     if (key == "ftx_fail_after") {  // test hook: the k-th scratch set of the pipeline "does not fit" (-1: never)
         ctx->ftxFailAfter = int(value);
+        return SPX_OK;
+    }
+    if (key == "ftx_fail_launch") {  // test hook: the k-th pass of the pipeline from now on "fails to launch" (-1: never)
+        ctx->ftxFailLaunch = int(value);
         return SPX_OK;
     }
     if (key == "king_sort") {  // one-kernel path: walk the perspectives in king-bucket order (1) or as they come (0)
@@ -1058,12 +1063,22 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             // a pipelined call: the preparation is not gated - it runs beside the other lane's gather and MLP -, the gather is
             // (the two lanes' gathers are chained). Gating the preparation too: 1.58 instead of 1.81e8 evals/s; no gate at all: 1.83e8,
             // but then the gather's event interval includes its wait for free CUs
-            SPX_HIP(launchFtxPrepare(xp, s));
-            if (lo == 0) {
+            // A launch the runtime refuses (the header promises the one-kernel path whenever the pipeline cannot run):
+            // the pipeline is given up for this context and the WHOLE batch goes through spx_ft_kernel - what the passes issued
+            // so far wrote is overwritten in stream order; the sort histogram a half-run preparation leaves behind is zeroed
+            hipError_t launched = (ctx->ftxFailLaunch >= 0 && ctx->ftxFailLaunch-- == 0) ? hipErrorLaunchFailure : launchFtxPrepare(xp, s);
+            if (launched == hipSuccess && lo == 0) {
                 if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
                 if (ev) SPX_HIP(hipEventRecord(ev[4], s));
             }
-            SPX_HIP(launchFtxGather(xp, s));
+            if (launched == hipSuccess) launched = launchFtxGather(xp, s);
+            if (launched != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->ftxUnavailable = true;
+                SPX_HIP(hipMemsetAsync(scratch.hist, 0, kFtxBins * 4, s));
+                if (ev) ctx->profUsed -= kProfEventsPerCall;
+                return spx_eval_full_device(ctx, d_positions, n, d_out, stream);
+            }
         }
     } else {
         if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
@@ -2754,6 +2769,36 @@ static uint16_t viriEncodeMove(const Move& m) {
     return uint16_t(m.from | (m.to << 6) | ((m.kind == kPromotion ? m.promo - 1 : 0) << 12) | kTypes[m.kind]);
 }
 
+// The move that ENDS a game through Position::isDrawn is pushed as filtered whatever it is (datagen.cpp:264-268:
+// output.push(true, move, 0)). `records` = the positions before each of the game's n moves (n >= 1), `lastMove` the viriformat
+// word of the last one: is the position after it drawn (position.cpp:603-667)? The halfmove clock at 100 decides alone (a draw
+// unless checkmate); else two earlier occurrences of the same position (only what the key distinguishes: placement with castling
+// rights, side to move, en-passant square) or insufficient material. (This library's own ply cap is not one of the reference's
+// rules: a game it cut short keeps its last position.)
+static bool lastMoveEndsInADraw(const spx_packed_pos* records, size_t n, uint16_t lastMove) {
+    Board b;
+    Move m;
+    if (!unpackBoard(records[n - 1], b) || !viriDecodeMove(b, lastMove, m)) return false;
+    makeMove(b, m);
+    if (b.halfmove >= 100) {
+        std::vector<Move> replies;
+        generateLegal(b, replies);
+        return !(b.inCheck() && replies.empty());
+    }
+    spx_packed_pos after;
+    packBoard(b, after);
+    size_t seen = 0;
+    for (size_t k = 0; k < n; ++k) {
+        seen += records[k].occupancy == after.occupancy && std::memcmp(records[k].pieces, after.pieces, 16) == 0 &&
+                records[k].stm_ep == after.stm_ep;
+    }
+    if (seen >= 2) return true;
+    uint64_t lo, hi;
+    std::memcpy(&lo, after.pieces, 8);
+    std::memcpy(&hi, after.pieces + 8, 8);
+    return insufficientMaterial(after.occupancy, lo, hi);
+}
+
 int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_t* scores, uint8_t* unfiltered,
                     size_t capacity, size_t* n_positions, size_t* n_games) {
     if (!data || !n_positions) {
@@ -2771,6 +2816,8 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
             setError("spx_viri_expand: bad initial board in game " + std::to_string(games));
             return SPX_ERR_BAD_POSITION;
         }
+        const size_t first = count;
+        uint16_t lastMove = 0;
         for (;;) {
             if (off + 4 > nbytes) {
                 setError("spx_viri_expand: truncated game " + std::to_string(games));
@@ -2803,8 +2850,10 @@ int spx_viri_expand(const void* data, size_t nbytes, spx_packed_pos* out, int16_
                 }
             }
             ++count;
+            lastMove = mv;
             makeMove(b, m);
         }
+        if (out && unfiltered && count > first && lastMoveEndsInADraw(out + first, count - first, lastMove)) unfiltered[count - 1] = 0;
         ++games;
     }
     *n_positions = count;
@@ -2967,6 +3016,15 @@ int spx_viri_expand_gpu(spx_ctx* ctx, const void* data, size_t nbytes, spx_packe
     if (unfiltered) SPX_HIP(hipMemcpyAsync(unfiltered, dKeep, count, hipMemcpyDeviceToHost, s));
     SPX_HIP(hipStreamSynchronize(s));
     if (bad_games) *bad_games = bad;
+    if (unfiltered && bad == 0) {  // the game-level rule on top of the kernel's per-position filter: one position per game on the host
+        for (size_t g = 0; g + 1 < outOffset.size(); ++g) {
+            const size_t lo = outOffset[g], hi = outOffset[g + 1];
+            if (hi == lo) continue;
+            uint16_t lastMove;
+            std::memcpy(&lastMove, p + gameOffset[g] + sizeof(spx_packed_pos) + (hi - lo - 1) * 4, 2);
+            if (lastMoveEndsInADraw(out + lo, hi - lo, lastMove)) unfiltered[hi - 1] = 0;
+        }
+    }
     return SPX_OK;
 }
 

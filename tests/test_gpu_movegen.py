@@ -165,6 +165,24 @@ def test_viriformat_expansion_on_the_device_matches_the_host_replay(sp, st):
     _, _, keep_host = sp.viri_expand(blob, with_filter=True)
     _, _, _, keep_gpu = st.viri_expand(blob, with_filter=True)
     assert np.array_equal(keep_gpu, keep_host) and 0.3 < keep_host.mean() < 0.95
+    # ... and so does the game-level rule (the move that ends a game in a draw is filtered whatever it is, datagen.cpp:264-268) on
+    # games that end in repetitions, bare material and on the 50-move clock (tests/golden/drawn_games.txt, cut where they are drawn)
+    import os
+
+    from test_host_logic import _viri_stream
+
+    drawn_blob, n_drawn = b"", 0
+    for ln in open(os.path.join(os.path.dirname(__file__), "golden", "drawn_games.txt")):
+        if ln.startswith("#"):
+            continue
+        start, _, line = ln.rstrip("\n").split(" | ")
+        items = [it.rsplit(":", 1) for it in line.split()]
+        cut = next((k for k, (_, w) in enumerate(items) if int(w)), len(items) - 1)
+        drawn_blob += _viri_stream(sp, start, [u for u, _ in items[:cut + 1]])
+        n_drawn += 1
+    _, games_host, keep_host = sp.viri_expand(drawn_blob, with_filter=True)
+    _, games_dev, bad, keep_gpu = st.viri_expand(drawn_blob, with_filter=True)
+    assert games_host == games_dev == n_drawn >= 70 and bad == 0 and np.array_equal(keep_gpu, keep_host)
     kinds = set()
     off = 0
     while off < len(blob):   # every move type occurs in the input

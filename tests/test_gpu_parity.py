@@ -556,6 +556,24 @@ def test_hot_row_sets_do_not_change_results(sp, oracle, net_blob, preset):
         assert np.array_equal(_evaluate_through(sp, st, other, "sliced_pipelined"), want_other)
 
 
+def test_pipeline_whose_launch_fails_falls_back_to_the_one_kernel_path(sp, net_blob):
+    """a launch of the pipeline that the runtime refuses (simulated: option ftx_fail_launch - the first pass of a call,
+    and the second pass of a call of three passes, after the first one has already written its part) must not surface as an error:
+    the whole batch is served by spx_ft_kernel, the pipeline stays off for the context, later calls keep working."""
+    blob = net_blob("wild")
+    pos = sp.random_positions(150000, seed=912, min_ply=0, max_ply=160, dfrc_every=3)
+    with sp.NnueState(sp.Network(blob), device=0, max_batch=1 << 18, sliced_ft=False) as plain:
+        want = plain.evaluate_once(pos)
+    for fail_at, n in ((0, 40000), (1, 150000)):
+        with _state_with_options(sp, blob, {}, max_batch=1 << 18) as st:
+            assert st.takes_sliced_pipeline(n)
+            assert np.array_equal(st.evaluate_once(pos[:n]), want[:n])  # (through the pipeline: scratch and hot set exist)
+            st.set_option("ftx_fail_launch", fail_at)
+            assert np.array_equal(st.evaluate_once(pos[:n]), want[:n]), fail_at
+            assert not st.takes_sliced_pipeline(n)
+            assert np.array_equal(st.evaluate_once(pos[:30000]), want[:30000])
+
+
 def test_pipeline_that_does_not_fit_falls_back_to_the_one_kernel_path(sp, net_blob):
     """The column-sliced pipeline allocates its table and scratch sets on first use; when one does not fit (a context sized to
     fill the HBM: simulated with option ftx_fail_after) that call and all later ones take spx_ft_kernel - another GPU path, same

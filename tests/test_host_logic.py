@@ -456,6 +456,49 @@ def test_position_is_drawn_equals_the_compiled_reference(sp):
     assert seen["repetition"] > 300 and seen["material"] > 200 and seen["fifty"] > 50 and seen["mate_at_100"] >= 3 and seen["not_drawn"] > 1000, seen
 
 
+def _viri_stream(sp, start_fen, ucis):
+    """A viriformat game (initial record, move words with score 0, terminator) of `ucis` played from `start_fen`."""
+    rec = sp.positions_from_fens([start_fen])[0]
+    blob = bytearray(np.ascontiguousarray(rec).tobytes())
+    for uci in ucis:
+        nxt = sp.apply_uci(rec, uci)
+        words, kids, _ = sp.legal_moves(rec)
+        hit = [i for i in range(len(words)) if kids[i].tobytes()[:28] == np.ascontiguousarray(nxt).tobytes()[:28]]
+        assert len(hit) == 1, (start_fen, uci)
+        blob += int(words[hit[0]]).to_bytes(2, "little") + b"\x00\x00"
+        rec = nxt
+    return bytes(blob) + b"\x00\x00\x00\x00"
+
+
+def test_converters_filter_the_move_that_ends_a_game_in_a_draw(sp):
+    """VERDICT r4 item 8: datagen pushes the move after which Position::isDrawn holds as FILTERED whatever the move is
+    (datagen.cpp:264-268); viriformat does not record the flag, so spx_viri_expand / spx_viri_to_marlinformat / spx_viri_to_fen
+    decide it from the game itself. Ground truth: the COMPILED reference's isDrawn flag after every move of the golden games
+    (tests/golden/drawn_games.txt: repetitions, bare material, the 50-move clock incl. checkmate on the 100th half-move). A game
+    cut after move k must keep position k exactly when the per-position filter keeps it (its flag in the game cut one move
+    later) AND the reference says the position after move k is not drawn."""
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "drawn_games.txt")
+    games = [ln.rstrip("\n").split(" | ") for ln in open(path) if not ln.startswith("#")]
+    checked = {"dropped because drawn": 0, "kept": 0, "dropped by the position filter": 0}
+    for start, _, line in games[::3]:
+        items = [it.rsplit(":", 1) for it in line.split()]
+        ucis, drawn = [u for u, _ in items], [int(w) for _, w in items]
+        ks = [k for k in range(len(ucis) - 1) if drawn[k]][:6] + list(range(0, len(ucis) - 1, 17))
+        for k in sorted(set(ks)):
+            _, _, keep_last = sp.viri_expand(_viri_stream(sp, start, ucis[:k + 1]), with_filter=True)
+            _, _, keep_next = sp.viri_expand(_viri_stream(sp, start, ucis[:k + 2]), with_filter=True)
+            assert list(keep_last[:k]) == list(keep_next[:k])
+            # (the longer game's own last move may end in a draw: only its flag for move k is used)
+            assert bool(keep_last[k]) == (bool(keep_next[k]) and not drawn[k]), (start, k, ucis[k])
+            what = "dropped because drawn" if drawn[k] and keep_next[k] else ("kept" if keep_last[k] else "dropped by the position filter")
+            checked[what] += 1
+            records, n_games = sp.viri_to_marlinformat(_viri_stream(sp, start, ucis[:k + 1]))
+            assert n_games == 1 and len(records) == int(np.count_nonzero(keep_last))
+    assert checked["dropped because drawn"] >= 40 and checked["kept"] >= 40, checked
+
+
 def test_wdl_normalisation_does_not_depend_on_fp_contraction(sp, oracle):
     """wdl::normalizeScore (wdl.cpp:28-79) is an f64 cubic; the device / host source evaluates it with fused multiply-adds
     (what the reference's x86-64 clang builds contract to), the oracle's plain-C restatement is built with -ffp-contract=off
