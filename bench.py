@@ -52,8 +52,8 @@ LDS_PEAK_GBS = 256 * 128 * CLOCK_HZ / 1e9  # LDS: 128 B per clock and CU = 78.6 
 L1_CYCLES_PER_WAVE_LOAD, LDS_CYCLES_PER_WAVE_READ, MFMA_CYCLES = 17.5, 8.8, 16.0
 # committed rocprofv3 PMC passes of this command, newest round first (tools/gpu_final.sh puts this round's in place before the
 # bench lines are taken; the kernels these counters describe did not change in round 3)
-PMC_FILES = {"full": ["r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
-             "incremental": ["r04_pmc_incremental.json", "r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
+PMC_FILES = {"full": ["r05_pmc_full_refresh.json", "r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
+             "incremental": ["r05_pmc_incremental.json", "r04_pmc_incremental.json", "r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
 
 
 def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):
@@ -409,12 +409,20 @@ def realistic_leg(args, sp, torch, group, d_pos, positions, pipelined):
         elapsed, (_, ft_ms, _, calls), _, last = timed_full_run(args, torch, group, st, d_pos, pipelined, settle_seconds=0.4)
         n_sample = min(1024, len(positions))
         exact = oracle_sample_check(sp, blob, positions[:n_sample], last[:n_sample].cpu().numpy())
-        wide_rows, compact_rows, thr_rows = st.count_rows(positions)
         fit, near, wide = net.psq_row_classes()
+        if st.takes_sliced_pipeline(min(args.batch, st.scratch_batch), pipelined=pipelined):
+            # what the gather walked (pack kernel's counts): every piece-square row outside i8 - near-compact ones too - brings a
+            # high-byte plane through the texture path
+            walk = st.ftx_walk(0 if pipelined else -1)
+            rows = {"through_the_texture_path_1KiB": walk["global_rows"], "from_lds_1KiB": walk["lds_rows"],
+                    "global_steps_per_slice": walk["global_steps"], "lds_steps_per_slice": walk["lds_steps"]}
+        else:
+            wide_rows, compact_rows, thr_rows = st.count_rows(positions)
+            rows = {"psq_wide_2KiB": wide_rows, "psq_1KiB_compact_or_near": compact_rows, "threat_1KiB": thr_rows}
         return {"value": args.batch * args.steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / args.steps * 1e3,
                 "ft_kernel_ms": ft_ms / max(calls, 1), "bit_exact_sample": bool(exact),
                 "psq_row_classes": {"fit_i8": fit, "near_compact_le_32_outliers": near, "wide": wide},
-                "rows_per_launch": {"psq_wide_2KiB": wide_rows, "psq_1KiB_compact_or_near": compact_rows, "threat_1KiB": thr_rows},
+                "rows_per_launch": rows,
                 "net": f"synthetic CBNF '{net.name}': two-sided geometric (Laplace-like) weights with heavy tails, the shape of a "
                        "trained QA = 255 net (spx_synth.cpp preset 3); reference goldens in tests/golden/evals.jsonl"}
     finally:
@@ -529,6 +537,63 @@ def incremental_leg(sp, torch, net, device, games=65536, chain=6, seconds=0.6):
                              "frac": compulsory * games / update_s / 1e9 / HBM_PEAK_GBS,
                              "note": "compulsory bytes (parent accumulators in, child accumulators out, records) x records / "
                                      "HIP-event time of the update kernel and its rebuild pass; PMC traffic: profiles/"}}
+    finally:
+        st.close()
+
+
+def siblings_leg(sp, torch, net, device, parents=2048, seconds=0.5):
+    """secondary.incremental_siblings (the other SHAPE of the incremental path, reported beside
+    secondary.incremental): `parents` positions with resident accumulators and ALL their legal children (~33 each) updated
+    and evaluated as eval-only children - one parent accumulator read per ~33 records (they are neighbours in the batch), no child
+    accumulator written. This is what the self-play drivers and a search's node expansion issue; secondary.incremental is the
+    other extreme (every record its own parent, every child stored: 65 536 independent games one ply on)."""
+    from stormphrax_amd import _lib
+
+    lib = _lib.load()
+    pos = sp.random_positions(parents, seed=777, min_ply=8, max_ply=120, dfrc_every=4)
+    st = sp.NnueState(net, device=device, max_batch=parents * 96)
+    try:
+        st.reserve_slots(parents)
+        slot_ids = np.arange(parents, dtype=np.uint32)
+        mg = st.movegen(pos, parent_values=slot_ids, capacity=parents * 96)
+        n = int(mg["count"].sum())
+        d_pos = torch.from_numpy(pos.view(np.uint8).reshape(parents, 32).copy()).cuda()
+        d_slots = torch.from_numpy(slot_ids.astype(np.int32)).cuda()
+        d_children = torch.from_numpy(mg["children"][:n].view(np.uint8).reshape(n, 32).copy()).cuda()
+        d_parents = torch.from_numpy(mg["parents"][:n].astype(np.int32)).cuda()
+        outs = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.spx_acc_refresh_device(st._h, d_pos.data_ptr(), d_slots.data_ptr(), parents, stream))
+        torch.cuda.synchronize()
+        no = [0]
+
+        def step():
+            _lib.check(lib.spx_acc_update_eval_device_async(st._h, d_parents.data_ptr(), None, d_children.data_ptr(), n,
+                                                            outs[no[0] & 1].data_ptr(), None))
+            no[0] += 1
+
+        def sync():
+            st.synchronize()
+            torch.cuda.synchronize()
+
+        settle(step, sync, min_seconds=0.2, max_seconds=1.5)
+        steps = 0
+        st.profile_begin(4096)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds and steps < 4000:
+            for _ in range(10):
+                step()
+            steps += 10
+            sync()
+        elapsed = time.perf_counter() - t0
+        _, update_ms, mlp_ms, calls = st.profile_end()
+        full = torch.empty(n, dtype=torch.int32, device="cuda")
+        st.evaluate_once_device(d_children.data_ptr(), n, full.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return {"value": n * steps / elapsed, "unit": "updates+evals/s", "parents": parents, "children": n,
+                "children_per_parent": n / parents, "ms_per_step": elapsed / steps * 1e3,
+                "update_kernel_ms": update_ms / max(calls, 1), "sort_mlp_ms": mlp_ms / max(calls, 1),
+                "bit_exact_vs_full_refresh": bool(torch.equal(full, outs[0]) and torch.equal(full, outs[1]))}
     finally:
         st.close()
 
@@ -694,6 +759,7 @@ def secondary_legs(args, sp, torch, group, state, net, d_pos, positions, pipelin
         run("full_refresh_paths", lambda: paths_leg(args, sp, torch, group, net, sp.synthetic_net_bytes(args.preset), d_pos, positions))
     if args.preset == "tame":  # (the trace was recorded on the tame net)
         run("incremental", lambda: incremental_leg(sp, torch, net, device))
+        run("incremental_siblings", lambda: siblings_leg(sp, torch, net, device))
         run("config3_replay", lambda: config3_leg(sp, net, device))
         run("config3_alpha_beta_replay", lambda: config3_leg(
             sp, net, device, "trace_search_startpos_tame_64k.txt.gz",
@@ -881,14 +947,18 @@ def main():
         if sliced:
             # the pipeline's gather asks the L2 for the threat / pawn-pair rows and the high-byte planes of the wide piece-square
             # rows (128 B per row and XCD = 1 KiB per row); the piece-square rows' low-byte planes come from the LDS slab
-            requested = 1024 * (thr_rows + wide_rows) + 36 * args.batch
-            lds_served = 1024 * psq_rows
+            # (counted by the pack kernel over what the gather really walks: cold threat / pawn-pair rows + the high-byte planes of every
+            # piece-square row that does not fit i8 - near-compact rows included, ADVICE r4 - against piece-square + hot rows from LDS)
+            walk = state.ftx_walk(0 if pipelined else -1)
+            requested = 1024 * walk["global_rows"] + 36 * args.batch
+            lds_served = 1024 * walk["lds_rows"]
         l2_gbs = requested / ft_avg_s / 1e9
         roofline = {
             "kernel": main_kernel, "bound": "l2", "achieved": l2_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s",
             "frac": l2_gbs / L2_PEAK_GBS, "traffic": hbm["traffic_bytes_per_launch"],
             "requested_bytes_per_launch": requested, "ft_kernel_ms": ft_avg_s * 1e3,
-            "rows_per_launch": {"psq_wide_2KiB": wide_rows, "psq_compact_1KiB": compact_rows, "threat_1KiB": thr_rows},
+            "rows_per_launch": ({"through_the_texture_path_1KiB": walk["global_rows"], "from_lds_1KiB": walk["lds_rows"]} if sliced else
+                                {"psq_wide_2KiB": wide_rows, "psq_compact_1KiB": compact_rows, "threat_1KiB": thr_rows}),
             "note": ("achieved = bytes the gather's row loads ask the L2s for (1 KiB per threat / pawn-pair row and per high-byte "
                      "plane of a wide piece-square row, summed over the 8 column slices; + record and score) / the gather "
                      "kernel's HIP-event duration, against the aggregate L2 bandwidth. The piece-square rows (lds_served_bytes) "
@@ -910,7 +980,6 @@ def main():
             # (a 16-byte-per-lane wave load holds it ~17.5 cycles whatever its mask or width), the LDS pipe (8.8 cycles per 1 KiB wave
             # read) and the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8, PMC) -, so the roofline is stated in them. The counts are
             # EXACT: the pack kernel sums what it lays out for the gather to walk (spx_debug_ftx_walk; steps per column slice x 8).
-            walk = state.ftx_walk(0 if pipelined else -1)
             steps_g, steps_l = 8 * walk["global_steps"], 8 * walk["lds_steps"]
             l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
             lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes

@@ -1,6 +1,6 @@
 # Round-end measurement set (GPU box): bench lines, secondary measurements, rocprofv3 stats + counters.
 # usage: bash tools/gpu_final.sh <tag>   -> gpurun_out/final_<tag>/   (copy what is quoted into profiles/)
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -29,8 +29,12 @@ python tools/spx_selfplay.py --games 4096 --target 8192 --dfrc > $OUT/selfplay_4
 python tools/spx_selfplay.py --games 4096 --target 65536 --dfrc > $OUT/selfplay_4096_long.json 2>> $OUT/selfplay.err
 python tools/spx_selfplay.py --games 16384 --target 65536 --dfrc > $OUT/selfplay_16384.json 2>> $OUT/selfplay.err
 python tools/spx_selfplay.py --games 1024 --target 8192 --dfrc > $OUT/selfplay_1024.json 2>> $OUT/selfplay.err
-python tools/gpu_gather_ceiling.py --out $OUT/gather_ceiling.json > /dev/null 2>> $OUT/selfplay.err
-python tools/gpu_gather_ceiling.py --wide --rounds 3 --out $OUT/gather_ceiling_wide_psq_rows.json > /dev/null 2>> $OUT/selfplay.err
+# round 5: the live fixed-node search in the driver (64 expansions per search: whole games; 1 000: games cut
+# at 16 plies so that the run stays bounded), the replay's segment length
+python tools/spx_selfplay.py --games 4096 --target 4096 --dfrc --temperature 0 --search-nodes 64 > $OUT/selfplay_search_64_nodes.json 2>> $OUT/selfplay.err
+python tools/spx_selfplay.py --games 4096 --target 4096 --dfrc --temperature 0 --search-nodes 1000 --max-plies 16 > $OUT/selfplay_search_1000_nodes.json 2>> $OUT/selfplay.err
+# (datagen's 24 000 nodes: 4 minutes for 1 024 games of 8 plies - run once by hand, profiles/r05_selfplay_search_24000_nodes_1024_seats_8_plies.json)
+python tools/gpu_replay_segment_ab.py > $OUT/replay_segment_ab.txt 2>&1
 ./stormphrax_amd/spx_raweval --preset tame --walk 7 6000 rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1 > $OUT/raweval_walk.txt 2>&1
 bash tools/gpu_selfplay_busy.sh 4096 32768 > $OUT/selfplay_gpu_busy.txt 2>&1
 python tools/gpu_movegen_rate.py > $OUT/movegen_rate.json 2>> $OUT/selfplay.err

@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"final_{TAG}")
 DST = os.path.join(ROOT, "profiles")
@@ -20,7 +20,8 @@ secondary = {"secondary_gpu_measure_py": last("secondary.json")}
 for key, name in [("selfplay_4096", "selfplay_4096.json"), ("selfplay_4096_long", "selfplay_4096_long.json"),
                   ("selfplay_16384", "selfplay_16384.json"),
                   ("selfplay_1024", "selfplay_1024.json"), ("config3_replay", "config3_replay.json"),
-                  ("movegen_rate", "movegen_rate.json")]:
+                  ("movegen_rate", "movegen_rate.json"), ("selfplay_search_64_nodes", "selfplay_search_64_nodes.json"),
+                  ("selfplay_search_1000_nodes", "selfplay_search_1000_nodes.json")]:
     secondary[key] = last(name)
 secondary["latency_txt"] = open(os.path.join(SRC, "latency.txt")).read()
 json.dump(secondary, open(os.path.join(DST, f"{TAG}_secondary_measurements.json"), "w"), indent=1)
@@ -39,7 +40,7 @@ names = {
     "rocprofv3_kernel_stats_headline_only.txt": "rocprofv3_kernel_stats_headline_only.txt",
     "reference_differential.json": "reference_differential.json", "reference_trace_differential.json": "reference_trace_differential.json",
     "pmc_selfplay_4096_seats.txt": "pmc_selfplay_4096_seats.txt",
-    "gather_ceiling.json": "gather_ceiling.json", "gather_ceiling_wide_psq_rows.json": "gather_ceiling_wide_psq_rows.json",
+    "replay_segment_ab.txt": "ab_replay_segment_length.txt",
     "raweval_walk.txt": "raweval_walk_evaluate_by_pending_plies.txt", "selfplay_gpu_busy.txt": "selfplay_gpu_busy_4096_seats.txt",
     "bench_n2_two_ranks_sharing_one_gpu.json": "bench_n2_two_ranks_sharing_one_gpu.json",
     "bench_n1_config5_hbm_filling.json": "bench_n1_config5_hbm_filling.json",
@@ -69,6 +70,7 @@ for f in sorted(glob.glob(os.path.join(DST, f"{TAG}_bench*.json"))):
     print(os.path.basename(f), "%.4e" % j["value"], "ms/step %.4f" % j["ms_per_step"], "frac %.3f" % r.get("frac", 0),
           "wide", (j.get("wide_psq_rows") or {}).get("value"), "cpu", (j.get("cpu_baseline") or {}).get("value"),
           "kernel_ms", j["config"].get("kernel_ms"), "update", r.get("update_kernel_ms"), "traffic/hbm", r.get("traffic_over_hbm_peak"))
+print("selfplay search 64 / 1000 nodes", *(secondary[k]["value"] for k in ("selfplay_search_64_nodes", "selfplay_search_1000_nodes")))
 print("selfplay", secondary["selfplay_4096"]["value"], secondary["selfplay_4096_long"]["value"], secondary["selfplay_16384"]["value"], secondary["selfplay_1024"]["value"],
       "replay ms", secondary["config3_replay"]["native_device_ms"])
 print(secondary["latency_txt"])
