@@ -1,4 +1,4 @@
-// Column-sliced full refresh for gfx950 (round 4): the feature-transformer pass of NnueState::evaluateOnce for big batches.
+// Column-sliced full refresh for gfx950 (rounds 4-5): the feature-transformer pass of NnueState::evaluateOnce for big batches.
 //
 // What the round-3 kernel (spx_ft_kernel: one wave per perspective, whole 1 KiB rows) left on the table, measured with the
 // load-only probes of spx_probe.hip on the bench batch (profiles/r04_sliced_probe_*):
@@ -12,17 +12,28 @@
 //     1 407 instructions per perspective) disappears onto the matrix pipe: ONE v_mfma_i32_16x16x64_i8 with a constant
 //     selection matrix widens AND adds up four gathered i8 rows (tools/probes/mfma_rowsum_probe.hip).
 //
-// Pipeline (all on one stream; on the two lanes of the pipelined entry point a batch's preparation runs beside the other lane's gather):
+// Round 5: a 16-byte-per-lane wave load holds that texture path ~17.5 cycles whatever its exec mask or
+// width (tools/probes/tcp_mask_probe.hip), a ds_read_b128 of the same 1 KiB 8.8: rows must LEAVE the path, not be fetched more
+// cleverly. The context's ~256 most popular threat / pawn-pair rows (chosen from data: a histogram over its first big batch, or
+// spx_ctx_calibrate) sit in LDS beside the slab - 35 % of those fetches -, and the walks of the groups are PACKED once per batch
+// instead of found out by each of the 8 XCDs (section boundaries, list searching, padding: 160 of the round-4 gather's 280 us were
+// that skeleton, profiles/r05_gather_anatomy.txt).
+//
+// Pipeline (all on one stream; on the three lanes of the pipelined entry point the preparation of two batches runs beside a gather):
 //   spx_ftx_extract_kernel  one wave per POSITION: board decode, attack sets and the feature candidates once, the row lists of both
-//                           perspectives (nnue_state.cpp:309-354, 440-449) to HBM, a head and a sort key (king bucket, list length)
+//                           perspectives (nnue_state.cpp:309-354, 440-449) to HBM - LDS section (piece-square rows, hot rows),
+//                           high-byte planes, cold rows -, a head and a sort key (king bucket, global quartets, LDS quartets)
 //   spx_ftx_rank_kernel     counting sort, part 1: rank of every perspective inside its key's bin
 //   spx_ftx_plan_kernel     bin starts (each bucket padded to whole groups of 8), and the PLAN: the groups cut into 32
 //                           contiguous, equally heavy ranges - one per CU of an XCD -, each a list of one-bucket segments
-//   spx_ftx_scatter_kernel  counting sort, part 2: every perspective's head and list at its place in the sorted order
+//   spx_ftx_scatter_kernel  counting sort, part 2: every perspective's head at its place in the sorted order
+//   spx_ftx_pack_kernel     one wave per group of 8 neighbours: the group's head (section lengths, output slots) and its walk as
+//                           stages of 8 steps x 8 perspectives x 4 rows (1 KiB each, padded with the zero row, sections stage-aligned)
 //   spx_ftx_gather_kernel   256 workgroups of 16 waves (workgroup b on XCD b % 8 = slice b % 8, CU slot b / 8): per segment
-//                           the bucket's piece-square slab slice into LDS, then one wave per group of 8 perspectives: it reads the
-//                           8 lists itself, 2 perspectives x 4 rows x 128 B per wave load / LDS read, one MFMA each, pairwise
-//                           activation (multilayer.h:92-152) from the i32 sums, 2 output bytes per lane.
+//                           the bucket's piece-square slab slice into LDS (the hot rows' slice once), then one wave per group:
+//                           stages through its own 1 KiB of LDS, steps walked in pairs without a branch, 2 perspectives x 4 rows
+//                           x 128 B per wave load / LDS read, one MFMA each, pairwise activation (multilayer.h:92-152) from the
+//                           i32 sums, outputs transposed through the stage: 8 bytes per lane.
 // (Round 4 also built the INCREMENTAL path on the same tables - spx_ftu_derive_kernel -> rank / plan / scatter ->
 // spx_ftu_apply_kernel -: bit-exact and slower than spx_update_kernel, 1.32 vs 2.15e8 updates+evals/s; retired in round 5 to
 // experiments/r04_incremental_pipeline_column_sliced.hip.txt.)
@@ -46,7 +57,7 @@ namespace {
 #define SPX_FTX_GATHER_WAVES 16
 #endif
 #ifndef SPX_FTX_SKIP
-#define SPX_FTX_SKIP 0  // measurement builds only (wrong sums): 1 no LDS row reads, 2 no global row loads, 4 no MFMAs, 8 no output stores,
+#define SPX_FTX_SKIP 0  // measurement builds only (wrong sums): 1 no LDS row reads, 2 no global row loads, 4 no MFMAs, 8 no output stores, 64 LDS reads without bank conflicts,
 #endif                  // 32 no ring writes (tools/build_variants.sh; profiles/r05_gather_anatomy.txt)
 
 #ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
@@ -599,6 +610,8 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
         for (int pr = 0; pr < 4; ++pr) {
             if constexpr (kLds) {
                 if (SPX_FTX_SKIP & 1) w[pr] = i32x4{int(en[pr]), 0, 0, 0};
+                else if (SPX_FTX_SKIP & 64)  // (measurement: every LDS row read forced onto the bank half of its kb - no bank conflicts, wrong rows)
+                    w[pr] = *reinterpret_cast<const i32x4*>(ldsRows + ((en[pr] & ~128u) | (((laneId() >> 4) & 1u) << 7)) + laneOff);
                 else w[pr] = *reinterpret_cast<const i32x4*>(ldsRows + en[pr] + laneOff);
             } else {
                 if (SPX_FTX_SKIP & 2) w[pr] = i32x4{int(en[pr]), 0, 0, 0};
