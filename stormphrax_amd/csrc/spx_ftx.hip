@@ -60,6 +60,9 @@ namespace {
 #define SPX_FTX_SKIP 0  // measurement builds only (wrong sums): 1 no LDS row reads, 2 no global row loads, 4 no MFMAs, 8 no output stores, 64 LDS reads without bank conflicts,
 #endif                  // 32 no ring writes (tools/build_variants.sh; profiles/r05_gather_anatomy.txt)
 
+#ifndef SPX_FTX_NT
+#define SPX_FTX_NT 1  // non-temporal (streaming) accesses, A/B (1 alone: +0.8 %; the gather's stage loads: -13 %) - 1 the pack kernel's stage stores, 2 the gather's stage loads, 4 the gather's
+#endif                // output stores, 8 the extraction's list / head stores, 16 the pack kernel's list loads
 #ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
 #define SPX_FTX_GATHER_WAVES_PER_SIMD 5  // register budget: 512 / this = 96 (a workgroup brings 4 waves per SIMD: the rest is room for two of the extraction's)
 #endif
@@ -227,8 +230,10 @@ __global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(
                 // ONE store for both kinds (beside a gather every vector-memory instruction of this kernel queues behind the gather's
                 // row loads: without the list stores the pass took 223 instead of 272 us there, profiles/r05_gather_anatomy.txt)
                 if (taken) {
-                    out[hot ? kFtxListLds + nPsq + nHot + prefixCount(hotMask) : kFtxListCold + nCold + prefixCount(coldMask)] =
-                        hot ? kFtxSlabBytes + slot * 128u : uint32_t(r) * 128u;
+                    uint32_t* at = out + (hot ? kFtxListLds + nPsq + nHot + prefixCount(hotMask) : kFtxListCold + nCold + prefixCount(coldMask));
+                    const uint32_t v = hot ? kFtxSlabBytes + slot * 128u : uint32_t(r) * 128u;
+                    if (SPX_FTX_NT & 8) __builtin_nontemporal_store(v, at);
+                    else *at = v;
                 }
                 nHot += uint32_t(popc64(hotMask));
                 nCold += uint32_t(popc64(coldMask));
@@ -486,88 +491,88 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Pack: one wave per group of 8 neighbours of the sorted order writes the group's walk (spx_ftx.h) - the sections' lengths, the
-// output slots, and the lists cut into interleaved stages with their padding. Lane (g = lane >> 3, ks = lane & 7) carries the
-// four rows of step ks of perspective g: 16 bytes of its list, 8 consecutive lanes one 128-byte line.
+// output slots, and the lists cut into interleaved stages with their padding. A lane LOADS what it stores: lane l owns words
+// 4 l .. 4 l + 3 of every stage = row kb = (l >> 1) & 3 of step ks = l >> 3 of the four perspectives 2 pr + (l & 1) - four 4-byte
+// loads from four lists (neighbouring lanes read neighbouring words) and one coalesced, non-temporal 16-byte store, no LDS, no
+// barrier. (The first version loaded 16 bytes of ONE list per lane and transposed through 4 KB of LDS per workgroup; measured equal
+// beside a gather - 86-140 us there against 21 alone, either way -, this one needs no LDS. Measurement builds that SKIP this kernel
+// run the pipelined step 8 % faster, those that skip the extraction 6.5 %: docs/experiments.md 6.)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxParams p) {
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
-    __shared__ __align__(16) uint32_t sStage[kWavesPerBlock][256];
     const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), G = blockIdx.x * kWavesPerBlock + wave;
     if (G >= p.plan[33]) return;
-    const uint32_t g = lane >> 3, ks = lane & 7u;
-    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
-    const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + g];
-    const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
-    // the sections' lengths: the longest of the 8 lists, in quartets (9 + 7 + 7 bits of one word per lane, three shuffles)
-    uint32_t dims = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
+    const uint32_t ks = lane >> 3, kb = (lane >> 1) & 3u, u = lane & 1u;
+    // the heads of this lane's four perspectives: {counts, output slot, list offset in bytes, -}
+    uint32_t counts[4], listAt[4], dst[4];
+    uint32_t dims = 0, rowsG = 0, rowsL = 0;
 #pragma unroll
-    for (int dlt = 8; dlt < 64; dlt <<= 1) {
-        const uint32_t other = uint32_t(__shfl_xor(int(dims), dlt, 64));
+    for (int pr = 0; pr < 4; ++pr) {
+        const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + 2 * pr + u];
+        counts[pr] = head[0], dst[pr] = head[1], listAt[pr] = head[2];
+        const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
+        // the sections' lengths: the longest of the 8 lists, in quartets (one byte each)
+        const uint32_t mine = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
+        dims = max(dims & 0xFFu, mine & 0xFFu) | max(dims & 0xFF00u, mine & 0xFF00u) | max(dims & 0xFF0000u, mine & 0xFF0000u);
+        rowsG += cHi + cCold;
+        rowsL += cLds;
+    }
+    {   // ... and the other four (the neighbouring lane has them)
+        const uint32_t other = uint32_t(__shfl_xor(int(dims), 1, 64));
         dims = max(dims & 0xFFu, other & 0xFFu) | max(dims & 0xFF00u, other & 0xFF00u) | max(dims & 0xFF0000u, other & 0xFF0000u);
+        rowsG += uint32_t(__shfl_xor(int(rowsG), 1, 64));
+        rowsL += uint32_t(__shfl_xor(int(rowsL), 1, 64));
     }
     dims = __builtin_amdgcn_readfirstlane(dims);
     const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
-    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
-    if (lane == 0) gh[0] = dims;
-    if (ks == 0) gh[1 + g] = head[1];
     const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
-    uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
-    {   // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
-        // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
-        uint32_t rowsG = ks == 0 ? cHi + cCold : 0u, rowsL = ks == 0 ? cLds : 0u;
+    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
+    if (lane < 2) {
 #pragma unroll
-        for (int dlt = 8; dlt < 64; dlt <<= 1) {
-            rowsG += uint32_t(__shfl_xor(int(rowsG), dlt, 64));
-            rowsL += uint32_t(__shfl_xor(int(rowsL), dlt, 64));
-        }
-        if (lane == 0) {
-            gh[9] = Q;
-            gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
-            gh[11] = (ldsQ + 1) & ~1u;
-            gh[12] = rowsG;
-            gh[13] = rowsL;
-        }
+        for (int pr = 0; pr < 4; ++pr) gh[1 + 2 * pr + u] = dst[pr];
     }
-    // stage q: which section, where this lane's four rows sit in its list, how many of them there are
-    auto place = [&](uint32_t q, uint32_t& at, uint32_t& left, uint32_t& zero) {
-        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS - 14 KB of it)
+    if (lane == 0) {
+        gh[0] = dims;
+        // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
+        // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
+        gh[9] = Q;
+        gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
+        gh[11] = (ldsQ + 1) & ~1u;
+        gh[12] = rowsG;
+        gh[13] = rowsL;
+    }
+    const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
+    uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256) + 4 * lane;
+    // stage q: which section, which word of the four lists, what pads a list that has ended; the next stage's words travel while
+    // this one is stored
+    auto fetch = [&](uint32_t q) {
+        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS)
         const uint32_t isLds = (q >= H && q < H + L) ? 1u : 0u, isCold = q >= H + L ? 1u : 0u, isHi = 1u - isLds - isCold;
         const uint32_t s = q - isLds * H - isCold * (H + L);
-        const uint32_t count = (head[0] >> (6u * isLds + 15u * isCold)) & (0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u));
+        const uint32_t shift = 6u * isLds + 15u * isCold, mask = 0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u);
         const uint32_t base = isHi * kFtxListHi + isLds * kFtxListLds + isCold * kFtxListCold;
-        const uint32_t first = 4 * (8 * s + ks);
-        zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
-        left = count > first ? count - first : 0u;
-        at = head[2] + 4 * (base + first);
+        const uint32_t idx = 4 * (8 * s + ks) + kb;
+        const uint32_t zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
+        u32x4 v;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            v[pr] = zero;
+            if (idx < ((counts[pr] >> shift) & mask)) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(lists + listAt[pr] + 4 * (base + idx));
+                v[pr] = (SPX_FTX_NT & 16) ? __builtin_nontemporal_load(src) : *src;
+            }
+        }
+        return v;
     };
-    const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
-    // the next stage's lists travel while this one is written; a stage passes through LDS so that it leaves as ONE coalesced 1 KiB
-    // store (beside a gather every vector-memory instruction queues behind the gather's row loads)
-    uint32_t at, left, zero;
     u32x4 next = {0, 0, 0, 0};
-    if (Q > 0) {
-        place(0, at, left, zero);
-        if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
-    }
+    if (Q > 0) next = fetch(0);
     for (uint32_t q = 0; q < Q; ++q) {
         const u32x4 v = next;
-        const uint32_t leftNow = left, zeroNow = zero;
-        if (q + 1 < Q) {
-            place(q + 1, at, left, zero);
-            next = u32x4{0, 0, 0, 0};
-            if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
-        }
-        uint32_t* st = &sStage[wave][fillAt];
-        st[0] = leftNow > 0 ? v[0] : zeroNow;
-        st[8] = leftNow > 1 ? v[1] : zeroNow;
-        st[16] = leftNow > 2 ? v[2] : zeroNow;
-        st[24] = leftNow > 3 ? v[3] : zeroNow;
-        __builtin_amdgcn_wave_barrier();
-        const u32x4 line = *reinterpret_cast<const u32x4*>(&sStage[wave][4 * lane]);
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<u32x4*>(out + size_t(q) * 256 + 4 * lane) = line;
+        if (q + 1 < Q) next = fetch(q + 1);
+        if (SPX_FTX_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + size_t(q) * 256));
+        else *reinterpret_cast<u32x4*>(out + size_t(q) * 256) = v;
     }
 }
 
@@ -675,7 +680,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
     }
     // (32-bit byte offsets from a scalar base: one address register per load instead of two)
     auto stageOfGroup = [&](uint32_t G, uint32_t q) {
-        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.stages) + (size_t(G) * kFtxMaxStages + q) * 1024 + 16 * lane);
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.stages) + (size_t(G) * kFtxMaxStages + q) * 1024 + 16 * lane);
+        return (SPX_FTX_NT & 2) ? __builtin_nontemporal_load(src) : *src;
     };
     auto headOfGroup = [&](uint32_t G) { return lane < 9 ? p.groupHead[size_t(G) * kFtxGroupHeadWords + lane] : 0u; };
     uint32_t loaded = 0xFFFFFFFFu;
@@ -746,7 +752,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                 const u32x2 mine = *reinterpret_cast<const u32x2*>(stage + 2 * lane);
                 const uint32_t dst = sHead[1 + (lane >> 3)];
                 if ((SPX_FTX_SKIP & 8) ? (mine[0] == 0x12345678u && dst == 77u) : (dst != 0xFFFFFFFFu)) {
-                    *reinterpret_cast<u32x2*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * (lane & 7u)) = mine;
+                    if (SPX_FTX_NT & 4) __builtin_nontemporal_store(mine, reinterpret_cast<u32x2*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * (lane & 7u)));
+                    else *reinterpret_cast<u32x2*>(p.ftOut + size_t(dst) * kPairs + 64 * xcd + 8 * (lane & 7u)) = mine;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -805,9 +812,30 @@ hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifndef SPX_MEASURE_SKIP
+#define SPX_MEASURE_SKIP 0  // measurement builds only (tools/build_variants.sh): after the first 12 batches of the process 1 = no extraction
+#endif                      // (the lists of the scratch set's last batch stay), 2 = no rank / plan / scatter / pack, 4 = no MLP (spx_kernels.hip)
+
 hipError_t launchFtxPrepare(const FtxParams& p, hipStream_t stream) {
-    const hipError_t e = launchFtxExtract(p, stream);
-    if (e != hipSuccess) return e;
+    static std::atomic<uint32_t> calls{0};
+    const bool warm = SPX_MEASURE_SKIP != 0 && calls.fetch_add(1) >= 12;
+    if (!(warm && (SPX_MEASURE_SKIP & 1))) {
+        const hipError_t e = launchFtxExtract(p, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (warm && (SPX_MEASURE_SKIP & 2)) return hipSuccess;
+    if (warm && (SPX_MEASURE_SKIP & 24)) {  // 8 = no pack, 16 = no rank / plan / scatter (the sorted order of the last batch stays)
+        const uint32_t nPersp = 2 * p.nPositions;
+        if (!(SPX_MEASURE_SKIP & 16)) {
+            hipLaunchKernelGGL(spx_ftx_rank_kernel, dim3((nPersp + 1023) / 1024), dim3(1024), 0, stream, p);
+            hipLaunchKernelGGL(spx_ftx_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, p);
+            hipLaunchKernelGGL(spx_ftx_scatter_kernel, dim3((nPersp + 255) / 256), dim3(256), 0, stream, p);
+        }
+        if (!(SPX_MEASURE_SKIP & 8)) {
+            hipLaunchKernelGGL(spx_ftx_pack_kernel, dim3((uint32_t(ftxGroups(p.nPositions)) + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, stream, p);
+        }
+        return hipGetLastError();
+    }
     return launchFtxSortAndPlan(p, stream);
 }
 
