@@ -506,12 +506,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
     if (G >= p.plan[33]) return;
     const uint32_t ks = lane >> 3, kb = (lane >> 1) & 3u, u = lane & 1u;
     // the heads of this lane's four perspectives: {counts, output slot, list offset in bytes, -}
-    uint32_t counts[4], listAt[4], dst[4];
+    uint32_t counts[4], listAt[4];
     uint32_t dims = 0, rowsG = 0, rowsL = 0;
+    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
         const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + 2 * pr + u];
-        counts[pr] = head[0], dst[pr] = head[1], listAt[pr] = head[2];
+        counts[pr] = head[0], listAt[pr] = head[2];
+        if (lane < 2) gh[1 + 2 * pr + u] = head[1];  // the output slot
         const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
         // the sections' lengths: the longest of the 8 lists, in quartets (one byte each)
         const uint32_t mine = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
@@ -528,11 +530,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
     dims = __builtin_amdgcn_readfirstlane(dims);
     const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
     const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
-    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
-    if (lane < 2) {
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) gh[1 + 2 * pr + u] = dst[pr];
-    }
     if (lane == 0) {
         gh[0] = dims;
         // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
