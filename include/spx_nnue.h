@@ -323,11 +323,11 @@ int spx_ctx_count_rows(const spx_ctx* ctx, const spx_packed_pos* positions, size
 
 /* Number of piece-square rows (of 11264) whose weights all fit i8: the context keeps a 1 KiB u8 copy of those and the
  * full-refresh kernel fetches it instead of the 2 KiB i16 row (identical sums, fewer bytes). Net dependent; 0 when
- * the environment sets SPX_NO_COMPACT=1. Reported by bench.py next to the algorithmic byte count. */
+ * the context was created with option compact_rows=0. Reported by bench.py next to the algorithmic byte count. */
 uint32_t spx_ctx_compact_psq_rows(const spx_ctx* ctx);
 /* Number of NEAR-compact piece-square rows: all but at most 32 of the 1 024 weights fit i8. The full-refresh kernel fetches
  * their 1 KiB copy too (those weights clamped) and adds the exact remainders from a side table - identical sums again;
- * the incremental kernels read such a row from the i16 table. 0 with SPX_NO_COMPACT=1 or SPX_NO_NEAR=1. */
+ * the incremental kernels read such a row from the i16 table. 0 with option compact_rows=0 or near_rows=0. */
 uint32_t spx_ctx_near_psq_rows(const spx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -438,7 +438,7 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * evaluated WITHOUT being stored (eval-only children), one step kernel per ply doing search, bookkeeping, repetition keys,
  * game records and the seating of new games from a device-side opening pool, one materialising update for the moves
  * played; the two halves of the seats run on the context's two lanes, each half's per-ply launch chain captured once as a
- * hipGraph (two plies per graph launch, four on runs of >= 8 games per seat; environment SPX_SELFPLAY_NO_GRAPH=1 = direct
+ * hipGraph (two plies per graph launch, four on runs of >= 8 games per seat; option selfplay_graph=0 = direct
  * launches, SPX_SELFPLAY_GRAPH_PLIES = plies per graph), and the host reads ~100
  * bytes of counters plus the finished games per ply. SPX_SELFPLAY_HOST_MOVEGEN selects the host chess core for moves, openings and bookkeeping (the
  * same rules; the validation path). Needs a context whose max_batch holds a ply's children of half the seats (48 * n_games

@@ -499,6 +499,49 @@ def test_converters_filter_the_move_that_ends_a_game_in_a_draw(sp):
     assert checked["dropped because drawn"] >= 40 and checked["kept"] >= 40, checked
 
 
+def test_restated_search_equals_plain_minimax(sp, oracle, net_blob):
+    """tests/_search_rules.py - the recursive restatement the live search's games are replayed through on the GPU box - checked
+    here against something simpler still: full-width negamax WITHOUT pruning to the depth the restated search reached, same child
+    order, leaf values from the CPU oracle. Alpha-beta with a full window at the root must return minimax's value and its first
+    best move; a budget of one node must return the depth-1 choice; a mate in one must be found with its mate score."""
+    from _datagen_rules import clamp_static
+    from _search_rules import INF, MATE, Searcher
+
+    oracle.use(net_blob("tame"), "tame")
+
+    class OracleState:  # what Searcher asks of an NnueState: raw evals of a batch of records
+        def evaluate_once(self, recs):
+            mail, stm = sp.positions_to_mailboxes(recs)
+            return oracle.eval_mailboxes(mail, stm)
+
+    st = OracleState()
+
+    def minimax(searcher, rec, depth, ply):
+        words, kids, values, in_check, order = searcher.expand(rec)
+        if len(words) == 0:
+            return -(MATE - ply) if in_check else 0
+        if depth == 1:
+            return values[order[0]]
+        return max(-minimax(searcher, kids[i], depth - 1, ply + 1) for i in order)
+
+    roots = sp.random_positions(5, seed=99, min_ply=20, max_ply=70, dfrc_every=2)
+    for budget in (1, 25, 90):
+        searcher = Searcher(sp, st, budget)
+        for rec in roots:
+            word, score, child, depth = searcher.root(rec)
+            assert depth == (1 if budget == 1 else (2 if budget == 25 else 3)), (budget, depth, searcher.nodes)
+            words, kids, values, _, order = searcher.expand(rec)
+            full = [-minimax(searcher, kids[i], depth - 1, 1) if depth > 1 else values[i] for i in range(len(words))]
+            assert score == max(full), (budget, score, max(full))
+            assert full[list(words).index(word)] == score   # the move played IS a best move
+            if budget == 1:
+                assert word == int(words[order[0]]) and score == clamp_static(-int(st.evaluate_once(kids[order[0]:order[0] + 1])[0]))
+    # mate in one (back-rank): found at depth 2 with the score MATE - 1 for the mover, decisive -> the search stops there
+    rec = sp.positions_from_fens(["6k1/5ppp/8/8/8/8/8/R3K3 w Q - 0 1"])[0]
+    word, score, child, depth = Searcher(sp, st, 10_000).root(rec)
+    assert score == MATE - 1 and depth == 2 and sp.legal_moves(child)[0].size == 0 and sp.legal_moves(child)[2]
+
+
 def test_wdl_normalisation_does_not_depend_on_fp_contraction(sp, oracle):
     """wdl::normalizeScore (wdl.cpp:28-79) is an f64 cubic; the device / host source evaluates it with fused multiply-adds
     (what the reference's x86-64 clang builds contract to), the oracle's plain-C restatement is built with -ffp-contract=off
