@@ -61,8 +61,8 @@ namespace {
 #endif                  // 32 no ring writes (tools/build_variants.sh; profiles/r05_gather_anatomy.txt)
 
 #ifndef SPX_FTX_NT
-#define SPX_FTX_NT 1  // non-temporal (streaming) accesses, A/B (1 alone: +0.8 %; the gather's stage loads: -13 %) - 1 the pack kernel's stage stores, 2 the gather's stage loads, 4 the gather's
-#endif                // output stores, 8 the extraction's list / head stores, 16 the pack kernel's list loads
+#define SPX_FTX_NT 0  // A/B, non-temporal (streaming) accesses: 2 the gather's stage loads (-13 %), 4 its output stores (nothing), 8 the
+#endif                // extraction's list stores (nothing); (1 / 16 belonged to the pack kernel variant without LDS: docs/experiments.md 6)
 #ifndef SPX_FTX_GATHER_WAVES_PER_SIMD
 #define SPX_FTX_GATHER_WAVES_PER_SIMD 5  // register budget: 512 / this = 96 (a workgroup brings 4 waves per SIMD: the rest is room for two of the extraction's)
 #endif
@@ -491,85 +491,91 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Pack: one wave per group of 8 neighbours of the sorted order writes the group's walk (spx_ftx.h) - the sections' lengths, the
-// output slots, and the lists cut into interleaved stages with their padding. A lane LOADS what it stores: lane l owns words
-// 4 l .. 4 l + 3 of every stage = row kb = (l >> 1) & 3 of step ks = l >> 3 of the four perspectives 2 pr + (l & 1) - four 4-byte
-// loads from four lists (neighbouring lanes read neighbouring words) and one coalesced, non-temporal 16-byte store, no LDS, no
-// barrier. (The first version loaded 16 bytes of ONE list per lane and transposed through 4 KB of LDS per workgroup; measured equal
-// beside a gather - 86-140 us there against 21 alone, either way -, this one needs no LDS. Measurement builds that SKIP this kernel
-// run the pipelined step 8 % faster, those that skip the extraction 6.5 %: docs/experiments.md 6.)
+// output slots, and the lists cut into interleaved stages with their padding. Lane (g = lane >> 3, ks = lane & 7) carries the
+// four rows of step ks of perspective g: 16 bytes of its list, 8 consecutive lanes one 128-byte line. (A variant without LDS - a lane
+// loads the four words it stores, 4-byte loads from four lists, 30 registers - and non-temporal stage stores were measured: equal
+// beside a gather, 1-2 % slower stream-ordered: docs/experiments.md 6. Measurement builds that SKIP this kernel run the pipelined
+// step 8 % faster, those that skip the extraction 6.5 %.)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxParams p) {
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
+    __shared__ __align__(16) uint32_t sStage[kWavesPerBlock][256];
     const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), G = blockIdx.x * kWavesPerBlock + wave;
     if (G >= p.plan[33]) return;
-    const uint32_t ks = lane >> 3, kb = (lane >> 1) & 3u, u = lane & 1u;
-    // the heads of this lane's four perspectives: {counts, output slot, list offset in bytes, -}
-    uint32_t counts[4], listAt[4];
-    uint32_t dims = 0, rowsG = 0, rowsL = 0;
-    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
+    const uint32_t g = lane >> 3, ks = lane & 7u;
+    const uint32_t fillAt = 32 * ks + 4 * (g & 1u) + (g >> 1);  // (+ 8 i for row i of the step)
+    const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + g];
+    const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
+    // the sections' lengths: the longest of the 8 lists, in quartets (9 + 7 + 7 bits of one word per lane, three shuffles)
+    uint32_t dims = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-        const u32x4 head = reinterpret_cast<const u32x4*>(p.sorted)[8 * G + 2 * pr + u];
-        counts[pr] = head[0], listAt[pr] = head[2];
-        if (lane < 2) gh[1 + 2 * pr + u] = head[1];  // the output slot
-        const uint32_t cHi = head[0] & 0x3Fu, cLds = (head[0] >> 6) & 0x1FFu, cCold = (head[0] >> 15) & 0x1FFu;
-        // the sections' lengths: the longest of the 8 lists, in quartets (one byte each)
-        const uint32_t mine = ((cHi + 3) >> 2) | (((cLds + 3) >> 2) << 8) | (((cCold + 3) >> 2) << 16);
-        dims = max(dims & 0xFFu, mine & 0xFFu) | max(dims & 0xFF00u, mine & 0xFF00u) | max(dims & 0xFF0000u, mine & 0xFF0000u);
-        rowsG += cHi + cCold;
-        rowsL += cLds;
-    }
-    {   // ... and the other four (the neighbouring lane has them)
-        const uint32_t other = uint32_t(__shfl_xor(int(dims), 1, 64));
+    for (int dlt = 8; dlt < 64; dlt <<= 1) {
+        const uint32_t other = uint32_t(__shfl_xor(int(dims), dlt, 64));
         dims = max(dims & 0xFFu, other & 0xFFu) | max(dims & 0xFF00u, other & 0xFF00u) | max(dims & 0xFF0000u, other & 0xFF0000u);
-        rowsG += uint32_t(__shfl_xor(int(rowsG), 1, 64));
-        rowsL += uint32_t(__shfl_xor(int(rowsL), 1, 64));
     }
     dims = __builtin_amdgcn_readfirstlane(dims);
     const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
+    uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
+    if (lane == 0) gh[0] = dims;
+    if (ks == 0) gh[1 + g] = head[1];
     const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
-    if (lane == 0) {
-        gh[0] = dims;
-        // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
+    uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
+    {   // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
         // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
-        gh[9] = Q;
-        gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
-        gh[11] = (ldsQ + 1) & ~1u;
-        gh[12] = rowsG;
-        gh[13] = rowsL;
+        uint32_t rowsG = ks == 0 ? cHi + cCold : 0u, rowsL = ks == 0 ? cLds : 0u;
+#pragma unroll
+        for (int dlt = 8; dlt < 64; dlt <<= 1) {
+            rowsG += uint32_t(__shfl_xor(int(rowsG), dlt, 64));
+            rowsL += uint32_t(__shfl_xor(int(rowsL), dlt, 64));
+        }
+        if (lane == 0) {
+            gh[9] = Q;
+            gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
+            gh[11] = (ldsQ + 1) & ~1u;
+            gh[12] = rowsG;
+            gh[13] = rowsL;
+        }
     }
-    const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
-    uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256) + 4 * lane;
-    // stage q: which section, which word of the four lists, what pads a list that has ended; the next stage's words travel while
-    // this one is stored
-    auto fetch = [&](uint32_t q) {
-        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS)
+    // stage q: which section, where this lane's four rows sit in its list, how many of them there are
+    auto place = [&](uint32_t q, uint32_t& at, uint32_t& left, uint32_t& zero) {
+        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS - 14 KB of it)
         const uint32_t isLds = (q >= H && q < H + L) ? 1u : 0u, isCold = q >= H + L ? 1u : 0u, isHi = 1u - isLds - isCold;
         const uint32_t s = q - isLds * H - isCold * (H + L);
-        const uint32_t shift = 6u * isLds + 15u * isCold, mask = 0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u);
+        const uint32_t count = (head[0] >> (6u * isLds + 15u * isCold)) & (0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u));
         const uint32_t base = isHi * kFtxListHi + isLds * kFtxListLds + isCold * kFtxListCold;
-        const uint32_t idx = 4 * (8 * s + ks) + kb;
-        const uint32_t zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
-        u32x4 v;
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-            v[pr] = zero;
-            if (idx < ((counts[pr] >> shift) & mask)) {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(lists + listAt[pr] + 4 * (base + idx));
-                v[pr] = (SPX_FTX_NT & 16) ? __builtin_nontemporal_load(src) : *src;
-            }
-        }
-        return v;
+        const uint32_t first = 4 * (8 * s + ks);
+        zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
+        left = count > first ? count - first : 0u;
+        at = head[2] + 4 * (base + first);
     };
+    const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
+    // the next stage's lists travel while this one is written; a stage passes through LDS so that it leaves as ONE coalesced 1 KiB
+    // store (beside a gather every vector-memory instruction queues behind the gather's row loads)
+    uint32_t at, left, zero;
     u32x4 next = {0, 0, 0, 0};
-    if (Q > 0) next = fetch(0);
+    if (Q > 0) {
+        place(0, at, left, zero);
+        if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
+    }
     for (uint32_t q = 0; q < Q; ++q) {
         const u32x4 v = next;
-        if (q + 1 < Q) next = fetch(q + 1);
-        if (SPX_FTX_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + size_t(q) * 256));
-        else *reinterpret_cast<u32x4*>(out + size_t(q) * 256) = v;
+        const uint32_t leftNow = left, zeroNow = zero;
+        if (q + 1 < Q) {
+            place(q + 1, at, left, zero);
+            next = u32x4{0, 0, 0, 0};
+            if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
+        }
+        uint32_t* st = &sStage[wave][fillAt];
+        st[0] = leftNow > 0 ? v[0] : zeroNow;
+        st[8] = leftNow > 1 ? v[1] : zeroNow;
+        st[16] = leftNow > 2 ? v[2] : zeroNow;
+        st[24] = leftNow > 3 ? v[3] : zeroNow;
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 line = *reinterpret_cast<const u32x4*>(&sStage[wave][4 * lane]);
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4*>(out + size_t(q) * 256 + 4 * lane) = line;
     }
 }
 
