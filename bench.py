@@ -997,23 +997,29 @@ def main():
                 "matrix_pipe": {"v_mfma_i32_16x16x64_i8_per_launch": mfma_instr, "cycles_each": MFMA_CYCLES,
                                 "floor_us": floors["matrix_pipe"] * 1e6, "busy_frac": floors["matrix_pipe"] / ft_avg_s},
             }
-            l1_bytes = l1_instr * 1024
+            # the roofline proper = the unit with the largest floor (1 KiB per wave instruction on either memory unit)
+            peaks = {"texture_path": L1_PEAK_GBS * 16.0 / L1_CYCLES_PER_WAVE_LOAD, "lds": LDS_PEAK_GBS * 8.0 / LDS_CYCLES_PER_WAVE_READ}
+            instr = {"texture_path": l1_instr, "lds": lds_instr}
+            mem_bound = bound if bound in peaks else "texture_path"
             roofline.update({
-                "bound": "l1", "achieved": l1_bytes / ft_avg_s / 1e9, "peak": L1_PEAK_GBS * 16.0 / L1_CYCLES_PER_WAVE_LOAD, "unit": "GB/s",
-                "frac": floors["texture_path"] / ft_avg_s, "binding_unit": bound, "units": units,
+                "bound": {"texture_path": "l1", "lds": "lds"}[mem_bound], "achieved": instr[mem_bound] * 1024 / ft_avg_s / 1e9,
+                "peak": peaks[mem_bound], "unit": "GB/s",
+                "frac": floors[mem_bound] / ft_avg_s, "binding_unit": bound, "units": units,
                 "walk": dict(walk, rows_useful=walk["global_rows"] + walk["lds_rows"], rows_walked_per_slice=rows_walked,
                              padding_efficiency=(walk["global_rows"] + walk["lds_rows"]) / max(rows_walked, 1),
                              hot_rows=int(state.hot_rows().size),
                              lds_share_of_rows=walk["lds_rows"] / max(walk["global_rows"] + walk["lds_rows"], 1)),
                 "l2": {"achieved": l2_gbs, "peak": L2_PEAK_GBS, "frac": l2_gbs / L2_PEAK_GBS, "requested_bytes_per_launch": requested},
-                "note": ("bound = the CU's texture / L1 path: achieved = 1 KiB x the gather's vector-memory wave instructions per launch "
-                         "(cold rows and high-byte planes 4 per step, one stage load per 8 steps, a head load and an output store per "
-                         "group; counted by the pack kernel, all 8 column slices) / the gather's HIP-event duration IN THE TIMED REGION "
-                         "(pipelined steps: beside two other batches' preparation), peak = 256 CUs x 1 KiB / 17.5 cycles x 2.4 GHz "
-                         "(tools/probes/tcp_mask_probe.hip); frac = that unit's floor / the duration. units = the same for the LDS pipe "
-                         "and the matrix pipe; binding_unit = the largest floor. Rows the gather adds from LDS (piece-square slab + "
-                         "hot threat / pawn-pair rows: walk.lds_share_of_rows) never touch the texture path. l2 = round 4's figure "
-                         "(bytes the row loads ask the L2s for / aggregate L2 bandwidth): the kernel got faster by asking for LESS. "
+                "note": ("What binds the gather is instruction slots of three units of a CU, so the roofline is stated in them: bound = the unit "
+                         "with the largest floor - 'lds' (the LDS pipe: 8.8 cycles per 1 KiB wave read; piece-square slab + hot threat / "
+                         "pawn-pair rows, stage entries) or 'l1' (the texture / L1 path: 17.5 cycles per 16-byte-per-lane wave load whatever "
+                         "its mask or width, tools/probes/tcp_mask_probe.hip; cold rows and high-byte planes 4 per step, one stage load per 8 "
+                         "steps, a head load and an output store per group). achieved = 1 KiB x that unit's wave instructions per launch "
+                         "(counted by the pack kernel, all 8 column slices) / the gather's HIP-event duration IN THE TIMED REGION (pipelined "
+                         "steps: beside two other batches' preparation), peak = 256 CUs x 1 KiB / cycles per instruction x 2.4 GHz, frac = "
+                         "the unit's floor / the duration. units = all three incl. the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8). "
+                         "l2 = round 4's figure (bytes the row loads ask the L2s for / aggregate L2 bandwidth): the kernel got faster by "
+                         "asking for LESS; hbm = SURVEY 8(d)'s algorithmic bytes and the measured fabric traffic. "
                          "secondary.full_refresh_paths has the kernel alone (stream-ordered)"),
             })
             roofline["pipeline"] = ("spx_ftx_extract_kernel -> spx_ftx_rank_kernel -> spx_ftx_plan_kernel -> spx_ftx_scatter_kernel "

@@ -491,6 +491,40 @@ def test_live_search_games_follow_the_restated_search(sp, net_blob, oracle, tmp_
         st.close()
 
 
+@pytest.mark.parametrize("n_games,target,budget", [(1, 1, 7), (1, 3, 30), (5, 2, 12), (33, 70, 3)])
+def test_live_search_edge_sizes(sp, net_blob, oracle, tmp_path, n_games, target, budget):
+    """One seat, fewer games than seats, more games than seats, tiny budgets: the search driver finishes exactly `target` games and
+    every one of them follows the restated search."""
+    from _search_rules import verify_search_file
+
+    with sp.NnueState(sp.Network(net_blob("tame")), device=0, max_batch=4096) as st:
+        path = str(tmp_path / "edge.vf")
+        stats = st.selfplay(n_games=n_games, target_games=target, out_path=path, max_plies=30, dfrc=False, temperature_cp=0, seed=11,
+                            search_nodes=budget)
+        assert stats["games"] == target
+        oracle.use(net_blob("tame"), "tame")
+        checked, _, _ = verify_search_file(sp, st, oracle, open(path, "rb").read(), 30, budget)
+        assert checked == stats["positions"]
+
+
+def test_live_search_argument_checks_and_group(sp, net_blob, tmp_path):
+    """The search lives in the device-resident driver: asking for it together with host move generation is an argument error; a
+    device group hands the budget on to its members."""
+    from _datagen_rules import parse_games
+    from stormphrax_amd import _lib
+
+    net = sp.Network(net_blob("tame"))
+    with sp.NnueState(net, device=0, max_batch=4096) as st:
+        with pytest.raises(_lib.SpxError):
+            st.selfplay(n_games=4, target_games=4, max_plies=20, host_movegen=True, search_nodes=8)
+    with sp.DeviceGroup(net, devices=[0, 0], max_batch_per_device=4096) as grp:
+        stats = grp.selfplay(n_games=6, target_games=9, out_path=str(tmp_path / "g"), max_plies=24, dfrc=True, temperature_cp=0, seed=2,
+                             search_nodes=10)
+        assert stats["games"] == 9 and stats["steps"] >= stats["positions"]
+        games = sum(len(parse_games(open(str(tmp_path / f"g.{r}.vf"), "rb").read())) for r in (0, 1))
+        assert games == 9
+
+
 def test_selfplay_direct_launch_fallback(sp, net_blob, oracle, tmp_path, monkeypatch):
     """Option selfplay_graph = 0 (what a HIP runtime that refuses the stream capture falls back to): the per-ply chain enqueued
     launch by launch, lanes gated. Same rules, same verification; and the same SET of games as graph mode for the same seed."""
