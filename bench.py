@@ -980,6 +980,10 @@ def main():
             # (a 16-byte-per-lane wave load holds it ~17.5 cycles whatever its mask or width), the LDS pipe (8.8 cycles per 1 KiB wave
             # read) and the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8, PMC) -, so the roofline is stated in them. The counts are
             # EXACT: the pack kernel sums what it lays out for the gather to walk (spx_debug_ftx_walk; steps per column slice x 8).
+            # (a batch above one pass of the pipeline - 65 536 positions - is walked in passes: the pack kernel's counts are the last
+            # pass's, the HIP events bracket all of a call's passes)
+            passes = max(1, -(-args.batch // 65536))
+            ft_launch_s = ft_avg_s / passes
             steps_g, steps_l = 8 * walk["global_steps"], 8 * walk["lds_steps"]
             l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
             lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes
@@ -991,21 +995,21 @@ def main():
             rows_walked = 32 * (walk["global_steps"] + walk["lds_steps"])
             units = {
                 "texture_path": {"wave_instructions_per_launch": l1_instr, "cycles_each": L1_CYCLES_PER_WAVE_LOAD,
-                                 "floor_us": floors["texture_path"] * 1e6, "busy_frac": floors["texture_path"] / ft_avg_s},
+                                 "floor_us": floors["texture_path"] * 1e6, "busy_frac": floors["texture_path"] / ft_launch_s},
                 "lds": {"wave_instructions_per_launch": lds_instr, "cycles_each": LDS_CYCLES_PER_WAVE_READ,
-                        "floor_us": floors["lds"] * 1e6, "busy_frac": floors["lds"] / ft_avg_s},
+                        "floor_us": floors["lds"] * 1e6, "busy_frac": floors["lds"] / ft_launch_s},
                 "matrix_pipe": {"v_mfma_i32_16x16x64_i8_per_launch": mfma_instr, "cycles_each": MFMA_CYCLES,
-                                "floor_us": floors["matrix_pipe"] * 1e6, "busy_frac": floors["matrix_pipe"] / ft_avg_s},
+                                "floor_us": floors["matrix_pipe"] * 1e6, "busy_frac": floors["matrix_pipe"] / ft_launch_s},
             }
             # the roofline proper = the unit with the largest floor (1 KiB per wave instruction on either memory unit)
             peaks = {"texture_path": L1_PEAK_GBS * 16.0 / L1_CYCLES_PER_WAVE_LOAD, "lds": LDS_PEAK_GBS * 8.0 / LDS_CYCLES_PER_WAVE_READ}
             instr = {"texture_path": l1_instr, "lds": lds_instr}
             mem_bound = bound if bound in peaks else "texture_path"
             roofline.update({
-                "bound": {"texture_path": "l1", "lds": "lds"}[mem_bound], "achieved": instr[mem_bound] * 1024 / ft_avg_s / 1e9,
+                "bound": {"texture_path": "l1", "lds": "lds"}[mem_bound], "achieved": instr[mem_bound] * 1024 / ft_launch_s / 1e9,
                 "peak": peaks[mem_bound], "unit": "GB/s",
-                "frac": floors[mem_bound] / ft_avg_s, "binding_unit": bound, "units": units,
-                "walk": dict(walk, rows_useful=walk["global_rows"] + walk["lds_rows"], rows_walked_per_slice=rows_walked,
+                "frac": floors[mem_bound] / ft_launch_s, "binding_unit": bound, "units": units,
+                "passes_per_call": passes, "walk": dict(walk, rows_useful=walk["global_rows"] + walk["lds_rows"], rows_walked_per_slice=rows_walked,
                              padding_efficiency=(walk["global_rows"] + walk["lds_rows"]) / max(rows_walked, 1),
                              hot_rows=int(state.hot_rows().size),
                              lds_share_of_rows=walk["lds_rows"] / max(walk["global_rows"] + walk["lds_rows"], 1)),
