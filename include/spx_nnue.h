@@ -114,7 +114,9 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  * LOCAL_WORLD_SIZE (self-play's host-thread share per rank) - applies to every context the process creates. Unknown names / malformed values: SPX_ERR_INVALID_ARG.
  *   ftx 0|1                 big full refreshes through the column-sliced pipeline (as SPX_CTX_SLICED_FT / _ONE_KERNEL_FT)
  *   ftx_min N               smallest batch that takes it (default 16 384; 12 288 for pipelined calls)
- *   ftx_hot_rows N          threat / pawn-pair rows the gather keeps in LDS beside the piece-square slab (default: what fits)
+ *   ftx_hot_rows N          threat / pawn-pair rows the gather keeps in LDS beside the piece-square slab (default 256, at most 384)
+ *   eval_lanes 2|3          scratch sets spx_eval_full_device_async rotates its batches over (default 3: the preparation of two
+ *                           batches runs beside a gather)
  *   tiny_batch_max N        batches up to N positions skip the sorts (default 8 192)
  *   mlp_share_max N         positions up to which four waves share one MLP tile (default 8 192)
  *   ft_team_max N           full refreshes of up to N perspectives run one workgroup per perspective (default 512)
@@ -124,7 +126,7 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  *   refresh_waves N         waves of the rebuild pass behind an update (default 0 = automatic)
  *   ft_blocks_per_cu N, update_blocks_per_cu N    grid caps of the one-kernel full refresh / the update kernel (48 / 24)
  *   king_sort 0|1           one-kernel path: perspectives in king-bucket order (default 1)
- *   replay_paths -1|0|1, replay_segment N         spx_acc_replay_tree: by heavy paths / by levels / its own choice; plies per segment
+ *   replay_paths -1|0|1, replay_segment N         spx_acc_replay_tree: by heavy paths / by levels / its own choice; plies per path segment (default 8)
  *   selfplay_graph 0|1, selfplay_graph_plies N, selfplay_trace 0|1    spx_selfplay_run: plies captured into hipGraphs (default) or
  *                           launched one by one; plies per graph (0 = automatic; even, 2..16); a timing line on stderr at the end
  *   ftx_fail_after K        test hook: the K-th scratch set of the pipeline "does not fit" (default -1: never)
