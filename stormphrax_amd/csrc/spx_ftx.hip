@@ -132,14 +132,13 @@ __global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(
     __shared__ uint32_t sLut[kLutCompactBase + kLutCompactWords];  // threat LUT + the compact-row bitmap
     __shared__ uint64_t sPseudo[kDeltaPseudoWords];
     __shared__ __align__(16) uint32_t sHot[kFtxHotHashWords];
-    __shared__ uint16_t sItems[kExtractWaves][2][kItemCap];
+    __shared__ uint16_t sItems[kExtractWaves][2 * kItemCap];  // threat items, behind them the pawn items (bit 15)
     for (int i = threadIdx.x; i < kLutCompactBase + kLutCompactWords; i += blockDim.x) sLut[i] = p.t.lut[i];
     for (int i = threadIdx.x; i < kDeltaPseudoWords; i += blockDim.x) sPseudo[i] = p.t.deltaTab[kDeltaRayWords + i];
     for (int i = threadIdx.x; i < int(kFtxHotHashWords); i += blockDim.x) sHot[i] = p.hotRows ? p.hotHash[i] : 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t lane = laneId(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint16_t* const threatItems = sItems[wave][0];
-    uint16_t* const pawnItems = sItems[wave][1];
+    uint16_t* const items = sItems[wave];
     // records through the scalar cache, one position ahead: the vector-memory counter is in order, a record asked for through it
     // could only be waited for together with all the list stores of the position before (their round trip, once per position)
     const uint32_t posStride = gridDim.x * kExtractWaves;
@@ -173,13 +172,13 @@ __global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(
                 if (targets) {
                     const uint32_t to = uint32_t(ctz64(targets));
                     targets &= targets - 1;
-                    if (atThreat < kItemCap) threatItems[atThreat] = uint16_t(lane | (to << 6));
+                    if (atThreat < kItemCap) items[atThreat] = uint16_t(lane | (to << 6));
                     ++atThreat;
                 }
                 if (partners) {
                     const uint32_t to = uint32_t(ctz64(partners));
                     partners &= partners - 1;
-                    if (atPawn < kItemCap) pawnItems[atPawn] = uint16_t(lane | (to << 6) | (uint32_t((same >> to) & 1) << 12));
+                    if (atPawn < kItemCap) items[nThreatItems + atPawn] = uint16_t(lane | (to << 6) | (uint32_t((same >> to) & 1) << 12) | 0x8000u);
                     ++atPawn;
                 }
             }
@@ -239,29 +238,23 @@ __global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(
                 nCold += uint32_t(popc64(coldMask));
                 nThr = min(nThr + uint32_t(popc64(valid)), uint32_t(kThreatCap));
             };
-            // threat rows (addThreatFeatures, nnue_state.cpp:309-328): the reference drops the pairs whose index is negative
-            for (uint32_t base = 0; base < nThreatItems; base += 64) {
-                const bool active = base + lane < nThreatItems;
-                const uint32_t item = active ? threatItems[base + lane] : 0u;
-                const int from = item & 63u, to = item >> 6;
-                const int pieceRel = __shfl(piece, from, 64) ^ flipColour, victimRel = __shfl(piece, to, 64) ^ flipColour;
+            // threat rows (addThreatFeatures, nnue_state.cpp:309-328: the reference drops the pairs whose index is negative), then
+            // the pawn pairs (:330-351) - ONE walk over the items of both kinds, 64 at a time (a position has ~55: one round)
+            const uint32_t nItems = nThreatItems + nPawnItems;
+            for (uint32_t base = 0; base < nItems; base += 64) {
+                const bool active = base + lane < nItems;
+                const uint32_t item = active ? items[base + lane] : 0u;
+                const int from = item & 63u, to = (item >> 6) & 63u;
+                const int pieceFrom = __shfl(piece, from, 64), pieceTo = __shfl(piece, to, 64);
                 int32_t r = -1;
-                if (active) {
-                    const int sqRel = from ^ x;
+                if (active && !(item & 0x8000u)) {
+                    const int pieceRel = pieceFrom ^ flipColour, victimRel = pieceTo ^ flipColour, sqRel = from ^ x;
                     const uint64_t pseudoRel = sPseudo[(pieceRel >= 2 ? (pieceRel >> 1) + 1 : pieceRel) * 64 + sqRel];
                     r = threatRow(sLut, pieceRel, sqRel, pseudoRel, victimRel, to ^ x);
+                } else if (active) {
+                    const bool sameColour = (item >> 12) & 1u, own = (pieceFrom & 1) == c;
+                    if (sameColour || own) r = int32_t(ppRow(ppId(from ^ x, !own), ppId(to ^ x, sameColour ? !own : true)));
                 }
-                emit(r);
-            }
-            // pawn pairs (:330-351)
-            for (uint32_t base = 0; base < nPawnItems; base += 64) {
-                const bool active = base + lane < nPawnItems;
-                const uint32_t item = active ? pawnItems[base + lane] : 0u;
-                const int from = item & 63u, to = (item >> 6) & 63u;
-                const bool sameColour = item >> 12;
-                const bool own = (__shfl(piece, from, 64) & 1) == c;
-                int32_t r = -1;
-                if (active && (sameColour || own)) r = int32_t(ppRow(ppId(from ^ x, !own), ppId(to ^ x, sameColour ? !own : true)));
                 emit(r);
             }
             if (lane == 0) {
