@@ -984,7 +984,7 @@ def main():
             # pass's, the HIP events bracket all of a call's passes)
             passes = max(1, -(-args.batch // 65536))
             ft_launch_s = ft_avg_s / passes
-            steps_g, steps_l = 8 * walk["global_steps"], 8 * walk["lds_steps"]
+            steps_g, steps_l = 8 * walk["cold_steps"] + walk["high_plane_steps_all_slices"], 8 * walk["lds_steps"]
             l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
             lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes
             mfma_instr = 4 * (steps_g + steps_l)
@@ -992,7 +992,7 @@ def main():
                       "lds": lds_instr * LDS_CYCLES_PER_WAVE_READ / 256 / CLOCK_HZ,
                       "matrix_pipe": mfma_instr * MFMA_CYCLES / N_SIMDS / CLOCK_HZ}
             bound = max(floors, key=floors.get)
-            rows_walked = 32 * (walk["global_steps"] + walk["lds_steps"])
+            rows_walked = 4 * (steps_g + steps_l)
             units = {
                 "texture_path": {"wave_instructions_per_launch": l1_instr, "cycles_each": L1_CYCLES_PER_WAVE_LOAD,
                                  "floor_us": floors["texture_path"] * 1e6, "busy_frac": floors["texture_path"] / ft_launch_s},

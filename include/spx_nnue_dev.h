@@ -80,9 +80,11 @@ int spx_debug_datagen_rules(uint32_t* counters, int32_t norm_score, uint32_t ply
                             const spx_packed_pos* pos, int* insufficient);
 
 /* What the last packed walk of scratch set `slot` (-1 = the context's own, 0 .. 2 = a lane's) holds, 8 words: [0] groups of 8
- * perspectives, [1] stages, [2] global steps and [3] LDS steps as the gather walks them PER COLUMN SLICE (a step = 4 wave loads /
- * LDS reads + 4 MFMAs; sections walk in pairs of steps), [4] rows fetched through the texture path (high-byte planes + cold threat /
- * pawn-pair rows), [5] rows read from LDS (piece-square + hot rows). bench.py derives the gather's instruction counts from it. */
+ * perspectives, [1] stages, [2] steps of the cold sections and [3] of the LDS sections as the gather walks them PER COLUMN SLICE (a
+ * step = 4 wave loads / LDS reads + 4 MFMAs; sections walk in pairs of steps), [4] cold threat / pawn-pair rows fetched through the
+ * texture path, [5] rows read from LDS (piece-square + hot rows); the high-byte planes of wide piece-square rows are walked per slice
+ * - an XCD drops the planes that are all zero in its slice -: [6] their steps as walked, SUMMED over the 8 slices, [7] plane slices
+ * (128 B each) fetched, summed over the 8 slices. bench.py derives the gather's instruction counts from it. */
 int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out);
 
 /* The row lists the column-sliced pipeline's extraction pass wrote for the LAST batch of scratch set `slot`, decoded back to the

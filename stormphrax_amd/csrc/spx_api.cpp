@@ -80,6 +80,7 @@ struct spx_ctx {
     uint8_t* dHotS = nullptr;        // [8][hotRows][128 B]
     uint32_t* dHotIds = nullptr;     // [kFtxHotRowsMax]
     uint32_t* dHotCounts = nullptr;  // [kThreatRows + 16] the calibration's histogram (+ statistics)
+    uint8_t* dHiMask = nullptr;      // [kPsqRows] slices in which a piece-square row's high-byte plane is not all zero (spx_ftx.h)
     std::vector<uint32_t> hotIds;    // host copy of the set, in slot order
     uint32_t hotRowsWanted = kFtxHotRowsDefault;  // option ftx_hot_rows
     uint32_t hotRows = 0, coldShift = 1;
@@ -772,7 +773,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     }
     ctx->ftx.release();
     for (void* q : {static_cast<void*>(ctx->dRowS), static_cast<void*>(ctx->dHotHash), static_cast<void*>(ctx->dHotS),
-                    static_cast<void*>(ctx->dHotIds), static_cast<void*>(ctx->dHotCounts)}) {
+                    static_cast<void*>(ctx->dHotIds), static_cast<void*>(ctx->dHotCounts), static_cast<void*>(ctx->dHiMask)}) {
         if (q) (void)hipFree(q);
     }
     for (hipEvent_t e : ctx->profEvents) (void)hipEventDestroy(e);
@@ -967,11 +968,13 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
         if (hipMalloc(reinterpret_cast<void**>(&ctx->dHotHash), kFtxHotHashWords * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&ctx->dHotS), size_t(8) * kFtxHotRowsMax * 128) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&ctx->dHotIds), kFtxHotRowsMax * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&ctx->dHotCounts), (kThreatRows + 16) * sizeof(uint32_t)) != hipSuccess) {
+            hipMalloc(reinterpret_cast<void**>(&ctx->dHotCounts), (kThreatRows + 16) * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->dHiMask), kPsqRows) != hipSuccess) {
             return fail();
         }
         if (hipMemsetAsync(ctx->dHotHash, 0xFF, kFtxHotHashWords * sizeof(uint32_t), s) != hipSuccess) return fail();
         if (launchFtxBuildTable(ctx->dThrW, ctx->dPsqW, ctx->dLut, ctx->dRowS, s) != hipSuccess) return fail();
+        if (launchFtxBuildHiMask(ctx->dRowS, ctx->dHiMask, s) != hipSuccess) return fail();
         // (other streams may use the tables next: the lanes' streams do not wait for this one)
         if (hipStreamSynchronize(s) != hipSuccess) return fail();
         if (!ctx->hotIds.empty() && installHotRows(ctx, ctx->hotIds, s) != SPX_OK) return fail();  // (a set given before the first batch)
@@ -1051,6 +1054,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.plan = scratch.plan;
             xp.groupHead = scratch.groupHead;
             xp.stages = scratch.stages;
+            xp.hiMask = ctx->dHiMask;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
             if (!ctx->hotCalibrated) {  // the first big batch of this context chooses the hot set (synchronises the stream once)
                 if ((rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;
@@ -2345,8 +2349,11 @@ int spx_debug_ftx_block_times(spx_ctx* ctx, int slot, uint64_t* out) {
     return SPX_OK;
 }
 
-// what the LAST packed walk of that scratch set holds (summed over the group heads, spx_ftx.h): out[0] groups, [1] stages, [2] global steps and [3] LDS
-// steps as walked per column slice, [4] rows fetched through the texture path (high planes + cold rows), [5] rows read from LDS
+// what the LAST packed walk of that scratch set holds (summed over the group heads, spx_ftx.h): out[0] groups, [1] stages, [2] steps of
+// the COLD sections and [3] of the LDS sections as walked per column slice, [4] cold rows fetched through the texture path, [5] rows read
+// from LDS; the high-byte planes differ per slice - an XCD drops the planes that are all zero in its slice (spx_ftx_gather_kernel) -,
+// so they are recounted here from the groups' first stages: [6] steps of the high-byte sections as walked, summed over the 8 slices,
+// [7] plane slices (128 B each) fetched, summed over the 8 slices
 int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
     if (!ctx || !out || slot < -1 || slot > 2) {
         setError("spx_debug_ftx_walk: invalid argument");
@@ -2363,11 +2370,34 @@ int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
     SPX_HIP(hipMemcpy(&nGroups, x.plan + 33, sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint32_t> heads(size_t(nGroups) * kFtxGroupHeadWords);
     SPX_HIP(hipMemcpy(heads.data(), x.groupHead, heads.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    uint64_t sums[6] = {nGroups, 0, 0, 0, 0, 0};  // (the pack kernel leaves every group's own figures in its head's spare words)
+    uint64_t sums[8] = {nGroups, 0, 0, 0, 0, 0, 0, 0};  // (the pack kernel leaves every group's own figures in its head's spare words)
+    bool anyHi = false;
     for (uint32_t g = 0; g < nGroups; ++g) {
         for (int k = 1; k < 6; ++k) sums[k] += heads[size_t(g) * kFtxGroupHeadWords + 8 + k];
+        anyHi = anyHi || (heads[size_t(g) * kFtxGroupHeadWords] & 0xFFu);
     }
-    for (int k = 0; k < 8; ++k) out[k] = k < 6 ? uint32_t(std::min<uint64_t>(sums[k], 0xFFFFFFFFull)) : 0u;
+    if (anyHi) {
+        // the high-byte stage of every group (its first: <= 32 planes per perspective are one stage), word 32 k + 4 (2 kb + u) + pr =
+        // plane kb of step k of perspective 2 pr + u, bits 24 + x: the plane is not all zero in slice x
+        std::vector<uint32_t> stage(size_t(nGroups) * 256);
+        SPX_HIP(hipMemcpy2D(stage.data(), 1024, x.stages, size_t(kFtxMaxStages) * 1024, 1024, nGroups, hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < nGroups; ++g) {
+            if (!(heads[size_t(g) * kFtxGroupHeadWords] & 0xFFu)) continue;
+            const uint32_t* w = stage.data() + size_t(g) * 256;
+            for (uint32_t xs = 0; xs < 8; ++xs) {
+                uint32_t kept[8] = {0, 0, 0, 0, 0, 0, 0, 0}, longest = 0;
+                for (uint32_t i = 0; i < 256; ++i) {
+                    if ((w[i] >> (24 + xs)) & 1u) ++kept[2 * (i & 3u) + ((i >> 2) & 1u)];
+                }
+                for (uint32_t q = 0; q < 8; ++q) {
+                    longest = std::max(longest, kept[q]);
+                    sums[7] += kept[q];
+                }
+                sums[6] += (((longest + 3) / 4) + 1) & ~1u;  // (steps are walked in pairs)
+            }
+        }
+    }
+    for (int k = 0; k < 8; ++k) out[k] = uint32_t(std::min<uint64_t>(sums[k], 0xFFFFFFFFull));
     return SPX_OK;
 }
 

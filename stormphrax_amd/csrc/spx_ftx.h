@@ -21,6 +21,10 @@ namespace spx {
 // rows: [0, 64368) threat / pawn-pair rows (i8 as in the net file); [64368, +11264) piece-square rows, LOW-byte plane
 // l = int8(w) (the row itself when it fits i8); [75632, +11264) piece-square rows, HIGH-byte plane h = int8((w - l) >> 8)
 // (all zero for a row that fits i8); 86896: an all-zero row (list padding).
+// hiMask[piece-square row] (round 6): bit x = the row's high-byte plane has a non-zero byte in slice x. A heavy-tailed net's wide rows
+// mostly have a handful of weights outside i8 (the `realistic` preset: 4 282 of its 6 553 wide rows have <= 8), so a row's plane is
+// all zero in most slices: the gather of XCD x drops those rows from its walk (spx_ftx_gather_kernel: the high-byte stage is
+// compacted per slice; 108 -> 92 row loads per position on that net, tools/sim_hi_slices.py).
 constexpr uint32_t kFtxPsqLoBase = kThreatRows;
 constexpr uint32_t kFtxPsqHiBase = kThreatRows + kPsqRows;
 constexpr uint32_t kFtxZeroRow = kThreatRows + 2 * kPsqRows;
@@ -68,9 +72,11 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 // longest of the 8 lists there (in quartets of rows = steps), cut into STAGES of 8 steps. groupHead[G] = 16 words: {hiQ | ldsQ << 8
 // | coldQ << 16, output slots of the 8 perspectives (~0 = hole), then what the group costs (spx_debug_ftx_walk sums these): stages, global
 // steps and LDS steps as walked (pairs: odd sections walk one step of zero rows), rows through the texture path (high planes +
-// cold), rows from LDS, -}; stages[G][q] = 256 words, stage q in the order of the
+// cold), rows from LDS, -}; words 10 / 12 count the COLD section only, 14 / 15 the high-byte section as packed (steps, rows): what an XCD
+// walks of it after dropping the planes that are zero in its slice is smaller (spx_debug_ftx_walk recounts it on the host). stages[G][q] = 256 words, stage q in the order of the
 // sections: word 32 k + 4 e + pr = the row (byte offset, as in the lists) that row kb of step k adds to perspective 2 pr + u,
-// e = 2 kb + u; rows past a list's end are the section's all-zero row. Every XCD's gather walks every group: packing once what
+// e = 2 kb + u; rows past a list's end are the section's all-zero row; a high-byte plane's entry carries the row's hiMask in bits
+// 24-31 (the all-zero row: 0). Every XCD's gather walks every group: packing once what
 // round 4 made each of the eight find out for itself (section boundaries per lane, list gathers, padding) took 40 % of the
 // gather's instructions off it (profiles/r05_gather_anatomy.txt).
 constexpr uint32_t kFtxMaxStages = 1 + 9 + 8;  // <= 32 high planes, <= 32 + 256 LDS rows, <= 256 cold rows
@@ -114,6 +120,7 @@ struct FtxParams {
     const uint8_t* hotS;     // [8 slices][hotRows][128 B] the hot rows' slices, in slot order
     uint32_t hotRows;        // rows of the hot set (0: none - every row is fetched through the texture path)
     uint32_t coldShift;      // sort key: global quartets >> this (1 for nets / sets with long cold sections)
+    const uint8_t* hiMask;   // [kPsqRows] slices in which a piece-square row's high-byte plane is not all zero
 };
 
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }
@@ -121,6 +128,7 @@ inline size_t ftxGroups(size_t n) { return (2 * n + 128) / 8; }
 inline size_t ftxStageBytes(size_t n) { return ftxGroups(n) * kFtxMaxStages * 1024; }
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream);
+hipError_t launchFtxBuildHiMask(const uint8_t* rowS, uint8_t* hiMask, hipStream_t stream);  // from the finished table
 // the hot set: counts[row] += fetches of threat / pawn-pair row `row` in the lists of p (extracted with hotRows = 0), stats[0] +=
 // high-byte planes fetched; then the slices of a chosen set in slot order (its hash is built on the host: spx_api.cpp)
 hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream);

@@ -106,6 +106,21 @@ __global__ void spx_ftx_build_table_kernel(const uint8_t* thrU8, const int16_t* 
     *reinterpret_cast<u32x4*>(rowS + (size_t(x) * kFtxRows + r) * 128 + 16 * t) = *reinterpret_cast<const u32x4*>(out);
 }
 
+// hiMask[row] bit x = slice x of the row's high-byte plane holds a non-zero byte (spx_ftx.h). One thread per (row, slice).
+__global__ void spx_ftx_build_himask_kernel(const uint8_t* rowS, uint32_t* hiMaskWords) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kPsqRows * 8u) return;
+    const uint32_t row = idx >> 3, x = idx & 7u;
+    const u32x4* src = reinterpret_cast<const u32x4*>(rowS + (size_t(x) * kFtxRows + kFtxPsqHiBase + row) * 128);
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) {
+        const u32x4 v = src[t];
+        any |= v[0] | v[1] | v[2] | v[3];
+    }
+    if (any) atomicOr(&hiMaskWords[row >> 2], 1u << (8 * (row & 3u) + x));  // (byte `row` of the table, zeroed by the caller)
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Extraction: one wave per position, lane = square. Everything that does not depend on the perspective is done once (VERDICT
 // r3 item 5): the record decode, the attack sets, and the ENUMERATION of the feature candidates - every (attacker, victim)
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
     uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
     {   // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
         // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
-        uint32_t rowsG = ks == 0 ? cHi + cCold : 0u, rowsL = ks == 0 ? cLds : 0u;
+        uint32_t rowsG = ks == 0 ? cCold | (cHi << 16) : 0u, rowsL = ks == 0 ? cLds : 0u;  // (cold | high planes << 16: <= 2 048 | 256 per group)
 #pragma unroll
         for (int dlt = 8; dlt < 64; dlt <<= 1) {
             rowsG += uint32_t(__shfl_xor(int(rowsG), dlt, 64));
@@ -526,10 +541,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
         }
         if (lane == 0) {
             gh[9] = Q;
-            gh[10] = ((hiQ + 1) & ~1u) + ((coldQ + 1) & ~1u);
+            gh[10] = (coldQ + 1) & ~1u;
             gh[11] = (ldsQ + 1) & ~1u;
-            gh[12] = rowsG;
+            gh[12] = rowsG & 0xFFFFu;
             gh[13] = rowsL;
+            gh[14] = (hiQ + 1) & ~1u;  // as packed: an XCD walks what is left after dropping the planes that are zero in its slice
+            gh[15] = rowsG >> 16;
         }
     }
     // stage q: which section, where this lane's four rows sit in its list, how many of them there are
@@ -554,12 +571,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
         if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
     }
     for (uint32_t q = 0; q < Q; ++q) {
-        const u32x4 v = next;
+        u32x4 v = next;
         const uint32_t leftNow = left, zeroNow = zero;
         if (q + 1 < Q) {
             place(q + 1, at, left, zero);
             next = u32x4{0, 0, 0, 0};
             if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
+        }
+        if (q < H) {  // a high-byte plane's entry says in which slices the plane is not all zero (bits 24-31; the entry itself < 2^24)
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (leftNow > i) v[i] |= uint32_t(p.hiMask[(v[i] >> 7) - kFtxPsqHiBase]) << 24;
+            }
         }
         uint32_t* st = &sStage[wave][fillAt];
         st[0] = leftNow > 0 ? v[0] : zeroNow;
@@ -708,7 +731,28 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             if (haveNext) headNext = headOfGroup(nextG);
             i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
             for (uint32_t q = 0; q < Q; ++q) {
-                if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
+                uint32_t hiSteps = 0;
+                if (q < H) {
+                    // A stage of high-byte planes, compacted for THIS slice: a plane that is all zero in slice `xcd` (bit 24 + xcd of its
+                    // entry, spx_ftx_pack_kernel) is dropped, the perspective's remaining planes move up. Lane 8 k + 2 kb + u holds the
+                    // entries of step k, row kb of perspectives 2 pr + u (pr = 0 .. 3): the j-th kept entry of a perspective goes to
+                    // step j >> 2, row j & 3 - word 8 j + 4 u + pr. (Most wide rows of a heavy-tailed net have a handful of weights
+                    // outside i8: their plane is zero in most slices - 108 -> 92 row loads per position on the `realistic` preset.)
+                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = u32x4{kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u};
+                    uint32_t longest = 0;
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const bool keep = (ents[pr] >> (24u + xcd)) & 1u;
+                        const uint64_t kept = __ballot(keep);
+                        const uint64_t even = kept & 0x5555555555555555ull, odd = kept & 0xAAAAAAAAAAAAAAAAull;
+                        const uint32_t j = prefixCount((lane & 1u) ? odd : even);
+                        if (keep) stage[8 * j + 4 * (lane & 1u) + pr] = ents[pr] & 0xFFFFFFu;
+                        longest = max(longest, uint32_t(max(popc64(even), popc64(odd))));
+                    }
+                    hiSteps = (longest + 3) >> 2;
+                } else if (!(SPX_FTX_SKIP & 32)) {
+                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
+                }
                 __builtin_amdgcn_wave_barrier();
                 // what travels while this stage is walked: the next stage - at the last one: the next group's first
                 if (q + 1 < Q) {
@@ -720,12 +764,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                 const uint32_t steps = (sec == 0 ? hiQ : (sec == 1 ? ldsQ : coldQ)) - 8 * s;
                 if (sec == 1) {
                     walkStage<true>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
-                } else {
+                } else if (sec == 2) {
                     walkStage<false>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
-                }
-                if (sec == 0 && s + 1 == H) {  // the high-byte planes' sums count 256-fold
+                } else {
+                    if (hiSteps) walkStage<false>(hiSteps, stage, sSlab, slice, e, laneOff, sel, d);
+                    if (s + 1 == H) {  // the high-byte planes' sums count 256-fold
 #pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
+                        for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
+                    }
                 }
             }
             if (Q == 0 && haveNext) ents = stageOfGroup(nextG, 0);  // (a group of records without a single piece: malformed input)
@@ -800,6 +846,13 @@ hipError_t launchFtxBuildHot(const uint8_t* rowS, const uint32_t* hotIds, uint32
 
 hipError_t launchFtxBuildTable(const uint8_t* thrU8, const int16_t* psqW, const uint32_t* lut, uint8_t* rowS, hipStream_t stream) {
     hipLaunchKernelGGL(spx_ftx_build_table_kernel, dim3((kFtxRows * 64u + 255) / 256), dim3(256), 0, stream, thrU8, psqW, lut, rowS);
+    return hipGetLastError();
+}
+
+hipError_t launchFtxBuildHiMask(const uint8_t* rowS, uint8_t* hiMask, hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(hiMask, 0, kPsqRows, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spx_ftx_build_himask_kernel, dim3((kPsqRows * 8u + 255) / 256), dim3(256), 0, stream, rowS, reinterpret_cast<uint32_t*>(hiMask));
     return hipGetLastError();
 }
 

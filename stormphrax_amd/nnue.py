@@ -134,11 +134,15 @@ class NnueState:
         check(_lib.load().spx_ctx_set_option(self._h, name.encode(), int(value)))
 
     def ftx_walk(self, slot=-1):
-        """spx_debug_ftx_walk: what the last packed walk of a scratch set holds -> dict (steps are per column slice)."""
+        """spx_debug_ftx_walk: what the last packed walk of a scratch set holds -> dict. `global_steps` / `lds_steps` are per column
+        slice (the high-byte planes' steps differ per slice - an XCD drops the planes that are all zero in its slice -: their sum
+        over the 8 slices / 8), `global_rows` / `lds_rows` in rows of 1 KiB (8 slices of 128 B)."""
         out = np.zeros(8, dtype=np.uint32)
         check(_lib.load().spx_debug_ftx_walk(self._h, slot, out.ctypes.data))
-        keys = ("groups", "stages", "global_steps", "lds_steps", "global_rows", "lds_rows")
-        return {k: int(v) for k, v in zip(keys, out)}
+        groups, stages, cold_steps, lds_steps, cold_rows, lds_rows, hi_steps_all, hi_slices = (int(v) for v in out)
+        return {"groups": groups, "stages": stages, "global_steps": cold_steps + hi_steps_all / 8.0, "lds_steps": lds_steps,
+                "global_rows": cold_rows + hi_slices / 8.0, "lds_rows": lds_rows, "cold_steps": cold_steps, "cold_rows": cold_rows,
+                "high_plane_steps_all_slices": hi_steps_all, "high_plane_slices_fetched": hi_slices}
 
     def ftx_lists(self, n, slot=-1):
         """spx_debug_ftx_lists: the extraction pass's row lists of the last batch (n positions) in the net's row numbering ->
