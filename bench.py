@@ -950,6 +950,13 @@ def main():
             # (counted by the pack kernel over what the gather really walks: cold threat / pawn-pair rows + the high-byte planes of every
             # piece-square row that does not fit i8 - near-compact rows included, ADVICE r4 - against piece-square + hot rows from LDS)
             walk = state.ftx_walk(0 if pipelined else -1)
+            # (the walk is the LAST pass's, the HIP events bracket all passes of a call (65 536 positions each, the last one
+            # the rest): everything below is per CALL - the last pass's counts scaled by positions of the call / positions of that pass,
+            # counts being proportional to positions)
+            passes = max(1, -(-args.batch // 65536))
+            call_scale = args.batch / (args.batch - 65536 * (passes - 1))
+            if call_scale != 1.0:
+                walk = {k: v * call_scale for k, v in walk.items()}
             requested = 1024 * walk["global_rows"] + 36 * args.batch
             lds_served = 1024 * walk["lds_rows"]
         l2_gbs = requested / ft_avg_s / 1e9
@@ -982,8 +989,7 @@ def main():
             # EXACT: the pack kernel sums what it lays out for the gather to walk (spx_debug_ftx_walk; steps per column slice x 8).
             # (a batch above one pass of the pipeline - 65 536 positions - is walked in passes: the pack kernel's counts are the last
             # pass's, the HIP events bracket all of a call's passes)
-            passes = max(1, -(-args.batch // 65536))
-            ft_launch_s = ft_avg_s / passes
+            ft_launch_s = ft_avg_s  # (the events' interval: all passes of a call; the walk above is scaled to the call)
             steps_g, steps_l = 8 * walk["cold_steps"] + walk["high_plane_steps_all_slices"], 8 * walk["lds_steps"]
             l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
             lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes
@@ -1005,10 +1011,16 @@ def main():
             peaks = {"texture_path": L1_PEAK_GBS * 16.0 / L1_CYCLES_PER_WAVE_LOAD, "lds": LDS_PEAK_GBS * 8.0 / LDS_CYCLES_PER_WAVE_READ}
             instr = {"texture_path": l1_instr, "lds": lds_instr}
             mem_bound = bound if bound in peaks else "texture_path"
+            hw_peaks = {"texture_path": L1_PEAK_GBS, "lds": LDS_PEAK_GBS}
+            achieved = instr[mem_bound] * 1024 / ft_launch_s / 1e9
             roofline.update({
-                "bound": {"texture_path": "l1", "lds": "lds"}[mem_bound], "achieved": instr[mem_bound] * 1024 / ft_launch_s / 1e9,
-                "peak": peaks[mem_bound], "unit": "GB/s",
-                "frac": floors[mem_bound] / ft_launch_s, "binding_unit": bound, "units": units,
+                #  peak = the HARDWARE figure of the binding unit (64 B / clock / CU through the texture path, 128 B / clock / CU
+                # out of LDS); the ceiling this repo measured for the instruction forms the gather uses (17.5 / 8.8 cycles per 1 KiB
+                # wave instruction instead of 16 / 8) is stated beside it
+                "bound": {"texture_path": "l1", "lds": "lds"}[mem_bound], "achieved": achieved,
+                "peak": hw_peaks[mem_bound], "unit": "GB/s", "frac": achieved / hw_peaks[mem_bound],
+                "measured_ceiling": peaks[mem_bound], "frac_of_measured_ceiling": floors[mem_bound] / ft_launch_s,
+                "binding_unit": bound, "units": units,
                 "passes_per_call": passes, "walk": dict(walk, rows_useful=walk["global_rows"] + walk["lds_rows"], rows_walked_per_slice=rows_walked,
                              padding_efficiency=(walk["global_rows"] + walk["lds_rows"]) / max(rows_walked, 1),
                              hot_rows=int(state.hot_rows().size),
@@ -1020,8 +1032,10 @@ def main():
                          "its mask or width, tools/probes/tcp_mask_probe.hip; cold rows and high-byte planes 4 per step, one stage load per 8 "
                          "steps, a head load and an output store per group). achieved = 1 KiB x that unit's wave instructions per launch "
                          "(counted by the pack kernel, all 8 column slices) / the gather's HIP-event duration IN THE TIMED REGION (pipelined "
-                         "steps: beside two other batches' preparation), peak = 256 CUs x 1 KiB / cycles per instruction x 2.4 GHz, frac = "
-                         "the unit's floor / the duration. units = all three incl. the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8). "
+                         "steps: beside two other batches' preparation), peak = the unit's HARDWARE rate (256 CUs x 64 B / clock through the "
+                         "texture path, x 128 B / clock out of LDS, at 2.4 GHz), frac = achieved / peak; measured_ceiling = 256 CUs x 1 KiB / the "
+                         "cycles one such wave instruction was measured to hold the unit x 2.4 GHz, frac_of_measured_ceiling = the unit's floor / "
+                         "the duration. units = all three incl. the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8). "
                          "l2 = round 4's figure (bytes the row loads ask the L2s for / aggregate L2 bandwidth): the kernel got faster by "
                          "asking for LESS; hbm = SURVEY 8(d)'s algorithmic bytes and the measured fabric traffic. "
                          "secondary.full_refresh_paths has the kernel alone (stream-ordered)"),

@@ -90,12 +90,19 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
  * pass writes every perspective's row lists, a counting sort groups them by king bucket and length, and the gather - XCD x
  * reads slice x of every row, the bucket's piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.7 x
  * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's
- * tables and scratch (89 MB + 2.6 KB per position of a 65 536-position pass, four passes' worth for pipelined calls) are
- * allocated on the first such batch; if that fails the one-kernel path serves it.
+ * tables (89 MB per context) and scratch - 9.3 KB per position of a pass of min(max_batch, 65 536) positions: 4.6 KB of row lists
+ * (2 x 576 words) and 4.6 KB of packed walks (the worst case of 18 one-KiB stages per group of 8 perspectives), i.e. ~610 MB per
+ * scratch set at full size; stream-ordered calls use the context's set, pipelined calls one per lane (option eval_lanes, default 3):
+ * ~2.4 GB in all - are allocated on the first such batch; if that fails the one-kernel path serves it.
  * SPX_CTX_ONE_KERNEL_FT (or option ftx = 0): never take the pipeline. SPX_CTX_SLICED_FT (or ftx = 1): take it (the default; kept
  * from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
 enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2, SPX_CTX_ONE_KERNEL_FT = 4 };
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out);
+/* As spx_ctx_create_ex, with this context's own options: `options` = "name=value,name=value" (NULL / "" = none), the names of
+ * spx_ctx_set_option below plus the three that shape what a context allocates (scratch_cap, compact_rows, near_rows). Applied after
+ * SPX_OPTIONS from the environment (a later item overrides an earlier one). The thread-safe way to give creation-time options:
+ * nothing process-global is touched. */
+int spx_ctx_create_opts(const spx_net* net, int device, size_t max_batch, uint32_t flags, const char* options, spx_ctx** out);
 /* Does a full refresh of n positions take the column-sliced pipeline on this context as things stand (enabled, n at or above the
  * threshold, no failed allocation of its tables so far)? Bit 0: a stream-ordered call (spx_eval_full[_device]) does; bit 1: a
  * pipelined call (spx_eval_full_device_async) does - its threshold is lower. 0 = the one-kernel path either way. */
@@ -103,7 +110,10 @@ int spx_ctx_sliced_ft(const spx_ctx* ctx, size_t n);
 /* The pipeline's gather keeps the context's most popular threat / pawn-pair rows (option ftx_hot_rows, default 256 of 64 368) in
  * LDS beside the king bucket's piece-square slab: an LDS read costs half a trip through the CU's texture path, and on random legal
  * positions 256 rows serve 35 % of those fetches. The set is chosen from DATA: by default from the first batch that takes the
- * pipeline (one extra extraction pass + a histogram + a stream synchronisation inside that call), or from the device-resident batch
+ * pipeline (one extra extraction pass + a histogram inside that call, for which the HOST WAITS - also in
+ * spx_eval_full_device_async, once per context and after every change of ftx_hot_rows; a call on a stream that is being captured
+ * into a hipGraph never calibrates - it runs with the set as it is -, and option ftx_auto_calibrate = 0 switches the automatic
+ * choice off), or from the device-resident batch
  * handed to spx_ctx_calibrate (the first <= 65 536 positions of it; call it while no evaluation of this context is in flight - it
  * waits for the context's streams). Results never depend on the set (a row is added from wherever it lives); a self-play or data
  * rescoring host calibrates once on a sample of ITS positions. No reference counterpart: the reference has no cache to configure. */
@@ -115,6 +125,8 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  *   ftx 0|1                 big full refreshes through the column-sliced pipeline (as SPX_CTX_SLICED_FT / _ONE_KERNEL_FT)
  *   ftx_min N               smallest batch that takes it (default 16 384; 12 288 for pipelined calls)
  *   ftx_hot_rows N          threat / pawn-pair rows the gather keeps in LDS beside the piece-square slab (default 256, at most 384)
+ *   ftx_auto_calibrate 0|1  1 (default): the first big batch chooses that set (the host waits once inside that call); 0: only
+ *                           spx_ctx_calibrate / spx_ctx_set_hot_rows do - until then the set is empty
  *   eval_lanes 2|3          scratch sets spx_eval_full_device_async rotates its batches over (default 3: the preparation of two
  *                           batches runs beside a gather)
  *   tiny_batch_max N        batches up to N positions skip the sorts (default 8 192)
@@ -129,11 +141,10 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  *   replay_paths -1|0|1, replay_segment N         spx_acc_replay_tree: by heavy paths / by levels / its own choice; plies per path segment (default 8)
  *   selfplay_graph 0|1, selfplay_graph_plies N, selfplay_trace 0|1    spx_selfplay_run: plies captured into hipGraphs (default) or
  *                           launched one by one; plies per graph (0 = automatic; even, 2..16); a timing line on stderr at the end
- *   ftx_fail_after K        test hook: the K-th scratch set of the pipeline "does not fit" (default -1: never)
- *   ftx_fail_launch K       test hook: the K-th pass of the pipeline from now on "fails to launch" (default -1: never); either
- *                           way the batch and all later ones are served by the one-kernel path
- * SPX_OPTIONS only (they shape what a context allocates): scratch_cap N (below), compact_rows 0|1, near_rows 0|1 (A/B of the
- * lossless 1 KiB copies of piece-square rows that fit i8 / almost fit i8). */
+ * At creation only - spx_ctx_create_opts or SPX_OPTIONS - (they shape what a context allocates): scratch_cap N (below),
+ * compact_rows 0|1, near_rows 0|1 (A/B of the lossless 1 KiB copies of piece-square rows that fit i8 / almost fit i8).
+ * (The fault-injection hooks of the fall-back tests - ftx_fail_after, ftx_fail_launch - are unknown options here: they exist only
+ * behind spx_debug_enable_test_hooks of include/spx_nnue_dev.h, which this library does not export.) */
 int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value);
 /* Positions the context keeps intermediates for at once: min(max_batch, scratch_cap = 4 Mi by default). The
  * spx_eval_full* entry points accept up to max_batch positions per call and walk them in chunks of this size (an
@@ -168,7 +179,12 @@ int spx_group_eval_full(spx_group* group, const spx_packed_pos* positions, size_
  *   spx_eval_full        host buffers in/out, synchronous (H2D, kernels, D2H on the context's stream); any n
  *                        (processed in chunks of max_batch)
  *   spx_eval_full_device device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = the context's own
- *                        stream) without synchronising; n <= max_batch
+ *                        stream) without synchronising; n <= max_batch. Two exceptions to "without synchronising": the first
+ *                        batch that takes the column-sliced pipeline allocates its tables, and - unless ftx_auto_calibrate = 0 or
+ *                        a set was given - chooses the gather's hot rows, for which the host waits once (spx_ctx_calibrate).
+ *                        Under hipStreamBeginCapture: make one call of the same size outside the capture first (allocations);
+ *                        a captured call never calibrates; capture an EVEN number of calls per graph (the output-bucket sort
+ *                        alternates two histogram buffers, each call clearing the other one's - as spx_selfplay_run's graphs do).
  * ---------------------------------------------------------------------------------------------------------------- */
 int spx_eval_full(spx_ctx* ctx, const spx_packed_pos* positions, size_t n, int32_t* out);
 int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void* stream);
@@ -178,7 +194,8 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
  * batch run beside the feature-transformer kernel of the next (the FT kernels themselves are chained). The inputs must
  * be valid when the call is made and stay untouched, like d_out, until the batch is done: *done_event (a hipEvent_t,
  * owned by the context, valid until two more async calls) or spx_ctx_synchronize(ctx). Results are bit-identical to
- * spx_eval_full_device. Allocates the second scratch set on first use (~1.1 KB per position of max_batch, twice). */
+ * spx_eval_full_device. Allocates the lanes' scratch sets on first use (~1.1 KB per position of max_batch per lane, plus the
+ * column-sliced pipeline's 9.3 KB per position of a pass where it runs - see spx_ctx_create_ex). */
 int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event);
 /* waits for everything the context has enqueued on its own streams */
 int spx_ctx_synchronize(spx_ctx* ctx);
@@ -441,7 +458,7 @@ int spx_pos_legal_moves(const spx_packed_pos* pos, uint16_t* moves, spx_packed_p
  * game records and the seating of new games from a device-side opening pool, one materialising update for the moves
  * played; the two halves of the seats run on the context's two lanes, each half's per-ply launch chain captured once as a
  * hipGraph (two plies per graph launch, four on runs of >= 8 games per seat; option selfplay_graph=0 = direct
- * launches, SPX_SELFPLAY_GRAPH_PLIES = plies per graph), and the host reads ~100
+ * launches, option selfplay_graph_plies = plies per graph), and the host reads ~100
  * bytes of counters plus the finished games per ply. SPX_SELFPLAY_HOST_MOVEGEN selects the host chess core for moves, openings and bookkeeping (the
  * same rules; the validation path). Needs a context whose max_batch holds a ply's children of half the seats (48 * n_games
  * is always enough); reserves 2 * n_games + 1 arena slots (129 * n_games with host move generation, 9 * n_games + 1 with a search).

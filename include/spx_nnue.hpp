@@ -74,8 +74,9 @@ class NnueState {
 public:
     static constexpr uint32_t kMaxDepth = 256;  // the reference's accumulator stack holds 256 entries (nnue_state.h:104)
 
-    explicit NnueState(const Network& net, int device = 0, size_t maxBatch = 4096) {
-        check(spx_ctx_create(net.handle(), device, maxBatch, &ctx_));
+    // `options`: "name=value,..." tuning knobs of this context (spx_ctx_create_opts; nullptr = the defaults)
+    explicit NnueState(const Network& net, int device = 0, size_t maxBatch = 4096, const char* options = nullptr) {
+        check(spx_ctx_create_opts(net.handle(), device, maxBatch, 0u, options, &ctx_));
         try {
             check(spx_acc_reserve(ctx_, kMaxDepth + 1));  // one slot per stack entry + a spare for applyImmediately
         } catch (...) {

@@ -24,6 +24,12 @@ extern "C" {
 size_t spx_synth_net_bytes(void);
 int spx_synth_net(uint64_t seed, int preset, void* buf, size_t nbytes);
 
+/* Fault injection for the tests of the pipeline's fall-back paths: after spx_debug_enable_test_hooks(1) spx_ctx_set_option /
+ * spx_ctx_create_opts accept ftx_fail_after K (the K-th scratch set of the column-sliced pipeline "does not fit"; -1: never) and
+ * ftx_fail_launch K (the K-th pass of the pipeline from now on "fails to launch"; -1: never) - either way the batch and all later ones
+ * are served by the one-kernel path. libspx_nnue.so does not export this function: there the two names are unknown options. */
+int spx_debug_enable_test_hooks(int on);
+
 /* Device-side intermediates of the last spx_eval_full* call on this context, for tests and profiling:
  * the u8 feature-transformer activations [n][1024] (stm half first; multilayer.h:92-152 activateFt output). */
 int spx_debug_copy_ft(spx_ctx* ctx, size_t n, uint8_t* out);

@@ -87,6 +87,7 @@ SYMBOLS = {
     "spx_fnv1a64": (ctypes.c_uint64, [_P, ctypes.c_size_t]),
     "spx_ctx_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_P)]),
     "spx_ctx_create_ex": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
+    "spx_ctx_create_opts": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_char_p, ctypes.POINTER(_P)]),
     "spx_ctx_scratch_batch": (ctypes.c_size_t, [_P]),
     "spx_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "spx_group_create": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(_P)]),
@@ -139,6 +140,7 @@ SYMBOLS = {
     "spx_ctx_set_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "spx_ctx_get_hot_rows": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "spx_debug_copy_ft": (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
+    "spx_debug_enable_test_hooks": (ctypes.c_int, [ctypes.c_int]),
     "spx_debug_ftx_block_times": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_debug_ftx_plan": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "spx_debug_ftx_walk": (ctypes.c_int, [_P, ctypes.c_int, _P]),

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -85,6 +86,7 @@ struct spx_ctx {
     uint32_t hotRowsWanted = kFtxHotRowsDefault;  // option ftx_hot_rows
     uint32_t hotRows = 0, coldShift = 1;
     bool hotCalibrated = false;      // the set was chosen (or given: spx_ctx_set_hot_rows); false: the next big batch chooses it
+    bool hotAutoCalibrate = true;    // option ftx_auto_calibrate: 0 = only spx_ctx_calibrate / spx_ctx_set_hot_rows choose the set
     bool ftxEnabled = true;     // big full refreshes take the column-sliced pipeline (spx_ftx.hip); option ftx = 0 / SPX_CTX_ONE_KERNEL_FT: never
     size_t ftxMin = kFtxMinPositions;  // option ftx_min: smallest batch that takes the sliced pipeline
     int ftxFailAfter = -1, ftxScratchSets = 0;  // (option ftx_fail_after: simulated allocation failure)
@@ -467,10 +469,9 @@ int spx_device_count(int* count) {
 // ---- options: the tuning knobs of a context (what the reference keeps in tunable.h / its UCI options) ----
 // SPX_OPTIONS="name=value,name=value" applies to every context the process creates (the ONE environment variable this file
 // reads); spx_ctx_set_option changes a knob of one context between calls. Unknown names and malformed values are refused.
-static int parseOptionsEnv(std::vector<std::pair<std::string, long long>>& out) {
-    const char* env = std::getenv("SPX_OPTIONS");
-    if (!env) return SPX_OK;
-    std::string text(env);
+static int parseOptions(const char* text0, const char* source, std::vector<std::pair<std::string, long long>>& out) {
+    if (!text0) return SPX_OK;
+    std::string text(text0);
     size_t at = 0;
     while (at < text.size()) {
         size_t end = text.find(',', at);
@@ -482,11 +483,20 @@ static int parseOptionsEnv(std::vector<std::pair<std::string, long long>>& out) 
         char* tail = nullptr;
         const long long v = eq == std::string::npos ? 0 : std::strtoll(item.c_str() + eq + 1, &tail, 10);
         if (eq == std::string::npos || eq == 0 || eq + 1 == item.size() || (tail && *tail)) {
-            setError("SPX_OPTIONS: malformed item '" + item + "' (expected name=integer)");
+            setError(std::string(source) + ": malformed item '" + item + "' (expected name=integer)");
             return SPX_ERR_INVALID_ARG;
         }
         out.emplace_back(item.substr(0, eq), v);
     }
+    return SPX_OK;
+}
+
+// Fault-injection hooks (options ftx_fail_after / ftx_fail_launch) exist for the tests of the fall-back paths. They are honoured only
+// after spx_debug_enable_test_hooks(1) - an entry point of include/spx_nnue_dev.h, which libspx_nnue.so does not export:
+// in the product library the two names are unknown options.
+static std::atomic<bool> gTestHooks{false};
+int spx_debug_enable_test_hooks(int on) {
+    gTestHooks.store(on != 0);
     return SPX_OK;
 }
 
@@ -526,6 +536,10 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         ctx->hotCalibrated = false;
         return SPX_OK;
     }
+    if (key == "ftx_auto_calibrate") {  // 0: the library never chooses the hot set by itself (no blocking first call: ADVICE r5)
+        ctx->hotAutoCalibrate = value != 0;
+        return SPX_OK;
+    }
     if (key == "eval_lanes") {  // scratch sets spx_eval_full_device_async rotates its batches over (the preparation of up to N - 1 batches beside a gather)
         if (value < 2 || value > 3) {
             setError("option eval_lanes must be 2 or 3");
@@ -536,6 +550,10 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         ctx->evalLanes = unsigned(value);
         ctx->laneNext = 0;
         return SPX_OK;
+    }
+    if ((key == "ftx_fail_after" || key == "ftx_fail_launch") && !gTestHooks.load()) {
+        setError("unknown option '" + key + "'");
+        return SPX_ERR_INVALID_ARG;
     }
     if (key == "ftx_fail_after") {  // test hook: the k-th scratch set of the pipeline "does not fit" (-1: never)
         ctx->ftxFailAfter = int(value);
@@ -581,7 +599,7 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         return SPX_OK;
     }
     if (key == "scratch_cap" || key == "compact_rows" || key == "near_rows") {
-        setError("option " + key + " shapes what a context allocates: set it through SPX_OPTIONS before the context is created");
+        setError("option " + key + " shapes what a context allocates: give it to spx_ctx_create_opts (or through SPX_OPTIONS) when the context is created");
         return SPX_ERR_INVALID_ARG;
     }
     setError("unknown option '" + key + "'");
@@ -599,6 +617,10 @@ struct CtxDeleter {  // a context that fails half-way through its creation relea
 }  // namespace
 
 int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t flags, spx_ctx** out) {
+    return spx_ctx_create_opts(net, device, max_batch, flags, nullptr, out);
+}
+
+int spx_ctx_create_opts(const spx_net* net, int device, size_t max_batch, uint32_t flags, const char* options, spx_ctx** out) {
     if (!net || !out || max_batch == 0 || max_batch > (1ull << 40) || (flags & ~uint32_t(SPX_CTX_WIDE_PSQ_ROWS | SPX_CTX_SLICED_FT | SPX_CTX_ONE_KERNEL_FT))) {
         setError("spx_ctx_create: invalid argument");
         return SPX_ERR_INVALID_ARG;
@@ -615,12 +637,14 @@ int spx_ctx_create_ex(const spx_net* net, int device, size_t max_batch, uint32_t
     // Intermediates (1 KiB of activations + sort scratch per position) are kept for at most scratch_cap positions
     // (default 4 Mi): a context created for an HBM-filling batch (BASELINE config 5: 36 bytes per resident position -
     // record in, score out) walks it in chunks of that size instead of reserving ~1.1 KB of scratch per position
+    // SPX_OPTIONS (every context of the process) first, then the caller's own string: a later item overrides an earlier one
     std::vector<std::pair<std::string, long long>> envOptions;
-    int rc = parseOptionsEnv(envOptions);
+    int rc = parseOptions(std::getenv("SPX_OPTIONS"), "SPX_OPTIONS", envOptions);
     if (rc != SPX_OK) return rc;
+    if ((rc = parseOptions(options, "spx_ctx_create_opts", envOptions)) != SPX_OK) return rc;
     size_t scratchCap = size_t(1) << 22;
     bool optCompactRows = true, optNearRows = true;
-    for (const auto& [name, v] : envOptions) {  // the options that shape what a context allocates: SPX_OPTIONS only
+    for (const auto& [name, v] : envOptions) {  // the options that shape what a context allocates: at creation only
         if (name == "scratch_cap") {
             // launch parameters are 32-bit (2 * n perspective ids, n * 1024 activation offsets are 64-bit): positions per chunk
             // stay at or below 2^30; a non-positive value is refused rather than turned into a huge size_t
@@ -908,12 +932,15 @@ static int installHotRows(spx_ctx* ctx, const std::vector<uint32_t>& ids, hipStr
 // Chooses the set from the batch `xp` describes: its lists extracted with an EMPTY set, a histogram of their threat / pawn-pair
 // rows, the most popular hotRowsWanted of them (ties: the lower row id - the choice is deterministic for a batch).
 static int calibrateHotRows(spx_ctx* ctx, FtxParams xp, hipStream_t s) {
-    ctx->hotCalibrated = true;
+    ctx->hotCalibrated = false;  // (true once the set is installed: a failure on the way leaves the empty set and the next batch retries)
     ctx->hotRows = 0;
     ctx->coldShift = 1;
     ctx->hotIds.clear();
     const uint32_t wanted = std::min(ctx->hotRowsWanted, kFtxHotRowsMax);
-    if (!wanted || xp.nPositions == 0) return SPX_OK;
+    if (!wanted || xp.nPositions == 0) {
+        ctx->hotCalibrated = true;
+        return SPX_OK;
+    }
     xp.hotHash = ctx->dHotHash;
     xp.hotHashMul = ctx->hotHashMul;
     xp.hotS = ctx->dHotS;
@@ -946,6 +973,7 @@ static int calibrateHotRows(spx_ctx* ctx, FtxParams xp, hipStream_t s) {
     const double perPersp = 2.0 * xp.nPositions;
     const double globalQ = double(total - covered) / perPersp / 4.0 + double(counts[kThreatRows]) / perPersp / 4.0 + 1.0;
     ctx->coldShift = globalQ > 9.0 ? 1u : 0u;
+    ctx->hotCalibrated = true;
     return SPX_OK;
 }
 
@@ -1056,8 +1084,15 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.stages = scratch.stages;
             xp.hiMask = ctx->dHiMask;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
-            if (!ctx->hotCalibrated) {  // the first big batch of this context chooses the hot set (synchronises the stream once)
-                if ((rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;
+            if (!ctx->hotCalibrated && ctx->hotAutoCalibrate) {
+                // the first big batch of this context chooses the hot set: one extra extraction + a histogram, and the host WAITS for
+                // them (and for the context's other streams) inside this call. A stream that is being captured into a hipGraph must
+                // not be synchronised: such a call runs with the set as it is - empty unless one was given - and the
+                // first call outside a capture calibrates; option ftx_auto_calibrate = 0 leaves the choice to spx_ctx_calibrate /
+                // spx_ctx_set_hot_rows altogether
+                hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(s, &capture) != hipSuccess) (void)hipGetLastError();
+                if (capture == hipStreamCaptureStatusNone && (rc = calibrateHotRows(ctx, xp, s)) != SPX_OK) return rc;
             }
             xp.hotHash = ctx->dHotHash;
             xp.hotHashMul = ctx->hotHashMul;

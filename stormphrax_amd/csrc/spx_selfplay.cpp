@@ -1280,7 +1280,7 @@ int runDeviceGames(spx_ctx* ctx, const spx_selfplay_params* p, const char* out_p
                      static_cast<unsigned long long>(latest.discarded), published,
                      useGraph ? (kGraphPlies == 2 ? "graph mode: two plies per launch, two launches ahead"
                                                   : kGraphPlies == 4 ? "graph mode: four plies per launch, two launches ahead"
-                                                                     : "graph mode: SPX_SELFPLAY_GRAPH_PLIES plies per launch, two launches ahead")
+                                                                     : "graph mode: option selfplay_graph_plies plies per launch, two launches ahead")
                               : "direct launches");
     }
     return rc;

@@ -97,33 +97,22 @@ class Network:
 class NnueState:
     """Device context (spx_ctx): weights resident on one GPU + scratch for `max_batch` positions."""
 
-    CREATION_OPTIONS = ("scratch_cap", "compact_rows", "near_rows")  # shape what a context allocates: SPX_OPTIONS only
+    CREATION_OPTIONS = ("scratch_cap", "compact_rows", "near_rows")  # shape what a context allocates: at creation only
+    TEST_HOOKS = ("ftx_fail_after", "ftx_fail_launch")  # fault injection: dev library only (spx_debug_enable_test_hooks)
 
     def __init__(self, network, device=0, max_batch=65536, wide_psq_rows=False, sliced_ft=None, options=None):
-        """options: {name: int} tuning knobs (spx_ctx_set_option, include/spx_nnue.h); the three that shape the context's
-        allocations travel through SPX_OPTIONS around its creation."""
-        import os
-
+        """options: {name: int} tuning knobs (include/spx_nnue.h); all of them travel in spx_ctx_create_opts' option string -
+        nothing process-global is touched (the environment rewrite of round 5 was not thread-safe)."""
         lib = _lib.load()
         handle = ctypes.c_void_p()
         flags = (CTX_WIDE_PSQ_ROWS if wide_psq_rows else 0) | (0 if sliced_ft is None else CTX_SLICED_FT if sliced_ft else CTX_ONE_KERNEL_FT)
         options = dict(options or {})
-        early = {k: options.pop(k) for k in self.CREATION_OPTIONS if k in options}
-        old = os.environ.get("SPX_OPTIONS")
-        if early:
-            os.environ["SPX_OPTIONS"] = ",".join(([old] if old else []) + [f"{k}={int(v)}" for k, v in early.items()])
-        try:
-            check(lib.spx_ctx_create_ex(network._h, device, max_batch, flags, ctypes.byref(handle)))
-        finally:
-            if early:
-                if old is None:
-                    os.environ.pop("SPX_OPTIONS", None)
-                else:
-                    os.environ["SPX_OPTIONS"] = old
+        if any(k in options for k in self.TEST_HOOKS):
+            check(lib.spx_debug_enable_test_hooks(1))
+        text = ",".join(f"{k}={int(v)}" for k, v in options.items())
+        check(lib.spx_ctx_create_opts(network._h, device, max_batch, flags, text.encode() if text else None, ctypes.byref(handle)))
         self._h = handle
         self._net = network
-        for k, v in options.items():
-            self.set_option(k, v)
         # what one arena call (reset / update / evaluate) accepts: the scratch capacity (option scratch_cap, 4 Mi positions by
         # default) when the context was created for a larger full-refresh batch - trace.replay chunks by this
         self.max_batch = min(max_batch, int(lib.spx_ctx_scratch_batch(handle)))
@@ -131,6 +120,8 @@ class NnueState:
 
     def set_option(self, name, value):
         """spx_ctx_set_option: one tuning knob of this context (never changes a result)."""
+        if name in self.TEST_HOOKS:
+            check(_lib.load().spx_debug_enable_test_hooks(1))
         check(_lib.load().spx_ctx_set_option(self._h, name.encode(), int(value)))
 
     def ftx_walk(self, slot=-1):

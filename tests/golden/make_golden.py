@@ -265,6 +265,18 @@ def make_drawn():
             others += 1
             games.append((start, moves))
     assert mates >= 3, mates
+    # round 6: checkmate on the 100th half-move whose only "defence" is a PINNED piece - the queen on f6 could take the
+    # knight if the queen on b2 did not pin her, and a knight's check cannot be blocked. Position::isDrawn asks generateAll for the
+    # evasions (position.cpp:622-633); movegen.cpp:290-330 keeps pinned sliders on their pin ray, so the answer is "not drawn"
+    pinned = 0
+    for seed in range(1, 200):
+        start, moves = play(seed, 1, 0, "6rk/7p/5q1P/6N1/8/8/1Q6/7K w - - 99 80")
+        if moves and moves[0][0] == "g5f7":
+            assert moves[0][1] == 0, moves
+            games.append((start, moves))
+            pinned += 1
+            break
+    assert pinned == 1
     with open(os.path.join(HERE, "drawn_games.txt"), "w") as f:
         f.write("# oracle/ref_probe.cpp `drawn <seed> <plies> <undo permille> <fen>`: <start fen> | <final fen> | <uci>:<Position::isDrawn(0, keyHistory) after the move> ...\n")
         for start, moves in games:
