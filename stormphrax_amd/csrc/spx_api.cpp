@@ -320,6 +320,15 @@ void relayoutL1(const int8_t* src, int8_t* dst) {
                     }
 }
 
+// L2 weights as the MLP tail reads them (spx_mlp_kernel): [bucket][i / 4][o][i % 4] - lane o fetches the weights of four inputs
+// with ONE 16-byte load, a coalesced 1 KiB per wave (the net file: [bucket][i][o], multilayer.h:261-343)
+void relayoutL2(const int32_t* src, int32_t* dst) {
+    for (uint32_t b = 0; b < kOutputBuckets; ++b)
+        for (uint32_t i = 0; i < kL2Full; ++i)
+            for (uint32_t o = 0; o < kL3; ++o)
+                dst[((size_t(b) * (kL2Full / 4) + i / 4) * kL3 + o) * 4 + (i % 4)] = src[(size_t(b) * kL2Full + i) * kL3 + o];
+}
+
 FtTables tablesOf(const spx_ctx* ctx) {
     FtTables t{};
     t.psqW = ctx->dPsqW;
@@ -717,7 +726,11 @@ int spx_ctx_create_opts(const spx_net* net, int device, size_t max_batch, uint32
         if ((rc = uploadArray(ctx->dL1W, l1.data(), l1.size(), ctx->stream)) != SPX_OK) return rc;
     }
     if ((rc = uploadArray(ctx->dL1B, b + kOffL1B, kL1BBytes, ctx->stream)) != SPX_OK) return rc;
-    if ((rc = uploadArray(ctx->dL2W, b + kOffL2W, kL2WBytes, ctx->stream)) != SPX_OK) return rc;
+    {
+        std::vector<int32_t> l2(kL2WBytes / 4);
+        relayoutL2(reinterpret_cast<const int32_t*>(b + kOffL2W), l2.data());
+        if ((rc = uploadArray(ctx->dL2W, l2.data(), kL2WBytes, ctx->stream)) != SPX_OK) return rc;
+    }
     if ((rc = uploadArray(ctx->dL2B, b + kOffL2B, kL2BBytes, ctx->stream)) != SPX_OK) return rc;
     if ((rc = uploadArray(ctx->dL3W, b + kOffL3W, kL3WBytes, ctx->stream)) != SPX_OK) return rc;
     if ((rc = uploadArray(ctx->dL3B, b + kOffL3B, kL3BBytes, ctx->stream)) != SPX_OK) return rc;
@@ -2428,7 +2441,7 @@ int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
                     longest = std::max(longest, kept[q]);
                     sums[7] += kept[q];
                 }
-                sums[6] += (((longest + 3) / 4) + 1) & ~1u;  // (steps are walked in pairs)
+                sums[6] += kFtxOddSteps ? (longest + 3) / 4 : (((longest + 3) / 4) + 1) & ~1u;  // (round 5: steps walked in pairs)
             }
         }
     }

@@ -36,6 +36,9 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SPX_MLP_WAVES_PER_SIMD
 #define SPX_MLP_WAVES_PER_SIMD 4  // A/B on MI355X with the batched tail: 3 -> 39.0 us, 4 -> 35.5 us per 65 536 positions (round-1 tail: 38.3)
 #endif
+#ifndef SPX_MLP_SORTED_WAVES_PER_SIMD
+#define SPX_MLP_SORTED_WAVES_PER_SIMD 4  // the big-batch tiling (L2 weights streamed, not held). A/B on MI355X, us per 65 536 positions alone: 4 -> 28.0, 5 -> 31.7, 6 -> 36.5 (round 5, weights held: 37.6)
+#endif
 constexpr int kThreatCap = 256;  // StaticVector<u16, 256> in addThreatFeatures (nnue_state.cpp:315)
 constexpr int kPsqCap = 32;
 constexpr int kU8Cap = kThreatCap + kPsqCap;  // u8-row list: compact piece-square rows first, then <= 256 threat rows

@@ -79,6 +79,10 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 // 24-31 (the all-zero row: 0). Every XCD's gather walks every group: packing once what
 // round 4 made each of the eight find out for itself (section boundaries per lane, list gathers, padding) took 40 % of the
 // gather's instructions off it (profiles/r05_gather_anatomy.txt).
+#ifndef SPX_FTX_WALK
+#define SPX_FTX_WALK 6  // A/B: 6 = round 6's walk of a stage (halves fenced, odd sections without a step of zero rows, entries read one half ahead), 5 = round 5's
+#endif
+constexpr bool kFtxOddSteps = SPX_FTX_WALK >= 6;  // (what the walk statistics count)
 constexpr uint32_t kFtxMaxStages = 1 + 9 + 8;  // <= 32 high planes, <= 32 + 256 LDS rows, <= 256 cold rows
 constexpr uint32_t kFtxGroupHeadWords = 16;
 

@@ -541,11 +541,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
         }
         if (lane == 0) {
             gh[9] = Q;
-            gh[10] = (coldQ + 1) & ~1u;
-            gh[11] = (ldsQ + 1) & ~1u;
+            gh[10] = kFtxOddSteps ? coldQ : (coldQ + 1) & ~1u;
+            gh[11] = kFtxOddSteps ? ldsQ : (ldsQ + 1) & ~1u;
             gh[12] = rowsG & 0xFFFFu;
             gh[13] = rowsL;
-            gh[14] = (hiQ + 1) & ~1u;  // as packed: an XCD walks what is left after dropping the planes that are zero in its slice
+            gh[14] = kFtxOddSteps ? hiQ : (hiQ + 1) & ~1u;  // as packed: an XCD walks what is left after dropping the planes that are zero in its slice
             gh[15] = rowsG >> 16;
         }
     }
@@ -621,11 +621,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
 namespace {
 
 // one stage - n <= 8 steps of ONE section - of a group's walk: rows from LDS (kLds) or through the texture path. The steps run in
-// PAIRS as a rolling window: the loads of steps k + 2, k + 3 are issued right behind the MFMAs of steps k, k + 1 - 8 loads in flight
-// all the time -, and the loop body has no branch: a stage holds 8 steps whatever the section's length (the pack kernel fills the
-// rest with the all-zero row), so an odd n walks one step of zero rows. With branches for the odd step the compiler's s_waitcnt
-// at their joins wait for ALL loads (paths with different numbers of loads in flight), and the accumulators travel through
-// copies (16 + 32 v_mov per stage and 48 spilled registers at the 96 the co-runners leave room for).
+// PAIRS as a rolling window: the loads of step k + 2 are issued right behind the MFMAs of step k, so four to eight loads are in
+// flight all the time, and the loop body has no branch. Round 5 padded an odd section with a step of zero rows (with a branch for the
+// odd step the compiler's s_waitcnt at the join wait for ALL loads and the accumulators travel through copies); round 6 enters the
+// loop through its second half instead (below).
 template <bool kLds>
 __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, const uint8_t* ldsRows, const uint8_t* slice, uint32_t e,
                                           uint32_t laneOff, const i32x4& sel, i32x4 (&d)[4]) {
@@ -651,9 +650,54 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
             else d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[pr], d[pr], 0, 0, 0);
         }
     };
-    const uint32_t nEven = (n + 1) & ~1u;
     i32x4 wa[4], wb[4];
-    u32x4 en = entries(0);
+    u32x4 en;
+#if SPX_FTX_WALK >= 6
+    // Round 6. (a) An odd section does NOT walk a step of zero rows: its first step goes to the window's second half while the first
+    // holds zeros - four MFMAs that add nothing instead of four row loads / LDS reads of the all-zero row (tools/sim_gather_steps.py:
+    // the padding to pairs was 7 % of the wave loads and 4 % of the LDS reads); both entries into the loop leave `wb` in flight LAST, so
+    // the waits at the join stay exact. (b) The halves of the loop are FENCED: left alone the scheduler clustered the loop's eight
+    // loads behind its eight MFMAs, and the window drained to nothing once per pair of steps. (c) A step's entries are read one half
+    // ahead: the LDS counter is in order, so an entries read issued behind the other half's row reads could only be waited for
+    // together with them (the LDS sections drained at every step), and in the global sections its latency sat between the MFMAs and
+    // the loads they make room for.
+    u32x4 enN;
+    uint32_t k;
+    if (n & 1u) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) wa[pr] = i32x4{0, 0, 0, 0};
+        en = entries(0);
+        enN = entries(1);
+        issue(en, wb);
+        k = 1;
+    } else {
+        en = entries(0);
+        enN = entries(1);
+        issue(en, wa);
+        en = enN;
+        enN = entries(2);
+        issue(en, wb);
+        k = 2;
+    }
+    for (; k < n; k += 2) {  // steps k - 2, k - 1 are in flight, enN = the entries of step k
+        en = enN;
+        enN = entries(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        add(wa);
+        issue(en, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        en = enN;
+        enN = entries(min(k + 2, 7u));
+        __builtin_amdgcn_sched_barrier(0);
+        add(wb);
+        issue(en, wb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    // (round 5: a section with an odd number of steps walks one more step of zero rows, and the compiler is free to cluster the
+    // loop's eight loads behind its eight MFMAs - it does)
+    const uint32_t nEven = (n + 1) & ~1u;
+    en = entries(0);
     issue(en, wa);
     en = entries(1);
     issue(en, wb);
@@ -665,6 +709,7 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
         add(wb);
         issue(en, wb);
     }
+#endif
     add(wa);
     add(wb);
 }
@@ -730,49 +775,54 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             const bool haveNext = nextG < gEnd;
             if (haveNext) headNext = headOfGroup(nextG);
             i32x4 d[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            for (uint32_t q = 0; q < Q; ++q) {
-                uint32_t hiSteps = 0;
-                if (q < H) {
-                    // A stage of high-byte planes, compacted for THIS slice: a plane that is all zero in slice `xcd` (bit 24 + xcd of its
-                    // entry, spx_ftx_pack_kernel) is dropped, the perspective's remaining planes move up. Lane 8 k + 2 kb + u holds the
-                    // entries of step k, row kb of perspectives 2 pr + u (pr = 0 .. 3): the j-th kept entry of a perspective goes to
-                    // step j >> 2, row j & 3 - word 8 j + 4 u + pr. (Most wide rows of a heavy-tailed net have a handful of weights
-                    // outside i8: their plane is zero in most slices - 108 -> 92 row loads per position on the `realistic` preset.)
-                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = u32x4{kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u};
-                    uint32_t longest = 0;
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const bool keep = (ents[pr] >> (24u + xcd)) & 1u;
-                        const uint64_t kept = __ballot(keep);
-                        const uint64_t even = kept & 0x5555555555555555ull, odd = kept & 0xAAAAAAAAAAAAAAAAull;
-                        const uint32_t j = prefixCount((lane & 1u) ? odd : even);
-                        if (keep) stage[8 * j + 4 * (lane & 1u) + pr] = ents[pr] & 0xFFFFFFu;
-                        longest = max(longest, uint32_t(max(popc64(even), popc64(odd))));
-                    }
-                    hiSteps = (longest + 3) >> 2;
-                } else if (!(SPX_FTX_SKIP & 32)) {
-                    *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
-                }
-                __builtin_amdgcn_wave_barrier();
-                // what travels while this stage is walked: the next stage - at the last one: the next group's first
+            // what travels while a stage is walked: the next stage - at the last one: the next group's first
+            auto prefetch = [&](uint32_t q) {
                 if (q + 1 < Q) {
                     ents = stageOfGroup(G, q + 1);
                 } else if (haveNext) {
                     ents = stageOfGroup(nextG, 0);
                 }
-                const uint32_t sec = q < H ? 0u : (q < H + L ? 1u : 2u), s = q - (sec == 0 ? 0u : (sec == 1 ? H : H + L));
-                const uint32_t steps = (sec == 0 ? hiQ : (sec == 1 ? ldsQ : coldQ)) - 8 * s;
-                if (sec == 1) {
-                    walkStage<true>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
-                } else if (sec == 2) {
-                    walkStage<false>(min(steps, 8u), stage, sSlab, slice, e, laneOff, sel, d);
-                } else {
-                    if (hiSteps) walkStage<false>(hiSteps, stage, sSlab, slice, e, laneOff, sel, d);
-                    if (s + 1 == H) {  // the high-byte planes' sums count 256-fold
+            };
+            // (three loops, one per section, instead of one loop with a three-way branch: the accumulators then flow through ONE walk
+            // each - as one loop they travelled through copies at every join, and the copies' registers were what spilled)
+            uint32_t q = 0;
+            for (; q < H; ++q) {
+                // A stage of high-byte planes, compacted for THIS slice: a plane that is all zero in slice `xcd` (bit 24 + xcd of its
+                // entry, spx_ftx_pack_kernel) is dropped, the perspective's remaining planes move up. Lane 8 k + 2 kb + u holds the
+                // entries of step k, row kb of perspectives 2 pr + u (pr = 0 .. 3): the j-th kept entry of a perspective goes to
+                // step j >> 2, row j & 3 - word 8 j + 4 u + pr. (Most wide rows of a heavy-tailed net have a handful of weights
+                // outside i8: their plane is zero in most slices - 108 -> 92 row loads per position on the `realistic` preset.)
+                *reinterpret_cast<u32x4*>(stage + 4 * lane) = u32x4{kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u, kFtxZeroRow * 128u};
+                uint32_t longest = 0;
 #pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
-                    }
+                for (int pr = 0; pr < 4; ++pr) {
+                    const bool keep = (ents[pr] >> (24u + xcd)) & 1u;
+                    const uint64_t kept = __ballot(keep);
+                    const uint64_t even = kept & 0x5555555555555555ull, odd = kept & 0xAAAAAAAAAAAAAAAAull;
+                    const uint32_t j = prefixCount((lane & 1u) ? odd : even);
+                    if (keep) stage[8 * j + 4 * (lane & 1u) + pr] = ents[pr] & 0xFFFFFFu;
+                    longest = max(longest, uint32_t(max(popc64(even), popc64(odd))));
                 }
+                const uint32_t hiSteps = (longest + 3) >> 2;
+                __builtin_amdgcn_wave_barrier();
+                prefetch(q);
+                if (hiSteps) walkStage<false>(hiSteps, stage, sSlab, slice, e, laneOff, sel, d);
+                if (q + 1 == H) {  // the high-byte planes' sums count 256-fold
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) d[pr] = d[pr] << 8;
+                }
+            }
+            for (; q < H + L; ++q) {
+                if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
+                __builtin_amdgcn_wave_barrier();
+                prefetch(q);
+                walkStage<true>(min(ldsQ - 8 * (q - H), 8u), stage, sSlab, slice, e, laneOff, sel, d);
+            }
+            for (; q < Q; ++q) {
+                if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;
+                __builtin_amdgcn_wave_barrier();
+                prefetch(q);
+                walkStage<false>(min(coldQ - 8 * (q - H - L), 8u), stage, sSlab, slice, e, laneOff, sel, d);
             }
             if (Q == 0 && haveNext) ents = stageOfGroup(nextG, 0);  // (a group of records without a single piece: malformed input)
             // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u; the 2 output bytes go

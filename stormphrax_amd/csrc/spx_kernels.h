@@ -248,7 +248,7 @@ struct MlpParams {
     const uint8_t* ftOut;       // [nPositions][1024]
     const int8_t* l1W;          // device layout [8 buckets][16 ksteps][2 ntiles][64 lanes][16 B]
     const int32_t* l1B;         // [8][32]
-    const int32_t* l2W;         // [8][64][64]
+    const int32_t* l2W;         // device layout [8 buckets][16 input quartets][64 outputs][4] (relayoutL2)
     const int32_t* l2B;         // [8][64]
     const int32_t* l3W;         // [8][64]
     const int32_t* l3B;         // [8]

@@ -1076,7 +1076,7 @@ hipError_t launchSort(const SortParams& p, hipStream_t stream) {
 // (4 096 positions: 16 us unshared); kMlpTilePerPosition = no sort at all, every position is its own tile and finds
 // its bucket from its record - the handful-of-positions drop-in call, where a sort launch costs more than it saves.
 template <bool kSmallL2W, int kTiling>
-__global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
+__global__ __launch_bounds__(256, kTiling == kMlpTileSorted ? SPX_MLP_SORTED_WAVES_PER_SIMD : SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(MlpParams p) {
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
@@ -1163,13 +1163,19 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     const int32_t l2Bias = p.l2B[bucket * kL3 + lane];
     const int32_t l3Weight = p.l3W[bucket * kL3 + lane];
     const int32_t l3Bias = p.l3B[bucket];
-    int32_t w2[kL2Full];
-    {
-        const int32_t* w2p = p.l2W + size_t(bucket) * kL2Full * kL3 + lane;
+    // L2 weights of this lane's output: [bucket][input quartet][o][4] (relayoutL2), one 16-byte load per four inputs. The small
+    // tilings hold all 64 in registers; the big-batch tiling STREAMS them, a quartet ahead of its use (round 6): with the 64 registers
+    // gone the kernel fits 6 waves per SIMD instead of 4, and the 4 100-odd tile waves of a 65 536-position batch - 4 096 full tiles
+    // plus every bucket's partial one - are resident AT ONCE; at 4 waves per SIMD the chip holds 4 096, the handful left over ran as a
+    // second generation behind the first, and the kernel took two tile latencies (35.5 us) for one generation's worth of work.
+    constexpr bool kStreamW2 = kTiling == kMlpTileSorted;
+    const i32x4* const w2q = reinterpret_cast<const i32x4*>(p.l2W) + size_t(bucket) * (kL2Full / 4) * kL3 + lane;
+    i32x4 w2[kStreamW2 ? 1 : kL2Full / 4];
+    i32x4 w2Next = w2q[0];
+    if constexpr (!kStreamW2) {
+        w2[0] = w2Next;
 #pragma unroll
-        for (int i = 0; i < int(kL2Full); ++i) {
-            w2[i] = w2p[i * kL3];
-        }
+        for (int i = 1; i < int(kL2Full / 4); ++i) w2[i] = w2q[i * kL3];
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -1201,19 +1207,52 @@ __global__ __launch_bounds__(256, SPX_MLP_WAVES_PER_SIMD) void spx_mlp_kernel(Ml
     uint32_t acc2[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; ++k) acc2[k] = uint32_t(l2Bias);
+    auto mac = [&](uint32_t& acc, int32_t in, int32_t w) {
+        if constexpr (kSmallL2W) {
+            // ONE v_mad_i32_i24 (left to itself the compiler multiplies twice and folds two products per v_add3_u32: 6 instructions
+            // per 4 terms instead of 4)
+            asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(in), "v"(w));
+        } else {
+            acc += uint32_t(in) * uint32_t(w);
+        }
+    };
+    if constexpr (kStreamW2) {
+        // (the rows past `count` of a partial tile are taken along - whatever their LDS words hold, the sums wrap and are never
+        // stored -: sixteen wave-uniform branches inside the loop cost it 100 bytes of spills. Four rows' inputs are asked for before
+        // the first is used: left to the compiler every broadcast read was waited for on the spot.)
+        static_assert(kRows % 4 == 0 || !kStreamW2, "rows in fours");
+#pragma unroll 1
+        for (int i4 = 0; i4 < int(kL2Full / 4); ++i4) {
+            const i32x4 w = w2Next;
+            w2Next = w2q[min(i4 + 1, int(kL2Full / 4) - 1) * int(kL3)];
+            i32x4 in4[4];
 #pragma unroll
-    for (int i = 0; i < int(kL2Full); i += 4) {
+            for (int j = 0; j < 4; ++j) in4[j] = *reinterpret_cast<const i32x4*>(&sInW[j][4 * i4]);
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) {
-            if (rowBegin + uint32_t(k) * rowStep < count) {  // wave-uniform
-                const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sInW[k][i]);
+            for (int kb = 0; kb < kRows; kb += 4) {
+                i32x4 cur[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = in4[j];
+                if (kb + 4 < kRows) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) in4[j] = *reinterpret_cast<const i32x4*>(&sInW[(kb + 4 + j) % kRows][4 * i4]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (kSmallL2W) {
-                        acc2[k] += uint32_t(__mul24(in4[j], w2[i + j]));
-                    } else {
-                        acc2[k] += uint32_t(in4[j]) * uint32_t(w2[i + j]);
-                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) mac(acc2[(kb + j) % kRows], cur[j][t], w[t]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i4 = 0; i4 < int(kL2Full / 4); ++i4) {
+#pragma unroll
+            for (int k = 0; k < kRows; ++k) {
+                if (rowBegin + uint32_t(k) * rowStep < count) {  // wave-uniform
+                    const i32x4 in4 = *reinterpret_cast<const i32x4*>(&sInW[k][4 * i4]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mac(acc2[k], in4[j], w2[i4][j]);
                 }
             }
         }
