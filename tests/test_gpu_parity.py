@@ -40,7 +40,9 @@ def path_states(sp, net_blob):
             if path == "one_kernel":
                 cache[key] = sp.NnueState(sp.Network(net_blob(preset)), device=0, max_batch=1 << 16, sliced_ft=False)
             else:
-                cache[key] = _state_with_options(sp, net_blob(preset), {"ftx_min": 1024, "tiny_batch_max": 0}, max_batch=1 << 16)
+                # (mlp_share_max = 0: the MLP in its big-batch form too - one wave per tile, the L2 weights streamed)
+                cache[key] = _state_with_options(sp, net_blob(preset), {"ftx_min": 1024, "tiny_batch_max": 0, "mlp_share_max": 0},
+                                                 max_batch=1 << 16)
                 assert cache[key].takes_sliced_pipeline(1024) and cache[key].takes_sliced_pipeline(1024, pipelined=True)
         return cache[key]
 
