@@ -52,8 +52,8 @@ LDS_PEAK_GBS = 256 * 128 * CLOCK_HZ / 1e9  # LDS: 128 B per clock and CU = 78.6 
 L1_CYCLES_PER_WAVE_LOAD, LDS_CYCLES_PER_WAVE_READ, MFMA_CYCLES = 17.5, 8.8, 16.0
 # committed rocprofv3 PMC passes of this command, newest round first (tools/gpu_final.sh puts this round's in place before the
 # bench lines are taken; the kernels these counters describe did not change in round 3)
-PMC_FILES = {"full": ["r05_pmc_full_refresh.json", "r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
-             "incremental": ["r05_pmc_incremental.json", "r04_pmc_incremental.json", "r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
+PMC_FILES = {"full": ["r06_pmc_full_refresh.json", "r05_pmc_full_refresh.json", "r04_pmc_full_refresh.json", "r03_pmc_full_refresh.json", "r02_pmc_full_refresh.json"],
+             "incremental": ["r06_pmc_incremental.json", "r05_pmc_incremental.json", "r04_pmc_incremental.json", "r03_pmc_incremental.json", "r02_pmc_incremental.json"]}
 
 
 def settle(step, sync, min_seconds=1.0, max_seconds=8.0, chunk=10):

@@ -1,6 +1,6 @@
 # Round-end measurement set (GPU box): bench lines, secondary measurements, rocprofv3 stats + counters.
 # usage: bash tools/gpu_final.sh <tag>   -> gpurun_out/final_<tag>/   (copy what is quoted into profiles/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 # The bench lines, kernel statistics and counters of the full-refresh path alone (after a change that touches nothing else):
 # bash tools/gpu_final_refresh.sh <tag>  -> gpurun_out/final_<tag>/ (same names as tools/gpu_final.sh; install with install_final_profiles.py)
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
