@@ -113,9 +113,6 @@ struct spx_ctx {
     uint32_t* dHist = nullptr;     // 3 sort-histogram buffers of kHistWords + 64 words of counters
     uint32_t* dPerspOrder = nullptr;  // perspective ids grouped by king bucket
     uint32_t* dPosOrder = nullptr;    // position ids grouped by output bucket
-    uint32_t* dUpdOrder = nullptr;    // big materialising update batches: keys | ranks | order [3][maxBatch] + kUpdateKeyBins counters (launchUpdateOrder)
-    bool updateSort = true;           // option update_sort
-    size_t updateSortMin = 32768;     // option update_sort_min
     uint32_t* dRefreshList = nullptr; // update kernel: perspectives deferred to the rebuild pass (its own buffer: the king sort
                                       // of a full refresh on another stream must not overwrite a list that is being consumed)
     // accumulator arena (incremental path): nSlots x (4 KiB accumulators + 32 B record)
@@ -136,7 +133,6 @@ struct spx_ctx {
     struct EvalLane {
         uint8_t *dFtOut = nullptr, *dKingKeys = nullptr, *dOutKeys = nullptr, *dStaged = nullptr;
         uint32_t *dHist = nullptr, *dPerspOrder = nullptr, *dPosOrder = nullptr, *dRefreshList = nullptr, *histUsed = nullptr;
-        uint32_t* dUpdOrder = nullptr;
         int histCur = 0, refreshCur = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ftDone = nullptr, done = nullptr;
@@ -580,11 +576,6 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         ctx->kingSortEnabled = value != 0;
         return SPX_OK;
     }
-    if (key == "update_sort") {  // big materialising update batches walked in (moved piece, from square) order (1) or as they come (0)
-        ctx->updateSort = value != 0;
-        return SPX_OK;
-    }
-    if (key == "update_sort_min") return nonNegative(ctx->updateSortMin);
     if (key == "tiny_batch_max") return nonNegative(ctx->tinyBatchMax);
     if (key == "mlp_share_max") return nonNegative(ctx->mlpShareMax);
     if (key == "stream_acc_min") return nonNegative(ctx->streamAccMin);
@@ -768,7 +759,6 @@ int spx_ctx_create_opts(const spx_net* net, int device, size_t max_batch, uint32
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPerspOrder), max_batch * 2 * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dPosOrder), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dRefreshList), max_batch * 2 * sizeof(uint32_t)));
-    SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dUpdOrder), (3 * max_batch + kUpdateKeyBins) * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsA), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dSlotsB), max_batch * sizeof(uint32_t)));
     SPX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->dStaged), max_batch * 32));
@@ -813,7 +803,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->dPsqW, ctx->dThrW, ctx->dFtBias, ctx->dL1W, ctx->dL1B, ctx->dL2W,  ctx->dL2B,
                     ctx->dL3W,  ctx->dL3B, ctx->dLut,    ctx->dDeltaTab, ctx->dOutlierTab, ctx->dPositions, ctx->dOut, ctx->dFtOut,
-                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder, ctx->dRefreshList, ctx->dUpdOrder,
+                    ctx->dKingKeys, ctx->dOutKeys, ctx->dHist, ctx->dPerspOrder, ctx->dPosOrder, ctx->dRefreshList,
                     ctx->dArena, ctx->dSlotRecords, ctx->dSlotsA, ctx->dSlotsB, ctx->dStaged, ctx->dDeltas};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
@@ -829,7 +819,7 @@ void spx_ctx_destroy(spx_ctx* ctx) {
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
-                            lane.dPosOrder, lane.dRefreshList, lane.dUpdOrder, lane.dIn, lane.dOutStage};
+                            lane.dPosOrder, lane.dRefreshList, lane.dIn, lane.dOutStage};
         if (lane.hIn) (void)hipHostFree(lane.hIn);
         if (lane.hOut) (void)hipHostFree(lane.hOut);
         for (void* q : lanePtrs) {
@@ -1171,7 +1161,6 @@ static void swapLane(spx_ctx* ctx, spx_ctx::EvalLane& lane) {
     std::swap(ctx->dPerspOrder, lane.dPerspOrder);
     std::swap(ctx->dPosOrder, lane.dPosOrder);
     std::swap(ctx->dRefreshList, lane.dRefreshList);
-    std::swap(ctx->dUpdOrder, lane.dUpdOrder);
     std::swap(ctx->histUsed, lane.histUsed);
     std::swap(ctx->histCur, lane.histCur);
     std::swap(ctx->refreshCur, lane.refreshCur);
@@ -1195,7 +1184,6 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPerspOrder), ctx->maxBatch * 2 * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dPosOrder), ctx->maxBatch * sizeof(uint32_t)));
         SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dRefreshList), ctx->maxBatch * 2 * sizeof(uint32_t)));
-        SPX_HIP(hipMalloc(reinterpret_cast<void**>(&lane.dUpdOrder), (3 * ctx->maxBatch + kUpdateKeyBins) * sizeof(uint32_t)));
         // (lanes 0 / 1: the two ends of the range; lane 2: the level between them, where the device has one)
         const int priority = laneIndex == 0 ? leastPriority : (laneIndex == 1 ? greatestPriority : (leastPriority + greatestPriority) / 2);
         ++laneIndex;
@@ -1212,7 +1200,7 @@ static void releaseLanes(spx_ctx* ctx) {
     for (auto& lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
         void* lanePtrs[] = {lane.dFtOut, lane.dKingKeys, lane.dOutKeys, lane.dStaged, lane.dHist, lane.dPerspOrder,
-                            lane.dPosOrder, lane.dRefreshList, lane.dUpdOrder, lane.dIn, lane.dOutStage};
+                            lane.dPosOrder, lane.dRefreshList, lane.dIn, lane.dOutStage};
         for (void* q : lanePtrs) {
             if (q) (void)hipFree(q);
         }
@@ -1457,16 +1445,6 @@ static int launchUpdateAndRefresh(spx_ctx* ctx, UpdateParams& up, size_t n, hipS
         cp.stagedRecords = up.stagedRecords;
         SPX_HIP(launchUpdateChain(cp, s));
         return SPX_OK;
-    }
-    if (ctx->updateSort && up.childSlots && !up.nRecordsPtr && !split && n >= ctx->updateSortMin) {
-        // big batches of independent, materialising updates are WALKED in (moved piece, from square) order: like moves fetch like
-        // delta rows, and the walk deals 64 neighbouring records to one XCD (spx_update_key_kernel). Eval-only batches are left as
-        // they come: theirs are siblings, which share the parent's accumulator instead
-        uint32_t* keys = ctx->dUpdOrder;
-        uint32_t *ranks = keys + ctx->maxBatch, *order = ranks + ctx->maxBatch, *hist = order + ctx->maxBatch;
-        SPX_HIP(hipMemsetAsync(hist, 0, kUpdateKeyBins * sizeof(uint32_t), s));
-        SPX_HIP(launchUpdateOrder(up, keys, ranks, hist, order, s));
-        up.order = order;
     }
     SPX_HIP(launchUpdate(up, updateGrid(ctx, split ? 2 * n : n), split, streamAcc, s));
     FtParams fp{};

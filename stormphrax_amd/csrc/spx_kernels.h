@@ -54,15 +54,7 @@ struct UpdateParams {
     uint8_t* stagedRecords;        // ... and [nRecords][32] their records (input of the MLP's bucket sort)
     uint32_t* refreshList;         // spx_update_kernel: ids (2 * record + colour) of the perspectives to rebuild ...
     uint32_t* refreshCount;        // ... and their number (zero on entry); the FT kernel launched next consumes both
-    const uint32_t* order;         // optional: the records are WALKED in this order (launchUpdateOrder: by (moved piece, from square) -
-                                   // records of like moves fetch like delta rows, and neighbours of the walk run on one XCD); every
-                                   // output stays at its record's own index
 };
-
-// Walk order of a big batch of independent updates (round 6): key = moved piece (the parent's nibble on the square that was left) x 64
-// + that square, counting sort. keys / ranks / order: [nRecords] words, hist: [kUpdateKeyBins] words, zero on entry.
-constexpr uint32_t kUpdateKeyBins = 1024;
-hipError_t launchUpdateOrder(const UpdateParams& p, uint32_t* keys, uint32_t* ranks, uint32_t* hist, uint32_t* order, hipStream_t stream);
 
 struct ChainParams {               // spx_update_chain_kernel: whole pending PATHS (NnueState::ensureUpToDate) in one launch
     uint32_t nChains;

@@ -513,8 +513,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4
     for (ItemWalk<true> walk(nItems, wave); walk.t < walk.tEnd; walk.t += walk.stride) {
         const uint32_t item = walk.item();
         if (item >= nItems) continue;  // (the last chunk round may be partial)
-        const uint32_t itWalk = kSplit ? item >> 1 : item;
-        const uint32_t it = p.order ? __builtin_amdgcn_readfirstlane(p.order[itWalk]) : itWalk;
+        const uint32_t it = kSplit ? item >> 1 : item;
         const int cFirst = kSplit ? int(item & 1) : 0, cLast = kSplit ? cFirst + 1 : 2;
         const uint32_t parentSlot = __builtin_amdgcn_readfirstlane(p.parentSlots[it]);
         // childSlots == nullptr: EVAL-ONLY children - the activations leave through ftOut, no accumulator and no record is
@@ -558,66 +557,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSplit ? (SPX_UPDATE_WAVES > 4
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Walk order of a big batch of INDEPENDENT updates (round 6). The update kernel is bound by the fabric: of the
-// ~17.5 delta rows a move fetches (1 KiB each, out of a 77 MB table) 60 % miss its XCD's 4 MiB L2 - 1.36 GB per 65 536 records against
-// 0.54 GB of compulsory accumulator traffic. Moves of the same piece from the same square fetch largely the same rows, and the walk
-// deals 64 neighbouring records to one XCD: with the records walked in (moved piece, from square) order an LRU model of the L2s
-// (tools/sim_update_order.py: the host emulation of this kernel's delta derivation on the bench's moves) hits 63-66 % instead of 32-39 %.
-// A counting sort in two launches: keys + block-local ranks (one global atomic per block and bin), then the scatter (every block
-// scans the 1 024 bin counts itself). The order only decides WHEN a record is processed: outputs stay at the record's index.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void spx_update_key_kernel(UpdateParams p, uint32_t* keys, uint32_t* ranks, uint32_t* hist) {
-    __shared__ uint32_t sCount[kUpdateKeyBins], sBase[kUpdateKeyBins];
-    for (uint32_t k = threadIdx.x; k < kUpdateKeyBins; k += blockDim.x) sCount[k] = 0;
-    __syncthreads();
-    const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = it < p.nRecords;
-    uint32_t key = 0, local = 0;
-    if (mine) {
-        const uint64_t* parent = reinterpret_cast<const uint64_t*>(p.slotRecords + size_t(p.parentSlots[it]) * 32);
-        const uint64_t occParent = parent[0], occChild = reinterpret_cast<const uint64_t*>(p.childPositions)[4 * size_t(it)];
-        const uint64_t left = occParent & ~occChild;  // the mover's square (castling, en passant: the lower of two)
-        if (left) {
-            const uint32_t from = uint32_t(ctz64(left)), idx = min(uint32_t(popc64(occParent & ((1ull << from) - 1))), 31u);
-            const uint32_t nibble = uint32_t(parent[1 + (idx >> 4)] >> (4 * (idx & 15u))) & 0xFu;
-            key = nibble * 64 + from;
-        }
-        local = atomicAdd(&sCount[key], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kUpdateKeyBins; k += blockDim.x) {
-        if (sCount[k]) sBase[k] = atomicAdd(&hist[k], sCount[k]);
-    }
-    __syncthreads();
-    if (mine) {
-        keys[it] = key;
-        ranks[it] = sBase[key] + local;
-    }
-}
-
-__global__ __launch_bounds__(1024) void spx_update_order_kernel(uint32_t nRecords, const uint32_t* keys, const uint32_t* ranks, const uint32_t* hist,
-                                                                  uint32_t* order) {
-    static_assert(kUpdateKeyBins == 1024, "one bin per thread");
-    __shared__ uint32_t sStart[kUpdateKeyBins], sWave[16];
-    const uint32_t count = hist[threadIdx.x], incl = waveInclusiveScan(count), lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 63) sWave[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; ++w) before += sWave[w];
-    sStart[threadIdx.x] = before + incl - count;
-    __syncthreads();
-    const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it < nRecords) order[sStart[keys[it]] + ranks[it]] = it;
-}
-
-hipError_t launchUpdateOrder(const UpdateParams& p, uint32_t* keys, uint32_t* ranks, uint32_t* hist, uint32_t* order, hipStream_t stream) {
-    const uint32_t blocks = (p.nRecords + 1023) / 1024;
-    hipLaunchKernelGGL(spx_update_key_kernel, dim3(blocks), dim3(1024), 0, stream, p, keys, ranks, hist);
-    hipLaunchKernelGGL(spx_update_order_kernel, dim3(blocks), dim3(1024), 0, stream, p.nRecords, keys, ranks, hist, order);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // A whole pending PATH per wavefront pair: NnueState::ensureUpToDate (nnue_state.cpp:636-697) walks forward from the last

@@ -258,12 +258,10 @@ def test_selfplay_driver_records_are_consistent(sp, net_blob, oracle, tmp_path, 
     st.close()
 
 
-@pytest.mark.parametrize("walk_order", ["by_move", "as_given"])
-def test_big_update_batches_take_the_streaming_store_variant(sp, net_blob, walk_order):
+def test_big_update_batches_take_the_streaming_store_variant(sp, net_blob):
     """From 32 768 records on the update kernel writes the child accumulators with non-temporal stores (and one wave per
-    perspective) and - round 6 - walks the records in (moved piece, from square) order (spx_update_key_kernel; option update_sort = 0:
-    as given): same bits as a full refresh, for the children and for grandchildren updated from them."""
-    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=40000, options={"update_sort": int(walk_order == "by_move")})
+    perspective): same bits as a full refresh, for the children and for grandchildren updated from them."""
+    st = sp.NnueState(sp.Network(net_blob("wild")), device=0, max_batch=40000)
     try:
         n = 40000
         pos = sp.random_positions(n, seed=21, min_ply=0, max_ply=120, dfrc_every=4)
