@@ -1035,7 +1035,7 @@ def main():
                          "steps: beside two other batches' preparation), peak = the unit's HARDWARE rate (256 CUs x 64 B / clock through the "
                          "texture path, x 128 B / clock out of LDS, at 2.4 GHz), frac = achieved / peak; measured_ceiling = 256 CUs x 1 KiB / the "
                          "cycles one such wave instruction was measured to hold the unit x 2.4 GHz, frac_of_measured_ceiling = the unit's floor / "
-                         "the duration. units = all three incl. the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8). "
+                         "the duration. units = all three incl. the matrix pipe (16 cycles per v_mfma_i32_16x16x64_i8; the count is the row-adding ones - a section with an odd number of steps enters its loop with four more that add zeros: +7 % by the PMC). "
                          "l2 = round 4's figure (bytes the row loads ask the L2s for / aggregate L2 bandwidth): the kernel got faster by "
                          "asking for LESS; hbm = SURVEY 8(d)'s algorithmic bytes and the measured fabric traffic. "
                          "secondary.full_refresh_paths has the kernel alone (stream-ordered)"),
