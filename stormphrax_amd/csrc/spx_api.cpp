@@ -52,10 +52,10 @@ constexpr size_t kProfEventsPerCall = 5;
 // scratch of the column-sliced full refresh (spx_ftx.hip): one set per context and per lane, allocated on first use
 struct FtxScratch {
     uint32_t *lists = nullptr, *heads = nullptr, *ranks = nullptr, *hist = nullptr, *binStart = nullptr,
-             *sorted = nullptr, *plan = nullptr, *groupHead = nullptr, *stages = nullptr;
+             *sorted = nullptr, *plan = nullptr, *groupHead = nullptr, *stages = nullptr, *outHist = nullptr;
     size_t capacity = 0;  // positions per pass
     void release() {
-        for (uint32_t* q : {lists, heads, ranks, hist, binStart, sorted, plan, groupHead, stages}) {
+        for (uint32_t* q : {lists, heads, ranks, hist, binStart, sorted, plan, groupHead, stages, outHist}) {
             if (q) (void)hipFree(q);
         }
         *this = FtxScratch{};
@@ -166,6 +166,7 @@ struct spx_ctx {
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // option king_sort = 0 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
+    bool ftxFoldSort = true;       // option ftx_fold_sort: one-pass batches of the pipeline sort the MLP's order themselves
     uint32_t computeUnits = 0;
     uint32_t ftGridCap = 0;
     uint32_t updateGridCap = 0;  // the update kernels' own cap (heavier workgroups: fewer, longer-lived ones win)
@@ -570,6 +571,10 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
     }
     if (key == "ftx_fail_launch") {  // test hook: the k-th pass of the pipeline from now on "fails to launch" (-1: never)
         ctx->ftxFailLaunch = int(value);
+        return SPX_OK;
+    }
+    if (key == "ftx_fold_sort") {  // one-pass batches of the column-sliced pipeline: the MLP's output-bucket order from the pipeline's own sort (1) or spx_sort_* (0)
+        ctx->ftxFoldSort = value != 0;
         return SPX_OK;
     }
     if (key == "king_sort") {  // one-kernel path: walk the perspectives in king-bucket order (1) or as they come (0)
@@ -1027,12 +1032,14 @@ static bool ensureFtx(spx_ctx* ctx, FtxScratch& x, size_t passPositions, hipStre
     const size_t cap = std::min(ctx->maxBatch, kFtxMaxPositions);
     auto alloc = [&](uint32_t*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
     if (!alloc(x.lists, ftxListBytes(cap)) || !alloc(x.heads, 2 * cap * 16) ||
-        !alloc(x.ranks, 2 * cap * 4) || !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17) * 4) ||
+        !alloc(x.ranks, 2 * cap * 4) || !alloc(x.hist, kFtxBins * 4) || !alloc(x.binStart, (kFtxBins + 17 + 8) * 4) ||
+        !alloc(x.outHist, (kHistOut + 16) * 4) ||
         !alloc(x.sorted, (2 * cap + 128) * 16) || !alloc(x.plan, kFtxPlanWords * 4) ||
         !alloc(x.groupHead, ftxGroups(cap) * kFtxGroupHeadWords * 4) || !alloc(x.stages, ftxStageBytes(cap))) {
         return fail();
     }
     if (hipMemsetAsync(x.hist, 0, kFtxBins * 4, s) != hipSuccess) return fail();
+    if (hipMemsetAsync(x.outHist, 0, (kHistOut + 16) * 4, s) != hipSuccess) return fail();
     x.capacity = cap;
     return true;
 }
@@ -1073,7 +1080,10 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     // profiles/r04_sliced_pipeline_crossover.txt)
     const size_t sliceFrom = (ctx->ftGateRecord && !ctx->ftxMinForced) ? std::min(ctx->ftxMin, kFtxMinPositionsPipelined) : ctx->ftxMin;
     const bool sliced = !tiny && n >= sliceFrom && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), s);
-    int rc = tiny ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, sliced);
+    // a one-pass batch of the pipeline gets the MLP's output-bucket order from the pipeline's own sort (FtxParams::posOrder): no
+    // spx_sort_* launches (option ftx_fold_sort = 0: as before)
+    const bool foldSort = sliced && ctx->ftxFoldSort && n <= scratch.capacity;
+    int rc = (tiny || foldSort) ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, sliced);
     if (rc != SPX_OK) return rc;
     if (ev) SPX_HIP(hipEventRecord(ev[1], s));
     if (sliced) {
@@ -1097,6 +1107,10 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             xp.stages = scratch.stages;
             xp.hiMask = ctx->dHiMask;
             xp.ftOut = ctx->dFtOut + lo * size_t(kL1);
+            xp.posOrder = foldSort ? ctx->dPosOrder : nullptr;
+            xp.outCounts = scratch.outHist + kHistOut + 8;  // (the 8 words behind the counts the MLP reads)
+            xp.mlpHist = scratch.outHist;
+            if (foldSort) ctx->histUsed = scratch.outHist;
             if (!ctx->hotCalibrated && ctx->hotAutoCalibrate) {
                 // the first big batch of this context chooses the hot set: one extra extraction + a histogram, and the host WAITS for
                 // them (and for the context's other streams) inside this call. A stream that is being captured into a hipGraph must
@@ -1128,6 +1142,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
                 (void)hipGetLastError();
                 ctx->ftxUnavailable = true;
                 SPX_HIP(hipMemsetAsync(scratch.hist, 0, kFtxBins * 4, s));
+                SPX_HIP(hipMemsetAsync(scratch.outHist, 0, (kHistOut + 16) * 4, s));
                 if (ev) ctx->profUsed -= kProfEventsPerCall;
                 return spx_eval_full_device(ctx, d_positions, n, d_out, stream);
             }

@@ -112,7 +112,7 @@ struct FtxParams {
     uint32_t* heads;         // [2 n][4]
     uint32_t* ranks;         // [2 n] rank inside the key's bin
     uint32_t* hist;          // [kFtxBins] counts per key; zero on entry of the rank kernel, zeroed again by the plan kernel
-    uint32_t* binStart;      // [kFtxBins + 17] first sorted position of each bin; then bucketStart[17]
+    uint32_t* binStart;      // [kFtxBins + 17 + 8] first sorted position of each bin; then bucketStart[17]; then the output buckets' starts in posOrder
     uint32_t* sorted;        // [2 n + 128][4]
     uint32_t* plan;          // [kFtxPlanWords]
     uint32_t* groupHead;     // [(2 n + 128) / 8][kFtxGroupHeadWords]
@@ -125,6 +125,13 @@ struct FtxParams {
     uint32_t hotRows;        // rows of the hot set (0: none - every row is fetched through the texture path)
     uint32_t coldShift;      // sort key: global quartets >> this (1 for nets / sets with long cold sections)
     const uint8_t* hiMask;   // [kPsqRows] slices in which a piece-square row's high-byte plane is not all zero
+    // The MLP's output-bucket order of a ONE-PASS batch, folded into this pipeline (round 6: two sort launches less per step): the
+    // extraction leaves a position's bucket in its heads' fourth word, the rank kernel ranks the positions inside their bucket, the
+    // plan kernel turns the counts into starts (and into the counts spx_mlp_kernel maps its tiles from), the scatter kernel writes
+    // the order. posOrder == nullptr: not wanted (multi-pass calls sort over the whole call, spx_sort_*)
+    uint32_t* posOrder;      // [n] out: position ids grouped by output bucket
+    uint32_t* outCounts;     // [8] zero on entry; zeroed again by the plan kernel
+    uint32_t* mlpHist;       // [kHistOut + 8] out: the counts at [kHistOut + bucket]
 };
 
 inline size_t ftxListBytes(size_t n) { return 2 * n * size_t(kFtxListStride) * 4; }

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * kExtractWaves, 2) void spx_ftx_extract_kernel(
                 head[1] = 2 * pos + ((c == b.stm) ? 0u : 1u);  // stm half first (nnue_state.cpp:396-438)
                 const uint32_t globalQ = (nHi + 3) / 4 + (nCold + 3) / 4, ldsQ = (nPsq + nHot + 3) / 4;
                 head[2] = ftxSortKey(bucket, globalQ, ldsQ, p.coldShift);
-                head[3] = 0;
+                head[3] = min((uint32_t(popc64(b.occ)) - 2u) / 4u, 7u);  // output bucket (MaterialCount<8>, output.h:44-55): FtxParams::posOrder
                 *reinterpret_cast<u32x4*>(p.heads + 4 * size_t(q)) = head;
             }
         }
@@ -294,20 +294,27 @@ __global__ __launch_bounds__(1024) void spx_ftx_rank_kernel(FtxParams p) {
 #if SPX_CORUNNER_PRIO
     __builtin_amdgcn_s_setprio(SPX_CORUNNER_PRIO);  // (A/B: the kernels that run beside the gather ask for issue priority)
 #endif
-    __shared__ uint32_t sCount[kFtxBins], sBase[kFtxBins];
+    __shared__ uint32_t sCount[kFtxBins], sBase[kFtxBins], sOut[8], sOutBase[8];
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) sCount[k] = 0;
+    if (threadIdx.x < 8) sOut[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, nPersp = 2 * p.nPositions;
-    uint32_t key = 0, local = 0;
-    const bool mine = q < nPersp;
+    uint32_t key = 0, local = 0, outKey = 0, outLocal = 0;
+    const bool mine = q < nPersp, ranksOut = mine && p.posOrder && !(q & 1u);  // (a position's first perspective speaks for it)
     if (mine) key = p.heads[4 * size_t(q) + 2];
     if (mine) local = atomicAdd(&sCount[key], 1u);
+    if (ranksOut) {
+        outKey = p.heads[4 * size_t(q) + 3] & 7u;
+        outLocal = atomicAdd(&sOut[outKey], 1u);
+    }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kFtxBins; k += blockDim.x) {
         if (sCount[k]) sBase[k] = atomicAdd(&p.hist[k], sCount[k]);
     }
+    if (threadIdx.x < 8 && sOut[threadIdx.x]) sOutBase[threadIdx.x] = atomicAdd(&p.outCounts[threadIdx.x], sOut[threadIdx.x]);
     __syncthreads();
     if (mine) p.ranks[q] = sBase[key] + local;
+    if (ranksOut) p.heads[4 * size_t(q) + 3] = outKey | ((sOutBase[outKey] + outLocal) << 3);  // (read again by the scatter kernel)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -374,7 +381,15 @@ __global__ __launch_bounds__(kPlanThreads) void spx_ftx_plan_kernel(FtxParams p)
         if (hole < sBucketStart[b + 1]) reinterpret_cast<u32x4*>(p.sorted)[hole] = u32x4{0u, 0xFFFFFFFFu, 0u, 0u};
     }
     if (tid < 17) p.binStart[kFtxBins + tid] = sBucketStart[tid];
+    if (p.posOrder && tid < 8) {  // the MLP's output buckets: counts for its tile map, starts for the scatter kernel
+        uint32_t start = 0;
+        for (uint32_t b2 = 0; b2 < tid; ++b2) start += p.outCounts[b2];
+        const uint32_t count = p.outCounts[tid];
+        p.mlpHist[kHistOut + tid] = count;
+        p.binStart[kFtxBins + 17 + tid] = start;
+    }
     __syncthreads();
+    if (p.posOrder && tid < 8) p.outCounts[tid] = 0;  // (ready for the next batch's rank kernel; every thread above has read them)
 
     // Cost of a group = the steps of its last valid perspective's bin (ftxBinCost: global steps count double; bins ascend inside a
     // bucket, global quartets first - the section every member pads to the group's longest) + a constant for the group's fixed work -
@@ -496,6 +511,7 @@ __global__ void spx_ftx_scatter_kernel(FtxParams p) {
     if (q >= 2 * p.nPositions) return;
     const u32x4 head = *reinterpret_cast<const u32x4*>(p.heads + 4 * size_t(q));
     reinterpret_cast<u32x4*>(p.sorted)[p.binStart[head[2]] + p.ranks[q]] = u32x4{head[0], head[1], q * (kFtxListStride * 4u), q};
+    if (p.posOrder && !(q & 1u)) p.posOrder[p.binStart[kFtxBins + 17 + (head[3] & 7u)] + (head[3] >> 3)] = q >> 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 
 namespace spx {
 
+constexpr int kHistOut = 256;      // where a sort-histogram buffer holds the 8 output-bucket counts the MLP maps its tiles from
 constexpr int kHistWords = 1024;  // one sort-histogram buffer (counts + cursors for up to 256 first keys and 8 output keys)
 
 constexpr size_t kAccSlotBytes = 2 * 1024 * 2;  // one arena slot: 2 perspectives x i16[1024] (psq + threat combined)

@@ -910,7 +910,7 @@ constexpr int kPairKeys = 256;  // capacity of the first-key histogram (16 king 
 constexpr int kOutKeys = 8;
 // hist layout (kHistWords u32 words per buffer): [0, 256) first-key counts (16 king keys or 256 pair keys),
 // [256, 264) output-bucket counts, [512, 768) first-key cursors, [768, 776) output-bucket cursors
-constexpr int kHistOut = 256, kCursorKing = 512, kCursorOut = 768;
+constexpr int kCursorKing = 512, kCursorOut = 768;  // (kHistOut = 256: spx_kernels.h)
 
 __global__ __launch_bounds__(256) void spx_sort_hist_kernel(SortParams p) {
 #if SPX_CORUNNER_PRIO

@@ -91,6 +91,25 @@ def test_random_positions_bit_exact(sp, oracle, net_blob, path_states, preset, p
     assert len(set(want.tolist())) > (500 if preset == "realistic" else 1000)  # the batch is not degenerate (the heavy-tailed net spreads evals less)
 
 
+@pytest.mark.parametrize("n", [16384, 20011, 65536])
+def test_the_pipeline_sorts_the_mlps_order_itself(sp, oracle, net_blob, n):
+    """Round 6: a one-pass batch of the column-sliced pipeline gets the MLP's output-bucket order (output.h:44-55) from the
+    pipeline's own counting sort - the extraction notes the bucket, the rank / plan / scatter kernels order the positions - instead of
+    two spx_sort_* launches (option ftx_fold_sort = 0). Same scores either way, and the oracle's; every output bucket occurs."""
+    pos = sp.random_positions(n, seed=4242, min_ply=0, max_ply=200, dfrc_every=3)
+    with _state_with_options(sp, net_blob("wild"), {"ftx_fold_sort": 1}, max_batch=n) as folded, \
+            _state_with_options(sp, net_blob("wild"), {"ftx_fold_sort": 0}, max_batch=n) as plain:
+        assert folded.takes_sliced_pipeline(n)
+        got = folded.evaluate_once(pos)
+        assert np.array_equal(got, plain.evaluate_once(pos))
+        assert np.array_equal(folded.evaluate_once(pos[: n - 77]), got[: n - 77])  # (the counters are back at zero for the next batch)
+    buckets = {(bin(int(o)).count("1") - 2) // 4 for o in pos["occupancy"][:4000]}
+    assert len(buckets) >= 7
+    mail, stm = sp.positions_to_mailboxes(pos[:2500])
+    oracle.use(net_blob("wild"), "wild")
+    assert np.array_equal(got[:2500], oracle.eval_mailboxes(mail, stm))
+
+
 def test_ft_activations_bit_exact(sp, oracle, net_blob, states):
     """Localises failures: the feature-transformer kernel's u8 activations vs activateFt (multilayer.h:92-152)."""
     oracle.use(net_blob("extreme"), "extreme")
