@@ -23,7 +23,8 @@
 //   spx_ftx_extract_kernel  one wave per POSITION: board decode, attack sets and the feature candidates once, the row lists of both
 //                           perspectives (nnue_state.cpp:309-354, 440-449) to HBM - LDS section (piece-square rows, hot rows),
 //                           high-byte planes, cold rows -, a head and a sort key (king bucket, global quartets, LDS quartets)
-//   spx_ftx_rank_kernel     counting sort, part 1: rank of every perspective inside its key's bin
+//   spx_ftx_rank_kernel     counting sort, part 1: rank of every perspective inside its key's bin (and, round 6, of every position
+//                           inside its OUTPUT bucket: a one-pass batch gets the MLP's order - posOrder - from this sort as well)
 //   spx_ftx_plan_kernel     bin starts (each bucket padded to whole groups of 8), and the PLAN: the groups cut into 32
 //                           contiguous, equally heavy ranges - one per CU of an XCD -, each a list of one-bucket segments
 //   spx_ftx_scatter_kernel  counting sort, part 2: every perspective's head at its place in the sorted order
@@ -31,12 +32,13 @@
 //                           stages of 8 steps x 8 perspectives x 4 rows (1 KiB each, padded with the zero row, sections stage-aligned)
 //   spx_ftx_gather_kernel   256 workgroups of 16 waves (workgroup b on XCD b % 8 = slice b % 8, CU slot b / 8): per segment
 //                           the bucket's piece-square slab slice into LDS (the hot rows' slice once), then one wave per group:
-//                           stages through its own 1 KiB of LDS, steps walked in pairs without a branch, 2 perspectives x 4 rows
+//                           stages through its own 1 KiB of LDS, steps walked in pairs as a rolling window, 2 perspectives x 4 rows
 //                           x 128 B per wave load / LDS read, one MFMA each, pairwise activation (multilayer.h:92-152) from the
 //                           i32 sums, outputs transposed through the stage: 8 bytes per lane.
 // (Round 4 also built the INCREMENTAL path on the same tables - spx_ftu_derive_kernel -> rank / plan / scatter ->
 // spx_ftu_apply_kernel -: bit-exact and slower than spx_update_kernel, 1.32 vs 2.15e8 updates+evals/s; retired in round 5 to
 // experiments/r04_incremental_pipeline_column_sliced.hip.txt.)
+// Round 6: the walk of a stage after a look at its ISA (walkStage), high-byte planes dropped per column slice (hiMask).
 // Results are bit-identical to spx_ft_kernel (sums of rows mod 2^16; tests/test_gpu_parity.py runs both).
 #include <hip/hip_runtime.h>
 

@@ -1164,10 +1164,9 @@ __global__ __launch_bounds__(256, kTiling == kMlpTileSorted ? SPX_MLP_SORTED_WAV
     const int32_t l3Weight = p.l3W[bucket * kL3 + lane];
     const int32_t l3Bias = p.l3B[bucket];
     // L2 weights of this lane's output: [bucket][input quartet][o][4] (relayoutL2), one 16-byte load per four inputs. The small
-    // tilings hold all 64 in registers; the big-batch tiling STREAMS them, a quartet ahead of its use (round 6): with the 64 registers
-    // gone the kernel fits 6 waves per SIMD instead of 4, and the 4 100-odd tile waves of a 65 536-position batch - 4 096 full tiles
-    // plus every bucket's partial one - are resident AT ONCE; at 4 waves per SIMD the chip holds 4 096, the handful left over ran as a
-    // second generation behind the first, and the kernel took two tile latencies (35.5 us) for one generation's worth of work.
+    // tilings hold all 64 in registers; the big-batch tiling STREAMS them, a quartet ahead of its use (round 6: 16 loads per tile
+    // instead of 64 four-byte ones, 64 registers less; alone 37.6 -> 28 us per 65 536 positions, and the gather this kernel runs
+    // beside 327 -> 305 us). More resident waves do NOT help it (5 / 6 waves per SIMD: 31.7 / 36.5 us): DESIGN.md 4.9c.
     constexpr bool kStreamW2 = kTiling == kMlpTileSorted;
     const i32x4* const w2q = reinterpret_cast<const i32x4*>(p.l2W) + size_t(bucket) * (kL2Full / 4) * kL3 + lane;
     i32x4 w2[kStreamW2 ? 1 : kL2Full / 4];
