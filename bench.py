@@ -992,7 +992,10 @@ def main():
             ft_launch_s = ft_avg_s  # (the events' interval: all passes of a call; the walk above is scaled to the call)
             steps_g, steps_l = 8 * walk["cold_steps"] + walk["high_plane_steps_all_slices"], 8 * walk["lds_steps"]
             l1_instr = 4 * steps_g + 8 * walk["stages"] + 2 * 8 * walk["groups"]  # row loads + stage loads + (head load, output store)
-            lds_instr = 4 * steps_l + (steps_g + steps_l) + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"]  # rows, entries, stage + output passes
+            # rows; entries (round 6: one read per PAIR of steps of the LDS / cold sections - 16-bit entries -, one per step of the
+            # high-byte sections); stage + output passes
+            lds_instr = (4 * steps_l + (8 * (walk["cold_steps"] + walk["lds_steps"]) + 1) // 2 + walk["high_plane_steps_all_slices"]
+                         + 2 * 8 * walk["stages"] + 6 * 8 * walk["groups"])
             mfma_instr = 4 * (steps_g + steps_l)
             floors = {"texture_path": l1_instr * L1_CYCLES_PER_WAVE_LOAD / 256 / CLOCK_HZ,
                       "lds": lds_instr * LDS_CYCLES_PER_WAVE_READ / 256 / CLOCK_HZ,

@@ -90,10 +90,10 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
  * pass writes every perspective's row lists, a counting sort groups them by king bucket and length, and the gather - XCD x
  * reads slice x of every row, the bucket's piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.7 x
  * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's
- * tables (89 MB per context) and scratch - 9.3 KB per position of a pass of min(max_batch, 65 536) positions: 4.6 KB of row lists
- * (2 x 576 words) and 4.6 KB of packed walks (the worst case of 18 one-KiB stages per group of 8 perspectives), i.e. ~610 MB per
+ * tables (89 MB per context) and scratch - 7.2 KB per position of a pass of min(max_batch, 65 536) positions: 4.6 KB of row lists
+ * (2 x 576 words) and 2.6 KB of packed walks (the worst case of 10 one-KiB stages per group of 8 perspectives), i.e. ~470 MB per
  * scratch set at full size; stream-ordered calls use the context's set, pipelined calls one per lane (option eval_lanes, default 3):
- * ~2.4 GB in all - are allocated on the first such batch; if that fails the one-kernel path serves it.
+ * ~1.9 GB in all - are allocated on the first such batch; if that fails the one-kernel path serves it.
  * SPX_CTX_ONE_KERNEL_FT (or option ftx = 0): never take the pipeline. SPX_CTX_SLICED_FT (or ftx = 1): take it (the default; kept
  * from round 4, when it was opt-in). SPX_CTX_WIDE_PSQ_ROWS implies SPX_CTX_ONE_KERNEL_FT. */
 enum { SPX_CTX_WIDE_PSQ_ROWS = 1, SPX_CTX_SLICED_FT = 2, SPX_CTX_ONE_KERNEL_FT = 4 };
@@ -197,7 +197,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
  * be valid when the call is made and stay untouched, like d_out, until the batch is done: *done_event (a hipEvent_t,
  * owned by the context, valid until two more async calls) or spx_ctx_synchronize(ctx). Results are bit-identical to
  * spx_eval_full_device. Allocates the lanes' scratch sets on first use (~1.1 KB per position of max_batch per lane, plus the
- * column-sliced pipeline's 9.3 KB per position of a pass where it runs - see spx_ctx_create_ex). */
+ * column-sliced pipeline's 7.2 KB per position of a pass where it runs - see spx_ctx_create_ex). */
 int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, void* d_out, void** done_event);
 /* waits for everything the context has enqueued on its own streams */
 int spx_ctx_synchronize(spx_ctx* ctx);

@@ -18,17 +18,21 @@ namespace spx {
 // slice x of row r = the 128 columns {64 x .. 64 x + 63} U {512 + 64 x ..} of the row, as 8 chunks of 16 bytes; byte m of
 // chunk t is column 64 x + 8 t + 2 (m >> 2) + (m & 1) (+ 512 if m & 2): a lane of the gather that ends up with D register
 // pairs (0, 1) / (2, 3) of chunk t holds columns (c, c + 1) and their pairwise partners (c + 512, c + 513).
-// rows: [0, 64368) threat / pawn-pair rows (i8 as in the net file); [64368, +11264) piece-square rows, LOW-byte plane
-// l = int8(w) (the row itself when it fits i8); [75632, +11264) piece-square rows, HIGH-byte plane h = int8((w - l) >> 8)
-// (all zero for a row that fits i8); 86896: an all-zero row (list padding).
+// rows: [0, 64368) threat / pawn-pair rows (i8 as in the net file); [64369, +11264) piece-square rows, LOW-byte plane
+// l = int8(w) (the row itself when it fits i8); [75633, +11264) piece-square rows, HIGH-byte plane h = int8((w - l) >> 8)
+// (all zero for a row that fits i8); an all-zero row (list padding) behind the threat rows and one at the very end.
 // hiMask[piece-square row] (round 6): bit x = the row's high-byte plane has a non-zero byte in slice x. A heavy-tailed net's wide rows
 // mostly have a handful of weights outside i8 (the `realistic` preset: 4 282 of its 6 553 wide rows have <= 8), so a row's plane is
 // all zero in most slices: the gather of XCD x drops those rows from its walk (spx_ftx_gather_kernel: the high-byte stage is
 // compacted per slice; 108 -> 92 row loads per position on that net, tools/sim_hi_slices.py).
-constexpr uint32_t kFtxPsqLoBase = kThreatRows;
-constexpr uint32_t kFtxPsqHiBase = kThreatRows + kPsqRows;
-constexpr uint32_t kFtxZeroRow = kThreatRows + 2 * kPsqRows;
+// (round 6: a second all-zero row right behind the threat rows, at an index that fits 16 bits - the padding of the COLD sections, whose
+// walk entries are 16-bit row indices)
+constexpr uint32_t kFtxColdZeroRow = kThreatRows;
+constexpr uint32_t kFtxPsqLoBase = kThreatRows + 1;
+constexpr uint32_t kFtxPsqHiBase = kFtxPsqLoBase + kPsqRows;
+constexpr uint32_t kFtxZeroRow = kFtxPsqHiBase + kPsqRows;
 constexpr uint32_t kFtxRows = kFtxZeroRow + 1;
+static_assert(kFtxColdZeroRow < 65536, "cold walk entries are 16-bit row indices");
 constexpr uint32_t kFtxSliceStride = kFtxRows * 128u;
 constexpr size_t kFtxTableBytes = size_t(8) * kFtxSliceStride;
 constexpr uint32_t kFtxSlabRows = 704;  // piece-square rows of one king bucket: 88 KiB per slice, LDS resident in the gather
@@ -42,7 +46,7 @@ constexpr uint32_t kFtxSlabBytes = (kFtxSlabRows + 1) * 128;
 constexpr uint32_t kFtxHotRowsMax = 384;       // capacity of the tables; what a context uses: option ftx_hot_rows
 constexpr uint32_t kFtxHotRowsDefault = 256;   // slab 88.1 + hot 32 + ring 16 = 136.1 KiB: one 14 / 16 KiB co-runner workgroup fits beside it
 constexpr uint32_t kFtxHotHashWords = 1024;    // the extraction's LDS copy of the set: 256 buckets x 4 entries
-constexpr uint32_t kFtxRingBytesPerWave = 1024 + 64;  // one stage of 8 steps x 8 perspectives x 4 entries + the group's head
+constexpr uint32_t kFtxRingBytesPerWave = 1024 + 64;  // one stage (16 steps x 8 perspectives x 4 entries of 16 bits; high-byte planes: 8 steps of 32-bit entries) + the group's head
 
 // ---- per-perspective lists written by the extraction pass: [perspective][kFtxListStride] words ----
 // [0, 288) the LDS section: the piece-square rows ((row - 704 bucket) * 128, into the slab), then the HOT threat / pawn-pair rows
@@ -69,21 +73,25 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 // ---- sorted[position in the sorted order] = {head word 0, output slot (~0 = hole), list offset in bytes, -} ----
 // ---- the packed walk of a group of 8 neighbours of that order (spx_ftx_pack_kernel; what the gather reads) ----
 // A group's walk has three SECTIONS - high-byte planes (global), the LDS section, cold rows (global) -, each as long as the
-// longest of the 8 lists there (in quartets of rows = steps), cut into STAGES of 8 steps. groupHead[G] = 16 words: {hiQ | ldsQ << 8
-// | coldQ << 16, output slots of the 8 perspectives (~0 = hole), then what the group costs (spx_debug_ftx_walk sums these): stages, global
-// steps and LDS steps as walked (pairs: odd sections walk one step of zero rows), rows through the texture path (high planes +
-// cold), rows from LDS, -}; words 10 / 12 count the COLD section only, 14 / 15 the high-byte section as packed (steps, rows): what an XCD
-// walks of it after dropping the planes that are zero in its slice is smaller (spx_debug_ftx_walk recounts it on the host). stages[G][q] = 256 words, stage q in the order of the
-// sections: word 32 k + 4 e + pr = the row (byte offset, as in the lists) that row kb of step k adds to perspective 2 pr + u,
-// e = 2 kb + u; rows past a list's end are the section's all-zero row; a high-byte plane's entry carries the row's hiMask in bits
-// 24-31 (the all-zero row: 0). Every XCD's gather walks every group: packing once what
-// round 4 made each of the eight find out for itself (section boundaries per lane, list gathers, padding) took 40 % of the
-// gather's instructions off it (profiles/r05_gather_anatomy.txt).
+// longest of the 8 lists there (in quartets of rows = steps), cut into STAGES of 1 KiB. groupHead[G] = 16 words: {hiQ | ldsQ << 8
+// | coldQ << 16, output slots of the 8 perspectives (~0 = hole), then what the group costs (spx_debug_ftx_walk sums these): stages, steps
+// of the cold and of the LDS section as walked, rows through the texture path (high planes + cold), rows from LDS, -}; words 10 / 12 count
+// the COLD section only, 14 / 15 the high-byte section as packed (steps, rows): what an XCD walks of it after dropping the planes that are
+// zero in its slice is smaller (spx_debug_ftx_walk recounts it on the host). stages[G][q], stage q in the order of the sections:
+//   * high-byte section: 8 steps a stage, 256 words: word 32 k + 4 e + pr = the plane (slice byte offset | the row's hiMask << 24) that
+//     row kb of step k adds to perspective 2 pr + u, e = 2 kb + u; behind a list's end the end-of-table zero row (mask 0);
+//   * LDS and cold sections (round 6): SIXTEEN steps a stage, 512 halfwords: halfword ((k >> 1) * 8 + e) * 8 + (k & 1) * 4 + pr = the
+//     row index from the section's base (the gather's LDS: slab row or 705 + hot slot; the slice: threat row) - the 16 bytes lane e
+//     of the gather reads for a PAIR of steps -, behind a list's end the section's zero row (704 / kFtxColdZeroRow). A stage with an
+//     odd number of steps holds them in steps 1 .. n behind one step of padding (the walk enters it through its second half).
+// Every XCD's gather walks every group: packing once what round 4 made each of the eight find out for itself (section boundaries
+// per lane, list gathers, padding) took 40 % of the gather's instructions off it (profiles/r05_gather_anatomy.txt); the 16-bit
+// entries halve the gather's entry reads and stage loads and this kernel's stores.
 #ifndef SPX_FTX_WALK
 #define SPX_FTX_WALK 6  // A/B: 6 = round 6's walk of a stage (halves fenced, odd sections without a step of zero rows, entries read one half ahead), 5 = round 5's
 #endif
 constexpr bool kFtxOddSteps = SPX_FTX_WALK >= 6;  // (what the walk statistics count)
-constexpr uint32_t kFtxMaxStages = 1 + 9 + 8;  // <= 32 high planes, <= 32 + 256 LDS rows, <= 256 cold rows
+constexpr uint32_t kFtxMaxStages = 1 + 5 + 4;  // <= 32 high planes (8 steps a stage), <= 32 + 256 LDS rows, <= 256 cold rows (16 steps a stage)
 constexpr uint32_t kFtxGroupHeadWords = 16;
 
 // ---- plan: [0, 33) first segment of CU slot c ([32] = number of segments); [33] number of groups; from word 64:

@@ -96,8 +96,8 @@ __global__ void spx_ftx_build_table_kernel(const uint8_t* thrU8, const int16_t* 
             // inverse of relayoutThreatRow: column c sits in lane l = (c & 511) >> 3 at byte k(j) (+ 8 for the upper half)
             const uint32_t l = (c & 511u) >> 3, j = c & 7u, k = (j & 4u) | ((j & 1u) << 1) | ((j & 2u) >> 1);
             v = int(thrU8[size_t(r) * kL1 + 16 * l + (c >= 512 ? 8 : 0) + k] ^ 0x80u);
-        } else if (r < kFtxZeroRow) {
-            const uint32_t row = (r - kThreatRows) % kPsqRows;
+        } else if (r >= kFtxPsqLoBase && r < kFtxZeroRow) {
+            const uint32_t row = (r - kFtxPsqLoBase) % kPsqRows;
             const int w = psqW[size_t(row) * kL1 + c];
             const bool fits = (lut[kLutCompactBase + (row >> 5)] >> (row & 31)) & 1u;  // (then l = w, h = 0)
             const int lo = int(int8_t(uint8_t(w & 0xFF)));
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
     uint32_t* gh = p.groupHead + size_t(G) * kFtxGroupHeadWords;
     if (lane == 0) gh[0] = dims;
     if (ks == 0) gh[1 + g] = head[1];
-    const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
+    const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 15) >> 4, Q = H + L + ((coldQ + 15) >> 4);
     uint32_t* out = p.stages + size_t(G) * (kFtxMaxStages * 256);
     {   // what the gather will walk, in the spare words of the group's head (spx_debug_ftx_walk sums them on the host: bench.py's
         // instruction counts. Six atomic adds per group on one cache line made this kernel the pipeline's longest - 0.4 ms)
@@ -567,46 +567,69 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
             gh[15] = rowsG >> 16;
         }
     }
-    // stage q: which section, where this lane's four rows sit in its list, how many of them there are
-    auto place = [&](uint32_t q, uint32_t& at, uint32_t& left, uint32_t& zero) {
-        // (arithmetic instead of three-way selects: the compiler turns those into lookup tables in scratch / LDS - 14 KB of it)
-        const uint32_t isLds = (q >= H && q < H + L) ? 1u : 0u, isCold = q >= H + L ? 1u : 0u, isHi = 1u - isLds - isCold;
-        const uint32_t s = q - isLds * H - isCold * (H + L);
-        const uint32_t count = (head[0] >> (6u * isLds + 15u * isCold)) & (0x3Fu | ((0u - (isLds | isCold)) & 0x1C0u));
-        const uint32_t base = isHi * kFtxListHi + isLds * kFtxListLds + isCold * kFtxListCold;
-        const uint32_t first = 4 * (8 * s + ks);
-        zero = isLds ? kFtxSlabRows * 128u : kFtxZeroRow * 128u;  // (the slab's zero row / the table's)
-        left = count > first ? count - first : 0u;
-        at = head[2] + 4 * (base + first);
-    };
     const uint8_t* lists = reinterpret_cast<const uint8_t*>(p.lists);
-    // the next stage's lists travel while this one is written; a stage passes through LDS so that it leaves as ONE coalesced 1 KiB
-    // store (beside a gather every vector-memory instruction queues behind the gather's row loads)
-    uint32_t at, left, zero;
-    u32x4 next = {0, 0, 0, 0};
-    if (Q > 0) {
-        place(0, at, left, zero);
-        if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
-    }
-    for (uint32_t q = 0; q < Q; ++q) {
-        u32x4 v = next;
-        const uint32_t leftNow = left, zeroNow = zero;
-        if (q + 1 < Q) {
-            place(q + 1, at, left, zero);
-            next = u32x4{0, 0, 0, 0};
-            if (left) next = *reinterpret_cast<const u32x4*>(lists + at);
-        }
-        if (q < H) {  // a high-byte plane's entry says in which slices the plane is not all zero (bits 24-31; the entry itself < 2^24)
+    // ---- the high-byte section: stages of 8 steps, 32-bit entries (slice offset | hiMask << 24): the gather compacts them per slice ----
+    for (uint32_t q = 0; q < H; ++q) {
+        const uint32_t first = 4 * (8 * q + ks), left = cHi > first ? cHi - first : 0u;
+        u32x4 v = {0, 0, 0, 0};
+        if (left) v = *reinterpret_cast<const u32x4*>(lists + head[2] + 4 * (kFtxListHi + first));
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                if (leftNow > i) v[i] |= uint32_t(p.hiMask[(v[i] >> 7) - kFtxPsqHiBase]) << 24;
-            }
+        for (uint32_t i = 0; i < 4; ++i) {  // in which slices the plane is not all zero (bits 24-31; the entry itself < 2^24)
+            if (left > i) v[i] |= uint32_t(p.hiMask[(v[i] >> 7) - kFtxPsqHiBase]) << 24;
         }
         uint32_t* st = &sStage[wave][fillAt];
-        st[0] = leftNow > 0 ? v[0] : zeroNow;
-        st[8] = leftNow > 1 ? v[1] : zeroNow;
-        st[16] = leftNow > 2 ? v[2] : zeroNow;
-        st[24] = leftNow > 3 ? v[3] : zeroNow;
+        st[0] = left > 0 ? v[0] : kFtxZeroRow * 128u;
+        st[8] = left > 1 ? v[1] : kFtxZeroRow * 128u;
+        st[16] = left > 2 ? v[2] : kFtxZeroRow * 128u;
+        st[24] = left > 3 ? v[3] : kFtxZeroRow * 128u;
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 line = *reinterpret_cast<const u32x4*>(&sStage[wave][4 * lane]);
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4*>(out + size_t(q) * 256 + 4 * lane) = line;
+    }
+    // ---- the LDS section and the cold section: stages of SIXTEEN steps, 16-bit entries = row index from the section's base (the
+    // gather's LDS / the slice), spx_ftx.h. This lane carries steps ks and ks + 8 of perspective g: two 16-byte pieces of its list.
+    // The next stage's pieces travel while this one is written; a stage passes through LDS so that it leaves as ONE coalesced 1 KiB
+    // store (beside a gather every vector-memory instruction queues behind the gather's row loads)
+    // (a stage with an ODD number of steps - a section's last - holds them in its steps 1 .. n, behind a step of padding the gather
+    // does not fetch: its walk takes the steps in aligned pairs and enters an odd stage through the second half of the first pair)
+    auto place = [&](uint32_t q, uint32_t c, uint32_t& at, uint32_t& left) {
+        const uint32_t isCold = q >= H + L ? 1u : 0u, s = q - H - isCold * L;
+        const uint32_t shift = min((isCold ? coldQ : ldsQ) - 16 * s, 16u) & 1u, k = ks + 8 * c;
+        const uint32_t count = isCold ? cCold : cLds, first = 4 * (16 * s + k - shift);
+        left = (k >= shift && count > first) ? count - first : 0u;
+        at = head[2] + 4 * ((isCold ? kFtxListCold : kFtxListLds) + first);
+    };
+    uint32_t at[2] = {0, 0}, left[2] = {0, 0};
+    u32x4 next[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (Q > H) {
+#pragma unroll
+        for (uint32_t c = 0; c < 2; ++c) {
+            place(H, c, at[c], left[c]);
+            if (left[c]) next[c] = *reinterpret_cast<const u32x4*>(lists + at[c]);
+        }
+    }
+    uint16_t* const sHalf = reinterpret_cast<uint16_t*>(sStage[wave]);
+    const uint32_t u = g & 1u, pr = g >> 1;
+    for (uint32_t q = H; q < Q; ++q) {
+        const u32x4 v[2] = {next[0], next[1]};
+        const uint32_t leftNow[2] = {left[0], left[1]};
+        const uint32_t zero = q >= H + L ? kFtxColdZeroRow : kFtxSlabRows;  // (the table's zero row behind the threat rows / the slab's)
+        if (q + 1 < Q) {
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                place(q + 1, c, at[c], left[c]);
+                next[c] = u32x4{0, 0, 0, 0};
+                if (left[c]) next[c] = *reinterpret_cast<const u32x4*>(lists + at[c]);
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 2; ++c) {
+            const uint32_t k = ks + 8 * c;  // halfword ((k >> 1) * 8 + 2 kb + u) * 8 + (k & 1) * 4 + pr: row kb of step k, perspective 2 pr + u
+            uint16_t* st = sHalf + ((k >> 1) * 8 + u) * 8 + (k & 1u) * 4 + pr;
+#pragma unroll
+            for (uint32_t kb = 0; kb < 4; ++kb) st[16 * kb] = uint16_t(leftNow[c] > kb ? v[c][kb] >> 7 : zero);
+        }
         __builtin_amdgcn_wave_barrier();
         const u32x4 line = *reinterpret_cast<const u32x4*>(&sStage[wave][4 * lane]);
         __builtin_amdgcn_wave_barrier();
@@ -732,6 +755,52 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
     add(wb);
 }
 
+// The same for the LDS and the cold sections, whose stages hold SIXTEEN steps of 16-bit entries (round 6; spx_ftx.h): one 16-byte LDS
+// read brings the entries of a PAIR of steps (words 0, 1: the four rows of step 2 p, perspectives 2 pr + u; words 2, 3: step 2 p + 1) -
+// half the entry reads of the 32-bit form, half the stage loads and the pack kernel's stores. A row's address is base + (entry << 7)
+// + the lane's 16 bytes. The window rolls as above; a pair's entries are read while the pair before it is added up; a stage with an
+// odd number of steps keeps them in steps 1 .. n and is entered through the second half of its first pair.
+template <bool kLds>
+__device__ __forceinline__ void walkStage16(uint32_t n, const uint32_t* stage, const uint8_t* ldsRows, const uint8_t* slice, uint32_t e,
+                                            uint32_t laneOff, const i32x4& sel, i32x4 (&d)[4]) {
+    auto entries = [&](uint32_t pair) { return *reinterpret_cast<const u32x4*>(stage + 4 * (8 * pair + e)); };
+    auto issue = [&](uint32_t lo, uint32_t hi, i32x4 (&w)[4]) {  // (lo: rows of perspectives u, 2 + u; hi: 4 + u, 6 + u)
+        const uint32_t off[4] = {((lo & 0xFFFFu) << 7) + laneOff, ((lo >> 16) << 7) + laneOff, ((hi & 0xFFFFu) << 7) + laneOff, ((hi >> 16) << 7) + laneOff};
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if constexpr (kLds) w[pr] = *reinterpret_cast<const i32x4*>(ldsRows + off[pr]);
+            else w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(off[pr]));
+        }
+    };
+    auto add = [&](const i32x4 (&w)[4]) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) d[pr] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, w[pr], d[pr], 0, 0, 0);
+    };
+    i32x4 wa[4], wb[4];
+    const uint32_t pairs = (n + 1) >> 1;
+    u32x4 en = entries(0), enN = entries(1);
+    if (n & 1u) {  // (an odd stage's first step is padding, spx_ftx_pack_kernel: zeros instead of four row fetches)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) wa[pr] = i32x4{0, 0, 0, 0};
+    } else {
+        issue(en[0], en[1], wa);
+    }
+    issue(en[2], en[3], wb);
+    for (uint32_t pair = 1; pair < pairs; ++pair) {  // the pair before is in flight, enN = this pair's entries
+        en = enN;
+        enN = entries(min(pair + 1, 7u));
+        __builtin_amdgcn_sched_barrier(0);
+        add(wa);
+        issue(en[0], en[1], wa);
+        __builtin_amdgcn_sched_barrier(0);
+        add(wb);
+        issue(en[2], en[3], wb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    add(wa);
+    add(wb);
+}
+
 }  // namespace
 
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kGatherWaves), amdgpu_waves_per_eu(SPX_FTX_GATHER_WAVES_PER_SIMD, 8))) void spx_ftx_gather_kernel(FtxParams p) {
@@ -788,7 +857,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
             __builtin_amdgcn_wave_barrier();
             const uint32_t dims = __builtin_amdgcn_readfirstlane(sHead[0]);
             const uint32_t hiQ = dims & 0xFFu, ldsQ = (dims >> 8) & 0xFFu, coldQ = dims >> 16;
-            const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 7) >> 3, Q = H + L + ((coldQ + 7) >> 3);
+            const uint32_t H = (hiQ + 7) >> 3, L = (ldsQ + 15) >> 4, Q = H + L + ((coldQ + 15) >> 4);
             const uint32_t nextG = G + kGatherWaves;
             const bool haveNext = nextG < gEnd;
             if (haveNext) headNext = headOfGroup(nextG);
@@ -834,13 +903,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * kGatherWaves, 64 * kG
                 if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;  // (the last stage's reads came first)
                 __builtin_amdgcn_wave_barrier();
                 prefetch(q);
-                walkStage<true>(min(ldsQ - 8 * (q - H), 8u), stage, sSlab, slice, e, laneOff, sel, d);
+                walkStage16<true>(min(ldsQ - 16 * (q - H), 16u), stage, sSlab, slice, e, laneOff, sel, d);
             }
             for (; q < Q; ++q) {
                 if (!(SPX_FTX_SKIP & 32)) *reinterpret_cast<u32x4*>(stage + 4 * lane) = ents;
                 __builtin_amdgcn_wave_barrier();
                 prefetch(q);
-                walkStage<false>(min(coldQ - 8 * (q - H - L), 8u), stage, sSlab, slice, e, laneOff, sel, d);
+                walkStage16<false>(min(coldQ - 16 * (q - H - L), 16u), stage, sSlab, slice, e, laneOff, sel, d);
             }
             if (Q == 0 && haveNext) ents = stageOfGroup(nextG, 0);  // (a group of records without a single piece: malformed input)
             // pairwise activation (multilayer.h:108-145) of this lane's two columns of perspectives 2 pr + u; the 2 output bytes go
