@@ -765,10 +765,16 @@ __device__ __forceinline__ void walkStage16(uint32_t n, const uint32_t* stage, c
                                             uint32_t laneOff, const i32x4& sel, i32x4 (&d)[4]) {
     auto entries = [&](uint32_t pair) { return *reinterpret_cast<const u32x4*>(stage + 4 * (8 * pair + e)); };
     auto issue = [&](uint32_t lo, uint32_t hi, i32x4 (&w)[4]) {  // (lo: rows of perspectives u, 2 + u; hi: 4 + u, 6 + u)
-        const uint32_t off[4] = {((lo & 0xFFFFu) << 7) + laneOff, ((lo >> 16) << 7) + laneOff, ((hi & 0xFFFFu) << 7) + laneOff, ((hi >> 16) << 7) + laneOff};
+        // offset = (16-bit entry << 7) + base: ONE v_mad_u32_u16 each (op_sel picks the half; as C the compiler spends 2-3 instructions)
+        uint32_t off[4];
+        const uint32_t base = kLds ? uint32_t(reinterpret_cast<uintptr_t>(ldsRows)) + laneOff : laneOff;
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(off[0]) : "v"(lo), "s"(128u), "v"(base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(off[1]) : "v"(lo), "s"(128u), "v"(base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(off[2]) : "v"(hi), "s"(128u), "v"(base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(off[3]) : "v"(hi), "s"(128u), "v"(base));
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-            if constexpr (kLds) w[pr] = *reinterpret_cast<const i32x4*>(ldsRows + off[pr]);
+            if constexpr (kLds) w[pr] = *reinterpret_cast<const __attribute__((address_space(3))) i32x4*>(off[pr]);
             else w[pr] = *reinterpret_cast<const i32x4*>(slice + size_t(off[pr]));
         }
     };
