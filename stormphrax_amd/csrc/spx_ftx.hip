@@ -999,8 +999,11 @@ hipError_t launchFtxBuildHiMask(const uint8_t* rowS, uint8_t* hiMask, hipStream_
     return hipGetLastError();
 }
 
+#ifndef SPX_FTX_EXTRACT_GRID
+#define SPX_FTX_EXTRACT_GRID 1024  // workgroups (8 waves each; A/B round 6: 512 and fewer lose 15 % pipelined - long-lived workgroups keep the next gather's off their CUs)
+#endif
 hipError_t launchFtxExtract(const FtxParams& p, hipStream_t stream) {
-    const uint32_t extractBlocks = min((p.nPositions + kExtractWaves - 1) / kExtractWaves, 256u * 4u);
+    const uint32_t extractBlocks = min((p.nPositions + kExtractWaves - 1) / kExtractWaves, uint32_t(SPX_FTX_EXTRACT_GRID));
     hipLaunchKernelGGL(spx_ftx_extract_kernel, dim3(extractBlocks), dim3(64 * kExtractWaves), 0, stream, p);
     return hipGetLastError();
 }
