@@ -86,7 +86,7 @@ int spx_ctx_create(const spx_net* net, int device, size_t max_batch, spx_ctx** o
 /* As spx_ctx_create, with option flags. SPX_CTX_WIDE_PSQ_ROWS: every piece-square row is gathered from the 2 KiB i16
  * table, i.e. the lossless "compact row" optimisation (1 KiB u8 copies of rows whose weights all fit i8) is off - what a
  * net whose piece-square weights do not fit i8 gets anyway; bench.py reports this configuration next to the default. */
-/* Full refreshes of 16 384 positions and more take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction
+/* Full refreshes of 10 240 positions and more (pipelined calls: 6 144) take the column-sliced pipeline (stormphrax_amd/csrc/spx_ftx.hip: an extraction
  * pass writes every perspective's row lists, a counting sort groups them by king bucket and length, and the gather - XCD x
  * reads slice x of every row, the bucket's piece-square slab sits in LDS, rows are added up on the matrix pipe - runs in 0.7 x
  * the one-kernel path's time); smaller ones the one-kernel path (spx_ft_kernel). Results are bit-identical. The pipeline's
@@ -123,7 +123,7 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  * in flight); SPX_OPTIONS="name=value,name=value" in the environment - the only environment variable the library reads besides
  * LOCAL_WORLD_SIZE (self-play's host-thread share per rank) - applies to every context the process creates. Unknown names / malformed values: SPX_ERR_INVALID_ARG.
  *   ftx 0|1                 big full refreshes through the column-sliced pipeline (as SPX_CTX_SLICED_FT / _ONE_KERNEL_FT)
- *   ftx_min N               smallest batch that takes it (default 16 384; 12 288 for pipelined calls)
+ *   ftx_min N               smallest batch that takes it (default 10 240; 6 144 for pipelined calls)
  *   ftx_hot_rows N          threat / pawn-pair rows the gather keeps in LDS beside the piece-square slab (default 256, at most 384)
  *   ftx_auto_calibrate 0|1  1 (default): the first big batch chooses that set (the host waits once inside that call); 0: only
  *                           spx_ctx_calibrate / spx_ctx_set_hot_rows do - until then the set is empty

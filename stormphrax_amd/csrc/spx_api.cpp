@@ -1072,13 +1072,15 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         ctx->profUsed += kProfEventsPerCall;
         SPX_HIP(hipEventRecord(ev[0], s));
     }
-    const bool tiny = n <= ctx->tinyBatchMax;  // a handful of positions: no sort launch, every position its own MLP tile
     // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
     // output-bucket order is sorted here
     FtxScratch& scratch = ctx->ftx;
-    // (pipelined calls - a lane's gate is set - gain from 12 Ki positions on, stream-ordered ones from 16 Ki:
-    // profiles/r04_sliced_pipeline_crossover.txt)
+    // (pipelined calls - a lane's gate is set - gain from 6 Ki positions on, stream-ordered ones from 10 Ki:
+    // profiles/r06_sliced_pipeline_small_batches.txt)
     const size_t sliceFrom = (ctx->ftGateRecord && !ctx->ftxMinForced) ? std::min(ctx->ftxMin, kFtxMinPositionsPipelined) : ctx->ftxMin;
+    // a handful of positions: no sort launch, every position its own MLP tile (a pipelined call that reaches the pipeline's
+    // threshold takes the pipeline, whatever tiny_batch_max says)
+    const bool tiny = n <= ctx->tinyBatchMax && !(ctx->ftGateRecord && n >= sliceFrom && ctx->ftxEnabled && !ctx->ftxUnavailable);
     const bool sliced = !tiny && n >= sliceFrom && ensureFtx(ctx, scratch, std::min(n, kFtxMaxPositions), s);
     // a one-pass batch of the pipeline gets the MLP's output-bucket order from the pipeline's own sort (FtxParams::posOrder): no
     // spx_sort_* launches (option ftx_fold_sort = 0: as before)

@@ -107,8 +107,11 @@ constexpr uint32_t kFtxSegmentCost = SPX_FTX_SEGMENT_COST;                  // p
 constexpr uint32_t kFtxPlanTimes = 64 + 3 * 64;            // per workgroup of the last gather: start / end timestamps (diagnostics)
 constexpr uint32_t kFtxPlanWords = kFtxPlanTimes + 4 * 256;
 
-constexpr size_t kFtxMinPositions = 16384;    // smaller full refreshes keep the one-kernel path (the paths cross at ~14 Ki: profiles/r04_sliced_pipeline_crossover.txt)
-constexpr size_t kFtxMinPositionsPipelined = 12288;  // ... of spx_eval_full_device_async (the preparation runs beside the other lane's gather)
+// smaller full refreshes keep the one-kernel path. Round 6 (profiles/r06_sliced_pipeline_small_batches.txt; rounds 4-5: 16 384 / 12 288):
+// stream-ordered calls cross at ~9.5 Ki positions (8 704 / 9 216: equal, 10 240: +5 %), pipelined calls - the preparation runs beside
+// the other lanes' gathers - gain from 6 Ki on (6 144: 1.04 against 0.87e8 evals/s, 8 192: 1.30 against 0.96, 10 240: 1.58 against 1.04)
+constexpr size_t kFtxMinPositions = 10240;
+constexpr size_t kFtxMinPositionsPipelined = 6144;
 constexpr size_t kFtxMaxPositions = 65536;    // positions per pass (scratch: ~2.6 KB each); larger batches walk in passes
 
 struct FtxParams {
