@@ -374,6 +374,16 @@ def timed_full_run(args, torch, group, state, d_pos, pipelined, n_outs=2, settle
     sync()
     elapsed = time.perf_counter() - t0
     sort_ms, ft_ms, mlp_ms, calls = state.profile_end()
+    if os.environ.get("SPX_BENCH_DIAG"):  # the last gather's own clock (workgroup start / end stamps) beside the events' interval
+        from stormphrax_amd import _lib
+        spans = []
+        for slot in ((0, 1, 2) if pipelined else (-1,)):
+            t = np.zeros(512, dtype=np.uint64)
+            if _lib.load().spx_debug_ftx_block_times(state._h, slot, t.ctypes.data) == 0:
+                start, end = t[0::2].astype(np.int64), t[1::2].astype(np.int64)
+                spans.append(round(float(end.max() - start.min()) / 100.0, 1))
+        print(f"[diag] gather span by its own clock (us) {spans}; events: ft {ft_ms / max(calls, 1) * 1e3:.1f} us, mlp {mlp_ms / max(calls, 1) * 1e3:.1f} us; "
+              f"step {elapsed / args.steps * 1e6:.1f} us", file=sys.stderr, flush=True)
     timed_full_run.prepare_ms = state.profile_prepare_ms() / max(calls / chunks, 1)  # per step; see spx_profile_last_prepare_ms
     prof = (sort_ms, ft_ms, mlp_ms, calls / chunks)  # per-kernel times per STEP (= per batch), as the byte counts are
     # per-rank view for the report (rank order): each rank's FT-kernel time is its own, free of the barrier wait

@@ -2458,7 +2458,7 @@ int spx_debug_ftx_walk(spx_ctx* ctx, int slot, uint32_t* out) {
                     longest = std::max(longest, kept[q]);
                     sums[7] += kept[q];
                 }
-                sums[6] += kFtxOddSteps ? (longest + 3) / 4 : (((longest + 3) / 4) + 1) & ~1u;  // (round 5: steps walked in pairs)
+                sums[6] += (longest + 3) / 4;
             }
         }
     }

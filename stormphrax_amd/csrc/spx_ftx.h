@@ -87,10 +87,6 @@ __host__ __device__ inline uint32_t ftxBinCost(uint32_t kk, uint32_t coldShift) 
 // Every XCD's gather walks every group: packing once what round 4 made each of the eight find out for itself (section boundaries
 // per lane, list gathers, padding) took 40 % of the gather's instructions off it (profiles/r05_gather_anatomy.txt); the 16-bit
 // entries halve the gather's entry reads and stage loads and this kernel's stores.
-#ifndef SPX_FTX_WALK
-#define SPX_FTX_WALK 6  // A/B: 6 = round 6's walk of a stage (halves fenced, odd sections without a step of zero rows, entries read one half ahead), 5 = round 5's
-#endif
-constexpr bool kFtxOddSteps = SPX_FTX_WALK >= 6;  // (what the walk statistics count)
 constexpr uint32_t kFtxMaxStages = 1 + 5 + 4;  // <= 32 high planes (8 steps a stage), <= 32 + 256 LDS rows, <= 256 cold rows (16 steps a stage)
 constexpr uint32_t kFtxGroupHeadWords = 16;
 

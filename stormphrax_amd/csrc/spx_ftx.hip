@@ -559,11 +559,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
         }
         if (lane == 0) {
             gh[9] = Q;
-            gh[10] = kFtxOddSteps ? coldQ : (coldQ + 1) & ~1u;
-            gh[11] = kFtxOddSteps ? ldsQ : (ldsQ + 1) & ~1u;
+            gh[10] = coldQ;
+            gh[11] = ldsQ;
             gh[12] = rowsG & 0xFFFFu;
             gh[13] = rowsL;
-            gh[14] = kFtxOddSteps ? hiQ : (hiQ + 1) & ~1u;  // as packed: an XCD walks what is left after dropping the planes that are zero in its slice
+            gh[14] = hiQ;  // as packed: an XCD walks what is left after dropping the planes that are zero in its slice
             gh[15] = rowsG >> 16;
         }
     }
@@ -661,7 +661,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spx_ftx_pack_kernel(FtxPa
 // hardware dispatcher - a slab reload per chunk, 18-34 % slower; s_setprio, a start gate, a high-priority stream - nothing or worse.)
 namespace {
 
-// one stage - n <= 8 steps of ONE section - of a group's walk: rows from LDS (kLds) or through the texture path. The steps run in
+// one stage - n <= 8 steps, 32-bit entries - of a group's walk (since the 16-bit entries of round 6: the HIGH-BYTE sections' stages, as
+// compacted per slice; the LDS and cold sections walk walkStage16 below): rows from LDS (kLds) or through the texture path. The steps run in
 // PAIRS as a rolling window: the loads of step k + 2 are issued right behind the MFMAs of step k, so four to eight loads are in
 // flight all the time, and the loop body has no branch. Round 5 padded an odd section with a step of zero rows (with a branch for the
 // odd step the compiler's s_waitcnt at the join wait for ALL loads and the accumulators travel through copies); round 6 enters the
@@ -693,7 +694,6 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
     };
     i32x4 wa[4], wb[4];
     u32x4 en;
-#if SPX_FTX_WALK >= 6
     // Round 6. (a) An odd section does NOT walk a step of zero rows: its first step goes to the window's second half while the first
     // holds zeros - four MFMAs that add nothing instead of four row loads / LDS reads of the all-zero row (tools/sim_gather_steps.py:
     // the padding to pairs was 7 % of the wave loads and 4 % of the LDS reads); both entries into the loop leave `wb` in flight LAST, so
@@ -734,23 +734,6 @@ __device__ __forceinline__ void walkStage(uint32_t n, const uint32_t* stage, con
         issue(en, wb);
         __builtin_amdgcn_sched_barrier(0);
     }
-#else
-    // (round 5: a section with an odd number of steps walks one more step of zero rows, and the compiler is free to cluster the
-    // loop's eight loads behind its eight MFMAs - it does)
-    const uint32_t nEven = (n + 1) & ~1u;
-    en = entries(0);
-    issue(en, wa);
-    en = entries(1);
-    issue(en, wb);
-    for (uint32_t k = 2; k < nEven; k += 2) {  // steps k - 2, k - 1 are in flight
-        en = entries(k);  // (asked for before the wait for step k - 2's rows)
-        add(wa);
-        issue(en, wa);
-        en = entries(k + 1);
-        add(wb);
-        issue(en, wb);
-    }
-#endif
     add(wa);
     add(wb);
 }
