@@ -129,6 +129,8 @@ int spx_ctx_calibrate(spx_ctx* ctx, const void* d_positions, size_t n);
  *                           spx_ctx_calibrate / spx_ctx_set_hot_rows do - until then the set is empty
  *   ftx_fold_sort 0|1       1 (default): a one-pass batch of that pipeline orders the positions for the MLP (by output bucket,
  *                           output.h:44-55) in the pipeline's own counting sort; 0: two sort launches of their own, as for every other batch
+ *   pace_events 0|1         1 (default): a pipelined call records an event (nobody reads it) at the five points where a profile
+ *                           would - with those records in the lanes' streams the pipeline settles into a 12 % faster steady state
  *   eval_lanes 2|3          scratch sets spx_eval_full_device_async rotates its batches over (default 3: the preparation of two
  *                           batches runs beside a gather)
  *   tiny_batch_max N        batches up to N positions skip the sorts (default 8 192)

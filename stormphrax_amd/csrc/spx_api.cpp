@@ -136,6 +136,7 @@ struct spx_ctx {
         int histCur = 0, refreshCur = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ftDone = nullptr, done = nullptr;
+        hipEvent_t pace[kProfEventsPerCall] = {};  // see spx_ctx::paceEvents
         bool ftRecorded = false;
         // staging of the chunked host-buffer call (allocated on its first use): device in/out + page-locked mirrors
         void *dIn = nullptr, *hIn = nullptr;
@@ -166,6 +167,12 @@ struct spx_ctx {
     uint32_t compactBits[kLutCompactWords] = {};  // host copy of the LUT's compact-row bitmap (spx_ctx_count_rows)
     bool kingSortEnabled = true;   // option king_sort = 0 walks perspectives in input order (A/B of the L2-locality sort)
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
+    // Pipelined calls record an event at the five points of a call where spx_profile_* would (round 6): measured on the sustained
+    // loop of tools/probes/sustained_rate.py, the three lanes settle into 2.12e8 evals/s with those records in their streams and into
+    // 1.89e8 without - the records keep a lane's small kernels from running ahead into the other lanes' gathers. Nobody reads them
+    // (option pace_events = 0: none, unless a profile is open).
+    hipEvent_t* paceEvents = nullptr;
+    bool paceEnabled = true;
     bool ftxFoldSort = true;       // option ftx_fold_sort: one-pass batches of the pipeline sort the MLP's order themselves
     uint32_t computeUnits = 0;
     uint32_t ftGridCap = 0;
@@ -573,6 +580,10 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
         ctx->ftxFailLaunch = int(value);
         return SPX_OK;
     }
+    if (key == "pace_events") {  // pipelined calls: an event record at the five points of a call where a profile would put one (1) or none (0)
+        ctx->paceEnabled = value != 0;
+        return SPX_OK;
+    }
     if (key == "ftx_fold_sort") {  // one-pass batches of the column-sliced pipeline: the MLP's output-bucket order from the pipeline's own sort (1) or spx_sort_* (0)
         ctx->ftxFoldSort = value != 0;
         return SPX_OK;
@@ -833,6 +844,9 @@ void spx_ctx_destroy(spx_ctx* ctx) {
         lane.ftx.release();
         if (lane.ftDone) (void)hipEventDestroy(lane.ftDone);
         if (lane.done) (void)hipEventDestroy(lane.done);
+        for (hipEvent_t e : lane.pace) {
+            if (e) (void)hipEventDestroy(e);
+        }
         if (lane.stream) (void)hipStreamDestroy(lane.stream);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1067,11 +1081,15 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     SPX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     hipEvent_t* ev = nullptr;
+    bool profiled = false;
     if (ctx->profUsed + kProfEventsPerCall <= ctx->profEvents.size()) {
         ev = &ctx->profEvents[ctx->profUsed];
         ctx->profUsed += kProfEventsPerCall;
-        SPX_HIP(hipEventRecord(ev[0], s));
+        profiled = true;
+    } else if (ctx->paceEvents && ctx->paceEnabled) {
+        ev = ctx->paceEvents;
     }
+    if (ev) SPX_HIP(hipEventRecord(ev[0], s));
     // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
     // output-bucket order is sorted here
     FtxScratch& scratch = ctx->ftx;
@@ -1145,7 +1163,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
                 ctx->ftxUnavailable = true;
                 SPX_HIP(hipMemsetAsync(scratch.hist, 0, kFtxBins * 4, s));
                 SPX_HIP(hipMemsetAsync(scratch.outHist, 0, (kHistOut + 16) * 4, s));
-                if (ev) ctx->profUsed -= kProfEventsPerCall;
+                if (profiled) ctx->profUsed -= kProfEventsPerCall;
                 return spx_eval_full_device(ctx, d_positions, n, d_out, stream);
             }
         }
@@ -1207,6 +1225,7 @@ static int ensureLanes(spx_ctx* ctx) {
         SPX_HIP(hipStreamCreateWithPriority(&lane.stream, hipStreamNonBlocking, priority));
         SPX_HIP(hipEventCreateWithFlags(&lane.ftDone, hipEventDisableTiming));
         SPX_HIP(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+        for (hipEvent_t& e : lane.pace) SPX_HIP(hipEventCreate(&e));
     }
     SPX_HIP(hipDeviceSynchronize());  // the memsets ran on the null stream, the lanes' streams do not wait for it
     ctx->lanesReady = true;
@@ -1274,9 +1293,11 @@ int spx_eval_full_device_async(spx_ctx* ctx, const void* d_positions, size_t n, 
         swapLane(ctx, lane);
         ctx->ftGateWait = other.ftRecorded ? other.ftDone : nullptr;
         ctx->ftGateRecord = lane.ftDone;
+        ctx->paceEvents = lane.pace;
         rc = spx_eval_full_device(ctx, static_cast<const char*>(d_positions) + lo * sizeof(spx_packed_pos), m,
                                   static_cast<int32_t*>(d_out) + lo, lane.stream);
         ctx->ftGateWait = ctx->ftGateRecord = nullptr;
+        ctx->paceEvents = nullptr;
         swapLane(ctx, lane);
         if (rc != SPX_OK) return rc;
         if (m) lane.ftRecorded = true;
