@@ -169,10 +169,14 @@ struct spx_ctx {
     bool smallL2Weights = false;   // every |l2W| < 2^23: the MLP tail may use 24-bit multiplies
     // Pipelined calls record an event at the five points of a call where spx_profile_* would (round 6): measured on the sustained
     // loop of tools/probes/sustained_rate.py, the three lanes settle into 2.12e8 evals/s with those records in their streams and into
-    // 1.89e8 without - the records keep a lane's small kernels from running ahead into the other lanes' gathers. Nobody reads them
-    // (option pace_events = 0: none, unless a profile is open).
+    // 1.89e8 without - the records hold a lane's next preparation back until what the lane ran before has fully drained. Nobody reads
+    // them (option pace_events = 0: none, unless a profile is open; pace_mask / pace_head_extra: which).
     hipEvent_t* paceEvents = nullptr;
     bool paceEnabled = true;
+    // which of the five, and extra records at the head of the call (A/B on the sustained loop, x 1e8 evals/s: none 1.89 - all five 2.14 -
+    // only the two at the head 2.16 - those + one more 2.18 - + two / four more 2.17 / 2.15; the one behind the gather alone 2.10, with
+    // the head's 2.11; the one before the gather alone: nothing): three records in front of the extraction
+    uint32_t paceMask = 3, paceHeadExtra = 1;
     bool ftxFoldSort = true;       // option ftx_fold_sort: one-pass batches of the pipeline sort the MLP's order themselves
     uint32_t computeUnits = 0;
     uint32_t ftGridCap = 0;
@@ -578,6 +582,14 @@ int spx_ctx_set_option(spx_ctx* ctx, const char* name, int64_t value) {
     }
     if (key == "ftx_fail_launch") {  // test hook: the k-th pass of the pipeline from now on "fails to launch" (-1: never)
         ctx->ftxFailLaunch = int(value);
+        return SPX_OK;
+    }
+    if (key == "pace_head_extra") {
+        ctx->paceHeadExtra = uint32_t(value);
+        return SPX_OK;
+    }
+    if (key == "pace_mask") {
+        ctx->paceMask = uint32_t(value);
         return SPX_OK;
     }
     if (key == "pace_events") {  // pipelined calls: an event record at the five points of a call where a profile would put one (1) or none (0)
@@ -1089,7 +1101,10 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     } else if (ctx->paceEvents && ctx->paceEnabled) {
         ev = ctx->paceEvents;
     }
-    if (ev) SPX_HIP(hipEventRecord(ev[0], s));
+    if (ev && (profiled || (ctx->paceMask >> 0 & 1u))) SPX_HIP(hipEventRecord(ev[0], s));
+    if (ev && !profiled) {
+        for (uint32_t r = 0; r < ctx->paceHeadExtra; ++r) SPX_HIP(hipEventRecord(ev[0], s));
+    }
     // big batches: the column-sliced pipeline (spx_ftx.hip); it orders the perspectives itself, so only the MLP's
     // output-bucket order is sorted here
     FtxScratch& scratch = ctx->ftx;
@@ -1105,7 +1120,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
     const bool foldSort = sliced && ctx->ftxFoldSort && n <= scratch.capacity;
     int rc = (tiny || foldSort) ? SPX_OK : runSortAndMlp(ctx, d_positions, n, nullptr, s, false, nullptr, sliced);
     if (rc != SPX_OK) return rc;
-    if (ev) SPX_HIP(hipEventRecord(ev[1], s));
+    if (ev && (profiled || (ctx->paceMask >> 1 & 1u))) SPX_HIP(hipEventRecord(ev[1], s));
     if (sliced) {
         // passes of at most the scratch's capacity; a pass's preparation (extraction, sort, plan) comes before the
         // pipelined calls' gate, so that it runs beside another batch's gather
@@ -1155,7 +1170,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
             hipError_t launched = (ctx->ftxFailLaunch >= 0 && ctx->ftxFailLaunch-- == 0) ? hipErrorLaunchFailure : launchFtxPrepare(xp, s);
             if (launched == hipSuccess && lo == 0) {
                 if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));
-                if (ev) SPX_HIP(hipEventRecord(ev[4], s));
+                if (ev && (profiled || (ctx->paceMask >> 4 & 1u))) SPX_HIP(hipEventRecord(ev[4], s));
             }
             if (launched == hipSuccess) launched = launchFtxGather(xp, s);
             if (launched != hipSuccess) {
@@ -1169,7 +1184,7 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         }
     } else {
         if (ctx->ftGateWait) SPX_HIP(hipStreamWaitEvent(s, ctx->ftGateWait, 0));  // pipelined calls: FT kernels are chained
-        if (ev) SPX_HIP(hipEventRecord(ev[4], s));  // after the wait: the FT interval is the kernel alone
+        if (ev && (profiled || (ctx->paceMask >> 4 & 1u))) SPX_HIP(hipEventRecord(ev[4], s));  // after the wait: the FT interval is the kernel alone
         FtParams fp{};
         fp.positions = d_positions;
         fp.nPositions = uint32_t(n);
@@ -1179,10 +1194,10 @@ int spx_eval_full_device(spx_ctx* ctx, const void* d_positions, size_t n, void* 
         SPX_HIP(launchFullFt(ctx, fp, 2 * n, s));
     }
     if (ctx->ftGateRecord) SPX_HIP(hipEventRecord(ctx->ftGateRecord, s));
-    if (ev) SPX_HIP(hipEventRecord(ev[2], s));
+    if (ev && (profiled || (ctx->paceMask >> 2 & 1u))) SPX_HIP(hipEventRecord(ev[2], s));
     rc = tiny ? runTinyMlp(ctx, d_positions, n, d_out, s) : runSortAndMlp(ctx, d_positions, n, d_out, s, true);
     if (rc != SPX_OK) return rc;
-    if (ev) SPX_HIP(hipEventRecord(ev[3], s));
+    if (ev && (profiled || (ctx->paceMask >> 3 & 1u))) SPX_HIP(hipEventRecord(ev[3], s));
     return SPX_OK;
 }
 
